@@ -1,0 +1,276 @@
+"""DEV-ONLY: produce ``tests/golden/`` from the unmodified reference.
+
+TEST INFRASTRUCTURE.  Run in the development container (needs
+``/root/reference``; see ``oracle/ref_shim.py``)::
+
+    python oracle/make_golden.py
+
+Writes
+  tests/golden/boss/{model,data,cov}.npy     BOSS DR12 CMASS inputs, converted from the
+                                             reference's HDF5 data files to the ``.npy``
+                                             dict format the reference API reads natively
+                                             (ccf_model.py:62-63) - data, not source.
+  tests/golden/synth/{model,data2,cov2,data3,cov3}.npy
+                                             the deterministic synthetic metric-grid inputs
+                                             (SURVEY.md App. E); data vectors come from the
+                                             reference's own theory at the fiducial point.
+  tests/golden/ref_outputs.npz               reference outputs (theory vectors, chi2, lnL,
+                                             xi(s,mu)) for every golden case.
+"""
+
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, HERE)
+
+import ref_shim  # noqa: E402
+
+BOSS_DIR = "data/BOSS_DR12_CMASS_data/"
+BOSS_PREFIX = "CMASS_zobovVoids_reconRs10_0.43z0.7_medianRvcut_"
+
+
+def halton(n, bases=(2, 3, 5, 7), skip=1):
+    out = np.empty((n, len(bases)))
+    for j, b in enumerate(bases):
+        for i in range(n):
+            k, f, x = i + skip, 1.0, 0.0
+            while k > 0:
+                f /= b
+                x += f * (k % b)
+                k //= b
+            out[i, j] = x
+    return out
+
+
+def halton_params(n):
+    """prior box of boss_cobaya_config.yaml:51-97."""
+    h = halton(n)
+    return [dict(fsigma8=0.05 + 1.45 * a, sigma_v=100 + 400 * b, aperp=0.8 + 0.4 * c, apar=0.8 + 0.4 * d)
+            for a, b, c, d in h]
+
+
+def save_dict(path, d):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    np.save(path, {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in d.items()}, allow_pickle=True)
+
+
+# --------------------------------------------------------------------------- #
+def boss_options(variant="config"):
+    """Option dicts equivalent to config/boss_config.yaml (variant 'config') or the
+    model/data blocks of config/boss_cobaya_config.yaml (variant 'cobaya'), pointed at
+    the converted .npy inputs."""
+    model = {
+        "input_model_data_file": "boss/model.npy",
+        "rsd_model": "streaming",
+        "z_eff": 0.57,
+        "cosmology": {"Omega_m": 0.31},
+        "realspace_ccf": {"reconstruction": True, "beta_key": "beta", "format": "multipoles",
+                          "ccf_keys": ["r", "monopole", "quadrupole"], "assume_isotropic": True},
+        "matter_ccf": {"model": "template", "integrated": False, "template_keys": ["rdelta", "delta"],
+                       "template_sigma8": 0.628, "bias": 1.9},
+        "velocity_pdf": {"mean": {"model": "linear", "empirical_corr": False},
+                         "dispersion": {"model": "template", "template_keys": ["rsv", "sigmav"]}},
+    }
+    if variant == "config":
+        model["velocity_pdf"]["rescale_templates_independent_of_AP"] = False
+    data = {
+        "redshift_space_ccf": {"reconstruction": True, "data_file": "boss/data.npy", "format": "multipoles",
+                               "ccf_keys": ["s", "monopole", "quadrupole"], "beta_key": None},
+        "covariance_matrix": {"data_file": "boss/cov.npy", "cov_key": "covmat", "fixed_beta": False,
+                              "beta_key": "beta"},
+        "beta_interpolation": "datavector",
+        "likelihood": {"form": "sellentin", "nmocks": 1000, "nparams": 4},
+    }
+    return model, data
+
+
+def synth_tables():
+    """SURVEY.md App. E (deterministic, no RNG)."""
+    r = 1.5 + 3.0 * np.arange(40)
+
+    def h(x, dc=-0.9, rs=38.0, rv=45.0, a=2.2, b=7.5):
+        return dc * (1 - (x / rs) ** a) / (1 + (x / rv) ** b)
+
+    rdelta = 1.2 + 2.4 * np.arange(60)
+    rsv = 3.0 + 6.0 * np.arange(25)
+    model = {
+        "r": r,
+        "monopole": h(r),
+        "quadrupole": 0.02 * (r / 40) ** 2 * np.exp(-(r / 50) ** 2),
+        "hexadecapole": 0.005 * (r / 40) ** 4 * np.exp(-(r / 45) ** 2),
+        "rdelta": rdelta,
+        "delta": h(rdelta) / 2,
+        "rsv": rsv,
+        "sigmav": 385 * (1 - 0.45 * np.exp(-(rsv / 25) ** 2)),
+    }
+    return model
+
+
+def synth_cov(s, n_ell):
+    sig = 0.004 * (1 + 20 / s)
+    idx = np.arange(len(s))
+    T = np.outer(sig, sig) * 0.6 ** np.abs(idx[:, None] - idx[None, :])
+    K = np.array([[1, .2, .05], [.2, 1, .2], [.05, .2, 1]])[:n_ell, :n_ell]
+    return np.kron(K, T)
+
+
+def synth_options(config):
+    """config 2: isotropic xi_r, data l=0,2, template rescale independent of AP (default).
+    config 3: xi_r l=0,2,4, data l=0,2,4, AP-dependent rescale."""
+    aniso = config == 3
+    model = {
+        "input_model_data_file": "synth/model.npy",
+        "rsd_model": "streaming",
+        "z_eff": 0.57,
+        "cosmology": {"Omega_m": 0.31},
+        "realspace_ccf": {"reconstruction": False, "format": "multipoles",
+                          "ccf_keys": ["r", "monopole", "quadrupole", "hexadecapole"] if aniso else ["r", "monopole"],
+                          "assume_isotropic": not aniso},
+        "matter_ccf": {"model": "template", "integrated": False, "template_keys": ["rdelta", "delta"],
+                       "template_sigma8": 0.628},
+        "velocity_pdf": {"mean": {"model": "linear"},
+                         "dispersion": {"model": "template", "template_keys": ["rsv", "sigmav"]}},
+    }
+    if aniso:
+        model["velocity_pdf"]["rescale_templates_independent_of_AP"] = False
+    data = {
+        "redshift_space_ccf": {"reconstruction": False, "data_file": f"synth/data{config}.npy",
+                               "format": "multipoles",
+                               "ccf_keys": ["s", "monopole", "quadrupole", "hexadecapole"] if aniso
+                               else ["s", "monopole", "quadrupole"]},
+        "covariance_matrix": {"data_file": f"synth/cov{config}.npy", "cov_key": "covmat"},
+        "likelihood": {"form": "gaussian"},
+    }
+    return model, data
+
+
+# --------------------------------------------------------------------------- #
+def main():
+    v = ref_shim.load()
+    out = {}
+    meta = {}
+
+    # ---- BOSS inputs: HDF5 -> npy dict -------------------------------------
+    src = os.path.join(ref_shim.REFERENCE_ROOT, BOSS_DIR, BOSS_PREFIX)
+    save_dict(os.path.join(GOLD, "boss", "model.npy"), ref_shim._h5_read(src + "PatchyMean_model.hdf5"))
+    save_dict(os.path.join(GOLD, "boss", "data.npy"), ref_shim._h5_read(src + "data.hdf5"))
+    save_dict(os.path.join(GOLD, "boss", "cov.npy"), ref_shim._h5_read(src + "variable_D_covariance.hdf5"))
+
+    beta_grid = ref_shim._h5_read(src + "data.hdf5")["beta"]
+    boss_points = [
+        {"fsigma8": 0.47, "beta": 0.37, "sigma_v": 380, "epsilon": 1.0},
+        {"fsigma8": 0.55, "beta": 0.43, "sigma_v": 320, "epsilon": 1.04},
+        {"fsigma8": 0.30, "beta": 0.251, "sigma_v": 450, "aperp": 0.97, "apar": 1.05},
+        {"fsigma8": 0.62, "beta": float(beta_grid[12]), "sigma_v": 290, "epsilon": 0.97},   # exact grid match
+        {"fsigma8": 0.41, "beta": 0.150, "sigma_v": 410, "epsilon": 1.01},                  # below grid
+        {"fsigma8": 0.52, "beta": 0.660, "sigma_v": 365, "epsilon": 0.99, "alpha": 1.02},   # above grid
+        {"fsigma8": 0.35, "beta": 0.58, "sigma_v": 150, "aperp": 1.1, "apar": 0.85},
+        {"fsigma8": 1.20, "beta": 0.22, "sigma_v": 495, "aperp": 0.82, "apar": 1.18},
+    ]
+    meta["boss_points"] = boss_points
+
+    for variant in ("config", "cobaya"):
+        model, data = boss_options(variant)
+        model["dir"] = data["dir"] = GOLD
+        fit = v.CCFFit(model, data)
+        if variant == "config":
+            # sanity: the converted inputs reproduce the reference's own config + HDF5 files
+            info = ref_shim.boss_config()
+            fit0 = v.CCFFit(info["model"], info["data"])
+            a = fit0.log_likelihood(dict(boss_points[0]))
+            b = fit.log_likelihood(dict(boss_points[0]))
+            assert a == b, (a, b)
+            out["boss_iaH"] = np.array(fit.iaH)
+            out["boss_sv_rmu"] = fit.sv_rmu
+            r_ext = np.append([0.01], fit.r)
+            out["boss_delta_ext"] = fit.delta(r_ext)
+            out["boss_int_delta_ext"] = fit.integrated_delta(r_ext)
+            out["boss_icov_12"] = fit.icov[12]
+            out["boss_icov_30"] = fit.icov[30]
+        th, chi, lnl = [], [], []
+        for p in boss_points:
+            th.append(fit.theory_multipole_vector(fit.s, dict(p), fit.poles_s))
+            l, c = fit.log_likelihood(dict(p))
+            chi.append(c)
+            lnl.append(l)
+        out[f"boss_{variant}_theory"] = np.array(th)
+        out[f"boss_{variant}_chi2"] = np.array(chi)
+        out[f"boss_{variant}_lnl"] = np.array(lnl)
+        if variant == "config":
+            mu = np.linspace(0, 1, 100)
+            out["boss_config_xi_smu_p0"] = fit.theory_xi(*np.meshgrid(fit.s, mu), dict(boss_points[0]))
+            out["boss_config_xi_smu_p2"] = fit.theory_xi(*np.meshgrid(fit.s, mu), dict(boss_points[2]))
+            # the five notebook variants (victor_usage_demo.ipynb:505-518)
+            p = boss_points[0]
+            nb = {}
+            nb["streaming"] = fit.log_likelihood(dict(p))
+            nb["dispersion"] = fit.log_likelihood(dict(p), rsd_model="dispersion")
+            nb["kaiser"] = fit.log_likelihood(dict(p), rsd_model="kaiser")
+            nb["anisotropic"] = fit.log_likelihood(dict(p), assume_isotropic=False)
+            nb["beta_likelihood"] = fit.log_likelihood(dict(p), beta_interpolation="likelihood")
+            for k, (l, c) in nb.items():
+                out[f"boss_nb_{k}"] = np.array([c, l])
+            # likelihood forms
+            for form in ("gaussian", "hartlap", "percival", "sellentin"):
+                l, c = fit.log_likelihood(dict(p), likelihood={"form": form, "nmocks": 1000, "nparams": 4})
+                out[f"boss_form_{form}"] = np.array([c, l])
+            # other rsd branches, theory vectors at two points (f1 rows)
+            for rsd in ("dispersion", "kaiser", "euclid_special"):
+                out[f"boss_{rsd}_theory"] = np.array(
+                    [fit.theory_multipole_vector(fit.s, dict(q), fit.poles_s, rsd_model=rsd) for q in boss_points[:3]])
+            out["boss_kaiser_approx_theory"] = np.array(
+                [fit.theory_multipole_vector(fit.s, dict(q, M=1.1, Q=0.9), fit.poles_s, rsd_model="kaiser",
+                                             kaiser_approximation=True) for q in boss_points[:3]])
+            out["boss_aniso_theory"] = np.array(
+                [fit.theory_multipole_vector(fit.s, dict(q), fit.poles_s, assume_isotropic=False)
+                 for q in boss_points[:3]])
+
+    # ---- synthetic metric-grid inputs ---------------------------------------
+    tables = synth_tables()
+    save_dict(os.path.join(GOLD, "synth", "model.npy"), tables)
+    s = tables["r"].copy()
+    fid = {"fsigma8": 0.45, "sigma_v": 360, "aperp": 1.0, "apar": 1.0}
+    hp = halton_params(24)
+    meta["synth_points"] = hp
+    for config, n_ell in ((2, 2), (3, 3)):
+        model, data = synth_options(config)
+        model["dir"] = data["dir"] = GOLD
+        cm = v.CCFModel(model)
+        poles = [0, 2, 4][:n_ell]
+        t_fid = cm.theory_multipole_vector(s, dict(fid), poles)
+        dvec = t_fid * (1 + 0.01 * np.sin(np.arange(len(t_fid))))
+        d = {"s": s}
+        for i, name in enumerate(["monopole", "quadrupole", "hexadecapole"][:n_ell]):
+            d[name] = dvec[i * len(s):(i + 1) * len(s)]
+        save_dict(os.path.join(GOLD, "synth", f"data{config}.npy"), d)
+        save_dict(os.path.join(GOLD, "synth", f"cov{config}.npy"), {"covmat": synth_cov(s, n_ell)})
+        fit = v.CCFFit(model, data)
+        pts = list(hp)
+        if config == 3:
+            pts = [{"fsigma8": 0.47, "sigma_v": 380, "aperp": 1.02, "apar": 0.97}] + pts
+        th, chi, lnl = [], [], []
+        for p in pts:
+            th.append(fit.theory_multipole_vector(fit.s, dict(p), fit.poles_s))
+            l, c = fit.log_likelihood(dict(p))
+            chi.append(c)
+            lnl.append(l)
+        out[f"synth{config}_theory"] = np.array(th)
+        out[f"synth{config}_chi2"] = np.array(chi)
+        out[f"synth{config}_lnl"] = np.array(lnl)
+        out[f"synth{config}_xi_smu_p0"] = fit.theory_xi(*np.meshgrid(fit.s, np.linspace(0, 1, 100)), dict(pts[0]))
+
+    out["meta_json"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(GOLD, "ref_outputs.npz"), **out)
+    for k in sorted(out):
+        if k.endswith(("chi2", "lnl")) or k.startswith(("boss_nb", "boss_form")):
+            print(k, np.array2string(out[k], precision=12))
+
+
+if __name__ == "__main__":
+    main()
