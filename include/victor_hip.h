@@ -1,0 +1,204 @@
+/*
+ * victor_hip.h - C ABI of libvictor_hip.so, the MI355X (gfx950) implementation of
+ * victor's per-step likelihood hot path.
+ *
+ * The reference (seshnadathur/victor, pure Python) has no native boundary of its
+ * own; the replaceable interface is its Python class API.  Each entry point below
+ * names the reference method whose work it performs for a whole BATCH of parameter
+ * points (paths relative to the reference root):
+ *
+ *   vk_eval_batch        CCFFit.log_likelihood        victor/ccf_fit.py:356-483
+ *                        CCFFit.chi_squared           victor/ccf_fit.py:325-354
+ *                        CCFModel.theory_multipole_vector  victor/ccf_model.py:829-860
+ *   vk_theory_batch      CCFModel.theory_multipoles   victor/ccf_model.py:791-827
+ *                        (+ utils.multipoles_from_fn  victor/utils.py:9-58)
+ *   vk_xi_smu_batch      CCFModel.theory_xi           victor/ccf_model.py:538-789
+ *   vk_create            CCFModel.__init__ / CCFFit.__init__ table set-up
+ *                        victor/ccf_model.py:33-97, victor/ccf_fit.py:15-42
+ *                        (the host has already turned every spline into explicit
+ *                        piecewise-cubic coefficient tables; vk_create uploads them)
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all arrays are contiguous row-major doubles
+ *   - the caller owns every host buffer; the context owns device memory and one
+ *     HIP stream; a context is bound to one device and is not thread-safe
+ *   - return value 0 = success, negative = VK_E_* code; vk_last_error() gives text
+ *   - calls are synchronous unless the name ends in _async (then use vk_sync)
+ *   - there is no CPU fallback anywhere in the library
+ */
+#ifndef VICTOR_HIP_H
+#define VICTOR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VK_ABI_VERSION 1
+
+/* error codes */
+#define VK_OK 0
+#define VK_E_ARG (-1)      /* bad argument / unsupported option combination */
+#define VK_E_HIP (-2)      /* a HIP runtime call failed */
+#define VK_E_NODEVICE (-3) /* no usable GPU */
+#define VK_E_RCCL (-4)     /* an RCCL call failed */
+
+/* one row of the parameter batch: VK_NPAR doubles (ccf_model.py:583-613,638,695-696) */
+#define VK_NPAR 10
+#define VK_P_FSIGMA8 0 /* params['fsigma8']                                   */
+#define VK_P_SIGMAV 1  /* params.get('sigma_v', 380)                          */
+#define VK_P_APERP 2   /* alpha_perp  (from aperp, or epsilon*apar)           */
+#define VK_P_APAR 3    /* alpha_par   (from apar, or alpha*epsilon^(-2/3))    */
+#define VK_P_EPSILON 4 /* epsilon     (given, or aperp/apar)                  */
+#define VK_P_BETA 5    /* reconstruction beta (0.40 dummy when irrelevant)    */
+#define VK_P_ASTAR 6   /* params.get('astar', 1)                              */
+#define VK_P_M 7       /* Kaiser nuisance M (default 1)                       */
+#define VK_P_Q 8       /* Kaiser nuisance Q (default 1)                       */
+#define VK_P_SPARE 9
+
+/* vk_eval_opts.rsd_model (ccf_model.py:646-787) */
+#define VK_RSD_STREAMING 0
+#define VK_RSD_DISPERSION 1
+#define VK_RSD_KAISER 2
+#define VK_RSD_EUCLID 3
+
+/* vk_eval_opts.like_form (ccf_fit.py:455-473) */
+#define VK_LIKE_GAUSSIAN 0
+#define VK_LIKE_SELLENTIN 1
+#define VK_LIKE_HARTLAP 2
+#define VK_LIKE_PERCIVAL 3
+
+/* 'want' bit mask for vk_eval_batch */
+#define VK_WANT_LNL 1u
+#define VK_WANT_CHI2 2u
+#define VK_WANT_THEORY 4u
+
+/*
+ * A clamped piecewise-cubic table  f(u) = sum_p coef[i][p] * (u - knot_i)^p  on interval i.
+ * Evaluation clamps u to [knots[0], knots[n_int]] first (FITPACK ext=3 / box clamp).
+ * Interval search: the first `lead` intervals are irregular (searched linearly), the rest
+ * lie on a uniform grid starting at knots[lead] with spacing 1/inv_h.
+ */
+typedef struct vk_pp {
+  int32_t n_int;        /* number of intervals; knots has n_int+1 entries      */
+  int32_t lead;         /* 0 or 1 leading irregular interval                   */
+  double inv_h;         /* 1/spacing of the uniform part                       */
+  const double* knots;  /* [n_int+1]                                           */
+  const double* coef;   /* [n_var][n_int][4]; n_var is table specific          */
+} vk_pp;
+
+typedef struct vk_tables {
+  /* ---- redshift-space grid of the data vector and its projection ---------- */
+  int32_t n_s;          /* s bins of the data vector (ccf_fit.py:90)           */
+  int32_t n_mu;         /* mu nodes, 100 (ccf_model.py:819,822)                */
+  int32_t n_x;          /* velocity nodes, 50 (ccf_model.py:570)               */
+  int32_t n_ell;        /* multipoles in the data vector (ccf_fit.py:92)       */
+  const double* s;      /* [n_s]                                               */
+  const double* mu;     /* [n_mu]                                              */
+  const double* w_ell;  /* [n_ell][n_mu] projection weights (utils.py:45-56 composed with
+                           the cubic interp2d of ccf_model.py:824)             */
+  const double* x;      /* [n_x] v/sigma_v nodes, linspace(-6,6,n_x)           */
+  const double* w_x;    /* [n_x] Simpson weights * dx / sqrt(2 pi) (ccf_model.py:690) */
+
+  /* ---- real-space CCF multipoles xi^r_l(r) (ccf_model.py:615-621) ---------- */
+  int32_t n_ell_r;      /* real-space multipoles available: 1..3 (l = 0,2,4)   */
+  int32_t n_beta_r;     /* 0: tables fixed; else nodes of the reconstruction-beta grid */
+  const double* beta_r; /* [n_beta_r]                                          */
+  vk_pp xi;             /* fixed: coef[n_ell_r][n_int][4]
+                           beta-dependent: coef[n_ell_r][n_beta_r-1][n_int][4][4], the last
+                           index being the power of (beta - beta_r[k]) (PCHIP in beta,
+                           ccf_model.py:323-326, composed with the not-a-knot spline in r) */
+
+  /* ---- matter template -> velocity profile (ccf_model.py:421-450,625-636) -- */
+  vk_pp vr;             /* coef[2][n_int][4]: V(u) = u*Delta(u) and D(u) = delta - 2 Delta/3
+                           splined on r_ext = [0.01, r...]                     */
+  /* ---- velocity dispersion template (ccf_model.py:654-655) ----------------- */
+  vk_pp sv;             /* coef[1][n_int][4]: normalised sigma_v(r) shape       */
+
+  double iaH;           /* (1+z)/(100 E(z)) (ccf_model.py:43-45)               */
+  double template_sigma8; /* ccf_model.py:432-435                              */
+
+  /* ---- data vector (ccf_fit.py:166-193,306-323) ---------------------------- */
+  int32_t n_beta_d;     /* 0: fixed data vector; else beta nodes               */
+  const double* beta_d; /* [n_beta_d]                                          */
+  const double* data;   /* fixed: [N]; else PCHIP pieces [n_beta_d-1][N][4], N = n_ell*n_s */
+
+  /* ---- covariance / precision (ccf_fit.py:195-260, 445-453) ---------------- */
+  int32_t n_beta_c;     /* 0: fixed; else beta nodes of the covariance stack   */
+  const double* beta_c; /* [n_beta_c]                                          */
+  const double* prec;   /* fixed: [N][N]; else [n_beta_c][N][N] (inverse of each slice) */
+  const double* logdet; /* [n_beta_c] log det of each covariance slice (NULL if fixed) */
+  const double* eig;    /* [n_beta_c][N] generalised eigenvalues of (cov[last], cov[k]) so that
+                           logdet((1-t) cov[k] + t cov[last]) = logdet[k] + sum log(1-t+t*eig) */
+} vk_tables;
+
+typedef struct vk_eval_opts {
+  int32_t rsd_model;         /* VK_RSD_*                                        */
+  int32_t assume_isotropic;  /* use xi^r_0 only (ccf_model.py:681-687)          */
+  int32_t rescale_from_ap;   /* 0: c = astar; 1: c = AP integral (ccf_model.py:606-611) */
+  int32_t like_form;         /* VK_LIKE_*                                       */
+  double nmocks;             /* ccf_fit.py:456                                  */
+  double nparams;            /* ccf_fit.py:465                                  */
+  int32_t kaiser_approx;     /* ccf_model.py:730-738                            */
+  int32_t kaiser_coord_shift;/* ccf_model.py:698-707                            */
+  int32_t niter;             /* fixed-point iterations (ccf_model.py:661,701), default 5 */
+  int32_t reserved;
+} vk_eval_opts;
+
+typedef struct vk_ctx vk_ctx;
+
+int vk_abi_version(void);
+int vk_device_count(void);
+
+/* Copies every table to `device`.  On failure returns NULL and writes a message to err. */
+vk_ctx* vk_create(const vk_tables* tables, int device, char* err, size_t errlen);
+void vk_destroy(vk_ctx* ctx);
+const char* vk_last_error(const vk_ctx* ctx);
+void vk_default_opts(vk_eval_opts* opts);
+
+/* Full likelihood for n parameter rows (host buffers).  Any of lnl/chi2/theory may be NULL.
+ * lnl[i] = -inf, chi2[i] = +inf where the reference returns (-inf, inf) (ccf_fit.py:447-450,477-481).
+ * theory is [n][n_ell*n_s]. */
+int vk_eval_batch(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, int64_t n,
+                  double* lnl, double* chi2, double* theory);
+
+/* Theory multipoles on a caller-supplied s grid: out[n][n_ell][n_s] with the caller's own
+ * projection weights w_ell[n_ell][n_mu] on mu[n_mu] (host buffers). */
+int vk_theory_batch(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, int64_t n,
+                    const double* s, int32_t n_s, const double* mu, int32_t n_mu,
+                    const double* w_ell, int32_t n_ell, double* out);
+
+/* xi^s(mu_i, s_j) for every point: out[n][n_mu][n_s] (host buffers). */
+int vk_xi_smu_batch(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, int64_t n,
+                    const double* s, int32_t n_s, const double* mu, int32_t n_mu, double* out);
+
+/* ---- device-resident variants (inputs/outputs already in HBM) ----------------------- */
+void* vk_device_alloc(vk_ctx* ctx, size_t bytes);
+void vk_device_free(vk_ctx* ctx, void* ptr);
+int vk_memcpy_h2d(vk_ctx* ctx, void* dst, const void* src, size_t bytes);
+int vk_memcpy_d2h(vk_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* enqueue on the context's stream; d_theory_ws is a device workspace of n*N doubles */
+int vk_eval_batch_device_async(vk_ctx* ctx, const vk_eval_opts* opts, const double* d_params,
+                               int64_t n, double* d_lnl, double* d_chi2, double* d_theory_ws);
+int vk_sync(vk_ctx* ctx);
+
+/* ---- timing on the context's stream (HIP events) ------------------------------------ */
+/* Marks: 0 = before theory kernel, 1 = between kernels, 2 = after likelihood kernel, recorded by
+ * the next vk_eval_batch_device_async when enabled.  Times accumulate until reset. */
+int vk_timing_enable(vk_ctx* ctx, int on);
+int vk_timing_read(vk_ctx* ctx, double* theory_ms, double* like_ms, int64_t* launches, int reset);
+
+/* ---- multi-GPU gather of log-likelihoods over RCCL/xGMI ------------------------------ */
+#define VK_COMM_ID_BYTES 128
+int vk_comm_unique_id(char* id_out /* [VK_COMM_ID_BYTES] */);
+int vk_comm_init(vk_ctx* ctx, const char* id, int rank, int nranks);
+/* all ranks contribute count doubles at d_send, every rank receives nranks*count at d_recv */
+int vk_comm_allgather_async(vk_ctx* ctx, const double* d_send, double* d_recv, int64_t count);
+int vk_comm_destroy(vk_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VICTOR_HIP_H */

@@ -1,0 +1,228 @@
+"""GPU parity: HIP path (through the C ABI) vs the reference's golden vectors and the CPU oracle.
+
+Tolerances: the north star asks for multipoles and chi-square within 1e-6 relative.  The tests hold the
+HIP path to RTOL = 1e-9 (multipoles are compared relative to max|xi_l| over the vector, because individual
+bins cross zero).
+"""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+ORACLE_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    sys.path.insert(0, ORACLE_DIR)
+    import victor_oracle
+    return victor_oracle
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return cases.golden_outputs()
+
+
+@pytest.fixture(scope="module")
+def boss_fit():
+    import victor_amd
+    return {v: victor_amd.CCFFit(*cases.boss_options(v)) for v in ("config", "cobaya")}
+
+
+@pytest.fixture(scope="module")
+def synth_fit():
+    import victor_amd
+    return {c: victor_amd.CCFFit(*cases.synth_options(c)) for c in (2, 3)}
+
+
+def vec_close(a, b, rtol=RTOL):
+    scale = np.max(np.abs(b))
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) <= rtol * scale
+
+
+def test_native_library_is_loaded():
+    from victor_amd import _native
+    lib = _native.load()
+    assert lib.vk_device_count() >= 1
+    with open("/proc/self/maps") as fh:
+        assert "libvictor_hip.so" in fh.read()
+
+
+@pytest.mark.parametrize("variant", ["config", "cobaya"])
+def test_boss_golden_single_point_api(boss_fit, gold, variant):
+    g, meta = gold
+    fit = boss_fit[variant]
+    for i, p in enumerate(meta["boss_points"]):
+        lnl, chi2 = fit.log_likelihood(dict(p))
+        t = fit.theory_multipole_vector(fit.s, dict(p), fit.poles_s)
+        assert vec_close(t, g[f"boss_{variant}_theory"][i]), (variant, i)
+        assert abs(chi2 - g[f"boss_{variant}_chi2"][i]) <= RTOL * abs(g[f"boss_{variant}_chi2"][i]), (variant, i)
+        assert abs(lnl - g[f"boss_{variant}_lnl"][i]) <= RTOL * abs(g[f"boss_{variant}_lnl"][i]), (variant, i)
+
+
+def test_boss_known_answer_from_reference_notebook(boss_fit):
+    # victor_usage_demo.ipynb:491 prints 65.01, 284.76 for this point
+    lnl, chi2 = boss_fit["config"].log_likelihood({"fsigma8": 0.47, "beta": 0.37, "sigma_v": 380, "epsilon": 1.0})
+    assert round(chi2, 2) == 65.01 and round(lnl, 2) == 284.76
+    chi2_only, cov = boss_fit["config"].chi_squared({"fsigma8": 0.47, "beta": 0.37, "sigma_v": 380, "epsilon": 1.0})
+    assert abs(chi2_only - chi2) < 1e-12 * chi2
+    assert cov.shape == (60, 60)
+
+
+def test_boss_batch_equals_single(boss_fit, gold):
+    g, meta = gold
+    fit = boss_fit["config"]
+    pts = meta["boss_points"]
+    # rows in ABI column order, built by the class itself
+    rows = np.concatenate([fit._fit_rows(dict(p), fit.model) for p in pts])
+    lnl, chi2 = fit.log_likelihood_batch(rows)
+    assert np.max(np.abs(chi2 / g["boss_config_chi2"] - 1)) < RTOL
+    assert np.max(np.abs(lnl / g["boss_config_lnl"] - 1)) < RTOL
+
+
+def test_boss_theory_xi_grid(boss_fit, gold):
+    g, meta = gold
+    fit = boss_fit["config"]
+    mu = np.linspace(0, 1, 100)
+    for tag, idx in (("p0", 0), ("p2", 2)):
+        xi = fit.theory_xi(*np.meshgrid(fit.s, mu), dict(meta["boss_points"][idx]))
+        ref = g[f"boss_config_xi_smu_{tag}"]
+        assert xi.shape == ref.shape == (100, 30)
+        assert np.max(np.abs(xi - ref)) < RTOL * np.max(np.abs(ref))
+
+
+def test_boss_anisotropic_kwarg(boss_fit, gold):
+    g, meta = gold
+    fit = boss_fit["config"]
+    for i, p in enumerate(meta["boss_points"][:3]):
+        t = fit.theory_multipole_vector(fit.s, dict(p), fit.poles_s, assume_isotropic=False)
+        assert vec_close(t, g["boss_aniso_theory"][i])
+    lnl, chi2 = fit.log_likelihood(dict(meta["boss_points"][0]), assume_isotropic=False)
+    assert abs(chi2 - g["boss_nb_anisotropic"][0]) < RTOL * chi2
+    assert abs(lnl - g["boss_nb_anisotropic"][1]) < RTOL * abs(lnl)
+
+
+def test_boss_beta_likelihood_interpolation(boss_fit, gold):
+    g, meta = gold
+    lnl, chi2 = boss_fit["config"].log_likelihood(dict(meta["boss_points"][0]), beta_interpolation="likelihood")
+    assert abs(chi2 - g["boss_nb_beta_likelihood"][0]) < RTOL * chi2
+    assert abs(lnl - g["boss_nb_beta_likelihood"][1]) < RTOL * abs(lnl)
+
+
+@pytest.mark.parametrize("form", ["gaussian", "hartlap", "percival", "sellentin"])
+def test_boss_likelihood_forms(boss_fit, gold, form):
+    g, meta = gold
+    lnl, chi2 = boss_fit["config"].log_likelihood(dict(meta["boss_points"][0]),
+                                                  likelihood={"form": form, "nmocks": 1000, "nparams": 4})
+    assert abs(chi2 - g[f"boss_form_{form}"][0]) < RTOL * chi2
+    assert abs(lnl - g[f"boss_form_{form}"][1]) < RTOL * abs(lnl)
+
+
+@pytest.mark.parametrize("config", [2, 3])
+def test_synthetic_golden(synth_fit, gold, config):
+    g, meta = gold
+    fit = synth_fit[config]
+    pts = list(meta["synth_points"])
+    if config == 3:
+        pts = [{"fsigma8": 0.47, "sigma_v": 380, "aperp": 1.02, "apar": 0.97}] + pts
+    batch = {k: np.array([p[k] for p in pts]) for k in pts[0]}
+    lnl, chi2 = fit.log_likelihood_batch(batch)
+    th = fit.theory_vector_batch(batch)
+    ref_t = g[f"synth{config}_theory"]
+    assert th.shape == ref_t.shape
+    for i in range(len(pts)):
+        assert vec_close(th[i], ref_t[i]), i
+    assert np.max(np.abs(chi2 / g[f"synth{config}_chi2"] - 1)) < RTOL
+    assert np.max(np.abs(lnl / g[f"synth{config}_lnl"] - 1)) < RTOL
+    xi = fit.theory_xi(fit.s, np.linspace(0, 1, 100), dict(pts[0]))
+    ref = g[f"synth{config}_xi_smu_p0"]
+    assert np.max(np.abs(xi - ref)) < RTOL * np.max(np.abs(ref))
+
+
+def test_oracle_parity_on_fresh_halton_points(synth_fit, boss_fit, oracle):
+    """Seeded points that are NOT in the fixtures: HIP vs the oracle run live (sizes the oracle finishes fast)."""
+    for config in (2, 3):
+        fit = synth_fit[config]
+        ora = oracle.OracleFit(*cases.synth_options(config))
+        hp = cases.halton_params(300)
+        sel = [40, 123, 299]
+        batch = {k: v[sel] for k, v in hp.items()}
+        lnl, chi2 = fit.log_likelihood_batch(batch)
+        for j, i in enumerate(sel):
+            lo, co = ora.log_likelihood(cases.point(hp, i))
+            assert abs(chi2[j] / co - 1) < RTOL and abs(lnl[j] / lo - 1) < RTOL
+    fit = boss_fit["config"]
+    ora = oracle.OracleFit(*cases.boss_options("config"))
+    hp = cases.halton_params(200, with_beta=True)
+    sel = [7, 77, 177]
+    batch = {k: v[sel] for k, v in hp.items()}
+    lnl, chi2 = fit.log_likelihood_batch(batch)
+    for j, i in enumerate(sel):
+        lo, co = ora.log_likelihood(cases.point(hp, i))
+        assert abs(chi2[j] / co - 1) < RTOL and abs(lnl[j] / lo - 1) < RTOL
+
+
+def test_batch_split_modes_agree(synth_fit):
+    """The kernel picks a different work split for small / medium / large batches; results must not depend on it."""
+    fit = synth_fit[3]
+    hp = cases.halton_params(1200)
+    lnl_big, chi_big = fit.log_likelihood_batch(hp)                       # one workgroup per point
+    for n in (1, 3, 30, 300):                                             # split s bins / split the (mu, v) plane
+        sub = {k: v[:n] for k, v in hp.items()}
+        lnl, chi = fit.log_likelihood_batch(sub)
+        assert np.max(np.abs(chi / chi_big[:n] - 1)) < 1e-12
+        assert np.max(np.abs(lnl / lnl_big[:n] - 1)) < 1e-12
+
+
+def test_general_s_grid_and_poles(synth_fit, oracle):
+    fit = synth_fit[3]
+    ora = oracle.OracleModel(cases.synth_options(3)[0])
+    s = np.array([5.0, 17.5, 33.0, 61.0, 90.0, 110.0])
+    p = {"fsigma8": 0.5, "sigma_v": 300, "aperp": 1.03, "apar": 0.96}
+    got = fit.theory_multipoles(s, dict(p), poles=[0, 2, 4])
+    want, _ = ora.theory_multipoles(s, dict(p), poles=[0, 2, 4])
+    for key in ("0", "2", "4"):
+        assert np.max(np.abs(got[key] - want[key])) < RTOL * np.max(np.abs(want[key]))
+    got = fit.theory_multipoles(s, dict(p), poles=[0])
+    assert set(got) == {"0"}
+    assert np.max(np.abs(got["0"] - want["0"])) < RTOL * np.max(np.abs(want["0"]))
+
+
+def test_large_batch_properties(synth_fit):
+    """Full-size batch (BASELINE config 3: 65536 points): size-independent checks."""
+    fit = synth_fit[3]
+    n = 65536
+    hp = cases.halton_params(n)
+    lnl, chi2 = fit.log_likelihood_batch(hp)
+    assert lnl.shape == chi2.shape == (n,)
+    assert np.all(np.isfinite(lnl)) and np.all(chi2 > 0)
+    assert np.max(np.abs(lnl + 0.5 * chi2)) < 1e-9 * np.max(chi2)          # gaussian form, fixed covariance
+    # any permutation of the batch gives the permuted result bit for bit
+    perm = np.random.default_rng(0).permutation(n)
+    lnl_p, chi_p = fit.log_likelihood_batch({k: v[perm] for k, v in hp.items()})
+    assert np.array_equal(chi_p, chi2[perm])
+    # a sub-batch run on its own (different work split) agrees
+    idx = np.arange(0, n, 4099)
+    lnl_s, chi_s = fit.log_likelihood_batch({k: v[idx] for k, v in hp.items()})
+    assert np.max(np.abs(chi_s / chi2[idx] - 1)) < 1e-12
+
+
+def test_failure_guards(boss_fit):
+    fit = boss_fit["config"]
+    lnl, chi2 = fit.log_likelihood({"fsigma8": np.nan, "beta": 0.37, "sigma_v": 380, "epsilon": 1.0})
+    assert lnl == -np.inf and chi2 == np.inf                                # ccf_fit.py:477-481
+    from victor_amd import InputError
+    with pytest.raises(InputError):
+        fit.log_likelihood({"fsigma8": 0.47, "beta": 0.37}, rsd_model="nonsense")
+    with pytest.raises(KeyError):
+        fit.log_likelihood({"beta": 0.37})
+    with pytest.raises(InputError):
+        fit.log_likelihood({"fsigma8": 0.47, "beta": 0.37}, likelihood={"form": "bogus"})

@@ -1,0 +1,129 @@
+"""Host table compiler vs the SciPy primitives the reference calls (CPU only)."""
+import numpy as np
+import pytest
+import scipy.interpolate as si
+from scipy.integrate import simpson
+from scipy.special import legendre
+
+from victor_amd import tables as T
+
+
+def _grid(rng, n, uniform):
+    if uniform:
+        return 2.0 + 4.0 * np.arange(n)
+    return np.cumsum(rng.uniform(0.5, 3.0, n))
+
+
+@pytest.mark.parametrize("n", [4, 5, 25, 30, 31, 55])
+@pytest.mark.parametrize("uniform", [True, False])
+def test_notaknot_matches_fitpack_ius(n, uniform):
+    rng = np.random.default_rng(n)
+    x = _grid(rng, n, uniform)
+    y = rng.normal(size=n)
+    ours = T.notaknot(x, y)
+    ref = si.InterpolatedUnivariateSpline(x, y, ext=3)
+    u = np.concatenate([np.linspace(x[0] - 5, x[-1] + 5, 2001), x])
+    assert np.max(np.abs(ours(u) - ref(u))) <= 5e-13 * max(1.0, np.max(np.abs(y)))
+
+
+def test_notaknot_extra_leading_node_and_vector_valued():
+    x = np.append([0.01], 2.0 + 4.0 * np.arange(30))
+    rng = np.random.default_rng(3)
+    Y = rng.normal(size=(31, 3))
+    ours = T.notaknot(x, Y)
+    u = np.linspace(0, 130, 777)
+    for k in range(3):
+        ref = si.InterpolatedUnivariateSpline(x, Y[:, k], ext=3)
+        assert np.max(np.abs(ours(u)[:, k] - ref(u))) < 1e-12
+
+
+def test_spline_abscissa_rescaling_identity():
+    # ccf_model.py:613-621: spline(c*r, y)(x) == spline(r, y)(x/c)
+    r = 2.0 + 4.0 * np.arange(30)
+    y = np.sin(r / 9.0)
+    c = 1.0375
+    u = np.linspace(0, 140, 500)
+    a = si.InterpolatedUnivariateSpline(c * r, y, ext=3)(u)
+    b = T.notaknot(r, y)(u / c)
+    assert np.max(np.abs(a - b)) < 1e-13
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_pchip_matches_scipy(seed):
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(3, 32))
+    x = np.cumsum(rng.uniform(0.01, 0.03, n)) + 0.15
+    y = rng.normal(size=(n, 7))
+    y[:, 0] = np.sort(y[:, 0])          # monotone column
+    y[:, 1] = 0.3                       # flat column
+    if n > 4:
+        y[2:4, 2] = y[2, 2]             # zero slope segment
+    ours = T.pchip(x, y)
+    ref = si.PchipInterpolator(x, y, axis=0)
+    u = np.concatenate([np.linspace(x[0] - 0.05, x[-1] + 0.05, 501), x])
+    assert np.max(np.abs(ours(u) - ref(u))) < 1e-12
+
+
+@pytest.mark.parametrize("n", [3, 5, 49, 50, 51, 8])
+def test_simpson_weights_match_scipy(n):
+    rng = np.random.default_rng(n)
+    y = rng.normal(size=n)
+    x = np.linspace(-6, 6, n) * 380.0
+    h = x[1] - x[0]
+    assert abs(T.simpson_weights(n) @ y * h - simpson(y, x=x)) < 1e-10 * h
+
+
+@pytest.mark.parametrize("poles", [[0, 2], [0, 2, 4], [0], [1, 3], [0, 1, 2]])
+def test_projection_weights_match_reference_construction(poles):
+    """Same construction as ccf_model.py:822-825 with FITPACK bicubic + utils.py:45-56."""
+    rng = np.random.default_rng(1)
+    s = 2.0 + 4.0 * np.arange(12)
+    mu = T.mu_nodes_for(poles)
+    xi = rng.normal(size=(len(mu), len(s))) * 0.1 + np.cos(3 * mu)[:, None] * np.exp(-s / 50)[None, :]
+    W = T.projection_weights(mu, poles)
+    got = W @ xi
+    spl = si.RectBivariateSpline(s, mu, xi.T, kx=3, ky=3, s=0)
+    even = not np.any(np.asarray(poles) % 2)
+    m200 = np.linspace(0, 1, 200) if even else np.linspace(-1, 1, 200)
+    for a, l in enumerate(poles):
+        f = (2 * l + 1) if even else (2 * l + 1) / 2
+        for j, sj in enumerate(s):
+            want = f * np.trapz(spl(sj, m200)[0] * legendre(l)(m200), m200)
+            assert abs(got[a, j] - want) < 2e-13
+
+
+def test_projection_weight_sums_are_not_exact():
+    # the "-1" of ccf_model.py:690 projects to -sum(W_l), not to zero
+    W = T.projection_weights(np.linspace(0, 1, 100), [0, 2, 4])
+    assert abs(W[0].sum() - 1) < 1e-13
+    assert 1e-5 < W[1].sum() < 1e-4
+    assert 1e-4 < W[2].sum() < 1e-3
+
+
+def test_beta_dependent_table_equals_pchip_then_spline():
+    rng = np.random.default_rng(5)
+    r = 2.0 + 4.0 * np.arange(30)
+    beta = np.linspace(0.16, 0.65, 31)
+    vals = rng.normal(size=(31, 30)).cumsum(axis=0) * 0.01
+    tab = T.beta_dependent_spline_table(r, beta, vals)
+    for b in (0.37, 0.16, 0.2004, 0.649, 0.1, 0.7):
+        k = int(np.clip(np.searchsorted(beta, b, side="right") - 1, 0, len(beta) - 2))
+        db = b - beta[k]
+        coef = ((tab[k, :, :, 3] * db + tab[k, :, :, 2]) * db + tab[k, :, :, 1]) * db + tab[k, :, :, 0]
+        nodal = si.PchipInterpolator(beta, vals, axis=0)(b)
+        ref = si.InterpolatedUnivariateSpline(r, nodal, ext=3)
+        u = np.linspace(0, 125, 400)
+        ours = T.PiecewiseCubic(r, coef)(u)
+        assert np.max(np.abs(ours - ref(u))) < 1e-12
+
+
+def test_legendre_closed_forms():
+    mu = np.linspace(-1, 1, 33)
+    for l in range(5):
+        assert np.max(np.abs(T.legendre_values(l, mu) - legendre(l)(mu))) < 1e-14
+
+
+def test_uniform_spacing_detection():
+    assert T.uniform_spacing(2.0 + 4.0 * np.arange(30)) == pytest.approx(4.0)
+    assert T.uniform_spacing(np.append([0.01], 2.0 + 4.0 * np.arange(30))) is None
+    assert T.uniform_spacing(np.append([0.01], 2.0 + 4.0 * np.arange(30)), lead=1) == pytest.approx(4.0)

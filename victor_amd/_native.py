@@ -1,0 +1,120 @@
+"""ctypes binding of ``libvictor_hip.so`` (declared in ``include/victor_hip.h``).
+
+There is deliberately no fallback: if the shared library has not been built, or no
+GPU is usable, every evaluation entry point raises.  Build with::
+
+    python -c "import __graft_entry__ as g; g.build()"      # or: make -C victor_amd/csrc
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+VK_ABI_VERSION = 1
+VK_NPAR = 10
+(P_FSIGMA8, P_SIGMAV, P_APERP, P_APAR, P_EPSILON, P_BETA, P_ASTAR, P_M, P_Q, P_SPARE) = range(10)
+RSD = {"streaming": 0, "dispersion": 1, "kaiser": 2, "euclid_special": 3}
+LIKE = {"gaussian": 0, "sellentin": 1, "hartlap": 2, "percival": 3}
+VK_COMM_ID_BYTES = 128
+
+_dp = C.POINTER(C.c_double)
+
+
+class vk_pp(C.Structure):
+    _fields_ = [("n_int", C.c_int32), ("lead", C.c_int32), ("inv_h", C.c_double),
+                ("knots", _dp), ("coef", _dp)]
+
+
+class vk_tables(C.Structure):
+    _fields_ = [
+        ("n_s", C.c_int32), ("n_mu", C.c_int32), ("n_x", C.c_int32), ("n_ell", C.c_int32),
+        ("s", _dp), ("mu", _dp), ("w_ell", _dp), ("x", _dp), ("w_x", _dp),
+        ("n_ell_r", C.c_int32), ("n_beta_r", C.c_int32), ("beta_r", _dp), ("xi", vk_pp),
+        ("vr", vk_pp), ("sv", vk_pp),
+        ("iaH", C.c_double), ("template_sigma8", C.c_double),
+        ("n_beta_d", C.c_int32), ("beta_d", _dp), ("data", _dp),
+        ("n_beta_c", C.c_int32), ("beta_c", _dp), ("prec", _dp), ("logdet", _dp), ("eig", _dp),
+    ]
+
+
+class vk_eval_opts(C.Structure):
+    _fields_ = [
+        ("rsd_model", C.c_int32), ("assume_isotropic", C.c_int32), ("rescale_from_ap", C.c_int32),
+        ("like_form", C.c_int32), ("nmocks", C.c_double), ("nparams", C.c_double),
+        ("kaiser_approx", C.c_int32), ("kaiser_coord_shift", C.c_int32), ("niter", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class NativeError(RuntimeError):
+    """The HIP library is missing or a device call failed."""
+
+
+def library_path():
+    env = os.environ.get("VICTOR_HIP_LIB")
+    if env:
+        return env
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libvictor_hip.so")
+
+
+# every symbol include/victor_hip.h declares: name -> (restype, argtypes)
+_vp = C.c_void_p
+_optp = C.POINTER(vk_eval_opts)
+SYMBOLS = {
+    "vk_abi_version": (C.c_int, []),
+    "vk_device_count": (C.c_int, []),
+    "vk_create": (_vp, [C.POINTER(vk_tables), C.c_int, C.c_char_p, C.c_size_t]),
+    "vk_destroy": (None, [_vp]),
+    "vk_last_error": (C.c_char_p, [_vp]),
+    "vk_default_opts": (None, [_optp]),
+    "vk_eval_batch": (C.c_int, [_vp, _optp, _dp, C.c_int64, _dp, _dp, _dp]),
+    "vk_theory_batch": (C.c_int, [_vp, _optp, _dp, C.c_int64, _dp, C.c_int32, _dp, C.c_int32, _dp, C.c_int32, _dp]),
+    "vk_xi_smu_batch": (C.c_int, [_vp, _optp, _dp, C.c_int64, _dp, C.c_int32, _dp, C.c_int32, _dp]),
+    "vk_device_alloc": (_vp, [_vp, C.c_size_t]),
+    "vk_device_free": (None, [_vp, _vp]),
+    "vk_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "vk_memcpy_d2h": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "vk_eval_batch_device_async": (C.c_int, [_vp, _optp, _vp, C.c_int64, _vp, _vp, _vp]),
+    "vk_sync": (C.c_int, [_vp]),
+    "vk_timing_enable": (C.c_int, [_vp, C.c_int]),
+    "vk_timing_read": (C.c_int, [_vp, _dp, _dp, C.POINTER(C.c_int64), C.c_int]),
+    "vk_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "vk_comm_init": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int]),
+    "vk_comm_allgather_async": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
+    "vk_comm_destroy": (C.c_int, [_vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and declare every prototype."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.isfile(path):
+        raise NativeError(
+            f"{path} not found: the HIP extension has not been built "
+            "(run `python -c \"import __graft_entry__ as g; g.build()\"`). There is no CPU fallback.")
+    try:
+        lib = C.CDLL(path)
+    except OSError as exc:
+        raise NativeError(f"cannot load {path}: {exc}") from exc
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.vk_abi_version() != VK_ABI_VERSION:
+        raise NativeError("libvictor_hip.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def as_dp(a):
+    return a.ctypes.data_as(_dp)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)

@@ -1,0 +1,283 @@
+"""Device engine: uploads the compiled tables and runs batches through the C ABI.
+
+One :class:`Engine` owns one ``vk_ctx`` (one GPU, one stream).  It is created by
+:class:`victor_amd.ccf_model.CCFModel` / :class:`victor_amd.ccf_fit.CCFFit` from their host
+tables; users normally do not touch it, except for the device-resident batch API used by
+``bench.py`` and :mod:`victor_amd.sharding`.
+"""
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from . import tables as T
+from .utils import InputError
+
+
+def _pp(knots, coef, lead=0):
+    """Build a vk_pp (plus the arrays that must stay alive while it is used)."""
+    knots = N.f64(knots)
+    coef = N.f64(coef)
+    h = T.uniform_spacing(knots, lead=lead)
+    pp = N.vk_pp()
+    pp.n_int = len(knots) - 1
+    pp.lead = lead if h is not None else 0
+    pp.inv_h = 1.0 / h if h is not None else 0.0
+    pp.knots = N.as_dp(knots)
+    pp.coef = N.as_dp(coef)
+    return pp, (knots, coef)
+
+
+def build_tables(model, fit=None):
+    """Compile a :class:`CCFModel` (and optionally the data side of a :class:`CCFFit`) into vk_tables.
+
+    Returns ``(tables, keepalive)``.
+    """
+    keep = []
+
+    def arr(a):
+        a = N.f64(a)
+        keep.append(a)
+        return a
+
+    t = N.vk_tables()
+    if fit is not None:
+        s = arr(fit.s)
+        poles = np.atleast_1d(fit.poles_s)
+    else:
+        s = arr(model.r)
+        poles = np.array([0, 2])
+    mu = arr(T.mu_nodes_for(poles))
+    w = arr(T.projection_weights(mu, poles))
+    n_x = 50                                   # ccf_model.py:570 (np.linspace default num)
+    x = arr(np.linspace(-6, 6, n_x))
+    w_x = arr(T.simpson_weights(n_x) * (12.0 / (n_x - 1)) / np.sqrt(2 * np.pi))
+    t.n_s, t.n_mu, t.n_x, t.n_ell = len(s), len(mu), n_x, len(poles)
+    t.s, t.mu, t.w_ell, t.x, t.w_x = map(N.as_dp, (s, mu, w, x, w_x))
+
+    # real-space multipoles ---------------------------------------------------------------
+    r = N.f64(model.r)
+    n_ell_r = len(model.poles_r)
+    if n_ell_r > 3:
+        raise InputError("at most three real-space multipoles are supported")
+    if model.fixed_real_input:
+        coef = np.stack([T.notaknot_coefficients(r, model.real_multipoles[f"{l}"]) for l in model.poles_r])
+        t.n_beta_r = 0
+        t.beta_r = None
+    else:
+        beta = arr(model.beta)
+        coef = np.stack([T.beta_dependent_spline_table(r, beta, model.real_multipoles[f"{l}"])
+                         for l in model.poles_r])
+        t.n_beta_r = len(beta)
+        t.beta_r = N.as_dp(beta)
+    t.n_ell_r = n_ell_r
+    t.xi, k = _pp(r, coef)
+    keep.append(k)
+
+    # velocity profile: V = r*Delta(r) and D = delta - 2 Delta/3 on r_ext (ccf_model.py:625, 449-450)
+    r_ext = np.append([0.01], r)
+    delta_ext = model.delta(r_ext)
+    int_delta_ext = model.integrated_delta(r_ext)
+    V = T.notaknot_coefficients(r_ext, r_ext * int_delta_ext)
+    D = T.notaknot_coefficients(r_ext, delta_ext - 2 * int_delta_ext / 3)
+    t.vr, k = _pp(r_ext, np.stack([V, D]), lead=1)
+    keep.append(k)
+
+    # dispersion template (isotropic): the bicubic RectBivariateSpline of ccf_model.py:654 through
+    # mu-independent data is the 1-D not-a-knot spline in r
+    sv_r = model.sv_rmu[0]
+    t.sv, k = _pp(model.r_for_sv, T.notaknot_coefficients(model.r_for_sv, sv_r)[None])
+    keep.append(k)
+
+    t.iaH = float(model.iaH)
+    t.template_sigma8 = float(model.template_sigma8)
+
+    # data side -----------------------------------------------------------------------------
+    if fit is not None:
+        Nd = len(s) * len(poles)
+        stack = np.array([fit.redshift_multipoles[f"{l}"] for l in poles])   # (n_ell, [n_beta,] n_s)
+        if fit.fixed_data:
+            t.n_beta_d = 0
+            d = arr(stack.reshape(Nd))
+        else:
+            bd = arr(fit.beta_ccf)
+            vals = np.transpose(stack, (1, 0, 2)).reshape(len(bd), Nd)     # (n_beta, N)
+            pc = T.pchip_coefficients(bd, vals)                            # (n_beta-1, 4, N)
+            d = arr(np.transpose(pc, (0, 2, 1)))                           # (n_beta-1, N, 4)
+            t.n_beta_d = len(bd)
+            t.beta_d = N.as_dp(bd)
+        t.data = N.as_dp(d)
+        prec = arr(fit.icov)
+        t.prec = N.as_dp(prec)
+        if fit.fixed_covmat:
+            t.n_beta_c = 0
+        else:
+            import scipy.linalg as sl
+            bc = arr(fit.beta_covmat)
+            nb = len(bc)
+            logdet = np.empty(nb)
+            eig = np.ones((nb, Nd))
+            for kk in range(nb):
+                sign, ld = np.linalg.slogdet(fit.covmat[kk])
+                logdet[kk] = ld if sign == 1 else np.nan
+                if kk < nb - 1 and sign == 1:
+                    # cov[last] v = lambda cov[k] v  =>  det((1-t) cov[k] + t cov[last]) = det(cov[k]) prod(1-t+t lambda)
+                    eig[kk] = sl.eigh(fit.covmat[-1], fit.covmat[kk], eigvals_only=True)
+            logdet = arr(logdet)
+            eig = arr(eig)
+            t.n_beta_c = nb
+            t.beta_c = N.as_dp(bc)
+            t.logdet = N.as_dp(logdet)
+            t.eig = N.as_dp(eig)
+    return t, keep
+
+
+class Engine:
+    def __init__(self, model, fit=None, device=0):
+        self._lib = N.load()
+        if self._lib.vk_device_count() <= 0:
+            raise N.NativeError("no HIP device visible; victor_amd has no CPU fallback")
+        tables, keep = build_tables(model, fit)
+        err = C.create_string_buffer(512)
+        self._ctx = self._lib.vk_create(C.byref(tables), int(device), err, len(err))
+        del keep
+        if not self._ctx:
+            raise N.NativeError("vk_create failed: " + err.value.decode())
+        self.device = int(device)
+        self.n_data = tables.n_ell * tables.n_s
+        self.has_data = fit is not None
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.vk_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._lib.vk_last_error(self._ctx)
+            msg = msg.decode() if msg else "unknown error"
+            if rc == -1:
+                raise InputError(msg)
+            raise N.NativeError(f"libvictor_hip error {rc}: {msg}")
+
+    def make_opts(self, model_opts, fit_opts=None):
+        """Translate the reference's option dicts (ccf_model.py:85-97, ccf_fit.py:41-42)."""
+        o = N.vk_eval_opts()
+        self._lib.vk_default_opts(C.byref(o))
+        rsd = model_opts["rsd_model"]
+        if rsd not in N.RSD:
+            raise InputError(f"theory_xi: Unrecognised choice of model {rsd}")   # ccf_model.py:787
+        o.rsd_model = N.RSD[rsd]
+        o.assume_isotropic = 1 if model_opts["assume_isotropic"] else 0
+        o.rescale_from_ap = 0 if model_opts["velocity_independent_of_AP"] else 1
+        o.kaiser_approx = 1 if model_opts.get("kaiser_approximation", False) else 0
+        o.kaiser_coord_shift = 1 if model_opts.get("kaiser_coord_shift", True) else 0
+        o.niter = int(model_opts.get("niter", 5))
+        if fit_opts is not None:
+            like = fit_opts["likelihood"]
+            form = like["form"].lower()
+            if form not in N.LIKE:
+                raise InputError("Unrecognised likelihood form")                 # ccf_fit.py:473
+            o.like_form = N.LIKE[form]
+            o.nmocks = float(like.get("nmocks", 1))
+            if form == "percival":
+                o.nparams = float(like["nparams"])                                # KeyError as in ccf_fit.py:465
+        return o
+
+    # -- host-buffer entry points -----------------------------------------------------------
+    def eval_batch(self, opts, rows, want_theory=False):
+        rows = N.f64(rows).reshape(-1, N.VK_NPAR)
+        n = len(rows)
+        lnl = np.empty(n)
+        chi2 = np.empty(n)
+        theory = np.empty((n, self.n_data)) if want_theory else None
+        self._check(self._lib.vk_eval_batch(self._ctx, C.byref(opts), N.as_dp(rows), n, N.as_dp(lnl),
+                                            N.as_dp(chi2), N.as_dp(theory) if want_theory else None))
+        return lnl, chi2, theory
+
+    def theory_vector_batch(self, opts, rows):
+        rows = N.f64(rows).reshape(-1, N.VK_NPAR)
+        n = len(rows)
+        theory = np.empty((n, self.n_data))
+        self._check(self._lib.vk_eval_batch(self._ctx, C.byref(opts), N.as_dp(rows), n, None, None,
+                                            N.as_dp(theory)))
+        return theory
+
+    def theory_batch(self, opts, rows, s, poles):
+        rows = N.f64(rows).reshape(-1, N.VK_NPAR)
+        s = N.f64(np.atleast_1d(s))
+        poles = np.atleast_1d(poles)
+        mu = N.f64(T.mu_nodes_for(poles))
+        w = N.f64(T.projection_weights(mu, poles))
+        out = np.empty((len(rows), len(poles), len(s)))
+        self._check(self._lib.vk_theory_batch(self._ctx, C.byref(opts), N.as_dp(rows), len(rows), N.as_dp(s),
+                                              len(s), N.as_dp(mu), len(mu), N.as_dp(w), len(poles), N.as_dp(out)))
+        return out
+
+    def xi_smu_batch(self, opts, rows, s, mu):
+        rows = N.f64(rows).reshape(-1, N.VK_NPAR)
+        s = N.f64(np.atleast_1d(s))
+        mu = N.f64(np.atleast_1d(mu))
+        out = np.empty((len(rows), len(mu), len(s)))
+        self._check(self._lib.vk_xi_smu_batch(self._ctx, C.byref(opts), N.as_dp(rows), len(rows), N.as_dp(s),
+                                              len(s), N.as_dp(mu), len(mu), N.as_dp(out)))
+        return out
+
+    # -- device-resident API (bench, sharding) ------------------------------------------------
+    def alloc(self, n_doubles):
+        p = self._lib.vk_device_alloc(self._ctx, int(n_doubles) * 8)
+        if not p:
+            raise N.NativeError("device allocation failed")
+        return p
+
+    def free(self, ptr):
+        self._lib.vk_device_free(self._ctx, ptr)
+
+    def upload(self, ptr, host):
+        host = N.f64(host)
+        self._check(self._lib.vk_memcpy_h2d(self._ctx, ptr, host.ctypes.data, host.nbytes))
+
+    def download(self, ptr, n_doubles):
+        out = np.empty(int(n_doubles))
+        self._check(self._lib.vk_memcpy_d2h(self._ctx, out.ctypes.data, ptr, out.nbytes))
+        return out
+
+    def eval_device_async(self, opts, d_rows, n, d_lnl, d_chi2, d_theory_ws):
+        self._check(self._lib.vk_eval_batch_device_async(self._ctx, C.byref(opts), d_rows, int(n), d_lnl, d_chi2,
+                                                         d_theory_ws))
+
+    def sync(self):
+        self._check(self._lib.vk_sync(self._ctx))
+
+    def timing(self, on):
+        self._check(self._lib.vk_timing_enable(self._ctx, 1 if on else 0))
+
+    def read_timing(self, reset=True):
+        a, b, k = C.c_double(), C.c_double(), C.c_int64()
+        self._check(self._lib.vk_timing_read(self._ctx, C.byref(a), C.byref(b), C.byref(k), 1 if reset else 0))
+        return a.value, b.value, k.value
+
+    # -- RCCL ----------------------------------------------------------------------------------
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(N.VK_COMM_ID_BYTES)
+        rc = self._lib.vk_comm_unique_id(buf)
+        if rc != 0:
+            raise N.NativeError("vk_comm_unique_id failed (is librccl available?)")
+        return buf.raw
+
+    def comm_init(self, uid, rank, nranks):
+        self._check(self._lib.vk_comm_init(self._ctx, uid, int(rank), int(nranks)))
+
+    def comm_allgather_async(self, d_send, d_recv, count):
+        self._check(self._lib.vk_comm_allgather_async(self._ctx, d_send, d_recv, int(count)))
+
+    def comm_destroy(self):
+        self._check(self._lib.vk_comm_destroy(self._ctx))

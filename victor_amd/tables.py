@@ -1,0 +1,252 @@
+"""Host-side table compiler.
+
+The reference builds SciPy spline objects on every likelihood call
+(``ccf_model.py:615-636,654``; ``ccf_fit.py:193``).  The HIP kernels evaluate
+explicit piecewise-cubic tables instead, so everything the reference expresses
+as a spline object is turned here - once, at construction - into coefficient
+arrays:
+
+* not-a-knot cubic splines  == ``InterpolatedUnivariateSpline(k=3)`` (``ccf_model.py:17``;
+  FITPACK drops the 2nd and 2nd-last data points as knots, which *is* the not-a-knot
+  condition, so one cubic per data interval reproduces it exactly);
+* PCHIP pieces in the reconstruction parameter beta == ``PchipInterpolator``
+  (``ccf_model.py:326``, ``ccf_fit.py:193``);
+* Legendre projection weights == cubic ``interp2d`` + ``utils.multipoles_from_fn``
+  (``ccf_model.py:824-825``, ``utils.py:45-56``), a fixed linear map of the mu nodes;
+* composite Simpson weights == ``scipy.integrate.simpson`` (``ccf_model.py:690``),
+  including the SciPy >= 1.11 treatment of an even number of points.
+
+All routines are written from the textbook formulas (no SciPy spline objects are used
+here); ``tests/test_tables.py`` checks each against the SciPy primitive it replaces.
+"""
+
+import numpy as np
+
+_trapz = getattr(np, "trapezoid", None) or np.trapz
+
+
+# --------------------------------------------------------------------------- #
+# piecewise-cubic containers
+# --------------------------------------------------------------------------- #
+class PiecewiseCubic:
+    """f(u) = sum_p coef[i, p, ...] (u - knots[i])**p on [knots[i], knots[i+1]].
+
+    ``clamp=True`` evaluates with the argument clamped to the knot range, which is the
+    behaviour of FITPACK ``ext=3`` (``ccf_model.py:17``); ``clamp=False`` extrapolates
+    with the first / last piece (``PchipInterpolator`` default).
+    """
+
+    def __init__(self, knots, coef, clamp=True):
+        self.knots = np.ascontiguousarray(knots, dtype=np.float64)
+        self.coef = np.ascontiguousarray(coef, dtype=np.float64)  # (n_int, 4, ...)
+        self.clamp = clamp
+
+    def __call__(self, u):
+        u = np.asarray(u, dtype=np.float64)
+        k = self.knots
+        if self.clamp:
+            u = np.clip(u, k[0], k[-1])
+        i = np.clip(np.searchsorted(k, u, side="right") - 1, 0, len(k) - 2)
+        dx = u - k[i]
+        c = self.coef
+        extra = (1,) * (c.ndim - 2)
+        dxe = dx.reshape(dx.shape + extra)
+        return ((c[i, 3] * dxe + c[i, 2]) * dxe + c[i, 1]) * dxe + c[i, 0]
+
+
+def _hermite_to_power(y, d, h):
+    """Cubic Hermite data (values y, slopes d on intervals of width h) -> power-basis pieces."""
+    extra = (1,) * (y.ndim - 1)
+    hh = h.reshape(h.shape + extra)
+    m = (y[1:] - y[:-1]) / hh
+    c0 = y[:-1]
+    c1 = d[:-1]
+    c2 = (3 * m - 2 * d[:-1] - d[1:]) / hh
+    c3 = (d[:-1] + d[1:] - 2 * m) / (hh * hh)
+    return np.stack([c0, c1, c2, c3], axis=1)  # (n-1, 4, ...)
+
+
+def notaknot_coefficients(x, y):
+    """Interpolating cubic spline with not-a-knot end conditions.
+
+    ``x`` (n,) strictly increasing, n >= 4; ``y`` (n, ...).  Returns (n-1, 4, ...)
+    power-basis coefficients about the left end of each data interval.
+    """
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    n = len(x)
+    if n < 4:
+        raise ValueError("cubic not-a-knot spline needs at least 4 points")
+    if not np.all(np.diff(x) > 0):
+        raise ValueError("spline abscissae must be strictly increasing")
+    h = np.diff(x)
+    extra = (1,) * (y.ndim - 1)
+    hh = h.reshape(h.shape + extra)
+    m = (y[1:] - y[:-1]) / hh
+    A = np.zeros((n, n))
+    b = np.zeros(y.shape)
+    for i in range(1, n - 1):
+        A[i, i - 1] = h[i]
+        A[i, i] = 2 * (h[i - 1] + h[i])
+        A[i, i + 1] = h[i - 1]
+        b[i] = 3 * (h[i] * m[i - 1] + h[i - 1] * m[i])
+    # third derivative continuous across x[1] and x[n-2]
+    d0 = x[2] - x[0]
+    A[0, 0] = h[1]
+    A[0, 1] = d0
+    b[0] = ((h[0] + 2 * d0) * h[1] * m[0] + h[0] ** 2 * m[1]) / d0
+    d1 = x[-1] - x[-3]
+    A[-1, -1] = h[-2]
+    A[-1, -2] = d1
+    b[-1] = (h[-1] ** 2 * m[-2] + (2 * d1 + h[-1]) * h[-2] * m[-1]) / d1
+    slopes = np.linalg.solve(A, b.reshape(n, -1)).reshape(y.shape)
+    return _hermite_to_power(y, slopes, h)
+
+
+def notaknot(x, y, clamp=True):
+    return PiecewiseCubic(x, notaknot_coefficients(x, y), clamp=clamp)
+
+
+def pchip_coefficients(x, y):
+    """Fritsch-Carlson monotone cubic Hermite pieces along axis 0 of ``y`` (n, ...)."""
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    n = len(x)
+    h = np.diff(x)
+    extra = (1,) * (y.ndim - 1)
+    hh = h.reshape(h.shape + extra)
+    m = (y[1:] - y[:-1]) / hh
+    if n == 2:
+        d = np.stack([m[0], m[0]])
+        return _hermite_to_power(y, d, h)
+    d = np.zeros_like(y)
+    sm = np.sign(m)
+    flat = (sm[1:] != sm[:-1]) | (m[1:] == 0) | (m[:-1] == 0)
+    w1 = 2 * hh[1:] + hh[:-1]
+    w2 = hh[1:] + 2 * hh[:-1]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        whmean = (w1 / m[:-1] + w2 / m[1:]) / (w1 + w2)
+        inner = 1.0 / whmean
+    inner[flat] = 0.0
+    d[1:-1] = inner
+
+    def edge(h0, h1, m0, m1):
+        e = ((2 * h0 + h1) * m0 - h0 * m1) / (h0 + h1)
+        e = np.where(np.sign(e) != np.sign(m0), 0.0, e)
+        big = (np.sign(m0) != np.sign(m1)) & (np.abs(e) > 3 * np.abs(m0))
+        return np.where(big, 3 * m0, e)
+
+    d[0] = edge(h[0], h[1], m[0], m[1])
+    d[-1] = edge(h[-1], h[-2], m[-1], m[-2])
+    return _hermite_to_power(y, d, h)
+
+
+def pchip(x, y):
+    return PiecewiseCubic(x, pchip_coefficients(x, y), clamp=False)
+
+
+# --------------------------------------------------------------------------- #
+# quadrature / projection weights
+# --------------------------------------------------------------------------- #
+def legendre_values(ell, mu):
+    """P_ell(mu) for ell = 0..4 (closed forms)."""
+    mu = np.asarray(mu, dtype=np.float64)
+    if ell == 0:
+        return np.ones_like(mu)
+    if ell == 1:
+        return mu
+    if ell == 2:
+        return 1.5 * mu ** 2 - 0.5
+    if ell == 3:
+        return 2.5 * mu ** 3 - 1.5 * mu
+    if ell == 4:
+        return (35 * mu ** 4 - 30 * mu ** 2 + 3) / 8
+    raise ValueError("multipoles above ell=4 are not supported")
+
+
+def simpson_weights(n):
+    """Unit-spacing weights w with ``simpson(y, dx=1) == w @ y`` (SciPy >= 1.11 rule).
+
+    Odd n: composite Simpson.  Even n: composite Simpson on the first n-1 points plus the
+    three-point correction for the last interval (5/12, 2/3, -1/12), which is what
+    ``scipy.integrate.simpson`` does on the 50 velocity nodes of ``ccf_model.py:570,690``.
+    """
+    if n < 3:
+        raise ValueError("need at least 3 points")
+    w = np.zeros(n)
+    last = n if n % 2 == 1 else n - 1
+    w[0:last:2] += 2.0 / 3.0
+    w[1:last:2] += 4.0 / 3.0
+    w[0] -= 1.0 / 3.0
+    w[last - 1] -= 1.0 / 3.0
+    if n % 2 == 0:
+        w[n - 1] += 5.0 / 12.0
+        w[n - 2] += 2.0 / 3.0
+        w[n - 3] -= 1.0 / 12.0
+    return w
+
+
+def projection_weights(mu_nodes, poles, npts=200):
+    """W[l, i] with  xi_l(s_j) = sum_i W[l, i] xi(mu_i, s_j).
+
+    The reference fits a bicubic interpolant to xi(s, mu) on the (s, mu_nodes) grid
+    (``ccf_model.py:824``) and integrates it against (2l+1) P_l(mu) with a 200-point
+    trapezoid rule at the same s nodes (``utils.py:45-56``).  At a node s_j a tensor-product
+    interpolating spline reduces to the 1-D not-a-knot spline in mu through that column,
+    so the whole operation is a fixed linear map of the column.
+    """
+    mu_nodes = np.asarray(mu_nodes, dtype=np.float64)
+    poles = np.atleast_1d(poles)
+    even = not np.any(poles % 2)
+    if even:
+        mu = np.linspace(0.0, 1.0, npts)
+        factors = [2 * l + 1 for l in poles]
+    else:
+        mu = np.linspace(-1.0, 1.0, npts)
+        factors = [(2 * l + 1) / 2 for l in poles]
+    basis = notaknot(mu_nodes, np.eye(len(mu_nodes)))(mu)  # (npts, n_nodes)
+    tw = np.zeros(npts)
+    dmu = np.diff(mu)
+    tw[:-1] += 0.5 * dmu
+    tw[1:] += 0.5 * dmu
+    W = np.empty((len(poles), len(mu_nodes)))
+    for a, l in enumerate(poles):
+        W[a] = factors[a] * ((tw * legendre_values(int(l), mu)) @ basis)
+    return W
+
+
+def mu_nodes_for(poles, n=100):
+    """ccf_model.py:816-822."""
+    poles = np.atleast_1d(poles)
+    if np.any(poles % 2):
+        return np.linspace(-1, 1, n)
+    return np.linspace(0, 1, n)
+
+
+# --------------------------------------------------------------------------- #
+# helpers for the device table layout
+# --------------------------------------------------------------------------- #
+def uniform_spacing(knots, lead=0, rtol=1e-9):
+    """Return the spacing of knots[lead:] if they are uniform, else None."""
+    k = np.asarray(knots, dtype=np.float64)[lead:]
+    if len(k) < 2:
+        return None
+    d = np.diff(k)
+    h = (k[-1] - k[0]) / (len(k) - 1)
+    if np.all(np.abs(d - h) <= rtol * abs(h)):
+        return h
+    return None
+
+
+def beta_dependent_spline_table(r, beta, values):
+    """Coefficients of the r-spline of PCHIP-in-beta nodal values, as polynomials in beta.
+
+    ``values`` (n_beta, n_r).  Returns (n_beta-1, n_r-1, 4, 4): [k, i, q, p] multiplies
+    (u - r_i)^q (beta - beta_k)^p.  The not-a-knot spline is linear in its nodal values, so
+    composing it with the PCHIP pieces of every node (``ccf_model.py:323-326`` then
+    ``:619-621``) is exact.
+    """
+    values = np.asarray(values, dtype=np.float64)
+    pc = pchip_coefficients(beta, values)                       # (n_beta-1, 4[p], n_r)
+    lin = notaknot_coefficients(r, np.eye(len(r)))              # (n_r-1, 4[q], n_r)
+    return np.einsum("iqn,kpn->kiqp", lin, pc)
