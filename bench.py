@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""Throughput of the likelihood hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole path (theory kernel + likelihood kernel [+ RCCL all-gather of lnL when
+N > 1]) over one batch of synthetic parameter points per GPU.  Workload = BASELINE config 3, the grid the
+metric is quoted on: 40 s bins x 100 mu x 50 velocity nodes, data multipoles l = 0,2,4 (N = 120),
+anisotropic real-space xi (l = 0,2,4), AP-dependent template rescaling, sigma_v(r) template, batch of 65536
+Halton points PER GPU (weak scaling: rank g evaluates points [g*B, (g+1)*B) of one global sequence).
+Inputs are resident in HBM before the timed region; outputs stay in HBM.
+
+For N > 1 the driver launches one process per GPU with torch.distributed.run; torch is used only for the
+host-side rendezvous (gloo: barriers, the RCCL unique id, max-over-ranks of the time).  The data path
+is libvictor_hip.so + RCCL.
+"""
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH_PER_GPU = 65536
+CONFIG = 3
+PEAK_FP64_VALU_TFLOPS = 78.6     # MI355X vector FP64: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# flops per integrand point for l_r = 0,2,4 (sqrt, divide, exp counted as one each)
+F_PT_ANISO = 77
+F_PT_ISO = 47
+
+
+def flops_per_eval(n_s, n_mu, n_x, n_ell, aniso):
+    """Algorithmic flops of the theory kernel per evaluation (SURVEY.md 8d without the chi-square term)."""
+    return n_s * n_mu * n_x * (F_PT_ANISO if aniso else F_PT_ISO) + 2 * n_ell * n_s * n_mu
+
+
+def cpu_worker(args):
+    """Time the oracle on a slice of the sample (runs in a child process, one per host core)."""
+    idx, pts = args
+    os.environ["OMP_NUM_THREADS"] = os.environ["OPENBLAS_NUM_THREADS"] = "1"
+    import warnings
+    warnings.filterwarnings("ignore")
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import victor_oracle as vo
+    from tests import cases
+    fit = vo.OracleFit(*cases.synth_options(CONFIG))
+    out = []
+    t0 = time.perf_counter()
+    for p in pts:
+        out.append(fit.log_likelihood(dict(p)))
+    return idx, time.perf_counter() - t0, out
+
+
+def cpu_baseline(sample_pts):
+    """Oracle ('port' of the reference algorithm) on the host cores, bounded sample."""
+    import multiprocessing as mp
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, len(sample_pts)))
+    chunks = [(i, sample_pts[i::cores]) for i in range(cores)]
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(cores) as pool:
+        res = pool.map(cpu_worker, chunks)
+    wall = time.perf_counter() - t0
+    busy = max(r[1] for r in res)          # excludes interpreter start-up and table construction
+    vals = [None] * len(sample_pts)
+    for idx, _, out in res:
+        for k, v in enumerate(out):
+            vals[idx + k * cores] = v
+    return {"evals_per_s": len(sample_pts) / busy, "cores": cores, "wall_s": wall, "busy_s": busy}, vals
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="points per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="oracle evaluations (default: about 10 per core)")
+    args = ap.parse_args()
+
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        # start one rank per GPU as child processes (never exec: this process may already hold the GPU)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29511"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    from victor_amd.sharding import Dist
+    dist = Dist()
+    if launched:
+        dist.init_process_group("gloo")
+    rank, world = dist.rank, dist.world
+    if launched and world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    import numpy as np
+    import victor_amd
+    from victor_amd.build import build_native
+    from tests import cases
+    if rank == 0:
+        build_native()
+    dist.barrier()
+
+    model, data = cases.synth_options(CONFIG)
+    B = args.batch
+    hp_all = cases.halton_params(B * world)
+    mine = {k: v[rank * B:(rank + 1) * B] for k, v in hp_all.items()}
+
+    # CPU baseline first: it spawns worker processes, which must happen before this process touches the GPU
+    base = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        ns = min(args.cpu_sample or max(16, 10 * cores), B)
+        sel = np.linspace(0, B - 1, ns).astype(int)
+        base, vals = cpu_baseline([cases.point(mine, int(i)) for i in sel])
+
+    fit = victor_amd.CCFFit(model, data, device=dist.local_rank if launched else 0)
+    eng = fit._get_engine()
+    opts = eng.make_opts(fit.model, fit.fit_options)
+    rows = fit._fit_rows(mine, fit.model)
+    N = eng.n_data
+
+    d_rows = eng.alloc(rows.size)
+    d_lnl = eng.alloc(B)
+    d_chi = eng.alloc(B)
+    d_ws = eng.alloc(B * N)
+    d_all = eng.alloc(B * world) if world > 1 or launched else None
+    eng.upload(d_rows, rows)
+    use_comm = launched
+    if use_comm:
+        uid = eng.comm_unique_id() if rank == 0 else None
+        uid = dist.broadcast_bytes(uid, src=0, nbytes=128)
+        eng.comm_init(uid, rank, world)
+
+    def step():
+        eng.eval_device_async(opts, d_rows, B, d_lnl, d_chi, d_ws)
+        if use_comm:
+            eng.comm_allgather_async(d_lnl, d_all, B)
+
+    for _ in range(args.warmup):
+        step()
+    eng.sync()
+    dist.barrier()
+    eng.timing(True)
+    eng.read_timing(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    eng.sync()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    theory_ms, like_ms, launches = eng.read_timing(reset=True)
+    eng.timing(False)
+    elapsed = dist.max_float(elapsed)
+
+    lnl = eng.download(d_lnl, B)
+    chi2 = eng.download(d_chi, B)
+    gathered_ok = None
+    if use_comm:
+        allv = eng.download(d_all, B * world)
+        gathered_ok = bool(np.array_equal(allv[rank * B:(rank + 1) * B], lnl))
+    ok = bool(np.all(np.isfinite(lnl)) and np.all(chi2 > 0))
+
+    if rank == 0:
+        total = B * world * args.steps
+        value = total / elapsed
+        k1_ms = theory_ms / max(launches, 1)
+        k2_ms = like_ms / max(launches, 1)
+        aniso = not fit.model["assume_isotropic"]
+        F = flops_per_eval(len(fit.s), 100, 50, len(fit.poles_s), aniso)
+        achieved_tf = F * B / (k1_ms * 1e-3) / 1e12 if k1_ms > 0 else None
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.isfile(tfile):
+            with open(tfile) as fh:
+                tj = json.load(fh)
+            if tj.get("batch") == B:
+                traffic = tj.get("theory_kernel_hbm_bytes_per_launch")
+        alg_bytes = (8 * 10 + 16) * B     # 80 B of parameters in, lnL + chi2 out, per evaluation
+        out = {
+            "metric": "likelihood evals/sec (40 s-bins, 100 mu, l=0,2,4)",
+            "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE config 3: synthetic 40 s x 100 mu x 50 v grid, xi_r l=0,2,4, data l=0,2,4 "
+                                   "(N=120), AP-dependent rescale, sigma_v(r) template, gaussian likelihood",
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"batch-sharded x{world}",
+                       "gather": "rccl allgather of lnL" if use_comm else "none (single process)"},
+            "roofline": {"bound": "fp64-valu", "kernel": "vk_theory_kernel<3,3>",
+                         "achieved": achieved_tf, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved_tf / PEAK_FP64_VALU_TFLOPS if achieved_tf else None,
+                         "traffic": traffic, "flops_per_eval": F, "kernel_ms": k1_ms,
+                         "note": "path is FP64 vector-ALU bound (no MFMA, ~1e-5 of HBM peak); sqrt/div/exp counted "
+                                 "as one flop each per SURVEY.md 8(d)"},
+            "roofline_hbm": {"bound": "hbm", "achieved": alg_bytes / ((k1_ms + k2_ms) * 1e-3) / 1e9 if k1_ms else None,
+                             "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": alg_bytes / ((k1_ms + k2_ms) * 1e-3) / 1e9 / PEAK_HBM_GBS if k1_ms else None,
+                             "bytes_per_eval": 96},
+            "kernels_ms": {"theory": k1_ms, "likelihood": k2_ms},
+            "outputs_finite": ok,
+        }
+        if gathered_ok is not None:
+            out["gather_matches_local"] = gathered_ok
+        if base is not None:
+            chi_o = np.array([v[1] for v in vals])
+            lnl_o = np.array([v[0] for v in vals])
+            out["cpu_baseline"] = {"value": base["evals_per_s"], "unit": "evals/s", "cores": base["cores"],
+                                   "kind": "port",
+                                   "sample": f"{ns} of the {B} batch points through oracle/victor_oracle.py "
+                                             f"(NumPy/SciPy restatement, bit-identical to the reference here), "
+                                             f"{base['cores']} processes x 1 thread, {base['busy_s']:.1f} s busy"}
+            out["max_rel_dchi2_vs_oracle"] = float(np.max(np.abs(chi2[sel] / chi_o - 1)))
+            out["max_abs_dchi2_vs_oracle"] = float(np.max(np.abs(chi2[sel] - chi_o)))
+            out["max_rel_dlnl_vs_oracle"] = float(np.max(np.abs(lnl[sel] / lnl_o - 1)))
+        print(json.dumps(out))
+
+    for p in (d_rows, d_lnl, d_chi, d_ws, d_all):
+        if p:
+            eng.free(p)
+    if use_comm:
+        eng.comm_destroy()
+    dist.barrier()
+    if not ok:
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,47 @@
+"""Summarise rocprofv3 CSV output (kernel stats + PMC passes) of tools/gpu_profile.sh into text + JSON."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out_dir = sys.argv[1]
+summary = {}
+for f in glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    print("== kernel stats:", os.path.relpath(f, out_dir))
+    with open(f) as fh:
+        rows = list(csv.DictReader(fh))
+    for r in rows:
+        print("  {Name:60.60s} calls={Calls} total_ns={TotalDurationNs} avg_ns={AverageNs} pct={Percentage}".format(**r))
+    summary["kernel_stats"] = rows
+for f in glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    with open(f) as fh:
+        rows = list(csv.DictReader(fh))
+    by = defaultdict(list)
+    meta = {}
+    for r in rows:
+        d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        by[r["Kernel_Name"]].append(d)
+        meta[r["Kernel_Name"]] = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size",
+                                                       "Scratch_Size", "Grid_Size_X", "Workgroup_Size_X")}
+    print("== kernel trace (per-dispatch durations, ns)")
+    for k, v in by.items():
+        print(f"  {k[:60]:60s} n={len(v)} avg={sum(v)/len(v):.0f} min={min(v)} max={max(v)} {meta[k]}")
+    summary["kernel_trace"] = {k: {"n": len(v), "avg_ns": sum(v) / len(v), "min_ns": min(v), "max_ns": max(v), **meta[k]}
+                               for k, v in by.items()}
+pmc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(out_dir, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            pmc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+print("== PMC (average per dispatch)")
+summary["pmc"] = {}
+for k, cs in pmc.items():
+    summary["pmc"][k] = {}
+    for c, v in sorted(cs.items()):
+        avg = sum(v) / len(v)
+        summary["pmc"][k][c] = {"avg": avg, "n": len(v)}
+        print(f"  {k[:50]:50s} {c:28s} avg={avg:.6g} n={len(v)}")
+with open(os.path.join(out_dir, "summary.json"), "w") as fh:
+    json.dump(summary, fh, indent=1)
