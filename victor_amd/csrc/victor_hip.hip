@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "victor_hip.h"
+#include "vk_devmath.h"
 
 namespace {
 
@@ -139,6 +140,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 // per-point, wave-uniform quantities (ccf_model.py:589-613, 432-450, 638)
 struct PointScalars {
   double aperp, apar, inv_c, A, B;
+  double poison;  // 0, or NaN when any input of the point is NaN/inf: added to every output so that a bad
+                  // parameter can never be masked by a clamp (the reference propagates NaN, ccf_fit.py:477)
 };
 
 // layout of the dynamic LDS block (doubles)
@@ -286,6 +289,7 @@ __device__ __forceinline__ PointScalars point_scalars(const TheoryArgs& a, const
   const double iaH_true = a.iaH * ps.apar;
   ps.B = sigv * iaH_true;
   ps.A = fs8 * a.inv_sigma8 / (3.0 * iaH_true * sigv);
+  ps.poison = 0.0 * (fs8 + sigv + ps.aperp + ps.apar + eps + c + ps.A + (a.n_beta_r > 0 ? row[VK_P_BETA] : 0.0));
   return ps;
 }
 
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_kernel(TheoryArgs a) {
           double v = acc[0] - wsum[0];
 #pragma unroll
           for (int l = 1; l < NL; ++l) v = (lane == l) ? acc[l] - wsum[l] : v;
-          a.out[point * (long long)(a.n_ell * a.n_s) + (long long)lane * a.n_s + j] = v;
+          a.out[point * (long long)(a.n_ell * a.n_s) + (long long)lane * a.n_s + j] = v + ps.poison;
         }
       } else {
         __syncthreads();
@@ -381,7 +385,247 @@ __global__ __launch_bounds__(kBlock) void vk_theory_kernel(TheoryArgs a) {
           double ws = wsum[0];
 #pragma unroll
           for (int l = 1; l < NL; ++l) ws = (lane == l) ? wsum[l] : ws;
-          a.out[point * (long long)(a.n_ell * a.n_s) + (long long)lane * a.n_s + j] = v - ws;
+          a.out[point * (long long)(a.n_ell * a.n_s) + (long long)lane * a.n_s + j] = v - ws + ps.poison;
+        }
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
+// K1 fast path: all three tables on uniform grids, and the velocity table shares the xi^r knots behind its
+// extra leading node at 0.01 (always true for tables built by the reference's own recipe, ccf_model.py:625).
+//   * coefficients are re-expressed in interval units (tau = (u - knot_i)/h in [0,1)) when they are staged,
+//     so one fma + clamp + v_cvt + v_fract yields interval and local coordinate, with no knot read;
+//   * V, xi_0, xi_2, xi_4 of one r interval sit in one LDS record (one index for four cubics), records are
+//     padded to 4*(1+NLR)+2 doubles so that the ds_read_b128 of 16 consecutive intervals hit distinct banks;
+//   * sqrt and 1/r come from one refined v_rsq_f64, 1/sigma_v from a refined v_rcp_f64, exp from a 32-entry
+//     2^(j/32) table and a degree-6 polynomial (vk_devmath.h; all within 2 ulp).
+// --------------------------------------------------------------------------------------------------
+typedef double vk_d2 __attribute__((ext_vector_type(2)));
+constexpr int kMuRec = 6;   // {mu, sqrt(1-mu^2), W_0, W_1, W_2, pad}
+constexpr int kSvRec = 6;   // {c0..c3, pad, pad}
+
+struct FastPlan {
+  int murec, xrec, svrec, vxrec, lead, etab, betar, red, total, vx_stride;
+};
+
+__host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int sv_int, int xi_int, int nlr, int n_beta_r) {
+  FastPlan p;
+  int o = 0;
+  p.vx_stride = 4 * (1 + nlr) + 2;
+  p.murec = o; o += n_mu * kMuRec;
+  p.xrec = o;  o += n_x * 2;
+  p.svrec = o; o += sv_int * kSvRec;
+  p.vxrec = o; o += xi_int * p.vx_stride;
+  p.lead = o;  o += 4;
+  p.etab = o;  o += 32;
+  p.betar = o; o += n_beta_r;
+  o = (o + 1) & ~1;
+  p.red = o;   o += kWaves * kMaxEll;
+  p.total = o;
+  return p;
+}
+
+struct FastConsts {
+  double inv_hs, off_s, ns_eps;   // sigma_v table
+  double inv_hx, off_x, nx_eps;   // xi / V table (uniform part)
+  double inv_hl, off_l;           // V leading interval [0.01, r_0]
+};
+
+__device__ __forceinline__ double cubic_b128(const double* rec, double t) {
+  const vk_d2 lo = *reinterpret_cast<const vk_d2*>(rec);
+  const vk_d2 hi = *reinterpret_cast<const vk_d2*>(rec + 2);
+  return fma(fma(fma(hi.y, t, hi.x), t, lo.y), t, lo.x);
+}
+
+template <int NLR>
+__device__ __forceinline__ double fast_integrand(const double* __restrict__ svrec, const double* __restrict__ vxrec,
+                                                 const double* __restrict__ leadrec, const double* __restrict__ etab,
+                                                 const FastConsts& fc, const PointScalars& ps, int vx_stride,
+                                                 double s_perp, double s_par, double xk, double wk) {
+  const double r_par = fma(-xk, ps.B, s_par);
+  const double r2 = fma(s_perp, s_perp, r_par * r_par);
+  double r, inv_r;
+  vkm::sqrt_rsqrt(r2, r, inv_r);
+  const double mu_r = r_par * inv_r;
+  const double u = r * ps.inv_c;
+
+  const double ts = fmin(fmax(fma(u, fc.inv_hs, fc.off_s), 0.0), fc.ns_eps);
+  const double SV = cubic_b128(svrec + (int)ts * kSvRec, __builtin_amdgcn_fract(ts));
+
+  const double tr = fma(u, fc.inv_hx, fc.off_x);
+  const double tx = fmin(fmax(tr, 0.0), fc.nx_eps);
+  const double tq = __builtin_amdgcn_fract(tx);
+  const double* rec = vxrec + (int)tx * vx_stride;
+  double V = cubic_b128(rec, tq);
+  if (tr < 0.0) V = cubic_b128(leadrec, fmax(fma(u, fc.inv_hl, fc.off_l), 0.0));
+  double xir = cubic_b128(rec + 4, tq);
+  if (NLR > 1) {
+    const double m2 = mu_r * mu_r;
+    xir = fma(cubic_b128(rec + 8, tq), fma(1.5, m2, -0.5), xir);
+    if (NLR > 2) xir = fma(cubic_b128(rec + 12, tq), fma(fma(4.375, m2, -3.75), m2, 0.375), xir);
+  }
+  const double inv_sv = vkm::recip(SV);
+  const double z = fma(ps.A * V, mu_r, xk) * inv_sv;
+  const double e = vkm::exp_nonpos((-0.5 * z) * z, etab);
+  const double t1 = wk * inv_sv;
+  return fma(t1, xir, t1) * e;
+}
+
+__device__ __forceinline__ double hpow(double h, int q) {
+  return q == 0 ? 1.0 : (q == 1 ? h : (q == 2 ? h * h : h * h * h));
+}
+
+template <int NLR, int NL>
+__global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
+  extern __shared__ double lds[];
+  const FastPlan pl = make_fast_plan(a.n_mu, a.n_x, a.sv.n_int, a.xi.n_int, NLR, a.n_beta_r);
+  const int tid = threadIdx.x;
+  const double hs = 1.0 / a.sv.inv_h, hx = 1.0 / a.xi.inv_h;
+  const double hl = a.vr.knots[1] - a.vr.knots[0];
+  // ---- stage batch-constant tables -------------------------------------------------------------
+  for (int i = tid; i < a.n_mu; i += kBlock) {
+    const double m = a.mu[i];
+    double* rec = lds + pl.murec + i * kMuRec;
+    rec[0] = m;
+    rec[1] = sqrt(1.0 - m * m);
+#pragma unroll
+    for (int l = 0; l < kMaxEll; ++l) rec[2 + l] = (l < NL) ? a.w_ell[l * a.n_mu + i] : 0.0;
+    rec[5] = 0.0;
+  }
+  for (int i = tid; i < a.n_x; i += kBlock) {
+    lds[pl.xrec + 2 * i] = a.x[i];
+    lds[pl.xrec + 2 * i + 1] = a.w_x[i];
+  }
+  for (int e = tid; e < a.sv.n_int * 4; e += kBlock)
+    lds[pl.svrec + (e >> 2) * kSvRec + (e & 3)] = a.sv.coef[e] * hpow(hs, e & 3);
+  for (int e = tid; e < a.xi.n_int * 4; e += kBlock)   // V lives one interval further in its own table
+    lds[pl.vxrec + (e >> 2) * pl.vx_stride + (e & 3)] = a.vr.coef[4 + e] * hpow(hx, e & 3);
+  if (a.n_beta_r == 0) {
+    const int per_l = a.xi.n_int * 4;
+    for (int e = tid; e < NLR * per_l; e += kBlock) {
+      const int l = e / per_l, iq = e - l * per_l;
+      lds[pl.vxrec + (iq >> 2) * pl.vx_stride + 4 * (1 + l) + (iq & 3)] = a.xi.coef[e] * hpow(hx, iq & 3);
+    }
+  } else {
+    for (int i = tid; i < a.n_beta_r; i += kBlock) lds[pl.betar + i] = a.beta_r[i];
+  }
+  if (tid < 4) lds[pl.lead + tid] = a.vr.coef[tid] * hpow(hl, tid);
+  if (tid < 32) lds[pl.etab + tid] = vkm::exp2_frac32(tid);
+  FastConsts fc;
+  fc.inv_hs = a.sv.inv_h;
+  fc.off_s = -a.sv.knots[0] * a.sv.inv_h;
+  fc.ns_eps = (double)a.sv.n_int * (1.0 - 0x1p-52);
+  fc.inv_hx = a.xi.inv_h;
+  fc.off_x = -a.xi.knots[0] * a.xi.inv_h;
+  fc.nx_eps = (double)a.xi.n_int * (1.0 - 0x1p-52);
+  fc.inv_hl = 1.0 / hl;
+  fc.off_l = -a.vr.knots[0] * fc.inv_hl;
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int team = a.team;
+  const int nteams = kWaves / team;
+  const int my_team = wave / team;
+  const int my_rank = wave - my_team * team;
+  const int groups = (a.n_s + a.sbins_per_item - 1) / a.sbins_per_item;
+  const long long items = a.n * groups;
+  const int plane = a.n_mu * a.n_x;
+  const int step = 64 * team;
+  const int step_q = step / a.n_x, step_r = step - step_q * a.n_x;
+  const int rounds = (a.sbins_per_item + nteams - 1) / nteams;
+  const double* murec = lds + pl.murec;
+  const double* xrec = lds + pl.xrec;
+  const double* svrec = lds + pl.svrec;
+  const double* vxrec = lds + pl.vxrec;
+  const double* leadrec = lds + pl.lead;
+  const double* etab = lds + pl.etab;
+  double* l_red = lds + pl.red;
+
+  double wsum[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    double t = 0.0;
+    for (int i = lane; i < a.n_mu; i += 64) t += murec[i * kMuRec + 2 + l];
+    wsum[l] = wave_sum(t);
+  }
+
+  for (long long item = blockIdx.x; item < items; item += gridDim.x) {
+    const long long point = item / groups;
+    const int g = (int)(item - point * groups);
+    const double* row = a.params + point * VK_NPAR;
+    const PointScalars ps = point_scalars(a, row);
+    if (a.n_beta_r > 0) {
+      __syncthreads();
+      const double* bg = lds + pl.betar;
+      const double beta = row[VK_P_BETA];
+      int kb = 0;
+      for (int i = 1; i < a.n_beta_r - 1; ++i) kb = (beta >= bg[i]) ? i : kb;
+      const double db = beta - bg[kb];
+      const int per_l = a.xi.n_int * 4;
+      const size_t stride_l = (size_t)(a.n_beta_r - 1) * per_l * 4;
+      for (int e = tid; e < NLR * per_l; e += kBlock) {
+        const int l = e / per_l, iq = e - l * per_l;
+        const double* c = a.xi.coef + l * stride_l + ((size_t)kb * per_l + iq) * 4;
+        lds[pl.vxrec + (iq >> 2) * pl.vx_stride + 4 * (1 + l) + (iq & 3)] =
+            fma(fma(fma(c[3], db, c[2]), db, c[1]), db, c[0]) * hpow(hx, iq & 3);
+      }
+      __syncthreads();
+    }
+    for (int rd = 0; rd < rounds; ++rd) {
+      const int jl = rd * nteams + my_team;
+      const int j = g * a.sbins_per_item + jl;
+      const bool valid = (jl < a.sbins_per_item) && (j < a.n_s);
+      double acc[NL];
+#pragma unroll
+      for (int l = 0; l < NL; ++l) acc[l] = 0.0;
+      if (valid) {
+        const double sj = a.s[j];
+        const double s_aperp = sj * ps.aperp;
+        const double s_apar = sj * ps.apar;
+        int idx = lane + 64 * my_rank;
+        int i = idx / a.n_x;
+        int k = idx - i * a.n_x;
+        for (; idx < plane; idx += step) {
+          const double* mr = murec + i * kMuRec;
+          const vk_d2 m01 = *reinterpret_cast<const vk_d2*>(mr);
+          const vk_d2 xw = *reinterpret_cast<const vk_d2*>(xrec + 2 * k);
+          const double f = fast_integrand<NLR>(svrec, vxrec, leadrec, etab, fc, ps, pl.vx_stride, s_aperp * m01.y,
+                                               s_apar * m01.x, xw.x, xw.y);
+          const vk_d2 w01 = *reinterpret_cast<const vk_d2*>(mr + 2);
+          acc[0] = fma(w01.x, f, acc[0]);
+          if (NL > 1) acc[1] = fma(w01.y, f, acc[1]);
+          if (NL > 2) acc[2] = fma(mr[4], f, acc[2]);
+          k += step_r;
+          i += step_q;
+          if (k >= a.n_x) { k -= a.n_x; ++i; }
+        }
+      }
+#pragma unroll
+      for (int l = 0; l < NL; ++l) acc[l] = wave_sum(acc[l]);
+      if (team == 1) {
+        if (valid && lane < NL) {
+          double v = acc[0] - wsum[0];
+#pragma unroll
+          for (int l = 1; l < NL; ++l) v = (lane == l) ? acc[l] - wsum[l] : v;
+          a.out[point * (long long)(a.n_ell * a.n_s) + (long long)lane * a.n_s + j] = v + ps.poison;
+        }
+      } else {
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+          for (int l = 0; l < NL; ++l) l_red[wave * kMaxEll + l] = acc[l];
+        }
+        __syncthreads();
+        if (valid && my_rank == 0 && lane < NL) {
+          double v = 0.0;
+          for (int q = 0; q < team; ++q) v += l_red[(wave + q) * kMaxEll + lane];
+          double ws = wsum[0];
+#pragma unroll
+          for (int l = 1; l < NL; ++l) ws = (lane == l) ? wsum[l] : ws;
+          a.out[point * (long long)(a.n_ell * a.n_s) + (long long)lane * a.n_s + j] = v - ws + ps.poison;
         }
       }
     }
@@ -426,7 +670,7 @@ __global__ __launch_bounds__(kBlock) void vk_xi_smu_kernel(TheoryArgs a) {
       for (int k = lane; k < a.n_x; k += 64)
         acc += streaming_integrand<NLR>(sv, vr, xi, ps, s_perp, s_par, l_x[k], l_wx[k]);
       acc = wave_sum(acc);
-      if (lane == 0) a.out[(point * a.n_mu + i) * (long long)a.n_s + j] = acc - 1.0;
+      if (lane == 0) a.out[(point * a.n_mu + i) * (long long)a.n_s + j] = acc - 1.0 + ps.poison;
     }
   }
 }
@@ -566,6 +810,7 @@ struct vk_ctx {
                *d_beta_d = nullptr, *d_data = nullptr, *d_beta_c = nullptr, *d_prec = nullptr, *d_logdet = nullptr,
                *d_eig = nullptr;
   PPView xi{}, vr{}, sv{};
+  bool fast_ok = false;      // tables qualify for vk_theory_fast_kernel
   // scratch for the host-buffer entry points
   double* d_scratch = nullptr;
   size_t scratch_bytes = 0;
@@ -640,12 +885,21 @@ void choose_split(const vk_ctx* ctx, long long n, int n_s, int* spi, int* team) 
 }
 
 template <int NLR>
-int launch_theory_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
-  switch (a.n_ell) {
-    case 1: hipLaunchKernelGGL((vk_theory_kernel<NLR, 1>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-    case 2: hipLaunchKernelGGL((vk_theory_kernel<NLR, 2>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-    case 3: hipLaunchKernelGGL((vk_theory_kernel<NLR, 3>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-    default: return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
+int launch_theory_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds, bool fast) {
+  if (fast) {
+    switch (a.n_ell) {
+      case 1: hipLaunchKernelGGL((vk_theory_fast_kernel<NLR, 1>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+      case 2: hipLaunchKernelGGL((vk_theory_fast_kernel<NLR, 2>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+      case 3: hipLaunchKernelGGL((vk_theory_fast_kernel<NLR, 3>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+      default: return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
+    }
+  } else {
+    switch (a.n_ell) {
+      case 1: hipLaunchKernelGGL((vk_theory_kernel<NLR, 1>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+      case 2: hipLaunchKernelGGL((vk_theory_kernel<NLR, 2>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+      case 3: hipLaunchKernelGGL((vk_theory_kernel<NLR, 3>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+      default: return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
+    }
   }
   VK_HIP(ctx, hipGetLastError());
   return VK_OK;
@@ -671,17 +925,23 @@ int theory_args(vk_ctx* ctx, const vk_eval_opts* o, TheoryArgs* a, int* nlr) {
 int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   if (a.n <= 0) return VK_OK;
   choose_split(ctx, a.n, a.n_s, &a.sbins_per_item, &a.team);
-  const LdsPlan pl = make_plan(a.n_mu, a.n_x, a.n_ell, a.sv.n_int, a.vr.n_int, a.xi.n_int, nlr, a.n_beta_r);
-  const size_t lds = (size_t)pl.total * sizeof(double);
+  const bool fast = ctx->fast_ok && !getenv("VICTOR_HIP_FORCE_GENERIC");
+  size_t lds;
+  if (fast) {
+    lds = (size_t)make_fast_plan(a.n_mu, a.n_x, a.sv.n_int, a.xi.n_int, nlr, a.n_beta_r).total * sizeof(double);
+  } else {
+    lds = (size_t)make_plan(a.n_mu, a.n_x, a.n_ell, a.sv.n_int, a.vr.n_int, a.xi.n_int, nlr, a.n_beta_r).total *
+          sizeof(double);
+  }
   if (lds > 160 * 1024) return fail(ctx, VK_E_ARG, "tables need %zu bytes of LDS (> 160 KiB)", lds);
   const long long groups = (a.n_s + a.sbins_per_item - 1) / a.sbins_per_item;
   const long long items = a.n * groups;
   const long long cap = 8LL * ctx->n_cu;
   const int grid = (int)(items < cap ? items : cap);
   switch (nlr) {
-    case 1: return launch_theory_nl<1>(ctx, a, grid, lds);
-    case 2: return launch_theory_nl<2>(ctx, a, grid, lds);
-    case 3: return launch_theory_nl<3>(ctx, a, grid, lds);
+    case 1: return launch_theory_nl<1>(ctx, a, grid, lds, fast);
+    case 2: return launch_theory_nl<2>(ctx, a, grid, lds, fast);
+    case 3: return launch_theory_nl<3>(ctx, a, grid, lds, fast);
   }
   return fail(ctx, VK_E_ARG, "bad number of real-space multipoles %d", nlr);
 }
@@ -843,6 +1103,16 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
   ctx->n_beta_d = t->data ? t->n_beta_d : 0;
   ctx->n_beta_c = t->data ? t->n_beta_c : 0;
 
+  {
+    bool ok = t->xi.inv_h > 0 && t->xi.lead == 0 && t->sv.inv_h > 0 && t->sv.lead == 0 && t->vr.inv_h > 0 &&
+              t->vr.lead == 1 && t->vr.n_int == t->xi.n_int + 1;
+    if (ok) {
+      const double tol = 1e-12 * fabs(t->xi.knots[t->xi.n_int]);
+      for (int i = 0; i <= t->xi.n_int && ok; ++i) ok = fabs(t->vr.knots[i + 1] - t->xi.knots[i]) <= tol;
+      ok = ok && fabs(t->vr.inv_h - t->xi.inv_h) <= 1e-12 * t->xi.inv_h;
+    }
+    ctx->fast_ok = ok;
+  }
   Uploader up;
   const size_t o_s = up.add(t->s, t->n_s), o_mu = up.add(t->mu, t->n_mu),
                o_w = up.add(t->w_ell, (size_t)t->n_ell * t->n_mu), o_x = up.add(t->x, t->n_x),

@@ -1,0 +1,60 @@
+// vk_devmath.h - FP64 building blocks for the gfx950 kernels.
+//
+// The hot loop needs, per integrand point, one sqrt together with the matching 1/r, one reciprocal and
+// one exp of a non-positive argument.  The IEEE-correct library forms cost ~8 + 12 + 12 + 20 vector
+// instructions; the forms below cost ~9 + 5 + 12 and stay within 2 ulp (measured on hardware by
+// tools/devmath_check.hip, asserted in tests/test_gpu_devmath.py), far inside the 1e-6 relative parity
+// budget of the likelihood (the kernels are tested to 1e-9).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace vkm {
+
+// g ~ sqrt(x), returns also ir ~ 1/sqrt(x).  x must be a positive normal number (r^2 of a separation in
+// Mpc/h); x = 0 gives NaN, which is what the reference's r_par / r produces there too.
+__device__ __forceinline__ void sqrt_rsqrt(double x, double& g, double& ir) {
+  const double y = __builtin_amdgcn_rsq(x);   // v_rsq_f64, ~2^-26 relative
+  g = x * y;
+  double h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  const double d = fma(-g, g, x);             // residual of the square root
+  g = fma(d, h, g);
+  ir = h + h;
+  const double e = fma(-ir, g, 1.0);          // residual of the reciprocal square root
+  ir = fma(ir, e, ir);
+}
+
+// 1/x for a positive normal x (the velocity dispersion)
+__device__ __forceinline__ double recip(double x) {
+  double y = __builtin_amdgcn_rcp(x);         // v_rcp_f64
+  double e = fma(-x, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-x, y, 1.0);
+  return fma(y, e, y);
+}
+
+// 2^(j/32), j = 0..31, to be staged in LDS by the caller (256 B)
+__device__ __forceinline__ double exp2_frac32(int j) { return exp2((double)j * 0.03125); }
+
+// exp(a) for a <= 0 (NaN propagates).  a is split as a = (32 m + j) ln2/32 + f with |f| <= ln2/64, so
+// exp(a) = 2^m * T[j] * exp(f) and a degree-6 Taylor polynomial in f is exact to 4e-18.
+__device__ __forceinline__ double exp_nonpos(double a, const double* __restrict__ tab32) {
+  a = (a < -750.0) ? -750.0 : a;              // exp(-750) underflows to 0; tames -inf; keeps NaN (fmax would not)
+  const double n = rint(a * 46.166241308446828);                 // 32 / ln 2
+  double f = fma(n, -0x1.62e42fef80000p-6, a);                   // ln2/32, high 34 bits: n*hi is exact
+  f = fma(n, -0x1.1cf79abc9e3b4p-41, f);                         //         remainder
+  const int ni = (int)n;
+  const double t = tab32[ni & 31];
+  double p = fma(f, 1.0 / 720.0, 1.0 / 120.0);
+  p = fma(p, f, 1.0 / 24.0);
+  p = fma(p, f, 1.0 / 6.0);
+  p = fma(p, f, 0.5);
+  p = fma(p, f, 1.0);
+  p = fma(p, f, 1.0);
+  return ldexp(t * p, ni >> 5);
+}
+
+}  // namespace vkm
