@@ -1,0 +1,278 @@
+"""Host-side logic that needs no GPU: C-ABI surface, table compilation, option handling, readers."""
+
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from victor_amd.build import build_native
+    from victor_amd import _native
+    build_native()
+    return _native.load()
+
+
+def have_gpu(lib):
+    return lib.vk_device_count() > 0
+
+
+# --------------------------------------------------------------------------- C ABI surface
+def test_library_exports_every_declared_symbol(lib):
+    from victor_amd import _native
+    header = open(os.path.join(ROOT, "include", "victor_hip.h")).read()
+    declared = set(re.findall(r"\b(vk_[a-z0-9_]+)\s*\(", header))
+    declared -= {"vk_ctx"}
+    assert declared, "no prototypes found in the header"
+    assert declared == set(_native.SYMBOLS), declared ^ set(_native.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.vk_abi_version() == 1
+
+
+def test_struct_layouts_match_header(lib):
+    """ctypes mirrors must have the C sizes (compile a tiny C program against the header)."""
+    from victor_amd import _native
+    src = ('#include <stdio.h>\n#include "victor_hip.h"\nint main(){printf("%zu %zu %zu %d\\n", sizeof(vk_pp), '
+           'sizeof(vk_tables), sizeof(vk_eval_opts), VK_NPAR);return 0;}\n')
+    exe = os.path.join("/tmp", f"vk_sizes_{os.getpid()}")
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
+    out = subprocess.check_output([exe]).decode().split()
+    os.remove(exe)
+    assert int(out[0]) == ctypes.sizeof(_native.vk_pp)
+    assert int(out[1]) == ctypes.sizeof(_native.vk_tables)
+    assert int(out[2]) == ctypes.sizeof(_native.vk_eval_opts)
+    assert int(out[3]) == _native.VK_NPAR
+
+
+def test_no_cpu_fallback_without_gpu(lib):
+    if have_gpu(lib):
+        pytest.skip("a GPU is visible here")
+    import victor_amd
+    from victor_amd._native import NativeError
+    fit = victor_amd.CCFFit(*cases.synth_options(2))
+    with pytest.raises(NativeError):
+        fit.log_likelihood({"fsigma8": 0.45, "sigma_v": 360})
+    with pytest.raises(NativeError):
+        fit.theory_multipoles(fit.s, {"fsigma8": 0.45})
+
+
+def test_vk_create_rejects_bad_tables(lib):
+    from victor_amd import _native as N
+    err = ctypes.create_string_buffer(256)
+    t = N.vk_tables()
+    assert not lib.vk_create(ctypes.byref(t), 0, err, len(err))
+    assert b"grid sizes" in err.value or b"bad" in err.value
+    assert not lib.vk_create(None, 0, err, len(err))
+
+
+def test_product_never_imports_oracle():
+    """The shipped package must not reference anything under oracle/."""
+    for base, _, files in os.walk(os.path.join(ROOT, "victor_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(base, f)).read()
+                assert "victor_oracle" not in text and "ref_shim" not in text, f
+    for f in ("victor/__init__.py", "victor/likelihoods/CCFLikelihood.py"):
+        assert "oracle" not in open(os.path.join(ROOT, f)).read()
+
+
+# --------------------------------------------------------------------------- host set-up parity
+@pytest.fixture(scope="module")
+def boss_fit():
+    import victor_amd
+    return victor_amd.CCFFit(*cases.boss_options("config"))
+
+
+def test_boss_init_matches_reference(boss_fit):
+    g, _ = cases.golden_outputs()
+    f = boss_fit
+    assert f.iaH == float(g["boss_iaH"])
+    assert np.max(np.abs(f.sv_rmu - g["boss_sv_rmu"])) < 1e-15
+    r_ext = np.append([0.01], f.r)
+    assert np.max(np.abs(f.delta(r_ext) - g["boss_delta_ext"])) < 1e-14
+    assert np.max(np.abs(f.integrated_delta(r_ext) / g["boss_int_delta_ext"] - 1)) < 1e-12
+    assert np.max(np.abs(f.icov[12] - g["boss_icov_12"])) <= 1e-12 * np.max(np.abs(g["boss_icov_12"]))
+    assert list(f.poles_s) == [0, 2] and list(f.poles_r) == [0, 2]
+    assert f.s.shape == (30,) and f.covmat.shape == (31, 60, 60) and f.icov.shape == (31, 60, 60)
+    assert f.fit_options["likelihood"]["form"] == "sellentin"
+    assert f.model["velocity_independent_of_AP"] is False and f.model["assume_isotropic"] is True
+
+
+def test_host_accessors_match_oracle(boss_fit):
+    import victor_oracle as vo
+    ora = vo.OracleFit(*cases.boss_options("config"))
+    for beta in (0.37, 0.1, 0.7, float(ora.beta_covmat[7]), 0.6486):
+        assert np.max(np.abs(boss_fit.get_interpolated_covariance(beta) - ora._interp_stack(ora.covmat, beta))) == 0
+        assert np.max(np.abs(boss_fit.get_interpolated_precision(beta) - ora._interp_stack(ora.icov, beta))) == 0
+        assert np.max(np.abs(boss_fit.multipole_datavector(beta) - ora.data_vector(beta))) < 1e-15
+        assert np.max(np.abs(boss_fit.get_interpolated_real_multipoles(beta) - ora.real_multipoles_at(beta))) < 1e-15
+    assert boss_fit.diagonal_errors(0.4).shape == (2, 30)
+    c = boss_fit.correlation_matrix(0.4)
+    assert np.allclose(np.diag(c), 1.0)
+
+
+def test_compiled_tables(boss_fit):
+    from victor_amd.engine import build_tables
+    t, keep = build_tables(boss_fit, boss_fit)
+    assert (t.n_s, t.n_mu, t.n_x, t.n_ell, t.n_ell_r) == (30, 100, 50, 2, 2)
+    assert t.n_beta_r == t.n_beta_d == t.n_beta_c == 31
+    assert t.xi.n_int == 29 and t.xi.lead == 0 and t.xi.inv_h == pytest.approx(0.25)
+    assert t.vr.n_int == 30 and t.vr.lead == 1 and t.vr.inv_h == pytest.approx(0.25)
+    assert t.sv.n_int == 24 and t.sv.inv_h == pytest.approx(1 / 6)
+    # the generalised-eigenvalue identity used for log det of the blended covariance
+    n = 60
+    logdet = np.ctypeslib.as_array(t.logdet, shape=(31,))
+    eig = np.ctypeslib.as_array(t.eig, shape=(31, n))
+    for k, tt in ((12, 0.04537), (3, 0.5), (29, 0.9)):
+        blend = (1 - tt) * boss_fit.covmat[k] + tt * boss_fit.covmat[-1]
+        want = np.linalg.slogdet(blend)[1]
+        got = logdet[k] + np.sum(np.log(1 - tt + tt * eig[k]))
+        assert abs(got - want) < 1e-9
+    ft, _ = build_tables(__import__("victor_amd").CCFFit(*cases.synth_options(3)), None)
+    assert ft.n_beta_r == 0 and ft.n_ell_r == 3 and not ft.data
+
+
+def test_param_rows(boss_fit):
+    from victor_amd import _native as N
+    rows = boss_fit._fit_rows({"fsigma8": 0.47, "beta": 0.37, "sigma_v": 380, "epsilon": 1.04, "alpha": 1.02},
+                              boss_fit.model)
+    apar = 1.02 * 1.04 ** (-2 / 3)
+    assert rows.shape == (1, N.VK_NPAR)
+    assert rows[0, N.P_APAR] == apar and rows[0, N.P_APERP] == 1.04 * apar and rows[0, N.P_EPSILON] == 1.04
+    assert rows[0, N.P_BETA] == 0.37 and rows[0, N.P_ASTAR] == 1 and rows[0, N.P_M] == 1 and rows[0, N.P_Q] == 1
+    rows = boss_fit._fit_rows({"fsigma8": [0.4, 0.5], "beta": 0.3, "aperp": [0.9, 1.1], "apar": 1.05}, boss_fit.model)
+    assert rows.shape == (2, N.VK_NPAR) and np.all(rows[:, N.P_SIGMAV] == 380)
+    assert np.allclose(rows[:, N.P_EPSILON], np.array([0.9, 1.1]) / 1.05)
+    with pytest.raises(KeyError):
+        boss_fit._fit_rows({"beta": 0.3}, boss_fit.model)
+    from victor_amd import InputError
+    with pytest.raises(InputError):
+        boss_fit._fit_rows({"fsigma8": 0.4}, boss_fit.model)        # beta needed for beta-dependent data
+
+
+def test_input_errors(tmp_path):
+    import victor_amd
+    from victor_amd import InputError
+    model, data = cases.boss_options("config")
+    bad = cases.clone(model)
+    bad["input_model_data_file"] = "nope.npy"
+    with pytest.raises(InputError):
+        victor_amd.CCFModel(bad)
+    bad = cases.clone(model)
+    bad["realspace_ccf"]["ccf_keys"] = ["r"]
+    with pytest.raises(InputError):
+        victor_amd.CCFModel(bad)
+    bad = cases.clone(model)
+    bad["realspace_ccf"]["beta_key"] = None
+    with pytest.raises(InputError):
+        victor_amd.CCFModel(bad)
+    bad = cases.clone(model)
+    bad["matter_ccf"]["template_sigma8"] = None
+    with pytest.raises(InputError):
+        victor_amd.CCFModel(bad)
+    bad = cases.clone(model)
+    bad["velocity_pdf"]["dispersion"] = {"model": "constant"}      # crashes in the reference too
+    with pytest.raises(InputError):
+        victor_amd.CCFModel(bad)
+    bad = cases.clone(model)
+    bad["velocity_pdf"]["dispersion"]["model"] = "weird"
+    with pytest.raises(InputError):
+        victor_amd.CCFModel(bad)
+    badd = cases.clone(data)
+    badd["covariance_matrix"]["cov_key"] = "missing"
+    with pytest.raises(InputError):
+        victor_amd.CCFFit(model, badd)
+    badd = cases.clone(data)
+    badd["covariance_matrix"]["fixed_beta"] = True                 # stack given where a single matrix is expected
+    with pytest.raises(InputError):
+        victor_amd.CCFFit(model, badd)
+    badd = cases.clone(data)
+    badd["redshift_space_ccf"]["data_file"] = "nope.npy"
+    with pytest.raises(InputError):
+        victor_amd.CCFFit(model, badd)
+    m = victor_amd.CCFModel(model)
+    with pytest.raises(InputError):
+        m._check_supported(dict(m.model, rsd_model="bogus"))
+    with pytest.raises(InputError):
+        m._check_supported(dict(m.model, matter_model="linear_bias"))
+
+
+# --------------------------------------------------------------------------- readers
+def test_h5lite_reads_reference_style_file():
+    from victor_amd import h5lite
+    d = h5lite.read_all(os.path.join(cases.GOLDEN, "h5", "void_model_example.h5"))
+    assert sorted(d) == ["delta", "monopole", "r", "rdelta", "rsv", "sigmav"]
+    assert all(v.shape == (25,) and v.dtype == np.float64 for v in d.values())
+    assert np.all(np.diff(d["r"]) > 0) and np.all(np.diff(d["rsv"]) > 0)
+    assert d["monopole"].min() < -0.5 and abs(d["monopole"][-1]) < 0.1     # a void profile
+    with pytest.raises(h5lite.H5LiteError):
+        h5lite._Reader(b"not an hdf5 file" * 100)
+
+
+def test_model_from_hdf5_like_example_config():
+    """config/example_model_input.yaml of the reference, pointed at the HDF5 fixture."""
+    import victor_amd
+    model = {"dir": cases.GOLDEN, "input_model_data_file": "h5/void_model_example.h5", "rsd_model": "streaming",
+             "z_eff": 0.50, "cosmology": {"Omega_m": 0.31},
+             "realspace_ccf": {"reconstruction": False, "format": "multipoles", "ccf_keys": ["r", "monopole"]},
+             "matter_ccf": {"model": "template", "integrated": False, "template_keys": ["rdelta", "delta"],
+                            "template_sigma8": 0.628, "bias": 1.9},
+             "velocity_pdf": {"mean": {"model": "linear"},
+                              "dispersion": {"model": "template", "template_keys": ["rsv", "sigmav"]}}}
+    m = victor_amd.CCFModel(model)
+    import victor_oracle as vo
+    from victor_amd import h5lite
+    o = vo.OracleModel(model, h5lite.read_all(os.path.join(cases.GOLDEN, "h5", "void_model_example.h5")))
+    assert m.iaH == o.iaH and np.max(np.abs(m.sv_rmu - o.sv_rmu)) < 1e-15
+    r_ext = np.append([0.01], m.r)
+    assert np.max(np.abs(m.integrated_delta(r_ext) - o.integrated_delta(r_ext))) < 1e-12
+
+
+@pytest.mark.reference
+def test_h5lite_against_all_reference_files():
+    ref = "/root/reference/data"
+    if not os.path.isdir(ref) or not os.path.isfile("/opt/conda/bin/h5dump"):
+        pytest.skip("reference data or h5dump not present")
+    import glob
+    import tempfile
+    from victor_amd import h5lite
+    files = glob.glob(os.path.join(ref, "*", "*.hdf5"))
+    assert len(files) >= 12
+    for fn in files:
+        for key, arr in h5lite.read_all(fn).items():
+            with tempfile.NamedTemporaryFile(suffix=".bin") as tmp:
+                subprocess.check_call(["/opt/conda/bin/h5dump", "-d", "/" + key, "-b", "LE", "-o", tmp.name, fn],
+                                      stdout=subprocess.DEVNULL)
+                assert np.array_equal(np.fromfile(tmp.name, "<f8"), arr.ravel()), (fn, key)
+
+
+# --------------------------------------------------------------------------- drop-in alias + cobaya plug-in
+def test_victor_alias_and_plugin_host_side():
+    code = (
+        "import sys, os\n"
+        f"sys.path.insert(0, {ROOT!r}); os.chdir({ROOT!r})\n"
+        "import victor, victor_amd\n"
+        "assert victor.CCFFit is victor_amd.CCFFit and victor.CCFModel is victor_amd.CCFModel\n"
+        "sys.path.insert(0, './victor/likelihoods/')            # cobaya's python_path mechanism\n"
+        "from CCFLikelihood import CCFLikelihood\n"
+        "from tests import cases\n"
+        "m, d = cases.boss_options('cobaya')\n"
+        "lk = CCFLikelihood(dict(model=m, data=d))\n"
+        "assert lk.get_can_provide_params() == ['fsigma8'] and lk.ccf.s.shape == (30,)\n"
+        "import yaml\n"
+        "y = yaml.full_load(open('victor/likelihoods/CCFLikelihood.yaml'))\n"
+        "assert y['config_file'] == 'config/boss_config.yaml' and 'chi2_ccf_correct' in y['params']\n"
+        "print('ok')\n")
+    out = subprocess.check_output([sys.executable, "-c", code]).decode()
+    assert out.strip().endswith("ok")

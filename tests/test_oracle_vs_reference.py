@@ -1,0 +1,65 @@
+"""DEVELOPMENT CONTAINER ONLY: the oracle against the unmodified reference imported from /root/reference.
+
+Skipped wherever the reference is absent (the GPU box).  The committed golden vectors carry the same
+information there (tests/test_oracle_golden.py).
+"""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+pytestmark = pytest.mark.reference
+
+
+@pytest.fixture(scope="module")
+def ref():
+    import ref_shim
+    if not ref_shim.available():
+        pytest.skip("reference not present")
+    return ref_shim.load()
+
+
+def test_reference_runs_its_own_config_and_files(ref):
+    import ref_shim
+    info = ref_shim.boss_config()
+    fit = ref.CCFFit(info["model"], info["data"])
+    lnl, chi2 = fit.log_likelihood({"fsigma8": 0.47, "beta": 0.37, "sigma_v": 380, "epsilon": 1.0})
+    assert round(chi2, 2) == 65.01 and round(lnl, 2) == 284.76           # notebook line 491
+
+
+def test_oracle_equals_reference_on_fresh_points(ref):
+    import victor_oracle as vo
+    for opts in (cases.boss_options("config"), cases.boss_options("cobaya"), cases.synth_options(2),
+                 cases.synth_options(3)):
+        rfit = ref.CCFFit(cases.clone(opts[0]), cases.clone(opts[1]))
+        ofit = vo.OracleFit(*opts)
+        beta_dep = not ofit.fixed_data
+        hp = cases.halton_params(64, with_beta=beta_dep)
+        for i in (5, 33, 63):
+            p = cases.point(hp, i)
+            a = rfit.log_likelihood(dict(p))
+            b = ofit.log_likelihood(dict(p))
+            assert abs(a[0] - b[0]) <= 1e-12 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-12 * abs(a[1])
+            ta = rfit.theory_multipole_vector(rfit.s, dict(p), rfit.poles_s)
+            tb = ofit.theory_multipole_vector(ofit.s, dict(p), ofit.poles_s)
+            assert np.max(np.abs(ta - tb)) < 1e-13
+
+
+def test_cobaya_plugin_contract_matches_reference(ref):
+    import ref_shim
+    Plugin = ref_shim.load_cobaya_plugin()
+    model, data = cases.boss_options("cobaya")
+    lk = Plugin(model=cases.clone(model), data=cases.clone(data))
+    state = {}
+    lk.calculate(state, want_derived=True, fsigma8=0.47, beta=0.37, sigma_v=380, epsilon=1.0)
+    assert set(state) == {"logp", "derived"} and set(state["derived"]) == {"chi2_ccf_correct"}
+    assert lk.get_can_provide_params() == ["fsigma8"]
+    g, _ = cases.golden_outputs()
+    assert abs(state["derived"]["chi2_ccf_correct"] - g["boss_cobaya_chi2"][0]) < 1e-9

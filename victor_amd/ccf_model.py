@@ -168,9 +168,9 @@ class CCFModel:
             from scipy.integrate import quad
             self.delta = T.notaknot(r_for_delta, delta)
             integral = np.zeros_like(r)
+            dfun = self.delta.scalar_function()
             for i in range(len(r)):   # same adaptive quadrature as the reference so Delta agrees to round-off
-                integral[i] = quad(lambda x: 3 * float(self.delta(x)) * x ** 2 / r[i] ** 3, 0, r[i],
-                                   full_output=1)[0]
+                integral[i] = quad(lambda x: 3 * dfun(x) * x ** 2 / r[i] ** 3, 0, r[i], full_output=1)[0]
             self.integrated_delta = T.notaknot(r, integral)
 
     def _set_velocity_pdf(self, velocity_pdf, input_data):

@@ -53,6 +53,26 @@ class PiecewiseCubic:
         dxe = dx.reshape(dx.shape + extra)
         return ((c[i, 3] * dxe + c[i, 2]) * dxe + c[i, 1]) * dxe + c[i, 0]
 
+    def scalar_function(self):
+        """A fast float -> float evaluator of a scalar-valued table (for adaptive quadrature loops)."""
+        from bisect import bisect_right
+        if self.coef.ndim != 2:
+            raise ValueError("scalar_function needs a scalar-valued table")
+        k = self.knots.tolist()
+        c = self.coef.tolist()
+        lo, hi, last, clamp = k[0], k[-1], len(k) - 2, self.clamp
+
+        def f(u):
+            if clamp:
+                u = lo if u < lo else (hi if u > hi else u)
+            i = bisect_right(k, u) - 1
+            i = 0 if i < 0 else (last if i > last else i)
+            dx = u - k[i]
+            ci = c[i]
+            return ((ci[3] * dx + ci[2]) * dx + ci[1]) * dx + ci[0]
+
+        return f
+
 
 def _hermite_to_power(y, d, h):
     """Cubic Hermite data (values y, slopes d on intervals of width h) -> power-basis pieces."""
