@@ -407,7 +407,7 @@ constexpr int kMuRec = 6;   // {mu, sqrt(1-mu^2), W_0, W_1, W_2, pad}
 constexpr int kSvRec = 6;   // {c0..c3, pad, pad}
 
 struct FastPlan {
-  int murec, xrec, svrec, vxrec, lead, etab, betar, red, total, vx_stride;
+  int murec, xrec, svrec, vxrec, lead, etab, betar, red, node, total, vx_stride;
 };
 
 __host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int sv_int, int xi_int, int nlr, int n_beta_r) {
@@ -423,6 +423,7 @@ __host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int sv_int
   p.betar = o; o += n_beta_r;
   o = (o + 1) & ~1;
   p.red = o;   o += kWaves * kMaxEll;
+  p.node = o;  o += (n_mu * n_x + 1) / 2;   // one packed u32 per (mu, v) node
   p.total = o;
   return p;
 }
@@ -433,6 +434,18 @@ struct FastConsts {
   double inv_hl, off_l;           // V leading interval [0.01, r_0]
 };
 
+// v_min_f64 without the canonicalising v_max hipcc puts in front of fmin() for a bound it cannot prove quiet
+// (the bound is a finite table size; the other operand comes out of an fma/max and is canonical already)
+__device__ __forceinline__ double vmin_f64(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+__device__ __forceinline__ const double* lds_at(const double* base, int byte_off) {
+  return reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
 __device__ __forceinline__ double cubic_b128(const double* rec, double t) {
   const vk_d2 lo = *reinterpret_cast<const vk_d2*>(rec);
   const vk_d2 hi = *reinterpret_cast<const vk_d2*>(rec + 2);
@@ -442,8 +455,9 @@ __device__ __forceinline__ double cubic_b128(const double* rec, double t) {
 template <int NLR>
 __device__ __forceinline__ double fast_integrand(const double* __restrict__ svrec, const double* __restrict__ vxrec,
                                                  const double* __restrict__ leadrec, const double* __restrict__ etab,
-                                                 const FastConsts& fc, const PointScalars& ps, int vx_stride,
+                                                 const FastConsts& fc, const PointScalars& ps,
                                                  double s_perp, double s_par, double xk, double wk) {
+  constexpr int vx_stride = 4 * (1 + NLR) + 2;
   const double r_par = fma(-xk, ps.B, s_par);
   const double r2 = fma(s_perp, s_perp, r_par * r_par);
   double r, inv_r;
@@ -451,13 +465,13 @@ __device__ __forceinline__ double fast_integrand(const double* __restrict__ svre
   const double mu_r = r_par * inv_r;
   const double u = r * ps.inv_c;
 
-  const double ts = fmin(fmax(fma(u, fc.inv_hs, fc.off_s), 0.0), fc.ns_eps);
-  const double SV = cubic_b128(svrec + (int)ts * kSvRec, __builtin_amdgcn_fract(ts));
+  const double ts = vmin_f64(fmax(fma(u, fc.inv_hs, fc.off_s), 0.0), fc.ns_eps);
+  const double SV = cubic_b128(lds_at(svrec, __mul24((int)ts, kSvRec * 8)), __builtin_amdgcn_fract(ts));
 
   const double tr = fma(u, fc.inv_hx, fc.off_x);
-  const double tx = fmin(fmax(tr, 0.0), fc.nx_eps);
+  const double tx = vmin_f64(fmax(tr, 0.0), fc.nx_eps);
   const double tq = __builtin_amdgcn_fract(tx);
-  const double* rec = vxrec + (int)tx * vx_stride;
+  const double* rec = lds_at(vxrec, __mul24((int)tx, vx_stride * 8));
   double V = cubic_b128(rec, tq);
   if (tr < 0.0) V = cubic_b128(leadrec, fmax(fma(u, fc.inv_hl, fc.off_l), 0.0));
   double xir = cubic_b128(rec + 4, tq);
@@ -513,13 +527,20 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
   }
   if (tid < 4) lds[pl.lead + tid] = a.vr.coef[tid] * hpow(hl, tid);
   if (tid < 32) lds[pl.etab + tid] = vkm::exp2_frac32(tid);
+  // byte offsets of the mu record (low 16 bits) and the (x, w) record (high 16 bits) of every plane node, so the
+  // hot loop needs no index arithmetic: one ds_read_b32 per trip
+  unsigned* node = reinterpret_cast<unsigned*>(lds + pl.node);
+  for (int idx = tid; idx < a.n_mu * a.n_x; idx += kBlock) {
+    const int i = idx / a.n_x, k = idx - i * a.n_x;
+    node[idx] = (unsigned)(i * kMuRec * 8) | ((unsigned)(k * 16) << 16);
+  }
   FastConsts fc;
   fc.inv_hs = a.sv.inv_h;
   fc.off_s = -a.sv.knots[0] * a.sv.inv_h;
-  fc.ns_eps = (double)a.sv.n_int * (1.0 - 0x1p-52);
+  fc.ns_eps = __builtin_canonicalize((double)a.sv.n_int * (1.0 - 0x1p-52));
   fc.inv_hx = a.xi.inv_h;
   fc.off_x = -a.xi.knots[0] * a.xi.inv_h;
-  fc.nx_eps = (double)a.xi.n_int * (1.0 - 0x1p-52);
+  fc.nx_eps = __builtin_canonicalize((double)a.xi.n_int * (1.0 - 0x1p-52));
   fc.inv_hl = 1.0 / hl;
   fc.off_l = -a.vr.knots[0] * fc.inv_hl;
   __syncthreads();
@@ -534,7 +555,6 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
   const long long items = a.n * groups;
   const int plane = a.n_mu * a.n_x;
   const int step = 64 * team;
-  const int step_q = step / a.n_x, step_r = step - step_q * a.n_x;
   const int rounds = (a.sbins_per_item + nteams - 1) / nteams;
   const double* murec = lds + pl.murec;
   const double* xrec = lds + pl.xrec;
@@ -585,22 +605,19 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
         const double sj = a.s[j];
         const double s_aperp = sj * ps.aperp;
         const double s_apar = sj * ps.apar;
-        int idx = lane + 64 * my_rank;
-        int i = idx / a.n_x;
-        int k = idx - i * a.n_x;
-        for (; idx < plane; idx += step) {
-          const double* mr = murec + i * kMuRec;
+        const char* mu_bytes = reinterpret_cast<const char*>(murec);
+        const char* x_bytes = reinterpret_cast<const char*>(xrec);
+        for (int idx = lane + 64 * my_rank; idx < plane; idx += step) {
+          const unsigned pk = node[idx];
+          const double* mr = reinterpret_cast<const double*>(mu_bytes + (pk & 0xffffu));
           const vk_d2 m01 = *reinterpret_cast<const vk_d2*>(mr);
-          const vk_d2 xw = *reinterpret_cast<const vk_d2*>(xrec + 2 * k);
-          const double f = fast_integrand<NLR>(svrec, vxrec, leadrec, etab, fc, ps, pl.vx_stride, s_aperp * m01.y,
+          const vk_d2 xw = *reinterpret_cast<const vk_d2*>(x_bytes + (pk >> 16));
+          const double f = fast_integrand<NLR>(svrec, vxrec, leadrec, etab, fc, ps, s_aperp * m01.y,
                                                s_apar * m01.x, xw.x, xw.y);
           const vk_d2 w01 = *reinterpret_cast<const vk_d2*>(mr + 2);
           acc[0] = fma(w01.x, f, acc[0]);
           if (NL > 1) acc[1] = fma(w01.y, f, acc[1]);
           if (NL > 2) acc[2] = fma(mr[4], f, acc[2]);
-          k += step_r;
-          i += step_q;
-          if (k >= a.n_x) { k -= a.n_x; ++i; }
         }
       }
 #pragma unroll
@@ -925,7 +942,8 @@ int theory_args(vk_ctx* ctx, const vk_eval_opts* o, TheoryArgs* a, int* nlr) {
 int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   if (a.n <= 0) return VK_OK;
   choose_split(ctx, a.n, a.n_s, &a.sbins_per_item, &a.team);
-  const bool fast = ctx->fast_ok && !getenv("VICTOR_HIP_FORCE_GENERIC");
+  // the fast kernel packs LDS byte offsets of the mu and (x, w) records into 16 bits each
+  const bool fast = ctx->fast_ok && a.n_mu <= 1024 && a.n_x <= 2048 && !getenv("VICTOR_HIP_FORCE_GENERIC");
   size_t lds;
   if (fast) {
     lds = (size_t)make_fast_plan(a.n_mu, a.n_x, a.sv.n_int, a.xi.n_int, nlr, a.n_beta_r).total * sizeof(double);

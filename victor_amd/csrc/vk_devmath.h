@@ -13,27 +13,21 @@ namespace vkm {
 
 // g ~ sqrt(x), returns also ir ~ 1/sqrt(x).  x must be a positive normal number (r^2 of a separation in
 // Mpc/h); x = 0 gives NaN, which is what the reference's r_par / r produces there too.
+// One third-order (Halley-type) step from the 2^-24 hardware seed: y' = y (1 + e/2 + 3e^2/8), e = 1 - x y^2,
+// leaves a relative error of order e^3 ~ 1e-22, i.e. the result is limited by the final roundings only.
 __device__ __forceinline__ void sqrt_rsqrt(double x, double& g, double& ir) {
-  const double y = __builtin_amdgcn_rsq(x);   // v_rsq_f64, ~2^-26 relative
-  g = x * y;
-  double h = 0.5 * y;
-  double r = fma(-h, g, 0.5);
-  g = fma(g, r, g);
-  h = fma(h, r, h);
-  const double d = fma(-g, g, x);             // residual of the square root
-  g = fma(d, h, g);
-  ir = h + h;
-  const double e = fma(-ir, g, 1.0);          // residual of the reciprocal square root
-  ir = fma(ir, e, ir);
+  const double y = __builtin_amdgcn_rsq(x);   // v_rsq_f64
+  const double e = fma(-(x * y), y, 1.0);
+  const double p = fma(0.375, e, 0.5);
+  ir = fma(y * e, p, y);
+  g = x * ir;
 }
 
-// 1/x for a positive normal x (the velocity dispersion)
+// 1/x for a positive normal x (the velocity dispersion): y' = y (1 + e + e^2), e = 1 - x y, error ~ e^3
 __device__ __forceinline__ double recip(double x) {
-  double y = __builtin_amdgcn_rcp(x);         // v_rcp_f64
-  double e = fma(-x, y, 1.0);
-  y = fma(y, e, y);
-  e = fma(-x, y, 1.0);
-  return fma(y, e, y);
+  const double y = __builtin_amdgcn_rcp(x);   // v_rcp_f64
+  const double e = fma(-x, y, 1.0);
+  return fma(y, fma(e, e, e), y);
 }
 
 // 2^(j/32), j = 0..31, to be staged in LDS by the caller (256 B)
