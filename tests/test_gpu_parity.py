@@ -226,3 +226,63 @@ def test_failure_guards(boss_fit):
         fit.log_likelihood({"beta": 0.37})
     with pytest.raises(InputError):
         fit.log_likelihood({"fsigma8": 0.47, "beta": 0.37}, likelihood={"form": "bogus"})
+
+
+# --------------------------------------------------------------------------- other RSD mappings
+@pytest.mark.parametrize("rsd", ["dispersion", "kaiser", "euclid_special"])
+def test_other_rsd_models_golden(boss_fit, gold, rsd):
+    g, meta = gold
+    fit = boss_fit["config"]
+    for i, p in enumerate(meta["boss_points"][:3]):
+        t = fit.theory_multipole_vector(fit.s, dict(p), fit.poles_s, rsd_model=rsd)
+        assert vec_close(t, g[f"boss_{rsd}_theory"][i]), (rsd, i)
+
+
+def test_kaiser_linearised_with_nuisance_parameters(boss_fit, gold):
+    g, meta = gold
+    fit = boss_fit["config"]
+    for i, p in enumerate(meta["boss_points"][:3]):
+        t = fit.theory_multipole_vector(fit.s, dict(p, M=1.1, Q=0.9), fit.poles_s, rsd_model="kaiser",
+                                        kaiser_approximation=True)
+        assert vec_close(t, g["boss_kaiser_approx_theory"][i]), i
+
+
+def test_notebook_dispersion_and_kaiser_likelihoods(boss_fit, gold):
+    g, meta = gold
+    fit = boss_fit["config"]
+    p = meta["boss_points"][0]
+    for name, printed in (("dispersion", (65.03, 284.76)), ("kaiser", (103.90, 266.81))):
+        lnl, chi2 = fit.log_likelihood(dict(p), rsd_model=name)
+        assert abs(chi2 - g[f"boss_nb_{name}"][0]) < RTOL * chi2 and abs(lnl - g[f"boss_nb_{name}"][1]) < RTOL * abs(lnl)
+        assert (round(chi2, 2), round(lnl, 2)) == printed            # victor_usage_demo.ipynb:493,495
+
+
+def test_other_rsd_models_vs_oracle_on_synthetic(synth_fit, oracle):
+    fit = synth_fit[3]
+    ora = oracle.OracleFit(*cases.synth_options(3))
+    hp = cases.halton_params(50)
+    for rsd, kw in (("dispersion", {}), ("kaiser", {}), ("kaiser", {"kaiser_coord_shift": False}),
+                    ("euclid_special", {}), ("dispersion", {"niter": 2})):
+        p = dict(cases.point(hp, 17), M=0.95, Q=1.2)
+        got = fit.log_likelihood(dict(p), rsd_model=rsd, **kw)
+        want = ora.log_likelihood(dict(p), rsd_model=rsd, **kw)
+        assert abs(got[1] / want[1] - 1) < RTOL and abs(got[0] / want[0] - 1) < RTOL, (rsd, kw)
+        xi = fit.theory_xi(fit.s, np.linspace(0, 1, 100), dict(p), rsd_model=rsd, **kw)
+        xo = ora.theory_xi(ora.s, np.linspace(0, 1, 100), dict(p), rsd_model=rsd, **kw)
+        assert np.max(np.abs(xi - xo)) < RTOL * np.max(np.abs(xo)), (rsd, kw)
+
+
+def test_generic_kernel_matches_fast_kernel(synth_fit, boss_fit):
+    """VICTOR_HIP_FORCE_GENERIC routes streaming through the generic kernel (library sqrt/div/exp, knot search)."""
+    hp = cases.halton_params(64)
+    hb = cases.halton_params(64, with_beta=True)
+    a3 = synth_fit[3].log_likelihood_batch(hp)
+    ab = boss_fit["config"].log_likelihood_batch(hb)
+    os.environ["VICTOR_HIP_FORCE_GENERIC"] = "1"
+    try:
+        b3 = synth_fit[3].log_likelihood_batch(hp)
+        bb = boss_fit["config"].log_likelihood_batch(hb)
+    finally:
+        del os.environ["VICTOR_HIP_FORCE_GENERIC"]
+    assert np.max(np.abs(a3[1] / b3[1] - 1)) < 1e-11 and np.max(np.abs(ab[1] / bb[1] - 1)) < 1e-11
+    assert not np.array_equal(a3[1], b3[1])          # different arithmetic, so not bit-identical: both paths really ran

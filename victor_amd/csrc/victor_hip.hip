@@ -69,6 +69,10 @@ struct TheoryArgs {
   double iaH;
   double inv_sigma8;
   int rescale_from_ap;
+  int rsd;                // VK_RSD_*
+  int niter;              // fixed-point iterations of the dispersion / Kaiser coordinate shift
+  int kaiser_approx;      // ccf_model.py:730-738
+  int coord_shift;        // ccf_model.py:698-707
   int sbins_per_item;     // s bins handled by one workgroup visit
   int team;               // waves cooperating on one s bin (1, 2 or 4)
   double* out;            // theory: [n][n_ell*n_s];  xi_smu: [n][n_mu][n_s]
@@ -140,6 +144,9 @@ __device__ __forceinline__ double wave_sum(double v) {
 // per-point, wave-uniform quantities (ccf_model.py:589-613, 432-450, 638)
 struct PointScalars {
   double aperp, apar, inv_c, A, B;
+  double G;       // fsigma8/(3 sigma8_tmpl):  aH^-1 v_r(r)/r = -G V(r/c)/r
+  double gD;      // fsigma8/(sigma8_tmpl c):   aH^-1 v_r'(r)  = -gD D(r/c)
+  double M, Q;    // Kaiser nuisance parameters (ccf_model.py:695-696)
   double poison;  // 0, or NaN when any input of the point is NaN/inf: added to every output so that a bad
                   // parameter can never be masked by a clamp (the reference propagates NaN, ccf_fit.py:477)
 };
@@ -203,6 +210,65 @@ __device__ __forceinline__ double streaming_integrand(const PPLds& sv, const PPL
   const double z = fma(ps.A * V, mu_r, xk) * inv_sv;
   const double e = exp(-0.5 * z * z);
   return wk * (1.0 + xir) * e * inv_sv;
+}
+
+// The other RSD mappings of the reference on the same tables:
+//   dispersion     ccf_model.py:658-671   zero-mean Gaussian pdf, iterated real-space coordinate, Jacobian
+//   kaiser         ccf_model.py:692-741   no velocity integral; nuisance M, Q; optional linearised Jacobian
+//   euclid_special ccf_model.py:743-784   as kaiser with factors 3 and 2 and the linear form
+// With q(r) = aH^-1 v_r(r)/r = -G V(r/c)/r and dq(r) = aH^-1 v_r'(r) = -gD D(r/c) the reference's expressions read
+//   r_par <- (s_par - v/aH) / (1 + M q(r)),  J = a M q + b M Q mu_r^2 (dq - q).
+// Returns f such that xi^s = sum_v f - 1 (for kaiser/euclid the "plane" has the single node x = 0, weight 1).
+template <int RSD, int NLR>
+__device__ __forceinline__ double rsd_integrand(const PPLds& sv, const PPLds& vr, const PPLds& xi, const PointScalars& ps,
+                                                const TheoryArgs& a, double s_perp, double s_par, double xk, double wk) {
+  if (RSD == VK_RSD_STREAMING) return streaming_integrand<NLR>(sv, vr, xi, ps, s_perp, s_par, xk, wk);
+  const double mfac = (RSD == VK_RSD_DISPERSION) ? 1.0 : ps.M;
+  const double num = (RSD == VK_RSD_DISPERSION) ? fma(-xk, ps.B, s_par) : s_par;
+  const double sp2 = s_perp * s_perp;
+  auto q_of = [&](double r) {
+    const double uv = clampd(r * ps.inv_c, vr.lo, vr.hi);
+    return -ps.G * pp_eval_at(vr, 0, pp_interval(vr, uv), uv) / r;
+  };
+  double r_par = s_par;
+  if (RSD == VK_RSD_DISPERSION || a.coord_shift) {
+    const double s_true = sqrt(fma(s_par, s_par, sp2));
+    r_par = num / (1.0 + mfac * q_of(s_true));
+    for (int it = 0; it < a.niter; ++it) {
+      const double r = sqrt(fma(r_par, r_par, sp2));
+      r_par = num / (1.0 + mfac * q_of(r));
+    }
+  }
+  const double r = sqrt(fma(r_par, r_par, sp2));
+  const double mu_r = r_par / r;
+  const double u = r * ps.inv_c;
+  const double uv = clampd(u, vr.lo, vr.hi);
+  const int iv = pp_interval(vr, uv);
+  const double q = -ps.G * pp_eval_at(vr, 0, iv, uv) / r;
+  const double dq = -ps.gD * pp_eval_at(vr, 1, iv, uv);
+  const double ux = clampd(u, xi.lo, xi.hi);
+  const int ix = pp_interval(xi, ux);
+  const double m2 = mu_r * mu_r;
+  double xir = pp_eval_at(xi, 0, ix, ux);
+  if (NLR > 1) {
+    xir = fma(pp_eval_at(xi, 1, ix, ux), fma(1.5, m2, -0.5), xir);
+    if (NLR > 2) xir = fma(pp_eval_at(xi, 2, ix, ux), fma(fma(35.0, m2, -30.0), m2, 3.0) * 0.125, xir);
+  }
+  if (RSD == VK_RSD_DISPERSION) {
+    const double usv = clampd(u, sv.lo, sv.hi);
+    const double SV = pp_eval_at(sv, 0, pp_interval(sv, usv), usv);
+    const double inv_sv = 1.0 / SV;
+    const double z = xk * inv_sv;
+    const double jac = 1.0 / (1.0 + q + m2 * (dq - q));
+    return wk * (1.0 + xir) * jac * exp(-0.5 * z * z) * inv_sv;
+  }
+  if (RSD == VK_RSD_KAISER) {
+    const double J = ps.M * q + ps.M * ps.Q * m2 * (dq - q);
+    if (a.kaiser_approx) return 1.0 + (ps.M * xir - J);
+    return (1.0 + ps.M * xir) / (1.0 + J);
+  }
+  const double J = 3.0 * ps.M * q + 2.0 * ps.M * ps.Q * m2 * (dq - q);
+  return 1.0 + (ps.M * xir - J);
 }
 
 // stage the batch-constant tables into LDS and fill the PPLds views
@@ -289,6 +355,10 @@ __device__ __forceinline__ PointScalars point_scalars(const TheoryArgs& a, const
   const double iaH_true = a.iaH * ps.apar;
   ps.B = sigv * iaH_true;
   ps.A = fs8 * a.inv_sigma8 / (3.0 * iaH_true * sigv);
+  ps.G = fs8 * a.inv_sigma8 / 3.0;
+  ps.gD = fs8 * a.inv_sigma8 * ps.inv_c;
+  ps.M = row[VK_P_M];
+  ps.Q = row[VK_P_Q];
   ps.poison = 0.0 * (fs8 + sigv + ps.aperp + ps.apar + eps + c + ps.A + (a.n_beta_r > 0 ? row[VK_P_BETA] : 0.0));
   return ps;
 }
@@ -296,7 +366,7 @@ __device__ __forceinline__ PointScalars point_scalars(const TheoryArgs& a, const
 // --------------------------------------------------------------------------------------------------
 // K1: theory multipoles
 // --------------------------------------------------------------------------------------------------
-template <int NLR, int NL>
+template <int RSD, int NLR, int NL>
 __global__ __launch_bounds__(kBlock) void vk_theory_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
   const LdsPlan pl = make_plan(a.n_mu, a.n_x, a.n_ell, a.sv.n_int, a.vr.n_int, a.xi.n_int, NLR, a.n_beta_r);
@@ -355,8 +425,8 @@ __global__ __launch_bounds__(kBlock) void vk_theory_kernel(TheoryArgs a) {
         int i = idx / a.n_x;
         int k = idx - i * a.n_x;
         for (; idx < plane; idx += step) {
-          const double f = streaming_integrand<NLR>(sv, vr, xi, ps, s_aperp * l_smu[i], s_apar * l_mu[i],
-                                                    l_x[k], l_wx[k]);
+          const double f = rsd_integrand<RSD, NLR>(sv, vr, xi, ps, a, s_aperp * l_smu[i], s_apar * l_mu[i],
+                                                   l_x[k], l_wx[k]);
 #pragma unroll
           for (int l = 0; l < NL; ++l) acc[l] = fma(l_w[l * a.n_mu + i], f, acc[l]);
           k += step;
@@ -652,7 +722,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
 // --------------------------------------------------------------------------------------------------
 // K1x: xi^s(mu_i, s_j), one wave per (point, mu, s) cell, lanes over the velocity nodes
 // --------------------------------------------------------------------------------------------------
-template <int NLR>
+template <int RSD, int NLR>
 __global__ __launch_bounds__(kBlock) void vk_xi_smu_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
   const LdsPlan pl = make_plan(a.n_mu, a.n_x, a.n_ell, a.sv.n_int, a.vr.n_int, a.xi.n_int, NLR, a.n_beta_r);
@@ -685,7 +755,7 @@ __global__ __launch_bounds__(kBlock) void vk_xi_smu_kernel(TheoryArgs a) {
       const double s_par = sj * l_mu[i] * ps.apar;
       double acc = 0.0;
       for (int k = lane; k < a.n_x; k += 64)
-        acc += streaming_integrand<NLR>(sv, vr, xi, ps, s_perp, s_par, l_x[k], l_wx[k]);
+        acc += rsd_integrand<RSD, NLR>(sv, vr, xi, ps, a, s_perp, s_par, l_x[k], l_wx[k]);
       acc = wave_sum(acc);
       if (lane == 0) a.out[(point * a.n_mu + i) * (long long)a.n_s + j] = acc - 1.0 + ps.poison;
     }
@@ -823,6 +893,7 @@ struct vk_ctx {
   double iaH = 0, template_sigma8 = 0;
   double* d_tables = nullptr;  // one allocation holding every table
   // device pointers into d_tables
+  const double *d_x1 = nullptr, *d_w1 = nullptr;  // single velocity node for the Kaiser-type models
   const double *d_s = nullptr, *d_mu = nullptr, *d_w = nullptr, *d_x = nullptr, *d_wx = nullptr, *d_beta_r = nullptr,
                *d_beta_d = nullptr, *d_data = nullptr, *d_beta_c = nullptr, *d_prec = nullptr, *d_logdet = nullptr,
                *d_eig = nullptr;
@@ -885,8 +956,9 @@ int ensure_scratch(vk_ctx* ctx, size_t bytes) {
 
 int check_opts(vk_ctx* ctx, const vk_eval_opts* o) {
   if (!o) return fail(ctx, VK_E_ARG, "opts is NULL");
-  if (o->rsd_model != VK_RSD_STREAMING)
-    return fail(ctx, VK_E_ARG, "rsd_model %d is not implemented on the device (streaming only)", o->rsd_model);
+  if (o->rsd_model < VK_RSD_STREAMING || o->rsd_model > VK_RSD_EUCLID)
+    return fail(ctx, VK_E_ARG, "unknown rsd_model %d", o->rsd_model);
+  if (o->niter < 0 || o->niter > 64) return fail(ctx, VK_E_ARG, "niter must be in 0..64");
   if (o->like_form < VK_LIKE_GAUSSIAN || o->like_form > VK_LIKE_PERCIVAL)
     return fail(ctx, VK_E_ARG, "unknown likelihood form %d", o->like_form);
   return VK_OK;
@@ -901,22 +973,47 @@ void choose_split(const vk_ctx* ctx, long long n, int n_s, int* spi, int* team) 
   *spi = 1; *team = 4;
 }
 
+template <int RSD, int NLR>
+int launch_generic_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
+  switch (a.n_ell) {
+    case 1: hipLaunchKernelGGL((vk_theory_kernel<RSD, NLR, 1>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+    case 2: hipLaunchKernelGGL((vk_theory_kernel<RSD, NLR, 2>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+    case 3: hipLaunchKernelGGL((vk_theory_kernel<RSD, NLR, 3>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+    default: return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
+  }
+  VK_HIP(ctx, hipGetLastError());
+  return VK_OK;
+}
+
+template <int RSD>
+int launch_generic(vk_ctx* ctx, const TheoryArgs& a, int nlr, int grid, size_t lds) {
+  switch (nlr) {
+    case 1: return launch_generic_nl<RSD, 1>(ctx, a, grid, lds);
+    case 2: return launch_generic_nl<RSD, 2>(ctx, a, grid, lds);
+    case 3: return launch_generic_nl<RSD, 3>(ctx, a, grid, lds);
+  }
+  return fail(ctx, VK_E_ARG, "bad number of real-space multipoles %d", nlr);
+}
+
 template <int NLR>
-int launch_theory_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds, bool fast) {
-  if (fast) {
-    switch (a.n_ell) {
-      case 1: hipLaunchKernelGGL((vk_theory_fast_kernel<NLR, 1>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-      case 2: hipLaunchKernelGGL((vk_theory_fast_kernel<NLR, 2>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-      case 3: hipLaunchKernelGGL((vk_theory_fast_kernel<NLR, 3>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-      default: return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
-    }
-  } else {
-    switch (a.n_ell) {
-      case 1: hipLaunchKernelGGL((vk_theory_kernel<NLR, 1>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-      case 2: hipLaunchKernelGGL((vk_theory_kernel<NLR, 2>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-      case 3: hipLaunchKernelGGL((vk_theory_kernel<NLR, 3>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-      default: return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
-    }
+int launch_fast_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
+  switch (a.n_ell) {
+    case 1: hipLaunchKernelGGL((vk_theory_fast_kernel<NLR, 1>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+    case 2: hipLaunchKernelGGL((vk_theory_fast_kernel<NLR, 2>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+    case 3: hipLaunchKernelGGL((vk_theory_fast_kernel<NLR, 3>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+    default: return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
+  }
+  VK_HIP(ctx, hipGetLastError());
+  return VK_OK;
+}
+
+template <int RSD>
+int launch_xi_smu(vk_ctx* ctx, const TheoryArgs& a, int nlr, int grid, size_t lds) {
+  switch (nlr) {
+    case 1: hipLaunchKernelGGL((vk_xi_smu_kernel<RSD, 1>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+    case 2: hipLaunchKernelGGL((vk_xi_smu_kernel<RSD, 2>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+    case 3: hipLaunchKernelGGL((vk_xi_smu_kernel<RSD, 3>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+    default: return fail(ctx, VK_E_ARG, "bad number of real-space multipoles %d", nlr);
   }
   VK_HIP(ctx, hipGetLastError());
   return VK_OK;
@@ -932,9 +1029,19 @@ int theory_args(vk_ctx* ctx, const vk_eval_opts* o, TheoryArgs* a, int* nlr) {
   a->iaH = ctx->iaH;
   a->inv_sigma8 = 1.0 / ctx->template_sigma8;
   a->rescale_from_ap = o->rescale_from_ap;
-  a->n_x = ctx->n_x;
-  a->x = ctx->d_x;
-  a->w_x = ctx->d_wx;
+  a->rsd = o->rsd_model;
+  a->niter = o->niter;
+  a->kaiser_approx = o->kaiser_approx;
+  a->coord_shift = o->kaiser_coord_shift;
+  if (o->rsd_model == VK_RSD_KAISER || o->rsd_model == VK_RSD_EUCLID) {
+    a->n_x = 1;                 // no velocity integral: a single node x = 0 with unit weight
+    a->x = ctx->d_x1;
+    a->w_x = ctx->d_w1;
+  } else {
+    a->n_x = ctx->n_x;
+    a->x = ctx->d_x;
+    a->w_x = ctx->d_wx;
+  }
   *nlr = o->assume_isotropic ? 1 : ctx->n_ell_r;
   return VK_OK;
 }
@@ -942,8 +1049,9 @@ int theory_args(vk_ctx* ctx, const vk_eval_opts* o, TheoryArgs* a, int* nlr) {
 int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   if (a.n <= 0) return VK_OK;
   choose_split(ctx, a.n, a.n_s, &a.sbins_per_item, &a.team);
-  // the fast kernel packs LDS byte offsets of the mu and (x, w) records into 16 bits each
-  const bool fast = ctx->fast_ok && a.n_mu <= 1024 && a.n_x <= 2048 && !getenv("VICTOR_HIP_FORCE_GENERIC");
+  // the fast kernel (streaming only) packs LDS byte offsets of the mu and (x, w) records into 16 bits each
+  const bool fast = a.rsd == VK_RSD_STREAMING && ctx->fast_ok && a.n_mu <= 1024 && a.n_x <= 2048 &&
+                    !getenv("VICTOR_HIP_FORCE_GENERIC");
   size_t lds;
   if (fast) {
     lds = (size_t)make_fast_plan(a.n_mu, a.n_x, a.sv.n_int, a.xi.n_int, nlr, a.n_beta_r).total * sizeof(double);
@@ -956,12 +1064,21 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   const long long items = a.n * groups;
   const long long cap = 8LL * ctx->n_cu;
   const int grid = (int)(items < cap ? items : cap);
-  switch (nlr) {
-    case 1: return launch_theory_nl<1>(ctx, a, grid, lds, fast);
-    case 2: return launch_theory_nl<2>(ctx, a, grid, lds, fast);
-    case 3: return launch_theory_nl<3>(ctx, a, grid, lds, fast);
+  if (fast) {
+    switch (nlr) {
+      case 1: return launch_fast_nl<1>(ctx, a, grid, lds);
+      case 2: return launch_fast_nl<2>(ctx, a, grid, lds);
+      case 3: return launch_fast_nl<3>(ctx, a, grid, lds);
+    }
+    return fail(ctx, VK_E_ARG, "bad number of real-space multipoles %d", nlr);
   }
-  return fail(ctx, VK_E_ARG, "bad number of real-space multipoles %d", nlr);
+  switch (a.rsd) {
+    case VK_RSD_STREAMING: return launch_generic<VK_RSD_STREAMING>(ctx, a, nlr, grid, lds);
+    case VK_RSD_DISPERSION: return launch_generic<VK_RSD_DISPERSION>(ctx, a, nlr, grid, lds);
+    case VK_RSD_KAISER: return launch_generic<VK_RSD_KAISER>(ctx, a, nlr, grid, lds);
+    case VK_RSD_EUCLID: return launch_generic<VK_RSD_EUCLID>(ctx, a, nlr, grid, lds);
+  }
+  return fail(ctx, VK_E_ARG, "unknown rsd_model %d", a.rsd);
 }
 
 int launch_like(vk_ctx* ctx, const vk_eval_opts* o, const double* d_params, const double* d_theory, long long n,
@@ -1135,6 +1252,8 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
   const size_t o_s = up.add(t->s, t->n_s), o_mu = up.add(t->mu, t->n_mu),
                o_w = up.add(t->w_ell, (size_t)t->n_ell * t->n_mu), o_x = up.add(t->x, t->n_x),
                o_wx = up.add(t->w_x, t->n_x);
+  const double zero_one[2] = {0.0, 1.0};
+  const size_t o_x1 = up.add(zero_one, 2);
   const size_t o_br = t->n_beta_r > 0 ? up.add(t->beta_r, t->n_beta_r) : 0;
   const size_t xi_coef_n = t->n_beta_r > 0 ? (size_t)t->n_ell_r * (t->n_beta_r - 1) * t->xi.n_int * 16
                                            : (size_t)t->n_ell_r * t->xi.n_int * 4;
@@ -1163,6 +1282,7 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
   if ((rc = hipMemcpy(ctx->d_tables, up.host.data(), bytes, hipMemcpyHostToDevice)) != hipSuccess)
     return hip_bail(rc, "hipMemcpy(tables)");
   const double* base = ctx->d_tables;
+  ctx->d_x1 = base + o_x1; ctx->d_w1 = base + o_x1 + 1;
   ctx->d_s = base + o_s; ctx->d_mu = base + o_mu; ctx->d_w = base + o_w; ctx->d_x = base + o_x; ctx->d_wx = base + o_wx;
   ctx->d_beta_r = t->n_beta_r > 0 ? base + o_br : nullptr;
   auto view = [&](const vk_pp& p, size_t ok, size_t oc) {
@@ -1369,12 +1489,13 @@ static int general_grid(vk_ctx* ctx, const vk_eval_opts* opts, const double* par
     const int grid = (int)(n < cap ? n : cap);
     a.sbins_per_item = 1;
     a.team = 1;
-    switch (nlr) {
-      case 1: hipLaunchKernelGGL((vk_xi_smu_kernel<1>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-      case 2: hipLaunchKernelGGL((vk_xi_smu_kernel<2>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-      default: hipLaunchKernelGGL((vk_xi_smu_kernel<3>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+    switch (a.rsd) {
+      case VK_RSD_STREAMING: rc = launch_xi_smu<VK_RSD_STREAMING>(ctx, a, nlr, grid, lds); break;
+      case VK_RSD_DISPERSION: rc = launch_xi_smu<VK_RSD_DISPERSION>(ctx, a, nlr, grid, lds); break;
+      case VK_RSD_KAISER: rc = launch_xi_smu<VK_RSD_KAISER>(ctx, a, nlr, grid, lds); break;
+      default: rc = launch_xi_smu<VK_RSD_EUCLID>(ctx, a, nlr, grid, lds); break;
     }
-    VK_HIP(ctx, hipGetLastError());
+    if (rc) return rc;
   }
   VK_HIP(ctx, hipMemcpyAsync(out, d_out, out_n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
