@@ -90,11 +90,11 @@ def boss_options(variant="config"):
     return model, data
 
 
-def synth_tables():
-    """SURVEY.md App. E (deterministic, no RNG)."""
+def synth_tables(dc=-0.9, rs=38.0):
+    """SURVEY.md App. E (deterministic, no RNG); (dc, rs) vary per density-split quantile (section 8d config 5)."""
     r = 1.5 + 3.0 * np.arange(40)
 
-    def h(x, dc=-0.9, rs=38.0, rv=45.0, a=2.2, b=7.5):
+    def h(x, dc=dc, rs=rs, rv=45.0, a=2.2, b=7.5):
         return dc * (1 - (x / rs) ** a) / (1 + (x / rv) ** b)
 
     rdelta = 1.2 + 2.4 * np.arange(60)
@@ -264,6 +264,30 @@ def main():
         out[f"synth{config}_chi2"] = np.array(chi)
         out[f"synth{config}_lnl"] = np.array(lnl)
         out[f"synth{config}_xi_smu_p0"] = fit.theory_xi(*np.meshgrid(fit.s, np.linspace(0, 1, 100)), dict(pts[0]))
+
+    # ---- density-split style joint fit: 5 table sets sharing one parameter vector ----
+    dsplit_pts = hp[:6]
+    tot_chi = np.zeros(len(dsplit_pts))
+    tot_lnl = np.zeros(len(dsplit_pts))
+    for q in range(5):
+        tq = synth_tables(dc=-0.9 + 0.4 * q, rs=38.0 + 4.0 * q)
+        save_dict(os.path.join(GOLD, "dsplit", f"model_q{q}.npy"), tq)
+        model, data = synth_options(3)
+        model["input_model_data_file"] = f"dsplit/model_q{q}.npy"
+        data["redshift_space_ccf"]["data_file"] = f"dsplit/data_q{q}.npy"
+        model["dir"] = data["dir"] = GOLD
+        cm = v.CCFModel(model)
+        t_fid = cm.theory_multipole_vector(s, dict(fid), [0, 2, 4])
+        dvec = t_fid * (1 + 0.01 * np.sin(np.arange(len(t_fid)) + q))
+        save_dict(os.path.join(GOLD, "dsplit", f"data_q{q}.npy"),
+                  {"s": s, "monopole": dvec[:40], "quadrupole": dvec[40:80], "hexadecapole": dvec[80:]})
+        fit = v.CCFFit(model, data)
+        for i, p in enumerate(dsplit_pts):
+            l, c = fit.log_likelihood(dict(p))
+            tot_chi[i] += c
+            tot_lnl[i] += l
+    out["dsplit_chi2"] = tot_chi
+    out["dsplit_lnl"] = tot_lnl
 
     out["meta_json"] = np.array(json.dumps(meta))
     np.savez_compressed(os.path.join(GOLD, "ref_outputs.npz"), **out)

@@ -110,3 +110,18 @@ def point(pdict, i):
 
 def clone(d):
     return copy.deepcopy(d)
+
+
+def dsplit_options(q):
+    """Quantile q of the 5-quantile joint fit: config-3 options on its own tables."""
+    model, data = synth_options(3)
+    model["input_model_data_file"] = f"dsplit/model_q{q}.npy"
+    data["redshift_space_ccf"]["data_file"] = f"dsplit/data_q{q}.npy"
+    return model, data
+
+
+def cobaya_info():
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "config", "boss_cobaya_config.yaml")) as fh:
+        return yaml.full_load(fh)

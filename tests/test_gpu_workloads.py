@@ -1,0 +1,88 @@
+"""BASELINE.json configs [3] and [4] as parity cases on the GPU (the bench line is config [2])."""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+
+
+def test_walker_ensemble_matches_oracle_driven_chain():
+    """Config [3]: 8 Metropolis walkers on the BOSS cobaya configuration.  The same seeded chain is driven once
+    by the HIP likelihood and once by the CPU oracle: every accept/reject decision and position must coincide."""
+    import victor_amd
+    import victor_oracle as vo
+    from victor_amd.sampler import EnsembleMetropolis, parse_cobaya_params
+    info = cases.cobaya_info()
+    specs, fixed = parse_cobaya_params(info["params"])
+    lk = info["likelihood"]["CCFLikelihood"]
+    fit = victor_amd.CCFFit(lk["model"], lk["data"])
+    ora = vo.OracleFit(*cases.boss_options("cobaya"))
+
+    def gpu_eval(batch):
+        return fit.log_likelihood_batch(batch)[0]
+
+    def cpu_eval(batch):
+        n = len(batch["fsigma8"])
+        return np.array([ora.log_likelihood(cases.point(batch, i))[0] for i in range(n)])
+
+    g = EnsembleMetropolis(gpu_eval, specs, 8, seed=2024, fixed=fixed).initialise()
+    c = EnsembleMetropolis(cpu_eval, specs, 8, seed=2024, fixed=fixed).initialise()
+    cg, lg = g.run(5)
+    cc, lc = c.run(5)
+    assert np.array_equal(cg, cc)
+    assert np.max(np.abs(lg / lc - 1)) < 1e-9
+    assert g.n_accept == c.n_accept and g.n_evals == c.n_evals
+
+
+def test_cobaya_plugin_calculate_on_gpu():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "victor", "likelihoods"))
+    from CCFLikelihood import CCFLikelihood
+    info = cases.cobaya_info()["likelihood"]["CCFLikelihood"]
+    lk = CCFLikelihood(dict(model=info["model"], data=info["data"]))
+    state = {}
+    assert lk.calculate(state, want_derived=True, fsigma8=0.47, beta=0.37, sigma_v=380, epsilon=1.0) is None
+    g, _ = cases.golden_outputs()
+    assert abs(state["logp"] - g["boss_cobaya_lnl"][0]) < 1e-9 * abs(state["logp"])
+    assert abs(state["derived"]["chi2_ccf_correct"] - g["boss_cobaya_chi2"][0]) < 1e-9 * g["boss_cobaya_chi2"][0]
+    lnl, chi2 = lk.calculate_batch({"fsigma8": np.array([0.47, 0.5]), "beta": 0.37, "sigma_v": 380, "epsilon": 1.0})
+    assert abs(lnl[0] - state["logp"]) < 1e-12 * abs(lnl[0]) and lnl.shape == (2,)
+
+
+def test_config_file_route_of_plugin(tmp_path, monkeypatch):
+    """model/data omitted -> the plug-in loads config/boss_config.yaml relative to the working directory."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.chdir(root)
+    sys.path.insert(0, os.path.join(root, "victor", "likelihoods"))
+    from CCFLikelihood import CCFLikelihood
+    lk = CCFLikelihood(dict(model=None, data=None, config_file="config/boss_config.yaml"))
+    state = {}
+    lk.calculate(state, fsigma8=0.47, beta=0.37, sigma_v=380, epsilon=1.0)
+    assert round(state["derived"]["chi2_ccf_correct"], 2) == 65.01 and round(state["logp"], 2) == 284.76
+
+
+def test_density_split_joint_fit():
+    """Config [4]: five stacked data vectors with block-diagonal precision (N = 5 x 120), one parameter vector."""
+    import victor_amd
+    from victor_amd.joint import JointFit
+    joint = JointFit([victor_amd.CCFFit(*cases.dsplit_options(q)) for q in range(5)])
+    assert joint.n_data == 600
+    g, meta = cases.golden_outputs()
+    pts = meta["synth_points"][:6]
+    batch = {k: np.array([p[k] for p in pts]) for k in pts[0]}
+    lnl, chi2 = joint.log_likelihood_batch(batch)
+    assert np.max(np.abs(chi2 / g["dsplit_chi2"] - 1)) < 1e-9
+    assert np.max(np.abs(lnl / g["dsplit_lnl"] - 1)) < 1e-9
+    # full-size batch of the config: properties that do not need the oracle
+    hp = cases.halton_params(16384)
+    lnl, chi2 = joint.log_likelihood_batch(hp)
+    assert lnl.shape == (16384,) and np.all(np.isfinite(lnl))
+    assert np.max(np.abs(lnl + 0.5 * chi2)) < 1e-9 * np.max(chi2)
+    parts = sum(f.log_likelihood_batch({k: v[:64] for k, v in hp.items()})[1] for f in joint.fits)
+    assert np.max(np.abs(parts / chi2[:64] - 1)) < 1e-12      # sub-batches use a different work split / summation order
