@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 1
+#define VK_ABI_VERSION 2
 
 /* error codes */
 #define VK_OK 0
@@ -46,7 +46,7 @@ extern "C" {
 #define VK_E_RCCL (-4)     /* an RCCL call failed */
 
 /* one row of the parameter batch: VK_NPAR doubles (ccf_model.py:583-613,638,695-696) */
-#define VK_NPAR 10
+#define VK_NPAR 12
 #define VK_P_FSIGMA8 0 /* params['fsigma8']                                   */
 #define VK_P_SIGMAV 1  /* params.get('sigma_v', 380)                          */
 #define VK_P_APERP 2   /* alpha_perp  (from aperp, or epsilon*apar)           */
@@ -56,13 +56,19 @@ extern "C" {
 #define VK_P_ASTAR 6   /* params.get('astar', 1)                              */
 #define VK_P_M 7       /* Kaiser nuisance M (default 1)                       */
 #define VK_P_Q 8       /* Kaiser nuisance Q (default 1)                       */
-#define VK_P_SPARE 9
+#define VK_P_BIAS 9    /* params.get('bias', model['bias']) - linear_bias matter model (ccf_model.py:359,430) */
+#define VK_P_AV 10     /* params.get('Av', 0) - empirical velocity correction (ccf_model.py:453) */
+#define VK_P_SPARE 11
 
 /* vk_eval_opts.rsd_model (ccf_model.py:646-787) */
 #define VK_RSD_STREAMING 0
 #define VK_RSD_DISPERSION 1
 #define VK_RSD_KAISER 2
 #define VK_RSD_EUCLID 3
+
+/* vk_tables.matter_model (ccf_model.py:71,358-372) */
+#define VK_MATTER_TEMPLATE 0
+#define VK_MATTER_LINEAR_BIAS 1
 
 /* vk_eval_opts.like_form (ccf_fit.py:455-473) */
 #define VK_LIKE_GAUSSIAN 0
@@ -111,9 +117,16 @@ typedef struct vk_tables {
                            index being the power of (beta - beta_r[k]) (PCHIP in beta,
                            ccf_model.py:323-326, composed with the not-a-knot spline in r) */
 
-  /* ---- matter template -> velocity profile (ccf_model.py:421-450,625-636) -- */
-  vk_pp vr;             /* coef[2][n_int][4]: V(u) = u*Delta(u) and D(u) = delta - 2 Delta/3
-                           splined on r_ext = [0.01, r...]                     */
+  /* ---- matter profile -> velocity profile (ccf_model.py:421-459,625-636) --- */
+  int32_t matter_model; /* VK_MATTER_TEMPLATE or VK_MATTER_LINEAR_BIAS: selects the per-point amplitude
+                           (growth term and powers of 1/bias, ccf_model.py:426-435)                */
+  int32_t vr_beta_dep;  /* 0: velocity tables fixed; 1: they depend on the reconstruction beta through
+                           xi^r_0 (linear_bias with reconstruction): PCHIP-in-beta form on beta_r  */
+  vk_pp vr;             /* splined on r_ext = [0.01, r...]:
+                           fixed:  coef[5][n_int][4] = V1 = r*Delta, Da = delta - 2 Delta/3,
+                                   V2 = r*Delta*delta, Ge1, Ge2 (numerical-gradient tables of the
+                                   empirical_corr branch, ccf_model.py:455-459; /3 folded in)
+                           beta-dependent: coef[2][n_beta_r-1][n_int][4][4] = V1, Da              */
   /* ---- velocity dispersion template (ccf_model.py:654-655) ----------------- */
   vk_pp sv;             /* coef[1][n_int][4]: normalised sigma_v(r) shape       */
 
@@ -144,6 +157,9 @@ typedef struct vk_eval_opts {
   int32_t kaiser_approx;     /* ccf_model.py:730-738                            */
   int32_t kaiser_coord_shift;/* ccf_model.py:698-707                            */
   int32_t niter;             /* fixed-point iterations (ccf_model.py:661,701), default 5 */
+  int32_t from_data;         /* realspace_ccf_from_data: xi^r evaluated at fiducial coordinates, un-rescaled
+                                abscissae (ccf_model.py:618-619,675-679); growth term beta*bias for linear_bias */
+  int32_t empirical_corr;    /* velocity multiplied by (1 + Av delta(r)) (ccf_model.py:451-459)          */
   int32_t reserved;
 } vk_eval_opts;
 

@@ -265,6 +265,60 @@ def main():
         out[f"synth{config}_lnl"] = np.array(lnl)
         out[f"synth{config}_xi_smu_p0"] = fit.theory_xi(*np.meshgrid(fit.s, np.linspace(0, 1, 100)), dict(pts[0]))
 
+    # ---- remaining model options: linear_bias, empirical_corr, from_data + MD covariance ----
+    save_dict(os.path.join(GOLD, "boss", "measured_model.npy"), ref_shim._h5_read(src + "measured_model.hdf5"))
+    save_dict(os.path.join(GOLD, "boss", "cov_md_iso.npy"),
+              ref_shim._h5_read(src + "variable_isotropic_MD_covariance.hdf5"))
+    model, data = boss_options("config")
+    model["dir"] = data["dir"] = GOLD
+    fit = v.CCFFit(model, data)
+    pts3 = [dict(q, bias=2.1, Av=0.7, M=1.05, Q=0.95) for q in boss_points[:3]]
+    opt_cases = {
+        "lb_stream": dict(matter_model="linear_bias"),
+        "lb_kaiser": dict(matter_model="linear_bias", rsd_model="kaiser"),
+        "lb_disp": dict(matter_model="linear_bias", rsd_model="dispersion"),
+        "emp_stream": dict(empirical_corr=True),
+        "emp_disp": dict(empirical_corr=True, rsd_model="dispersion"),
+        "emp_kaiser": dict(empirical_corr=True, rsd_model="kaiser"),
+    }
+    for tag, kw in opt_cases.items():
+        out[f"opt_boss_{tag}"] = np.array([fit.theory_multipole_vector(fit.s, dict(q), fit.poles_s, **kw) for q in pts3])
+    # fixed real-space input (synthetic tables): linear_bias with and without the empirical correction
+    model, data = synth_options(3)
+    model["dir"] = data["dir"] = GOLD
+    fit = v.CCFFit(model, data)
+    spts = [dict(q, beta=0.4, bias=1.7, Av=-0.5, M=1.1, Q=0.9) for q in hp[:3]]   # beta: required key, value unused
+    for tag, kw in dict(opt_cases, lb_emp_stream=dict(matter_model="linear_bias", empirical_corr=True),
+                        lb_emp_disp=dict(matter_model="linear_bias", empirical_corr=True, rsd_model="dispersion")).items():
+        out[f"opt_synth_{tag}"] = np.array([fit.theory_multipole_vector(fit.s, dict(q), fit.poles_s, **kw) for q in spts])
+    # real-space ccf measured from the data itself + the matching (M+D) covariance on its own 15-node beta grid
+    model, data = boss_options("config")
+    model["dir"] = data["dir"] = GOLD
+    model["input_model_data_file"] = "boss/measured_model.npy"
+    model["realspace_ccf"]["from_data"] = True
+    data["covariance_matrix"]["data_file"] = "boss/cov_md_iso.npy"
+    fit = v.CCFFit(model, data)
+    fd_pts = [dict(q) for q in boss_points]
+    out["opt_fromdata_theory"] = np.array([fit.theory_multipole_vector(fit.s, dict(q), fit.poles_s) for q in fd_pts])
+    ll = [fit.log_likelihood(dict(q)) for q in fd_pts]
+    out["opt_fromdata_lnl"] = np.array([a for a, b in ll])
+    out["opt_fromdata_chi2"] = np.array([b for a, b in ll])
+    out["opt_fromdata_aniso_theory"] = np.array(
+        [fit.theory_multipole_vector(fit.s, dict(q), fit.poles_s, assume_isotropic=False) for q in fd_pts[:3]])
+    out["opt_fromdata_lb_kaiser"] = np.array(
+        [fit.theory_multipole_vector(fit.s, dict(q, bias=2.0), fit.poles_s, matter_model="linear_bias", rsd_model="kaiser")
+         for q in fd_pts[:3]])
+    # host-side accessors used in the notebooks
+    r_plot = np.linspace(0.01, 120, 100)
+    model, data = boss_options("config")
+    model["dir"] = data["dir"] = GOLD
+    cm = v.CCFModel(model)
+    out["acc_delta_lb"] = np.array(cm.delta_profiles(r_plot, {"beta": 0.37}, matter_model="linear_bias"))
+    out["acc_delta_tmpl"] = np.array(cm.delta_profiles(r_plot, {"beta": 0.37}))
+    out["acc_vterms"] = np.array(cm.velocity_terms(cm.r, {"fsigma8": 0.47, "epsilon": 1.0, "beta": 0.37}))
+    out["acc_vterms_emp"] = np.array(cm.velocity_terms(cm.r, {"fsigma8": 0.47, "epsilon": 1.0, "beta": 0.37, "Av": 1},
+                                                       empirical_corr=True))
+
     # ---- density-split style joint fit: 5 table sets sharing one parameter vector ----
     dsplit_pts = hp[:6]
     tot_chi = np.zeros(len(dsplit_pts))

@@ -37,7 +37,8 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_native.SYMBOLS), declared ^ set(_native.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.vk_abi_version() == 1
+    from victor_amd import _native as N2
+    assert lib.vk_abi_version() == N2.VK_ABI_VERSION == 2
 
 
 def test_struct_layouts_match_header(lib):
@@ -122,6 +123,20 @@ def test_host_accessors_match_oracle(boss_fit):
     assert np.allclose(np.diag(c), 1.0)
 
 
+def test_notebook_accessors_match_reference(boss_fit):
+    """delta_profiles / velocity_terms as called in the reference's notebooks (host-side accessors)."""
+    g, _ = cases.golden_outputs()
+    r_plot = np.linspace(0.01, 120, 100)
+    got = np.array(boss_fit.delta_profiles(r_plot, {"beta": 0.37}, matter_model="linear_bias"))
+    assert np.max(np.abs(got - g["acc_delta_lb"])) < 1e-14
+    got = np.array(boss_fit.delta_profiles(r_plot, {"beta": 0.37}))
+    assert np.max(np.abs(got - g["acc_delta_tmpl"])) < 1e-14
+    p = {"fsigma8": 0.47, "epsilon": 1.0, "beta": 0.37}
+    assert np.max(np.abs(np.array(boss_fit.velocity_terms(boss_fit.r, p)) / g["acc_vterms"] - 1)) < 1e-12
+    got = np.array(boss_fit.velocity_terms(boss_fit.r, dict(p, Av=1), empirical_corr=True))
+    assert np.max(np.abs(got / g["acc_vterms_emp"] - 1)) < 1e-12
+
+
 def test_compiled_tables(boss_fit):
     from victor_amd.engine import build_tables
     t, keep = build_tables(boss_fit, boss_fit)
@@ -140,7 +155,9 @@ def test_compiled_tables(boss_fit):
         got = logdet[k] + np.sum(np.log(1 - tt + tt * eig[k]))
         assert abs(got - want) < 1e-9
     ft, _ = build_tables(__import__("victor_amd").CCFFit(*cases.synth_options(3)), None)
-    assert ft.n_beta_r == 0 and ft.n_ell_r == 3 and not ft.data
+    assert ft.n_beta_r == 0 and ft.n_ell_r == 3 and not ft.data and ft.vr_beta_dep == 0 and ft.matter_model == 0
+    lb, _ = build_tables(boss_fit, None, "linear_bias")
+    assert lb.vr_beta_dep == 1 and lb.matter_model == 1 and lb.vr.n_int == 30
 
 
 def test_param_rows(boss_fit):
@@ -205,7 +222,10 @@ def test_input_errors(tmp_path):
     with pytest.raises(InputError):
         m._check_supported(dict(m.model, rsd_model="bogus"))
     with pytest.raises(InputError):
-        m._check_supported(dict(m.model, matter_model="linear_bias"))
+        m._check_supported(dict(m.model, matter_model="excursion_set"))
+    with pytest.raises(InputError):
+        m._check_supported(dict(m.model, matter_model="linear_bias", empirical_corr=True))   # beta-dependent input
+    m._check_supported(dict(m.model, matter_model="linear_bias"))
 
 
 # --------------------------------------------------------------------------- readers

@@ -11,9 +11,10 @@ import os
 
 import numpy as np
 
-VK_ABI_VERSION = 1
-VK_NPAR = 10
-(P_FSIGMA8, P_SIGMAV, P_APERP, P_APAR, P_EPSILON, P_BETA, P_ASTAR, P_M, P_Q, P_SPARE) = range(10)
+VK_ABI_VERSION = 2
+VK_NPAR = 12
+(P_FSIGMA8, P_SIGMAV, P_APERP, P_APAR, P_EPSILON, P_BETA, P_ASTAR, P_M, P_Q, P_BIAS, P_AV, P_SPARE) = range(12)
+MATTER = {"template": 0, "linear_bias": 1}
 RSD = {"streaming": 0, "dispersion": 1, "kaiser": 2, "euclid_special": 3}
 LIKE = {"gaussian": 0, "sellentin": 1, "hartlap": 2, "percival": 3}
 VK_COMM_ID_BYTES = 128
@@ -31,7 +32,7 @@ class vk_tables(C.Structure):
         ("n_s", C.c_int32), ("n_mu", C.c_int32), ("n_x", C.c_int32), ("n_ell", C.c_int32),
         ("s", _dp), ("mu", _dp), ("w_ell", _dp), ("x", _dp), ("w_x", _dp),
         ("n_ell_r", C.c_int32), ("n_beta_r", C.c_int32), ("beta_r", _dp), ("xi", vk_pp),
-        ("vr", vk_pp), ("sv", vk_pp),
+        ("matter_model", C.c_int32), ("vr_beta_dep", C.c_int32), ("vr", vk_pp), ("sv", vk_pp),
         ("iaH", C.c_double), ("template_sigma8", C.c_double),
         ("n_beta_d", C.c_int32), ("beta_d", _dp), ("data", _dp),
         ("n_beta_c", C.c_int32), ("beta_c", _dp), ("prec", _dp), ("logdet", _dp), ("eig", _dp),
@@ -43,7 +44,7 @@ class vk_eval_opts(C.Structure):
         ("rsd_model", C.c_int32), ("assume_isotropic", C.c_int32), ("rescale_from_ap", C.c_int32),
         ("like_form", C.c_int32), ("nmocks", C.c_double), ("nparams", C.c_double),
         ("kaiser_approx", C.c_int32), ("kaiser_coord_shift", C.c_int32), ("niter", C.c_int32),
-        ("reserved", C.c_int32),
+        ("from_data", C.c_int32), ("empirical_corr", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

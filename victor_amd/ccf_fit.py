@@ -162,17 +162,14 @@ class CCFFit(CCFModel):
         return self.get_interpolated_redshift_multipoles(beta).reshape(len(self.poles_s) * len(self.s))
 
     # ------------------------------------------------------------------ device plumbing -------
-    def _get_engine(self):
-        if self._engine is None:
-            from .engine import Engine
-            self._engine = Engine(self, self, device=self._device)
-        return self._engine
+    def _fit_side(self):
+        return self
 
     def _fit_rows(self, params, model):
         need_beta = self._needs_beta(model) or not self.fixed_data
         if not isinstance(params, np.ndarray) and not self.fixed_data and params.get("beta", None) is None:
             raise InputError("Need to supply a valid value of beta for interpolation")   # ccf_fit.py:188-189
-        return self._param_rows(params, need_beta)
+        return self._param_rows(params, need_beta, self._needs_fsigma8(model))
 
     def _merged_fit(self, kwargs):
         fit_options = dict(self.fit_options)
@@ -183,7 +180,7 @@ class CCFFit(CCFModel):
         model = self._merged(kwargs)
         self._check_supported(model)
         fit_options = self._merged_fit(kwargs)
-        eng = self._get_engine()
+        eng = self._get_engine(model["matter_model"])
         opts = eng.make_opts(model, fit_options)
         rows = self._fit_rows(params, model)
         if fit_options["beta_interpolation"] == "likelihood" and not self.fixed_data:
@@ -238,5 +235,5 @@ class CCFFit(CCFModel):
         """Theory vectors (n, N) on the data's own s grid and multipoles."""
         model = self._merged(kwargs)
         self._check_supported(model)
-        eng = self._get_engine()
+        eng = self._get_engine(model["matter_model"])
         return eng.theory_vector_batch(eng.make_opts(model), self._fit_rows(params, model))

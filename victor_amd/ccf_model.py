@@ -255,14 +255,101 @@ class CCFModel:
             raise InputError("Need to supply a valid value of beta for interpolation")
         return np.atleast_2d(T.pchip(self.beta, np.moveaxis(stack, 1, 0))(beta))
 
+    # ------------------------------------------------------------------ matter / velocity profiles ---
+    def _linear_bias_maps(self, r_nodes):
+        """Matrices (Bd, Td) with  b*delta(r_nodes) = Bd @ y  and  b*Delta(r_nodes) = Td @ y  for nodal values
+        y of the real-space monopole on ``self.r``: the reference's spline of xi^r_0 and its 100-point
+        trapezoid integral 3/(b r^3) int_0^r xi x^2 dx (ccf_model.py:358-370) are both linear in y."""
+        r_nodes = np.asarray(r_nodes, dtype=float)
+        basis = T.notaknot(self.r, np.eye(len(self.r)))
+        Bd = basis(r_nodes)
+        Td = np.empty_like(Bd)
+        for n, rn in enumerate(r_nodes):
+            x = np.linspace(0, rn, 100)
+            Td[n] = 3.0 / rn ** 3 * ((T.trapezoid_weights(x) * x ** 2) @ basis(x))
+        return Bd, Td
+
+    def _matter_nodal(self, matter_model, r_nodes, beta=None):
+        """(delta, Delta) at ``r_nodes`` with the 1/bias factors left out (they are per-point amplitudes)."""
+        if matter_model == "template":
+            return self.delta(r_nodes), self.integrated_delta(r_nodes)
+        if matter_model == "linear_bias":
+            y = self.get_interpolated_real_multipoles(beta)[0]
+            Bd, Td = self._linear_bias_maps(r_nodes)
+            return Bd @ y, Td @ y
+        if matter_model == "excursion_set":
+            raise InputError("matter_model 'excursion_set' is not implemented in victor_amd")
+        raise InputError(f"Invalid choice of matter_model {matter_model}")
+
     def delta_profiles(self, r, params, **kwargs):
-        """delta(r), Delta(r) for the template matter model (reference: ccf_model.py:328-372)."""
+        """delta(r) and its volume average Delta(r) (reference: ccf_model.py:328-383).  Host-side accessor (used
+        for plots and set-up); the likelihood kernels use the precompiled tables instead."""
         model = self._merged(kwargs)
-        if model["matter_model"] == "template":
-            return self.delta(r), self.integrated_delta(r)
-        if model["matter_model"] in ("linear_bias", "excursion_set"):
-            raise InputError(f"matter_model '{model['matter_model']}' is not implemented in victor_amd")
-        raise InputError(f"Invalid choice of matter_model {model['matter_model']}")
+        r = np.asarray(r, dtype=float)
+        d, D = self._matter_nodal(model["matter_model"], r, params.get("beta", None))
+        if model["matter_model"] == "linear_bias":
+            bias = params.get("bias", model["bias"])
+            return d / bias, D / bias
+        return d, D
+
+    def _empirical_gradient_tables(self, r_ext, delta_ext, int_delta_ext):
+        """Nodal values (at r_ext) of the two numerical-derivative pieces of the empirical_corr branch
+        (ccf_model.py:455-459): d/dr of r*Delta and of r*Delta*delta on linspace(0.1, r_max, 100)."""
+        rg = np.linspace(0.1, self.r.max(), 100)
+        Ds = T.notaknot(r_ext, int_delta_ext)(rg)
+        ds = T.notaknot(r_ext, delta_ext)(rg)
+        g1 = T.notaknot(rg, np.gradient(rg * Ds, rg))(r_ext)
+        g2 = T.notaknot(rg, np.gradient(rg * Ds * ds, rg))(r_ext)
+        return g1, g2
+
+    def velocity_terms(self, r, params, **kwargs):
+        """Mean radial velocity v_r(r) and its derivative (reference: ccf_model.py:385-492).  Host-side accessor
+        for the linear mean model; the kernels evaluate the same profile from tables with per-point amplitudes."""
+        model = self._merged(kwargs)
+        self._check_supported(model)
+        r = np.asarray(r, dtype=float)
+        if "epsilon" in params:
+            apar = params.get("alpha", 1) * params["epsilon"] ** (-2 / 3)
+        else:
+            apar = params.get("apar", 1)
+        iaH_true = self.iaH * apar
+        delta_r, int_delta_r = self.delta_profiles(r, params, **kwargs)
+        if model["matter_model"] == "linear_bias" and model["realspace_ccf_from_data"]:
+            growth = params["beta"] * params.get("bias", model["bias"])
+        else:
+            growth = params["fsigma8"] / self.template_sigma8
+        if not model["empirical_corr"]:
+            vr = -growth * r * int_delta_r / (3 * iaH_true)
+            dvr = -growth * (delta_r - 2 * int_delta_r / 3) / iaH_true
+        else:
+            Av = params.get("Av", 0)
+            vr = -growth * r * int_delta_r * (1 + Av * delta_r) / (3 * iaH_true)
+            rg = np.linspace(0.1, self.r.max(), 100)
+            Ds = T.notaknot(r, int_delta_r)(rg)
+            ds = T.notaknot(r, delta_r)(rg)
+            vg = -growth * rg * Ds * (1 + Av * ds) / (3 * iaH_true)
+            dvr = T.notaknot(rg, np.gradient(vg, rg))(r)
+        return vr, dvr
+
+    def _velocity_tables(self, matter_model):
+        """Coefficient arrays of the velocity tables on r_ext = [0.01, r...] for one matter model.
+
+        Returns ``(coef, beta_dependent)``: fixed -> (5, n_r, 4) for V1 = r*Delta, Da = delta - 2 Delta/3,
+        V2 = r*Delta*delta, Ge1, Ge2; beta-dependent -> (2, n_beta-1, n_r, 4, 4) for V1, Da.
+        """
+        r_ext = np.append([0.01], self.r)
+        if matter_model == "linear_bias" and not self.fixed_real_input:
+            Bd, Td = self._linear_bias_maps(r_ext)
+            ypoly = T.pchip_coefficients(self.beta, self.real_multipoles["0"])      # (n_beta-1, 4, n_r)
+            d_poly = np.einsum("nm,kpm->kpn", Bd, ypoly)
+            D_poly = np.einsum("nm,kpm->kpn", Td, ypoly)
+            V1 = T.spline_table_from_beta_poly(r_ext, r_ext * D_poly)
+            Da = T.spline_table_from_beta_poly(r_ext, d_poly - 2 * D_poly / 3)
+            return np.stack([V1, Da]), True
+        d, D = self._matter_nodal(matter_model, r_ext)
+        g1, g2 = self._empirical_gradient_tables(r_ext, d, D)
+        nodal = np.stack([r_ext * D, d - 2 * D / 3, r_ext * D * d, g1 / 3, g2 / 3], axis=1)   # (n_ext, 5)
+        return np.moveaxis(T.notaknot_coefficients(r_ext, nodal), 2, 0), False              # (5, n_r, 4)
 
     # ------------------------------------------------------------------ device plumbing -------
     def _merged(self, kwargs):
@@ -270,28 +357,39 @@ class CCFModel:
         model.update(kwargs)
         return model
 
-    def _get_engine(self):
+    def _get_engine(self, matter_model=None):
+        """One device context per matter model (its tables differ); created on first use."""
+        matter_model = matter_model or self.matter_model
         if self._engine is None:
+            self._engine = {}
+        if matter_model not in self._engine:
             from .engine import Engine
-            self._engine = Engine(self, None, device=self._device)
-        return self._engine
+            self._engine[matter_model] = Engine(self, self._fit_side(), device=self._device, matter_model=matter_model)
+        return self._engine[matter_model]
+
+    def _fit_side(self):
+        return None
 
     def _check_supported(self, model):
         problems = list(self._unsupported)
-        if model["matter_model"] != "template":
-            problems.append(f"matter_model '{model['matter_model']}'")
+        if model["matter_model"] == "excursion_set":
+            problems.append("matter_model 'excursion_set'")
+        elif model["matter_model"] not in ("template", "linear_bias"):
+            raise InputError(f"Invalid choice of matter_model {model['matter_model']}")
+        if model["matter_model"] == "template" and not hasattr(self, "delta"):
+            raise InputError("matter_model 'template' requested but no matter ccf template was loaded")
+        if model["matter_model"] == "linear_bias" and not model["realspace_ccf_from_data"] and not self.template_sigma8:
+            raise InputError("template_sigma8 must be provided for the linear_bias matter model")
         if model["mean_model"] != "linear":
             problems.append(f"velocity mean model '{model['mean_model']}'")
-        if model["empirical_corr"]:
-            problems.append("empirical_corr")
-        if model["realspace_ccf_from_data"]:
-            problems.append("realspace_ccf from_data")
+        if model["empirical_corr"] and model["matter_model"] == "linear_bias" and not self.fixed_real_input:
+            problems.append("empirical_corr together with linear_bias on a beta-dependent real-space ccf")
         if model["rsd_model"] not in N.RSD:
             raise InputError(f"theory_xi: Unrecognised choice of model {model['rsd_model']}")
         if problems:
             raise InputError("not implemented on the HIP path (and there is no CPU fallback): " + ", ".join(problems))
 
-    def _param_rows(self, params, need_beta):
+    def _param_rows(self, params, need_beta, need_fsigma8=True):
         """dict of scalars or equal-length arrays -> (n, VK_NPAR) rows (reference: ccf_model.py:583-613,638)."""
         if isinstance(params, np.ndarray):
             rows = N.f64(params)
@@ -308,7 +406,10 @@ class CCFModel:
         def col(v):
             return np.broadcast_to(np.asarray(v, dtype=float), (n,))
 
-        rows[:, N.P_FSIGMA8] = col(params["fsigma8"])            # KeyError if absent, as ccf_model.py:435
+        if need_fsigma8:
+            rows[:, N.P_FSIGMA8] = col(params["fsigma8"])        # KeyError if absent, as ccf_model.py:432-435
+        else:
+            rows[:, N.P_FSIGMA8] = col(get("fsigma8", 0.0))      # growth term is beta*bias (ccf_model.py:430)
         rows[:, N.P_SIGMAV] = col(get("sigma_v", 380))
         if "epsilon" in params:
             eps = col(params["epsilon"])
@@ -329,11 +430,25 @@ class CCFModel:
         rows[:, N.P_ASTAR] = col(get("astar", 1))
         rows[:, N.P_M] = col(get("M", 1.0))
         rows[:, N.P_Q] = col(get("Q", 1.0))
+        rows[:, N.P_BIAS] = col(get("bias", self.model["bias"]))
+        rows[:, N.P_AV] = col(get("Av", 0))
         rows[:, N.P_SPARE] = 0.0
         return rows
 
     def _needs_beta(self, model):
         return not (self.fixed_real_input and model["matter_model"] != "linear_bias")
+
+    def _needs_fsigma8(self, model):
+        # growth term: beta*bias for linear_bias on a measured real-space ccf, fsigma8/sigma8 otherwise
+        return not (model["matter_model"] == "linear_bias" and model["realspace_ccf_from_data"])
+
+    def _prepare(self, params, model):
+        """(engine, opts, rows) for one call with merged options ``model``."""
+        self._check_supported(model)
+        eng = self._get_engine(model["matter_model"])
+        opts = eng.make_opts(model)
+        rows = self._param_rows(params, self._needs_beta(model), self._needs_fsigma8(model))
+        return eng, opts, rows
 
     # ------------------------------------------------------------------ theory (device) --------
     def theory_xi(self, s, mu, params, **kwargs):
@@ -346,7 +461,6 @@ class CCFModel:
 
     def theory_xi_batch(self, s, mu, params, **kwargs):
         model = self._merged(kwargs)
-        self._check_supported(model)
         s = np.atleast_1d(s)
         mu = np.atleast_1d(mu)
         if np.ndim(s) == 2 and np.ndim(mu) == 2:
@@ -355,9 +469,7 @@ class CCFModel:
             s, mu = np.unique(s), np.unique(mu)
         elif not (np.ndim(s) == 1 and np.ndim(mu) == 1):
             raise InputError("theory_xi: arguments s and mu have incompatible dimensions")
-        eng = self._get_engine()
-        opts = eng.make_opts(model)
-        rows = self._param_rows(params, self._needs_beta(model))
+        eng, opts, rows = self._prepare(params, model)
         return eng.xi_smu_batch(opts, rows, s, mu)
 
     def theory_multipoles(self, s, params, poles=[0, 2], **kwargs):
@@ -369,13 +481,10 @@ class CCFModel:
     def theory_multipoles_batch(self, s, params, poles=[0, 2], **kwargs):
         """Batched form: returns an array of shape (n_points, n_poles, n_s)."""
         model = self._merged(kwargs)
-        self._check_supported(model)
         poles = np.atleast_1d(poles)
         if len(poles) > 3 or np.any(poles > 4) or np.any(poles < 0):
             raise InputError("at most three multipoles with 0 <= ell <= 4 are supported")
-        eng = self._get_engine()
-        opts = eng.make_opts(model)
-        rows = self._param_rows(params, self._needs_beta(model))
+        eng, opts, rows = self._prepare(params, model)
         return eng.theory_batch(opts, rows, np.asarray(s, dtype=float), poles)
 
     def theory_multipole_vector(self, s, params, poles=[0, 2], **kwargs):

@@ -42,6 +42,7 @@ namespace {
 constexpr int kBlock = 256;               // 4 wavefronts
 constexpr int kWaves = kBlock / 64;
 constexpr int kMaxEll = 3;
+constexpr int kVrVars = 5;               // V1, Da, V2, Ge1, Ge2 (see vk_tables.vr)
 
 // --------------------------------------------------------------------------------------------------
 // device-side views
@@ -69,6 +70,10 @@ struct TheoryArgs {
   double iaH;
   double inv_sigma8;
   int rescale_from_ap;
+  int matter_lb;          // linear_bias matter model: amplitudes carry 1/bias (ccf_model.py:358-370,426-435)
+  int vr_beta_dep;        // velocity tables are PCHIP-in-beta polynomials (rebuilt per point)
+  int from_data;          // ccf_model.py:618-619,675-679
+  int empirical;          // ccf_model.py:451-459
   int rsd;                // VK_RSD_*
   int niter;              // fixed-point iterations of the dispersion / Kaiser coordinate shift
   int kaiser_approx;      // ccf_model.py:730-738
@@ -147,6 +152,8 @@ struct PointScalars {
   double G;       // fsigma8/(3 sigma8_tmpl):  aH^-1 v_r(r)/r = -G V(r/c)/r
   double gD;      // fsigma8/(sigma8_tmpl c):   aH^-1 v_r'(r)  = -gD D(r/c)
   double M, Q;    // Kaiser nuisance parameters (ccf_model.py:695-696)
+  double av;      // Av (divided by bias for linear_bias) when empirical_corr is on, else 0
+  double inv_aperp, inv_apar;
   double poison;  // 0, or NaN when any input of the point is NaN/inf: added to every output so that a bad
                   // parameter can never be masked by a clamp (the reference propagates NaN, ccf_fit.py:477)
 };
@@ -170,7 +177,7 @@ __host__ __device__ inline LdsPlan make_plan(int n_mu, int n_x, int n_ell, int s
   p.svc = o;  o += sv_int * 4;
   p.vrk = o;  o += vr_int + 1;
   o = (o + 1) & ~1;
-  p.vrc = o;  o += 2 * vr_int * 4;
+  p.vrc = o;  o += kVrVars * vr_int * 4;
   p.xik = o;  o += xi_int + 1;
   o = (o + 1) & ~1;
   p.xic = o;  o += n_ell_r * xi_int * 4;
@@ -180,12 +187,43 @@ __host__ __device__ inline LdsPlan make_plan(int n_mu, int n_x, int n_ell, int s
   return p;
 }
 
+// xi^r(r, mu_r) summed over the first NLR real-space multipoles (ccf_model.py:681-687).  With
+// realspace_ccf_from_data the point is first mapped back to fiducial coordinates and the table abscissae are
+// not rescaled (ccf_model.py:618-619, 675-679).
+template <int NLR>
+__device__ __forceinline__ double xi_real(const PPLds& xi, const PointScalars& ps, const TheoryArgs& a, double u,
+                                          double mu_r, double r_par, double s_perp) {
+  if (a.from_data) {
+    const double rp = r_par * ps.inv_apar;
+    const double rt = s_perp * ps.inv_aperp;
+    u = sqrt(fma(rp, rp, rt * rt));
+    mu_r = rp / u;
+  }
+  const double ux = clampd(u, xi.lo, xi.hi);
+  const int ix = pp_interval(xi, ux);
+  double xir = pp_eval_at(xi, 0, ix, ux);
+  if (NLR > 1) {
+    const double m2 = mu_r * mu_r;
+    xir = fma(pp_eval_at(xi, 1, ix, ux), fma(1.5, m2, -0.5), xir);
+    if (NLR > 2) xir = fma(pp_eval_at(xi, 2, ix, ux), fma(fma(35.0, m2, -30.0), m2, 3.0) * 0.125, xir);
+  }
+  return xir;
+}
+
+// V(u) = V1 + av V2 : the velocity profile shape, v_r(r) = -gb V(r/c) / (3 aH)
+__device__ __forceinline__ double vel_shape(const PPLds& vr, const PointScalars& ps, const TheoryArgs& a, int iv,
+                                            double uv) {
+  double V = pp_eval_at(vr, 0, iv, uv);
+  if (a.empirical) V = fma(ps.av, pp_eval_at(vr, 2, iv, uv), V);
+  return V;
+}
+
 // One integrand point of the streaming model (ccf_model.py:648-657, 681-690), already multiplied by the
 // Simpson weight.  NLR = number of real-space multipoles summed (1 = assume_isotropic).
 template <int NLR>
 __device__ __forceinline__ double streaming_integrand(const PPLds& sv, const PPLds& vr, const PPLds& xi,
-                                                      const PointScalars& ps, double s_perp, double s_par,
-                                                      double xk, double wk) {
+                                                      const PointScalars& ps, const TheoryArgs& a, double s_perp,
+                                                      double s_par, double xk, double wk) {
   const double r_par = fma(-xk, ps.B, s_par);
   const double r = sqrt(fma(s_perp, s_perp, r_par * r_par));
   const double mu_r = r_par / r;
@@ -194,18 +232,8 @@ __device__ __forceinline__ double streaming_integrand(const PPLds& sv, const PPL
   const double usv = clampd(u, sv.lo, sv.hi);
   const double SV = pp_eval_at(sv, 0, pp_interval(sv, usv), usv);
   const double uv = clampd(u, vr.lo, vr.hi);
-  const double V = pp_eval_at(vr, 0, pp_interval(vr, uv), uv);
-  const double ux = clampd(u, xi.lo, xi.hi);
-  const int ix = pp_interval(xi, ux);
-  double xir = pp_eval_at(xi, 0, ix, ux);
-  if (NLR > 1) {
-    const double m2 = mu_r * mu_r;
-    xir = fma(pp_eval_at(xi, 1, ix, ux), fma(1.5, m2, -0.5), xir);
-    if (NLR > 2) {
-      const double p4 = fma(fma(35.0, m2, -30.0), m2, 3.0) * 0.125;
-      xir = fma(pp_eval_at(xi, 2, ix, ux), p4, xir);
-    }
-  }
+  const double V = vel_shape(vr, ps, a, pp_interval(vr, uv), uv);
+  const double xir = xi_real<NLR>(xi, ps, a, u, mu_r, r_par, s_perp);
   const double inv_sv = 1.0 / SV;
   const double z = fma(ps.A * V, mu_r, xk) * inv_sv;
   const double e = exp(-0.5 * z * z);
@@ -222,13 +250,13 @@ __device__ __forceinline__ double streaming_integrand(const PPLds& sv, const PPL
 template <int RSD, int NLR>
 __device__ __forceinline__ double rsd_integrand(const PPLds& sv, const PPLds& vr, const PPLds& xi, const PointScalars& ps,
                                                 const TheoryArgs& a, double s_perp, double s_par, double xk, double wk) {
-  if (RSD == VK_RSD_STREAMING) return streaming_integrand<NLR>(sv, vr, xi, ps, s_perp, s_par, xk, wk);
+  if (RSD == VK_RSD_STREAMING) return streaming_integrand<NLR>(sv, vr, xi, ps, a, s_perp, s_par, xk, wk);
   const double mfac = (RSD == VK_RSD_DISPERSION) ? 1.0 : ps.M;
   const double num = (RSD == VK_RSD_DISPERSION) ? fma(-xk, ps.B, s_par) : s_par;
   const double sp2 = s_perp * s_perp;
   auto q_of = [&](double r) {
     const double uv = clampd(r * ps.inv_c, vr.lo, vr.hi);
-    return -ps.G * pp_eval_at(vr, 0, pp_interval(vr, uv), uv) / r;
+    return -ps.G * vel_shape(vr, ps, a, pp_interval(vr, uv), uv) / r;
   };
   double r_par = s_par;
   if (RSD == VK_RSD_DISPERSION || a.coord_shift) {
@@ -244,16 +272,12 @@ __device__ __forceinline__ double rsd_integrand(const PPLds& sv, const PPLds& vr
   const double u = r * ps.inv_c;
   const double uv = clampd(u, vr.lo, vr.hi);
   const int iv = pp_interval(vr, uv);
-  const double q = -ps.G * pp_eval_at(vr, 0, iv, uv) / r;
-  const double dq = -ps.gD * pp_eval_at(vr, 1, iv, uv);
-  const double ux = clampd(u, xi.lo, xi.hi);
-  const int ix = pp_interval(xi, ux);
+  const double q = -ps.G * vel_shape(vr, ps, a, iv, uv) / r;
+  // derivative table: analytic delta - 2 Delta/3, or the numerical-gradient tables of the empirical branch
+  const double Dq = a.empirical ? fma(ps.av, pp_eval_at(vr, 4, iv, uv), pp_eval_at(vr, 3, iv, uv)) : pp_eval_at(vr, 1, iv, uv);
+  const double dq = -ps.gD * Dq;
   const double m2 = mu_r * mu_r;
-  double xir = pp_eval_at(xi, 0, ix, ux);
-  if (NLR > 1) {
-    xir = fma(pp_eval_at(xi, 1, ix, ux), fma(1.5, m2, -0.5), xir);
-    if (NLR > 2) xir = fma(pp_eval_at(xi, 2, ix, ux), fma(fma(35.0, m2, -30.0), m2, 3.0) * 0.125, xir);
-  }
+  const double xir = xi_real<NLR>(xi, ps, a, u, mu_r, r_par, s_perp);
   if (RSD == VK_RSD_DISPERSION) {
     const double usv = clampd(u, sv.lo, sv.hi);
     const double SV = pp_eval_at(sv, 0, pp_interval(sv, usv), usv);
@@ -288,7 +312,8 @@ __device__ void stage_tables(const TheoryArgs& a, const LdsPlan& pl, double* lds
   for (int i = tid; i <= a.sv.n_int; i += kBlock) lds[pl.svk + i] = a.sv.knots[i];
   for (int i = tid; i < a.sv.n_int * 4; i += kBlock) lds[pl.svc + i] = a.sv.coef[i];
   for (int i = tid; i <= a.vr.n_int; i += kBlock) lds[pl.vrk + i] = a.vr.knots[i];
-  for (int i = tid; i < 2 * a.vr.n_int * 4; i += kBlock) lds[pl.vrc + i] = a.vr.coef[i];
+  for (int i = tid; i < kVrVars * a.vr.n_int * 4; i += kBlock)
+    lds[pl.vrc + i] = a.vr_beta_dep ? 0.0 : a.vr.coef[i];
   for (int i = tid; i <= a.xi.n_int; i += kBlock) lds[pl.xik + i] = a.xi.knots[i];
   if (a.n_beta_r == 0) {
     for (int i = tid; i < n_ell_r_used * a.xi.n_int * 4; i += kBlock) lds[pl.xic + i] = a.xi.coef[i];
@@ -326,6 +351,16 @@ __device__ void build_beta_tables(const TheoryArgs& a, const LdsPlan& pl, double
     const double* c = a.xi.coef + l * stride_l + ((size_t)k * per_l + iq) * 4;
     lds[pl.xic + e] = fma(fma(fma(c[3], db, c[2]), db, c[1]), db, c[0]);
   }
+  if (a.vr_beta_dep) {   // V1 and Da follow xi^r_0(beta) (linear_bias with reconstruction)
+    const int per_v = a.vr.n_int * 4;
+    const size_t stride_v = (size_t)(a.n_beta_r - 1) * per_v * 4;
+    for (int e = threadIdx.x; e < 2 * per_v; e += kBlock) {
+      const int var = e / per_v;
+      const int iq = e - var * per_v;
+      const double* c = a.vr.coef + var * stride_v + ((size_t)k * per_v + iq) * 4;
+      lds[pl.vrc + e] = fma(fma(fma(c[3], db, c[2]), db, c[1]), db, c[0]);
+    }
+  }
 }
 
 __device__ __forceinline__ PointScalars point_scalars(const TheoryArgs& a, const double* row) {
@@ -353,13 +388,30 @@ __device__ __forceinline__ PointScalars point_scalars(const TheoryArgs& a, const
   }
   ps.inv_c = 1.0 / c;
   const double iaH_true = a.iaH * ps.apar;
+  // growth term and powers of the bias (ccf_model.py:426-435, 358-370): v_r = -gb [V1 + av V2](r/c) / (3 aH)
+  double growth = fs8 * a.inv_sigma8;
+  double binv = 1.0, extra = 0.0;
+  if (a.matter_lb) {
+    const double bias = row[VK_P_BIAS];
+    if (a.from_data) growth = row[VK_P_BETA] * bias;
+    binv = 1.0 / bias;
+    extra += bias;
+  }
+  const double gb = growth * binv;
+  ps.av = 0.0;
+  if (a.empirical) {
+    ps.av = row[VK_P_AV] * binv;
+    extra += ps.av;
+  }
   ps.B = sigv * iaH_true;
-  ps.A = fs8 * a.inv_sigma8 / (3.0 * iaH_true * sigv);
-  ps.G = fs8 * a.inv_sigma8 / 3.0;
-  ps.gD = fs8 * a.inv_sigma8 * ps.inv_c;
+  ps.A = gb / (3.0 * iaH_true * sigv);
+  ps.G = gb / 3.0;
+  ps.gD = gb * ps.inv_c;
   ps.M = row[VK_P_M];
   ps.Q = row[VK_P_Q];
-  ps.poison = 0.0 * (fs8 + sigv + ps.aperp + ps.apar + eps + c + ps.A + (a.n_beta_r > 0 ? row[VK_P_BETA] : 0.0));
+  ps.inv_aperp = 1.0 / ps.aperp;
+  ps.inv_apar = 1.0 / ps.apar;
+  ps.poison = 0.0 * (gb + sigv + ps.aperp + ps.apar + eps + c + ps.A + extra + (a.n_beta_r > 0 ? row[VK_P_BETA] : 0.0));
   return ps;
 }
 
@@ -899,6 +951,7 @@ struct vk_ctx {
                *d_eig = nullptr;
   PPView xi{}, vr{}, sv{};
   bool fast_ok = false;      // tables qualify for vk_theory_fast_kernel
+  int matter_lb = 0, vr_beta_dep = 0;
   // scratch for the host-buffer entry points
   double* d_scratch = nullptr;
   size_t scratch_bytes = 0;
@@ -1029,6 +1082,12 @@ int theory_args(vk_ctx* ctx, const vk_eval_opts* o, TheoryArgs* a, int* nlr) {
   a->iaH = ctx->iaH;
   a->inv_sigma8 = 1.0 / ctx->template_sigma8;
   a->rescale_from_ap = o->rescale_from_ap;
+  a->matter_lb = ctx->matter_lb;
+  a->vr_beta_dep = ctx->vr_beta_dep;
+  a->from_data = o->from_data ? 1 : 0;
+  a->empirical = o->empirical_corr ? 1 : 0;
+  if (a->empirical && a->vr_beta_dep)
+    return fail(ctx, VK_E_ARG, "empirical_corr with a beta-dependent linear_bias velocity profile is not implemented");
   a->rsd = o->rsd_model;
   a->niter = o->niter;
   a->kaiser_approx = o->kaiser_approx;
@@ -1050,8 +1109,8 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   if (a.n <= 0) return VK_OK;
   choose_split(ctx, a.n, a.n_s, &a.sbins_per_item, &a.team);
   // the fast kernel (streaming only) packs LDS byte offsets of the mu and (x, w) records into 16 bits each
-  const bool fast = a.rsd == VK_RSD_STREAMING && ctx->fast_ok && a.n_mu <= 1024 && a.n_x <= 2048 &&
-                    !getenv("VICTOR_HIP_FORCE_GENERIC");
+  const bool fast = a.rsd == VK_RSD_STREAMING && ctx->fast_ok && !a.from_data && !a.empirical && !a.vr_beta_dep &&
+                    a.n_mu <= 1024 && a.n_x <= 2048 && !getenv("VICTOR_HIP_FORCE_GENERIC");
   size_t lds;
   if (fast) {
     lds = (size_t)make_fast_plan(a.n_mu, a.n_x, a.sv.n_int, a.xi.n_int, nlr, a.n_beta_r).total * sizeof(double);
@@ -1166,6 +1225,8 @@ void vk_default_opts(vk_eval_opts* o) {
   o->kaiser_approx = 0;
   o->kaiser_coord_shift = 1;
   o->niter = 5;
+  o->from_data = 0;
+  o->empirical_corr = 0;
 }
 
 const char* vk_last_error(const vk_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
@@ -1205,6 +1266,8 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
   if (check_pp(&t->xi, "xi", &e) || check_pp(&t->vr, "vr", &e) || check_pp(&t->sv, "sv", &e)) return bail(e);
   if (t->n_beta_r == 1 || t->n_beta_d == 1 || t->n_beta_c == 1) return bail("beta grids need at least 2 nodes");
   if (t->n_beta_r > 0 && !t->beta_r) return bail("beta_r missing");
+  if (t->vr_beta_dep && t->n_beta_r < 2) return bail("beta-dependent velocity tables need the beta_r grid");
+  if (t->matter_model != VK_MATTER_TEMPLATE && t->matter_model != VK_MATTER_LINEAR_BIAS) return bail("unknown matter_model");
   const int N = t->n_ell * t->n_s;
   if (t->data || t->prec) {
     if (!t->data || !t->prec) return bail("data and prec must be given together");
@@ -1246,7 +1309,9 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
       for (int i = 0; i <= t->xi.n_int && ok; ++i) ok = fabs(t->vr.knots[i + 1] - t->xi.knots[i]) <= tol;
       ok = ok && fabs(t->vr.inv_h - t->xi.inv_h) <= 1e-12 * t->xi.inv_h;
     }
-    ctx->fast_ok = ok;
+    ctx->fast_ok = ok && !t->vr_beta_dep;
+    ctx->matter_lb = t->matter_model == VK_MATTER_LINEAR_BIAS;
+    ctx->vr_beta_dep = t->vr_beta_dep ? 1 : 0;
   }
   Uploader up;
   const size_t o_s = up.add(t->s, t->n_s), o_mu = up.add(t->mu, t->n_mu),
@@ -1258,7 +1323,8 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
   const size_t xi_coef_n = t->n_beta_r > 0 ? (size_t)t->n_ell_r * (t->n_beta_r - 1) * t->xi.n_int * 16
                                            : (size_t)t->n_ell_r * t->xi.n_int * 4;
   const size_t o_xik = up.add(t->xi.knots, t->xi.n_int + 1), o_xic = up.add(t->xi.coef, xi_coef_n);
-  const size_t o_vrk = up.add(t->vr.knots, t->vr.n_int + 1), o_vrc = up.add(t->vr.coef, (size_t)2 * t->vr.n_int * 4);
+  const size_t vr_coef_n = t->vr_beta_dep ? (size_t)2 * (t->n_beta_r - 1) * t->vr.n_int * 16 : (size_t)kVrVars * t->vr.n_int * 4;
+  const size_t o_vrk = up.add(t->vr.knots, t->vr.n_int + 1), o_vrc = up.add(t->vr.coef, vr_coef_n);
   const size_t o_svk = up.add(t->sv.knots, t->sv.n_int + 1), o_svc = up.add(t->sv.coef, (size_t)t->sv.n_int * 4);
   size_t o_bd = 0, o_data = 0, o_bc = 0, o_prec = 0, o_ld = 0, o_eig = 0;
   if (t->data) {
@@ -1389,7 +1455,8 @@ int vk_eval_batch_device_async(vk_ctx* ctx, const vk_eval_opts* opts, const doub
   VK_HIP(ctx, hipSetDevice(ctx->device));
   TheoryArgs a{};
   int nlr = 1;
-  theory_args(ctx, opts, &a, &nlr);
+  rc = theory_args(ctx, opts, &a, &nlr);
+  if (rc) return rc;
   a.params = d_params;
   a.n = n;
   a.n_s = ctx->n_s; a.n_mu = ctx->n_mu; a.n_ell = ctx->n_ell;
@@ -1472,7 +1539,8 @@ static int general_grid(vk_ctx* ctx, const vk_eval_opts* opts, const double* par
     VK_HIP(ctx, hipMemsetAsync(d_w, 0, (size_t)n_mu * sizeof(double), ctx->stream));
   TheoryArgs a{};
   int nlr = 1;
-  theory_args(ctx, opts, &a, &nlr);
+  rc = theory_args(ctx, opts, &a, &nlr);
+  if (rc) return rc;
   a.params = d_par;
   a.n = n;
   a.n_s = n_s; a.n_mu = n_mu; a.n_ell = ne;

@@ -29,7 +29,7 @@ def _pp(knots, coef, lead=0):
     return pp, (knots, coef)
 
 
-def build_tables(model, fit=None):
+def build_tables(model, fit=None, matter_model=None):
     """Compile a :class:`CCFModel` (and optionally the data side of a :class:`CCFFit`) into vk_tables.
 
     Returns ``(tables, keepalive)``.
@@ -75,13 +75,15 @@ def build_tables(model, fit=None):
     t.xi, k = _pp(r, coef)
     keep.append(k)
 
-    # velocity profile: V = r*Delta(r) and D = delta - 2 Delta/3 on r_ext (ccf_model.py:625, 449-450)
+    # velocity profile tables on r_ext = [0.01, r...] (ccf_model.py:625, 449-459) for the chosen matter model
+    matter_model = matter_model or model.matter_model
+    if matter_model not in N.MATTER:
+        raise InputError(f"matter_model '{matter_model}' is not implemented on the HIP path")
     r_ext = np.append([0.01], r)
-    delta_ext = model.delta(r_ext)
-    int_delta_ext = model.integrated_delta(r_ext)
-    V = T.notaknot_coefficients(r_ext, r_ext * int_delta_ext)
-    D = T.notaknot_coefficients(r_ext, delta_ext - 2 * int_delta_ext / 3)
-    t.vr, k = _pp(r_ext, np.stack([V, D]), lead=1)
+    vr_coef, vr_beta_dep = model._velocity_tables(matter_model)
+    t.matter_model = N.MATTER[matter_model]
+    t.vr_beta_dep = 1 if vr_beta_dep else 0
+    t.vr, k = _pp(r_ext, vr_coef, lead=1)
     keep.append(k)
 
     # dispersion template (isotropic): the bicubic RectBivariateSpline of ccf_model.py:654 through
@@ -91,7 +93,8 @@ def build_tables(model, fit=None):
     keep.append(k)
 
     t.iaH = float(model.iaH)
-    t.template_sigma8 = float(model.template_sigma8)
+    # not used when the growth term is beta*bias (linear_bias on a measured real-space ccf)
+    t.template_sigma8 = float(model.template_sigma8) if model.template_sigma8 else 1.0
 
     # data side -----------------------------------------------------------------------------
     if fit is not None:
@@ -134,11 +137,11 @@ def build_tables(model, fit=None):
 
 
 class Engine:
-    def __init__(self, model, fit=None, device=0):
+    def __init__(self, model, fit=None, device=0, matter_model=None):
         self._lib = N.load()
         if self._lib.vk_device_count() <= 0:
             raise N.NativeError("no HIP device visible; victor_amd has no CPU fallback")
-        tables, keep = build_tables(model, fit)
+        tables, keep = build_tables(model, fit, matter_model)
         err = C.create_string_buffer(512)
         self._ctx = self._lib.vk_create(C.byref(tables), int(device), err, len(err))
         del keep
@@ -181,6 +184,8 @@ class Engine:
         o.kaiser_approx = 1 if model_opts.get("kaiser_approximation", False) else 0
         o.kaiser_coord_shift = 1 if model_opts.get("kaiser_coord_shift", True) else 0
         o.niter = int(model_opts.get("niter", 5))
+        o.from_data = 1 if model_opts.get("realspace_ccf_from_data", False) else 0
+        o.empirical_corr = 1 if model_opts.get("empirical_corr", False) else 0
         if fit_opts is not None:
             like = fit_opts["likelihood"]
             form = like["form"].lower()

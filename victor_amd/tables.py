@@ -258,15 +258,30 @@ def uniform_spacing(knots, lead=0, rtol=1e-9):
     return None
 
 
+def spline_table_from_beta_poly(r, nodal_poly):
+    """Spline coefficients of nodal values given as polynomials in beta.
+
+    ``nodal_poly`` (n_beta-1, 4[p], n_r): nodal value at r_n on beta interval k is sum_p nodal_poly[k, p, n]
+    (beta - beta_k)^p.  Returns (n_beta-1, n_r-1, 4[q], 4[p]): coefficient of (u - r_i)^q (beta - beta_k)^p.
+    Exact, because the not-a-knot spline is linear in its nodal values.
+    """
+    lin = notaknot_coefficients(r, np.eye(len(r)))              # (n_r-1, 4[q], n_r)
+    return np.einsum("iqn,kpn->kiqp", lin, np.asarray(nodal_poly, dtype=np.float64))
+
+
 def beta_dependent_spline_table(r, beta, values):
     """Coefficients of the r-spline of PCHIP-in-beta nodal values, as polynomials in beta.
 
-    ``values`` (n_beta, n_r).  Returns (n_beta-1, n_r-1, 4, 4): [k, i, q, p] multiplies
-    (u - r_i)^q (beta - beta_k)^p.  The not-a-knot spline is linear in its nodal values, so
-    composing it with the PCHIP pieces of every node (``ccf_model.py:323-326`` then
-    ``:619-621``) is exact.
+    ``values`` (n_beta, n_r).  Composes ``ccf_model.py:323-326`` (PCHIP over beta) with ``:619-621`` (spline in r).
     """
-    values = np.asarray(values, dtype=np.float64)
-    pc = pchip_coefficients(beta, values)                       # (n_beta-1, 4[p], n_r)
-    lin = notaknot_coefficients(r, np.eye(len(r)))              # (n_r-1, 4[q], n_r)
-    return np.einsum("iqn,kpn->kiqp", lin, pc)
+    return spline_table_from_beta_poly(r, pchip_coefficients(beta, np.asarray(values, dtype=np.float64)))
+
+
+def trapezoid_weights(x):
+    """w with ``np.trapz(y, x) == w @ y``."""
+    x = np.asarray(x, dtype=np.float64)
+    w = np.zeros_like(x)
+    d = np.diff(x)
+    w[:-1] += 0.5 * d
+    w[1:] += 0.5 * d
+    return w
