@@ -140,7 +140,7 @@ def main():
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cores = host_cores()
-        ns = min(args.cpu_sample or max(16, 12 * cores), B)      # ~12 evaluations (~1.5 s each at N=120) per core
+        ns = min(args.cpu_sample or max(16, 25 * cores), B)      # ~25 oracle evaluations per core: 10-30 s of CPU work
         sel = np.linspace(0, B - 1, ns).astype(int)
         base, vals = cpu_baseline([cases.point(mine, int(i)) for i in sel])
 
@@ -216,7 +216,7 @@ def main():
                                    "(N=120), AP-dependent rescale, sigma_v(r) template, gaussian likelihood",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"batch-sharded x{world}",
                        "gather": "rccl allgather of lnL" if use_comm else "none (single process)"},
-            "roofline": {"bound": "fp64-valu", "kernel": "vk_theory_kernel<3,3>",
+            "roofline": {"bound": "fp64-valu", "kernel": "vk_theory_fast_kernel<3,3>",
                          "achieved": achieved_tf, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / PEAK_FP64_VALU_TFLOPS if achieved_tf else None,
                          "traffic": traffic, "flops_per_eval": F, "kernel_ms": k1_ms,

@@ -600,7 +600,7 @@ __device__ __forceinline__ double fast_integrand(const double* __restrict__ svre
   if (NLR > 1) {
     const double m2 = mu_r * mu_r;
     xir = fma(cubic_b128(rec + 8, tq), fma(1.5, m2, -0.5), xir);
-    if (NLR > 2) xir = fma(cubic_b128(rec + 12, tq), fma(fma(4.375, m2, -3.75), m2, 0.375), xir);
+    if (NLR > 2) xir = fma(cubic_b128(rec + 12, tq), vkm::fma3(vkm::fma3(m2, 4.375, -3.75), m2, 0.375), xir);
   }
   const double inv_sv = vkm::recip(SV);
   const double z = fma(ps.A * V, mu_r, xk) * inv_sv;
