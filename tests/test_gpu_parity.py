@@ -286,3 +286,31 @@ def test_generic_kernel_matches_fast_kernel(synth_fit, boss_fit):
         del os.environ["VICTOR_HIP_FORCE_GENERIC"]
     assert np.max(np.abs(a3[1] / b3[1] - 1)) < 1e-11 and np.max(np.abs(ab[1] / bb[1] - 1)) < 1e-11
     assert not np.array_equal(a3[1], b3[1])          # different arithmetic, so not bit-identical: both paths really ran
+
+
+def test_lanes_over_batch_mapping_matches_point_major(synth_fit, gold):
+    """The two work mappings of the theory kernel (wave = point x s-bin vs wave = s-bin x 64 points) must agree."""
+    g, meta = gold
+    out = {}
+    hp = cases.halton_params(8192 + 37)              # not a multiple of 64: exercises the ragged last chunk
+    for config in (2, 3):
+        fit = synth_fit[config]
+        for mapping in ("point", "lanes"):
+            os.environ["VICTOR_HIP_MAPPING"] = mapping
+            try:
+                out[mapping] = fit.log_likelihood_batch(hp)
+            finally:
+                del os.environ["VICTOR_HIP_MAPPING"]
+            # golden points through each mapping as well
+            pts = list(meta["synth_points"])
+            if config == 3:
+                pts = [{"fsigma8": 0.47, "sigma_v": 380, "aperp": 1.02, "apar": 0.97}] + pts
+            batch = {k: np.array([p[k] for p in pts]) for k in pts[0]}
+            os.environ["VICTOR_HIP_MAPPING"] = mapping
+            try:
+                lnl, chi2 = fit.log_likelihood_batch(batch)
+            finally:
+                del os.environ["VICTOR_HIP_MAPPING"]
+            assert np.max(np.abs(chi2 / g[f"synth{config}_chi2"] - 1)) < RTOL, (config, mapping)
+        assert np.max(np.abs(out["point"][1] / out["lanes"][1] - 1)) < 1e-11
+        assert not np.array_equal(out["point"][1], out["lanes"][1])

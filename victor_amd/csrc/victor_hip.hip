@@ -772,6 +772,183 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
 }
 
 // --------------------------------------------------------------------------------------------------
+// K1 "lanes over the batch" variant (the mapping BASELINE.json's north star sketches): one wavefront owns one s bin
+// of 64 consecutive parameter points, lane = point.  Everything that depends only on the (mu, v) node - mu_i,
+// sqrt(1-mu_i^2), x_k, w_k, W_l[i], the loop counters - is wave-uniform and lives in SGPRs / scalar loads, the
+// per-point factors live in VGPRs, no cross-lane reduction is needed and all 64 lanes are busy on every trip.
+// Per integrand point this saves the node-table read, two multiplies (s_perp, s_par are formed once per mu row),
+// two of the three projection FMAs (the v sum is closed per mu row first) and five LDS reads.
+// Needs batch-constant tables (no reconstruction beta) and a batch large enough to fill the chip with
+// n_s * n/64 wavefronts; the point-major kernel above serves every other case.
+// --------------------------------------------------------------------------------------------------
+struct LanesPlan {
+  int smu, svrec, vxrec, lead, etab, total, vx_stride;
+};
+
+__host__ __device__ inline LanesPlan make_lanes_plan(int n_mu, int sv_int, int xi_int, int nlr) {
+  LanesPlan p;
+  int o = 0;
+  p.vx_stride = 4 * (1 + nlr) + 2;
+  p.smu = o;   o += (n_mu + 1) & ~1;
+  p.svrec = o; o += sv_int * kSvRec;
+  p.vxrec = o; o += xi_int * p.vx_stride;
+  p.lead = o;  o += 4;
+  p.etab = o;  o += 32;
+  p.total = o;
+  return p;
+}
+
+// per-lane version of point_scalars (each lane integrates its own AP rescaling factor, ccf_model.py:609-611)
+__device__ __forceinline__ PointScalars point_scalars_lane(const TheoryArgs& a, const double* row) {
+  PointScalars ps;
+  const double fs8 = row[VK_P_FSIGMA8];
+  const double sigv = row[VK_P_SIGMAV];
+  ps.aperp = row[VK_P_APERP];
+  ps.apar = row[VK_P_APAR];
+  const double eps = row[VK_P_EPSILON];
+  double c;
+  if (a.rescale_from_ap) {
+    const double e2 = eps * eps - 1.0;
+    const double h = (1.0 - 1e-10) / 49.0;
+    double acc = 0.0;
+    for (int m = 0; m < 50; ++m) {
+      const double mm = (m == 49) ? 1.0 : fma((double)m, h, 1e-10);
+      const double v = sqrt(fma(1.0 - mm * mm, e2, 1.0));
+      acc += (m == 0 || m == 49) ? 0.5 * v : v;
+    }
+    c = ps.apar * acc * h;
+  } else {
+    c = row[VK_P_ASTAR];
+  }
+  ps.inv_c = 1.0 / c;
+  const double iaH_true = a.iaH * ps.apar;
+  double growth = fs8 * a.inv_sigma8;
+  double binv = 1.0, extra = 0.0;
+  if (a.matter_lb) {
+    const double bias = row[VK_P_BIAS];
+    binv = 1.0 / bias;
+    extra = bias;
+  }
+  const double gb = growth * binv;
+  ps.av = 0.0;
+  ps.B = sigv * iaH_true;
+  ps.A = gb / (3.0 * iaH_true * sigv);
+  ps.G = gb / 3.0;
+  ps.gD = gb * ps.inv_c;
+  ps.M = row[VK_P_M];
+  ps.Q = row[VK_P_Q];
+  ps.inv_aperp = 1.0 / ps.aperp;
+  ps.inv_apar = 1.0 / ps.apar;
+  ps.poison = 0.0 * (gb + sigv + ps.aperp + ps.apar + eps + c + ps.A + extra);
+  return ps;
+}
+
+template <int NLR, int NL>
+__global__ __launch_bounds__(kBlock) void vk_theory_lanes_kernel(TheoryArgs a) {
+  extern __shared__ double lds[];
+  constexpr int vx_stride = 4 * (1 + NLR) + 2;
+  const LanesPlan pl = make_lanes_plan(a.n_mu, a.sv.n_int, a.xi.n_int, NLR);
+  const int tid = threadIdx.x;
+  const double hs = 1.0 / a.sv.inv_h, hx = 1.0 / a.xi.inv_h;
+  const double hl = a.vr.knots[1] - a.vr.knots[0];
+  for (int i = tid; i < a.n_mu; i += kBlock) {
+    const double m = a.mu[i];
+    lds[pl.smu + i] = sqrt(1.0 - m * m);
+  }
+  for (int e = tid; e < a.sv.n_int * 4; e += kBlock)
+    lds[pl.svrec + (e >> 2) * kSvRec + (e & 3)] = a.sv.coef[e] * hpow(hs, e & 3);
+  for (int e = tid; e < a.xi.n_int * 4; e += kBlock)
+    lds[pl.vxrec + (e >> 2) * vx_stride + (e & 3)] = a.vr.coef[4 + e] * hpow(hx, e & 3);
+  {
+    const int per_l = a.xi.n_int * 4;
+    for (int e = tid; e < NLR * per_l; e += kBlock) {
+      const int l = e / per_l, iq = e - l * per_l;
+      lds[pl.vxrec + (iq >> 2) * vx_stride + 4 * (1 + l) + (iq & 3)] = a.xi.coef[e] * hpow(hx, iq & 3);
+    }
+  }
+  if (tid < 4) lds[pl.lead + tid] = a.vr.coef[tid] * hpow(hl, tid);
+  if (tid < 32) lds[pl.etab + tid] = vkm::exp2_frac32(tid);
+  FastConsts fc;
+  fc.inv_hs = a.sv.inv_h;
+  fc.off_s = -a.sv.knots[0] * a.sv.inv_h;
+  fc.ns_eps = (double)a.sv.n_int * (1.0 - 0x1p-52);
+  fc.inv_hx = a.xi.inv_h;
+  fc.off_x = -a.xi.knots[0] * a.xi.inv_h;
+  fc.nx_eps = (double)a.xi.n_int * (1.0 - 0x1p-52);
+  fc.inv_hl = 1.0 / hl;
+  fc.off_l = -a.vr.knots[0] * fc.inv_hl;
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const double* l_smu = lds + pl.smu;
+  const double* svrec = lds + pl.svrec;
+  const double* vxrec = lds + pl.vxrec;
+  const double* leadrec = lds + pl.lead;
+  const double* etab = lds + pl.etab;
+  const long long chunks = (a.n + 63) >> 6;
+  const long long items = chunks * a.n_s;
+  for (long long item = (long long)blockIdx.x * kWaves + wave; item < items; item += (long long)gridDim.x * kWaves) {
+    const long long chunk = item / a.n_s;
+    const int j = (int)(item - chunk * a.n_s);
+    long long point = chunk * 64 + lane;
+    const bool valid = point < a.n;
+    if (!valid) point = a.n - 1;
+    const PointScalars ps = point_scalars_lane(a, a.params + point * VK_NPAR);
+    const double sj = a.s[j];
+    const double sa = sj * ps.aperp, sp = sj * ps.apar;
+    const double AV = ps.A;
+    double acc[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) acc[l] = 0.0;
+    for (int i = 0; i < a.n_mu; ++i) {
+      const double s_perp = sa * l_smu[i];
+      const double sperp2 = s_perp * s_perp;
+      const double s_par = sp * a.mu[i];
+      double g = 0.0;
+      for (int k = 0; k < a.n_x; ++k) {
+        const double xk = a.x[k];
+        const double r_par = fma(-xk, ps.B, s_par);
+        const double r2 = fma(r_par, r_par, sperp2);
+        double r, inv_r;
+        vkm::sqrt_rsqrt(r2, r, inv_r);
+        const double mu_r = r_par * inv_r;
+        const double u = r * ps.inv_c;
+        const double ts = vmin_f64(fmax(fma(u, fc.inv_hs, fc.off_s), 0.0), fc.ns_eps);
+        const double SV = cubic_b128(lds_at(svrec, __mul24((int)ts, kSvRec * 8)), __builtin_amdgcn_fract(ts));
+        const double tr = fma(u, fc.inv_hx, fc.off_x);
+        const double tx = vmin_f64(fmax(tr, 0.0), fc.nx_eps);
+        const double tq = __builtin_amdgcn_fract(tx);
+        const double* rec = lds_at(vxrec, __mul24((int)tx, vx_stride * 8));
+        double V = cubic_b128(rec, tq);
+        if (tr < 0.0) V = cubic_b128(leadrec, fmax(fma(u, fc.inv_hl, fc.off_l), 0.0));
+        double xir = cubic_b128(rec + 4, tq);
+        if (NLR > 1) {
+          const double m2 = mu_r * mu_r;
+          xir = fma(cubic_b128(rec + 8, tq), fma(1.5, m2, -0.5), xir);
+          if (NLR > 2) xir = fma(cubic_b128(rec + 12, tq), vkm::fma3(vkm::fma3(m2, 4.375, -3.75), m2, 0.375), xir);
+        }
+        const double inv_sv = vkm::recip(SV);
+        const double z = fma(AV * V, mu_r, xk) * inv_sv;
+        const double e = vkm::exp_nonpos((-0.5 * z) * z, etab);
+        g = fma(a.w_x[k] * inv_sv, fma(e, xir, e), g);
+      }
+#pragma unroll
+      for (int l = 0; l < NL; ++l) acc[l] = fma(a.w_ell[l * a.n_mu + i], g, acc[l]);
+    }
+    if (valid) {
+      double* o = a.out + point * (long long)(a.n_ell * a.n_s) + j;
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        double ws = 0.0;
+        for (int i = 0; i < a.n_mu; ++i) ws += a.w_ell[l * a.n_mu + i];
+        o[(long long)l * a.n_s] = acc[l] - ws + ps.poison;
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
 // K1x: xi^s(mu_i, s_j), one wave per (point, mu, s) cell, lanes over the velocity nodes
 // --------------------------------------------------------------------------------------------------
 template <int RSD, int NLR>
@@ -1060,6 +1237,18 @@ int launch_fast_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   return VK_OK;
 }
 
+template <int NLR>
+int launch_lanes_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
+  switch (a.n_ell) {
+    case 1: hipLaunchKernelGGL((vk_theory_lanes_kernel<NLR, 1>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+    case 2: hipLaunchKernelGGL((vk_theory_lanes_kernel<NLR, 2>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+    case 3: hipLaunchKernelGGL((vk_theory_lanes_kernel<NLR, 3>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+    default: return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
+  }
+  VK_HIP(ctx, hipGetLastError());
+  return VK_OK;
+}
+
 template <int RSD>
 int launch_xi_smu(vk_ctx* ctx, const TheoryArgs& a, int nlr, int grid, size_t lds) {
   switch (nlr) {
@@ -1123,6 +1312,22 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   const long long items = a.n * groups;
   const long long cap = 8LL * ctx->n_cu;
   const int grid = (int)(items < cap ? items : cap);
+  // lanes-over-batch variant: batch-constant tables and enough points to fill the chip with n_s * n/64 waves
+  const char* mapping = getenv("VICTOR_HIP_MAPPING");
+  const bool lanes_ok = fast && a.n_beta_r == 0 && !a.matter_lb;
+  const bool lanes = lanes_ok && (mapping ? !strcmp(mapping, "lanes") : a.n >= 8192);
+  if (lanes) {
+    const size_t lds_l = (size_t)make_lanes_plan(a.n_mu, a.sv.n_int, a.xi.n_int, nlr).total * sizeof(double);
+    const long long waves = ((a.n + 63) >> 6) * (long long)a.n_s;
+    const long long blocks = (waves + kWaves - 1) / kWaves;
+    const long long capl = 16LL * ctx->n_cu;
+    const int grid_l = (int)(blocks < capl ? blocks : capl);
+    switch (nlr) {
+      case 1: return launch_lanes_nl<1>(ctx, a, grid_l, lds_l);
+      case 2: return launch_lanes_nl<2>(ctx, a, grid_l, lds_l);
+      case 3: return launch_lanes_nl<3>(ctx, a, grid_l, lds_l);
+    }
+  }
   if (fast) {
     switch (nlr) {
       case 1: return launch_fast_nl<1>(ctx, a, grid, lds);
