@@ -782,14 +782,15 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
 // n_s * n/64 wavefronts; the point-major kernel above serves every other case.
 // --------------------------------------------------------------------------------------------------
 struct LanesPlan {
-  int smu, svrec, vxrec, lead, etab, total, vx_stride;
+  int smu, xw, svrec, vxrec, lead, etab, total, vx_stride;
 };
 
-__host__ __device__ inline LanesPlan make_lanes_plan(int n_mu, int sv_int, int xi_int, int nlr) {
+__host__ __device__ inline LanesPlan make_lanes_plan(int n_mu, int n_x, int sv_int, int xi_int, int nlr) {
   LanesPlan p;
   int o = 0;
   p.vx_stride = 4 * (1 + nlr) + 2;
-  p.smu = o;   o += (n_mu + 1) & ~1;
+  p.smu = o;   o += 2 * n_mu;           // {mu_i, sqrt(1 - mu_i^2)}
+  p.xw = o;    o += 2 * n_x;            // {x_k, w_k}: read with a wave-uniform address (LDS broadcast)
   p.svrec = o; o += sv_int * kSvRec;
   p.vxrec = o; o += xi_int * p.vx_stride;
   p.lead = o;  o += 4;
@@ -847,13 +848,18 @@ template <int NLR, int NL>
 __global__ __launch_bounds__(kBlock) void vk_theory_lanes_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
   constexpr int vx_stride = 4 * (1 + NLR) + 2;
-  const LanesPlan pl = make_lanes_plan(a.n_mu, a.sv.n_int, a.xi.n_int, NLR);
+  const LanesPlan pl = make_lanes_plan(a.n_mu, a.n_x, a.sv.n_int, a.xi.n_int, NLR);
   const int tid = threadIdx.x;
   const double hs = 1.0 / a.sv.inv_h, hx = 1.0 / a.xi.inv_h;
   const double hl = a.vr.knots[1] - a.vr.knots[0];
   for (int i = tid; i < a.n_mu; i += kBlock) {
     const double m = a.mu[i];
-    lds[pl.smu + i] = sqrt(1.0 - m * m);
+    lds[pl.smu + 2 * i] = m;
+    lds[pl.smu + 2 * i + 1] = sqrt(1.0 - m * m);
+  }
+  for (int k = tid; k < a.n_x; k += kBlock) {
+    lds[pl.xw + 2 * k] = a.x[k];
+    lds[pl.xw + 2 * k + 1] = a.w_x[k];
   }
   for (int e = tid; e < a.sv.n_int * 4; e += kBlock)
     lds[pl.svrec + (e >> 2) * kSvRec + (e & 3)] = a.sv.coef[e] * hpow(hs, e & 3);
@@ -882,6 +888,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_lanes_kernel(TheoryArgs a) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const double* l_smu = lds + pl.smu;
+  const double* l_xw = lds + pl.xw;
   const double* svrec = lds + pl.svrec;
   const double* vxrec = lds + pl.vxrec;
   const double* leadrec = lds + pl.lead;
@@ -902,12 +909,14 @@ __global__ __launch_bounds__(kBlock) void vk_theory_lanes_kernel(TheoryArgs a) {
 #pragma unroll
     for (int l = 0; l < NL; ++l) acc[l] = 0.0;
     for (int i = 0; i < a.n_mu; ++i) {
-      const double s_perp = sa * l_smu[i];
+      const vk_d2 mm = *reinterpret_cast<const vk_d2*>(l_smu + 2 * i);
+      const double s_perp = sa * mm.y;
       const double sperp2 = s_perp * s_perp;
-      const double s_par = sp * a.mu[i];
+      const double s_par = sp * mm.x;
       double g = 0.0;
       for (int k = 0; k < a.n_x; ++k) {
-        const double xk = a.x[k];
+        const vk_d2 xw = *reinterpret_cast<const vk_d2*>(l_xw + 2 * k);
+        const double xk = xw.x;
         const double r_par = fma(-xk, ps.B, s_par);
         const double r2 = fma(r_par, r_par, sperp2);
         double r, inv_r;
@@ -931,7 +940,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_lanes_kernel(TheoryArgs a) {
         const double inv_sv = vkm::recip(SV);
         const double z = fma(AV * V, mu_r, xk) * inv_sv;
         const double e = vkm::exp_nonpos((-0.5 * z) * z, etab);
-        g = fma(a.w_x[k] * inv_sv, fma(e, xir, e), g);
+        g = fma(xw.y * inv_sv, fma(e, xir, e), g);
       }
 #pragma unroll
       for (int l = 0; l < NL; ++l) acc[l] = fma(a.w_ell[l * a.n_mu + i], g, acc[l]);
@@ -1317,7 +1326,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   const bool lanes_ok = fast && a.n_beta_r == 0 && !a.matter_lb;
   const bool lanes = lanes_ok && (mapping ? !strcmp(mapping, "lanes") : a.n >= 8192);
   if (lanes) {
-    const size_t lds_l = (size_t)make_lanes_plan(a.n_mu, a.sv.n_int, a.xi.n_int, nlr).total * sizeof(double);
+    const size_t lds_l = (size_t)make_lanes_plan(a.n_mu, a.n_x, a.sv.n_int, a.xi.n_int, nlr).total * sizeof(double);
     const long long waves = ((a.n + 63) >> 6) * (long long)a.n_s;
     const long long blocks = (waves + kWaves - 1) / kWaves;
     const long long capl = 16LL * ctx->n_cu;
