@@ -97,6 +97,42 @@ def cpu_baseline(sample_pts):
     return {"evals_per_s": len(sample_pts) / busy, "cores": cores, "wall_s": wall, "busy_s": busy}, vals
 
 
+def boss_measurement(args, batch=16384, steps=20):
+    """Secondary figure: the BOSS DR12 CMASS configuration the north star's 1e5 evals/s target is quoted on
+    (config/boss_config.yaml: 30 s bins x 100 mu x 50 v, l = 0,2, reconstruction-beta dependent tables, data and
+    covariance, Sellentin-Heavens likelihood).  Inputs resident in HBM; same timing discipline as the main line."""
+    import victor_amd
+    from tests import cases
+    fit = victor_amd.CCFFit(*cases.boss_options("config"))
+    eng = fit._get_engine()
+    opts = eng.make_opts(fit.model, fit.fit_options)
+    rows = fit._fit_rows(cases.halton_params(batch, with_beta=True), fit.model)
+    d_rows, d_lnl, d_chi, d_ws = eng.alloc(rows.size), eng.alloc(batch), eng.alloc(batch), eng.alloc(batch * eng.n_data)
+    eng.upload(d_rows, rows)
+    for _ in range(16):      # ~100 ms: the HIP runtime stalls once (~75 ms) shortly after fresh allocations
+        eng.eval_device_async(opts, d_rows, batch, d_lnl, d_chi, d_ws)
+    eng.sync()
+    eng.timing(True)
+    eng.read_timing(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.eval_device_async(opts, d_rows, batch, d_lnl, d_chi, d_ws)
+    eng.sync()
+    dt = time.perf_counter() - t0
+    k1, k2, launches = eng.read_timing(reset=True)
+    eng.timing(False)
+    import numpy as np
+    lnl = eng.download(d_lnl, batch)
+    for p in (d_rows, d_lnl, d_chi, d_ws):
+        eng.free(p)
+    F = flops_per_eval(30, 100, 50, 2, False)
+    k1 /= max(launches, 1)
+    return {"evals_per_s": batch * steps / dt, "batch": batch, "steps": steps, "kernel": eng.last_kernel() + "<1,2>",
+            "kernels_ms": {"theory": k1, "likelihood": k2 / max(launches, 1)},
+            "fp64_valu_frac": F * batch / (k1 * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if k1 > 0 else None,
+            "flops_per_eval": F, "all_finite": bool(np.all(np.isfinite(lnl)))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,6 +140,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="points per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-boss", action="store_true", help="skip the secondary BOSS CMASS measurement")
     ap.add_argument("--cpu-sample", type=int, default=0, help="oracle evaluations (default: about 10 per core)")
     args = ap.parse_args()
 
@@ -183,6 +220,7 @@ def main():
     eng.timing(False)
     elapsed = dist.max_float(elapsed)
 
+    kernel_name = eng.last_kernel()
     lnl = eng.download(d_lnl, B)
     chi2 = eng.download(d_chi, B)
     gathered_ok = None
@@ -216,7 +254,7 @@ def main():
                                    "(N=120), AP-dependent rescale, sigma_v(r) template, gaussian likelihood",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"batch-sharded x{world}",
                        "gather": "rccl allgather of lnL" if use_comm else "none (single process)"},
-            "roofline": {"bound": "fp64-valu", "kernel": "vk_theory_fast_kernel<3,3>",
+            "roofline": {"bound": "fp64-valu", "kernel": kernel_name + "<3,3>",
                          "achieved": achieved_tf, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / PEAK_FP64_VALU_TFLOPS if achieved_tf else None,
                          "traffic": traffic, "flops_per_eval": F, "kernel_ms": k1_ms,
@@ -231,6 +269,8 @@ def main():
         }
         if gathered_ok is not None:
             out["gather_matches_local"] = gathered_ok
+        if world == 1 and not args.no_boss:
+            out["boss_cmass"] = boss_measurement(args)
         if base is not None:
             chi_o = np.array([v[1] for v in vals])
             lnl_o = np.array([v[0] for v in vals])

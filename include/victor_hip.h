@@ -172,6 +172,8 @@ int vk_device_count(void);
 vk_ctx* vk_create(const vk_tables* tables, int device, char* err, size_t errlen);
 void vk_destroy(vk_ctx* ctx);
 const char* vk_last_error(const vk_ctx* ctx);
+/* name of the theory-kernel variant the most recent evaluation launched (diagnostics / benchmarks) */
+const char* vk_last_kernel(const vk_ctx* ctx);
 void vk_default_opts(vk_eval_opts* opts);
 
 /* Full likelihood for n parameter rows (host buffers).  Any of lnl/chi2/theory may be NULL.

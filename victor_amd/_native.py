@@ -68,6 +68,7 @@ SYMBOLS = {
     "vk_create": (_vp, [C.POINTER(vk_tables), C.c_int, C.c_char_p, C.c_size_t]),
     "vk_destroy": (None, [_vp]),
     "vk_last_error": (C.c_char_p, [_vp]),
+    "vk_last_kernel": (C.c_char_p, [_vp]),
     "vk_default_opts": (None, [_optp]),
     "vk_eval_batch": (C.c_int, [_vp, _optp, _dp, C.c_int64, _dp, _dp, _dp]),
     "vk_theory_batch": (C.c_int, [_vp, _optp, _dp, C.c_int64, _dp, C.c_int32, _dp, C.c_int32, _dp, C.c_int32, _dp]),

@@ -1138,6 +1138,7 @@ struct vk_ctx {
   PPView xi{}, vr{}, sv{};
   bool fast_ok = false;      // tables qualify for vk_theory_fast_kernel
   int matter_lb = 0, vr_beta_dep = 0;
+  const char* last_kernel = "none";  // theory kernel variant of the most recent launch
   // scratch for the host-buffer entry points
   double* d_scratch = nullptr;
   size_t scratch_bytes = 0;
@@ -1326,6 +1327,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   const bool lanes_ok = fast && a.n_beta_r == 0 && !a.matter_lb;
   const bool lanes = lanes_ok && (mapping ? !strcmp(mapping, "lanes") : a.n >= 8192);
   if (lanes) {
+    ctx->last_kernel = "vk_theory_lanes_kernel";
     const size_t lds_l = (size_t)make_lanes_plan(a.n_mu, a.n_x, a.sv.n_int, a.xi.n_int, nlr).total * sizeof(double);
     const long long waves = ((a.n + 63) >> 6) * (long long)a.n_s;
     const long long blocks = (waves + kWaves - 1) / kWaves;
@@ -1337,6 +1339,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
       case 3: return launch_lanes_nl<3>(ctx, a, grid_l, lds_l);
     }
   }
+  ctx->last_kernel = fast ? "vk_theory_fast_kernel" : "vk_theory_kernel";
   if (fast) {
     switch (nlr) {
       case 1: return launch_fast_nl<1>(ctx, a, grid, lds);
@@ -1444,6 +1447,8 @@ void vk_default_opts(vk_eval_opts* o) {
 }
 
 const char* vk_last_error(const vk_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+const char* vk_last_kernel(const vk_ctx* ctx) { return ctx ? ctx->last_kernel : "none"; }
 
 static int check_pp(const vk_pp* p, const char* name, std::string* err) {
   char buf[256];

@@ -259,6 +259,9 @@ class Engine:
         self._check(self._lib.vk_eval_batch_device_async(self._ctx, C.byref(opts), d_rows, int(n), d_lnl, d_chi2,
                                                          d_theory_ws))
 
+    def last_kernel(self):
+        return self._lib.vk_last_kernel(self._ctx).decode()
+
     def sync(self):
         self._check(self._lib.vk_sync(self._ctx))
 
