@@ -53,7 +53,9 @@ def cpu_worker(args):
     t0 = time.perf_counter()
     for p in pts:
         out.append(fit.log_likelihood(dict(p)))
-    return idx, time.perf_counter() - t0, out
+    busy = time.perf_counter() - t0
+    theory = [fit.theory_multipole_vector(fit.s, dict(p), fit.poles_s) for p in pts[:2]]   # untimed: for the xi_l check
+    return idx, busy, out, theory
 
 
 def host_cores():
@@ -91,10 +93,23 @@ def cpu_baseline(sample_pts):
     wall = time.perf_counter() - t0
     busy = max(r[1] for r in res)          # excludes interpreter start-up and table construction
     vals = [None] * len(sample_pts)
-    for idx, _, out in res:
+    theory = {}
+    for idx, _, out, th in res:
         for k, v in enumerate(out):
             vals[idx + k * cores] = v
-    return {"evals_per_s": len(sample_pts) / busy, "cores": cores, "wall_s": wall, "busy_s": busy}, vals
+        for k, t in enumerate(th):
+            theory[idx + k * cores] = t
+    return {"evals_per_s": len(sample_pts) / busy, "cores": cores, "wall_s": wall, "busy_s": busy}, vals, theory
+
+
+def warm_up(eng, launch, seconds=0.3):
+    """Run ``launch`` back to back for ``seconds``: the HIP runtime stalls once (~75 ms, kernels unaffected) some tens
+    of milliseconds after fresh allocations, which must not land in a short timed window."""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(4):
+            launch()
+        eng.sync()
 
 
 def boss_measurement(args, batch=16384, steps=20):
@@ -109,9 +124,7 @@ def boss_measurement(args, batch=16384, steps=20):
     rows = fit._fit_rows(cases.halton_params(batch, with_beta=True), fit.model)
     d_rows, d_lnl, d_chi, d_ws = eng.alloc(rows.size), eng.alloc(batch), eng.alloc(batch), eng.alloc(batch * eng.n_data)
     eng.upload(d_rows, rows)
-    for _ in range(16):      # ~100 ms: the HIP runtime stalls once (~75 ms) shortly after fresh allocations
-        eng.eval_device_async(opts, d_rows, batch, d_lnl, d_chi, d_ws)
-    eng.sync()
+    warm_up(eng, lambda: eng.eval_device_async(opts, d_rows, batch, d_lnl, d_chi, d_ws))
     eng.timing(True)
     eng.read_timing(reset=True)
     t0 = time.perf_counter()
@@ -131,6 +144,34 @@ def boss_measurement(args, batch=16384, steps=20):
             "kernels_ms": {"theory": k1, "likelihood": k2 / max(launches, 1)},
             "fp64_valu_frac": F * batch / (k1 * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if k1 > 0 else None,
             "flops_per_eval": F, "all_finite": bool(np.all(np.isfinite(lnl)))}
+
+
+def batch_sweep():
+    """evals/s with inputs resident in HBM at the batch sizes SURVEY.md 8(d) asks for: BASELINE config [1]
+    (batch 1024, isotropic xi_r, l = 0,2) and the metric grid (config 3) at batch 1, 64 and 1024."""
+    import victor_amd
+    from tests import cases
+    res = {}
+    for config, batches in ((2, (1024,)), (3, (1, 64, 1024))):
+        fit = victor_amd.CCFFit(*cases.synth_options(config))
+        eng = fit._get_engine()
+        opts = eng.make_opts(fit.model, fit.fit_options)
+        for batch in batches:
+            rows = fit._fit_rows(cases.halton_params(batch), fit.model)
+            bufs = [eng.alloc(rows.size), eng.alloc(batch), eng.alloc(batch), eng.alloc(batch * eng.n_data)]
+            eng.upload(bufs[0], rows)
+            steps = 200 if batch <= 64 else 50
+            warm_up(eng, lambda: eng.eval_device_async(opts, bufs[0], batch, bufs[1], bufs[2], bufs[3]))
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                eng.eval_device_async(opts, bufs[0], batch, bufs[1], bufs[2], bufs[3])
+            eng.sync()
+            dt = (time.perf_counter() - t0) / steps
+            res[f"config{config}_batch{batch}"] = {"evals_per_s": batch / dt, "ms_per_batch": dt * 1e3,
+                                                   "kernel": eng.last_kernel()}
+            for p in bufs:
+                eng.free(p)
+    return res
 
 
 def main():
@@ -179,7 +220,7 @@ def main():
         cores = host_cores()
         ns = min(args.cpu_sample or max(16, 25 * cores), B)      # ~25 oracle evaluations per core: 10-30 s of CPU work
         sel = np.linspace(0, B - 1, ns).astype(int)
-        base, vals = cpu_baseline([cases.point(mine, int(i)) for i in sel])
+        base, vals, theory_o = cpu_baseline([cases.point(mine, int(i)) for i in sel])
 
     fit = victor_amd.CCFFit(model, data, device=dist.local_rank if launched else 0)
     eng = fit._get_engine()
@@ -271,6 +312,7 @@ def main():
             out["gather_matches_local"] = gathered_ok
         if world == 1 and not args.no_boss:
             out["boss_cmass"] = boss_measurement(args)
+            out["batch_sweep"] = batch_sweep()
         if base is not None:
             chi_o = np.array([v[1] for v in vals])
             lnl_o = np.array([v[0] for v in vals])
@@ -282,6 +324,12 @@ def main():
             out["max_rel_dchi2_vs_oracle"] = float(np.max(np.abs(chi2[sel] / chi_o - 1)))
             out["max_abs_dchi2_vs_oracle"] = float(np.max(np.abs(chi2[sel] - chi_o)))
             out["max_rel_dlnl_vs_oracle"] = float(np.max(np.abs(lnl[sel] / lnl_o - 1)))
+            kk = sorted(theory_o)
+            th_g = fit.theory_vector_batch({k: v[sel[kk]] for k, v in mine.items()})
+            th_o = np.array([theory_o[k] for k in kk])
+            scale = np.max(np.abs(th_o.reshape(len(kk), len(fit.poles_s), -1)), axis=2, keepdims=True)
+            dxi = np.abs(th_g - th_o).reshape(len(kk), len(fit.poles_s), -1) / scale
+            out["max_rel_dxi_ell_vs_oracle"] = float(dxi.max())      # relative to max|xi_l| of each multipole
         print(json.dumps(out))
 
     for p in (d_rows, d_lnl, d_chi, d_ws, d_all):
