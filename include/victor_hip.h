@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 2
+#define VK_ABI_VERSION 3
 
 /* error codes */
 #define VK_OK 0
@@ -69,6 +69,8 @@ extern "C" {
 /* vk_tables.matter_model (ccf_model.py:71,358-372) */
 #define VK_MATTER_TEMPLATE 0
 #define VK_MATTER_LINEAR_BIAS 1
+#define VK_MATTER_VELOCITY_TEMPLATE 2 /* velocity_pdf.mean.model == 'template' (ccf_model.py:439-443,483-490): the
+                                         tables hold the template v_r(r) itself, amplitude = fsigma8 * vt_amp */
 
 /* vk_eval_opts.like_form (ccf_fit.py:455-473) */
 #define VK_LIKE_GAUSSIAN 0
@@ -127,8 +129,16 @@ typedef struct vk_tables {
                                    V2 = r*Delta*delta, Ge1, Ge2 (numerical-gradient tables of the
                                    empirical_corr branch, ccf_model.py:455-459; /3 folded in)
                            beta-dependent: coef[2][n_beta_r-1][n_int][4][4] = V1, Da              */
+  double vt_amp;        /* VK_MATTER_VELOCITY_TEMPLATE only: template_hubble_ratio * (1+z_sim)/(1+z_eff) /
+                           template_fsigma8 (ccf_model.py:442-443); apar cancels against aH_true       */
   /* ---- velocity dispersion template (ccf_model.py:654-655) ----------------- */
-  vk_pp sv;             /* coef[1][n_int][4]: normalised sigma_v(r) shape       */
+  vk_pp sv;             /* isotropic template: coef[1][n_int][4], normalised sigma_v(r) shape;
+                           anisotropic template: knots = r_for_sv only (coef unused, see sv2d)          */
+  int32_t sv_n_mu;      /* 0: isotropic.  else number of mu nodes of the sigma_v(r, mu) template        */
+  double sv_mu_inv_h;   /* 1/spacing of the mu nodes if uniform, else 0                                 */
+  const double* sv_mu;  /* [sv_n_mu] mu nodes                                                           */
+  const double* sv2d;   /* [sv.n_int][sv_n_mu-1][4][4] bicubic patches: coefficient of du^p dmu^q of the
+                           tensor-product not-a-knot spline (RectBivariateSpline, ccf_model.py:654)     */
 
   double iaH;           /* (1+z)/(100 E(z)) (ccf_model.py:43-45)               */
   double template_sigma8; /* ccf_model.py:432-435                              */

@@ -83,3 +83,71 @@ def test_realspace_ccf_from_data_with_md_covariance(gold):
                                               fit.poles_s, matter_model="linear_bias", rsd_model="kaiser")
                   for q in pts[:3]])
     assert close(t, g["opt_fromdata_lb_kaiser"])
+
+
+@pytest.mark.parametrize("with_beta", [False, True])
+def test_rmu_real_space_input_on_gpu(tmp_path, with_beta):
+    """format: rmu real-space input (with simulation_number) through the kernels vs the oracle."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import victor_amd
+    import victor_oracle as vo
+    from tests.test_host import _rmu_inputs
+    model, _ = _rmu_inputs(tmp_path, with_beta)
+    m = victor_amd.CCFModel(model)
+    o = vo.OracleModel(model)
+    s = np.linspace(4, 110, 25)
+    for p in ({"fsigma8": 0.5, "beta": 0.33, "sigma_v": 350, "epsilon": 1.02},
+              {"fsigma8": 0.4, "beta": 0.55, "sigma_v": 420, "aperp": 0.95, "apar": 1.04}):
+        got = m.theory_multipoles(s, dict(p), poles=[0, 2, 4])
+        want, _x = o.theory_multipoles(s, dict(p), poles=[0, 2, 4])
+        for key in ("0", "2", "4"):
+            assert np.max(np.abs(got[key] - want[key])) < RTOL * np.max(np.abs(want[key])), (with_beta, key)
+
+
+@pytest.mark.parametrize("non_uniform_mu", [False, True])
+def test_anisotropic_sigma_v_template_on_gpu(tmp_path, non_uniform_mu):
+    """3-key sigma_v(r, mu) template (bicubic, box-clamped) through the generic kernels vs the oracle."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import victor_amd
+    import victor_oracle as vo
+    from tests.test_host import _aniso_inputs
+    model, data = _aniso_inputs(tmp_path, non_uniform_mu)
+    fit = victor_amd.CCFFit(model, data)
+    ora = vo.OracleFit(model, data)
+    hp = cases.halton_params(40)
+    for i, kw in ((3, {}), (11, {"rsd_model": "dispersion"}), (29, {"assume_isotropic": True})):
+        p = cases.point(hp, i)
+        got = fit.log_likelihood(dict(p), **kw)
+        want = ora.log_likelihood(dict(p), **kw)
+        assert abs(got[1] / want[1] - 1) < RTOL and abs(got[0] / want[0] - 1) < RTOL, (i, kw)
+    assert fit._get_engine().last_kernel() == "vk_theory_kernel"          # not a fast-path configuration
+
+
+def test_velocity_template_mean_model_on_gpu(tmp_path):
+    """velocity_pdf.mean.model = 'template' (ccf_model.py:439-443, 483-490) for every RSD mapping vs the oracle."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import victor_amd
+    import victor_oracle as vo
+    from tests.test_host import _aniso_inputs
+    model, data = _aniso_inputs(tmp_path)
+    model["velocity_pdf"]["mean"]["model"] = "template"
+    model["velocity_pdf"]["dispersion"] = {"model": "template", "template_keys": ["rsv", "sigmav"]}
+    fit = victor_amd.CCFFit(model, data)
+    ora = vo.OracleFit(model, data)
+    hp = cases.halton_params(40)
+    for i, kw in ((5, {}), (6, {"rsd_model": "dispersion"}), (7, {"rsd_model": "kaiser"}),
+                  (8, {"rsd_model": "euclid_special"}), (9, {"empirical_corr": True})):
+        p = dict(cases.point(hp, i), M=1.05, Q=0.9, Av=0.4)
+        t = fit.theory_multipole_vector(fit.s, dict(p), fit.poles_s, **kw)
+        to = ora.theory_multipole_vector(ora.s, dict(p), ora.poles_s, **kw)
+        assert np.max(np.abs(t - to)) < RTOL * np.max(np.abs(to)), (i, kw)
+    # a per-call switch back to the linear mean model uses the other table set
+    t = fit.theory_multipole_vector(fit.s, cases.point(hp, 5), fit.poles_s, mean_model="linear")
+    to = ora.theory_multipole_vector(ora.s, cases.point(hp, 5), ora.poles_s, mean_model="linear")
+    assert np.max(np.abs(t - to)) < RTOL * np.max(np.abs(to))

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(lib):
     for name in declared:
         assert hasattr(lib, name)
     from victor_amd import _native as N2
-    assert lib.vk_abi_version() == N2.VK_ABI_VERSION == 2
+    assert lib.vk_abi_version() == N2.VK_ABI_VERSION == 3
 
 
 def test_struct_layouts_match_header(lib):
@@ -296,3 +296,105 @@ def test_victor_alias_and_plugin_host_side():
         "print('ok')\n")
     out = subprocess.check_output([sys.executable, "-c", code]).decode()
     assert out.strip().endswith("ok")
+
+
+# --------------------------------------------------------------------------- input variants
+def _rmu_inputs(tmp_path, with_beta):
+    """A tabulated xi(r, mu) real-space input plus several 'simulations' stacked on a leading axis."""
+    r = 2.0 + 4.0 * np.arange(30)
+    mu = np.linspace(0, 1, 21)
+    base = cases.golden_outputs  # noqa: F841  (keeps flake quiet about unused import paths)
+    prof = -0.8 * np.exp(-(r / 30.0) ** 2)[:, None] * (1 + 0.3 * (1.5 * mu[None, :] ** 2 - 0.5))
+    sims = np.stack([prof * (1 + 0.05 * k) for k in range(3)])                  # (n_sim, n_r, n_mu)
+    src = np.load(os.path.join(cases.GOLDEN, "boss", "model.npy"), allow_pickle=True).item()
+    d = {"r": r, "mu": mu, "rdelta": src["rdelta"], "delta": src["delta"], "rsv": src["rsv"], "sigmav": src["sigmav"]}
+    if with_beta:
+        beta = np.linspace(0.2, 0.6, 5)
+        d["beta"] = beta
+        d["xi_rmu"] = np.stack([sims * (1 + b) for b in beta], axis=1)          # (n_sim, n_beta, n_r, n_mu)
+    else:
+        d["xi_rmu"] = sims
+    fn = tmp_path / ("rmu_beta.npy" if with_beta else "rmu.npy")
+    np.save(fn, d, allow_pickle=True)
+    model = cases.boss_options("config")[0]
+    model["dir"] = str(tmp_path)
+    model["input_model_data_file"] = fn.name
+    model["realspace_ccf"] = {"reconstruction": with_beta, "beta_key": "beta", "format": "rmu",
+                              "ccf_keys": ["r", "mu", "xi_rmu"], "simulation_number": 1, "assume_isotropic": False}
+    return model, d
+
+
+@pytest.mark.parametrize("with_beta", [False, True])
+def test_rmu_format_and_simulation_number_match_oracle(tmp_path, with_beta):
+    import victor_amd
+    import victor_oracle as vo
+    model, d = _rmu_inputs(tmp_path, with_beta)
+    m = victor_amd.CCFModel(model)
+    o = vo.OracleModel(model)
+    assert list(m.poles_r) == [0, 2, 4]
+    for ell in ("0", "2", "4"):
+        assert m.real_multipoles[ell].shape == o.real_multipoles[ell].shape
+        assert np.max(np.abs(m.real_multipoles[ell] - o.real_multipoles[ell])) < 1e-14
+    # simulation 1 was selected, not 0
+    sim0 = dict(model, realspace_ccf=dict(model["realspace_ccf"], simulation_number=0))
+    assert not np.allclose(victor_amd.CCFModel(sim0).real_multipoles["0"], m.real_multipoles["0"])
+    from victor_amd import InputError
+    bad = dict(model, realspace_ccf=dict(model["realspace_ccf"], simulation_number="one"))
+    with pytest.raises(InputError):
+        victor_amd.CCFModel(bad)
+
+
+def _aniso_inputs(tmp_path, non_uniform_mu=False):
+    """Synthetic model file with a 3-key sigma_v(r, mu) template and a mean-velocity template."""
+    src = np.load(os.path.join(cases.GOLDEN, "synth", "model.npy"), allow_pickle=True).item()
+    d = dict(src)
+    mu = np.linspace(0, 1, 9) if not non_uniform_mu else np.array([0, 0.1, 0.25, 0.45, 0.6, 0.8, 0.93, 1.0])
+    rsv = d["rsv"]
+    d["musv"] = mu
+    d["sigmav2d"] = d["sigmav"][:, None] * (1 + 0.25 * mu[None, :] ** 2 - 0.1 * np.exp(-rsv[:, None] / 40) * mu[None, :])
+    rv = np.linspace(0.5, 125, 60)
+    d["rv"] = rv
+    d["vtemplate"] = -45.0 * (rv / 30) * np.exp(-(rv / 45) ** 2)
+    fn = tmp_path / ("aniso_nu.npy" if non_uniform_mu else "aniso.npy")
+    np.save(fn, d, allow_pickle=True)
+    model, data = cases.synth_options(3)
+    model["dir"] = str(tmp_path)
+    model["input_model_data_file"] = fn.name
+    model["velocity_pdf"]["dispersion"] = {"model": "template", "template_keys": ["rsv", "musv", "sigmav2d"]}
+    model["velocity_pdf"]["mean"] = {"model": "linear", "template_fsigma8": 0.45, "z_sim": 0.52,
+                                     "template_hubble_ratio": 1.03, "template_keys": ["rv", "vtemplate"]}
+    return model, data
+
+
+def test_anisotropic_dispersion_and_velocity_template_setup(tmp_path):
+    import victor_amd
+    import victor_oracle as vo
+    from victor_amd import tables as T
+    import scipy.interpolate as si
+    model, data = _aniso_inputs(tmp_path)
+    m = victor_amd.CCFModel(model)
+    o = vo.OracleModel(model)
+    assert m.sv_rmu.shape == o.sv_rmu.shape == (9, 25) and np.max(np.abs(m.sv_rmu - o.sv_rmu)) < 1e-14
+    patches = T.bicubic_patches(m.r_for_sv, m.mu_for_sv, m.sv_rmu.T)
+    ref = si.RectBivariateSpline(m.r_for_sv, m.mu_for_sv, m.sv_rmu.T)
+    rng = np.random.default_rng(2)
+    u = rng.uniform(m.r_for_sv[0], m.r_for_sv[-1], 300)
+    v = rng.uniform(0, 1, 300)
+    i = np.clip(np.searchsorted(m.r_for_sv, u, side="right") - 1, 0, len(m.r_for_sv) - 2)
+    j = np.clip(np.searchsorted(m.mu_for_sv, v, side="right") - 1, 0, len(m.mu_for_sv) - 2)
+    du, dv = u - m.r_for_sv[i], v - m.mu_for_sv[j]
+    val = sum(patches[i, j, p, q] * du ** p * dv ** q for p in range(4) for q in range(4))
+    assert np.max(np.abs(val - ref.ev(u, v))) < 1e-12
+    # mean model 'template' needs the template at construction time
+    mt = cases.clone(model)
+    mt["velocity_pdf"]["mean"]["model"] = "template"
+    mm = victor_amd.CCFModel(mt)
+    assert mm.has_velocity_template and mm.model["mean_model"] == "template"
+    from victor_amd import InputError
+    with pytest.raises(InputError):
+        m._check_supported(dict(m.model, mean_model="template"))       # no template was loaded for m
+    p = {"fsigma8": 0.5, "epsilon": 1.03}
+    om = vo.OracleModel(mt)
+    a = np.array(mm.velocity_terms(mm.r, p))
+    b = np.array(om.velocity_terms(om.r, p, om.model))
+    assert np.max(np.abs(a / b - 1)) < 1e-12

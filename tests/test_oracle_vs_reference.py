@@ -63,3 +63,36 @@ def test_cobaya_plugin_contract_matches_reference(ref):
     assert lk.get_can_provide_params() == ["fsigma8"]
     g, _ = cases.golden_outputs()
     assert abs(state["derived"]["chi2_ccf_correct"] - g["boss_cobaya_chi2"][0]) < 1e-9
+
+
+@pytest.mark.parametrize("with_beta", [False, True])
+def test_oracle_rmu_format_equals_reference(ref, tmp_path, with_beta):
+    import victor_oracle as vo
+    from tests.test_host import _rmu_inputs
+    model, _ = _rmu_inputs(tmp_path, with_beta)
+    rm = ref.CCFModel(cases.clone(model))
+    om = vo.OracleModel(model)
+    for ell in ("0", "2", "4"):
+        assert np.max(np.abs(rm.real_multipoles[ell] - om.real_multipoles[ell])) < 1e-15
+    s = np.linspace(4, 110, 12)
+    p = {"fsigma8": 0.5, "beta": 0.33, "sigma_v": 350, "epsilon": 1.02}
+    a = rm.theory_multipole_vector(s, dict(p), [0, 2, 4])
+    b = om.theory_multipole_vector(s, dict(p), [0, 2, 4])
+    assert np.max(np.abs(a - b)) < 1e-13
+
+
+def test_oracle_anisotropic_dispersion_and_velocity_template_equal_reference(ref, tmp_path):
+    import victor_oracle as vo
+    from tests.test_host import _aniso_inputs
+    model, data = _aniso_inputs(tmp_path, non_uniform_mu=True)
+    for mean in ("linear", "template"):
+        mdl = cases.clone(model)
+        mdl["velocity_pdf"]["mean"]["model"] = mean
+        rm = ref.CCFFit(cases.clone(mdl), cases.clone(data))
+        om = vo.OracleFit(mdl, data)
+        assert np.max(np.abs(rm.sv_rmu - om.sv_rmu)) < 1e-15
+        for kw in ({}, {"rsd_model": "dispersion"}, {"rsd_model": "kaiser"}):
+            p = {"fsigma8": 0.52, "sigma_v": 330, "aperp": 1.04, "apar": 0.95, "M": 1.05, "Q": 0.9}
+            a = rm.log_likelihood(dict(p), **kw)
+            b = om.log_likelihood(dict(p), **kw)
+            assert abs(a[0] - b[0]) <= 1e-11 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-11 * abs(a[1]), (mean, kw)

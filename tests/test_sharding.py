@@ -90,3 +90,46 @@ def test_two_rank_gloo_gather(tmp_path):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, out
         assert f"rank {rank} ok" in out
+
+
+ENSEMBLE_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from victor_amd.sharding import Dist
+from victor_amd.sampler import DistributedEnsemble, ParamSpec
+
+def evaluate(batch):
+    return -0.5 * ((batch["a"] - 0.2) ** 2 / 0.01 + (batch["b"] + 1.0) ** 2 / 0.25)
+
+dist = Dist()
+dist.init_process_group("gloo")
+specs = [ParamSpec("a", -1, 1, 0.2, 0.05, 0.1), ParamSpec("b", -4, 2, -1.0, 0.2, 0.5)]
+ens = DistributedEnsemble(evaluate, specs, walkers_per_rank=8, dist=dist, seed=5)
+chain, lnl, all_lnl = ens.run(25)
+assert chain.shape == (25, 8, 2) and all_lnl.shape == (25, 16)
+# every rank sees the whole ensemble's log-likelihoods, its own slice in its own slot
+assert np.array_equal(all_lnl[:, dist.rank * 8:(dist.rank + 1) * 8], lnl)
+other = all_lnl[:, (1 - dist.rank) * 8:(2 - dist.rank) * 8]
+assert not np.array_equal(other, lnl)          # the ranks run different walkers (different seeds)
+print("rank", dist.rank, "ok", float(all_lnl.sum()))
+'''
+
+
+def test_two_rank_distributed_ensemble(tmp_path):
+    script = tmp_path / "ens_worker.py"
+    script.write_text(ENSEMBLE_WORKER.format(root=ROOT))
+    port = str(_free_port())
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port, OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    sums = []
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert f"rank {rank} ok" in out
+        sums.append(out.strip().split()[-1])
+    assert sums[0] == sums[1]                       # both ranks hold the identical gathered log-likelihood history

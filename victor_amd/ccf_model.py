@@ -181,8 +181,10 @@ class CCFModel:
             if not self.template_fsigma8:
                 raise InputError("When using template model for the mean of the velocity pdf, a value for "
                                  "template_fsigma8 must be provided")
-            self.z_sim = velocity_pdf["mean"].get("z_sim", self.z_eff)
-            self.template_hubble_ratio = velocity_pdf["mean"].get("template_hubble_ratio", 1)
+            z_sim = velocity_pdf["mean"].get("z_sim", None)
+            ratio = velocity_pdf["mean"].get("template_hubble_ratio", None)
+            self.z_sim = self.z_eff if z_sim is None else z_sim
+            self.template_hubble_ratio = 1 if ratio is None else ratio
             template_keys = np.atleast_1d(velocity_pdf["mean"].get("template_keys"))
             if len(template_keys) != 2:
                 raise InputError(f"{len(template_keys)} velocity mean template keys provided, require 2")
@@ -239,8 +241,8 @@ class CCFModel:
         mono = utils.multipoles_from_fn(utils.bilinear_on_grid(self.r_for_sv, self.mu_for_sv, sv),
                                         self.r_for_sv[-1:], ell=[0])
         self.sv_rmu = sv / mono["0"][-1]
-        if not self._sv_isotropic:
-            self._unsupported.append("anisotropic (3-key) velocity dispersion template")
+        if not self._sv_isotropic and len(self.mu_for_sv) < 4:
+            raise InputError("Anisotropic dispersion template needs at least 4 mu values for cubic interpolation")
         if len(self.r_for_sv) < 4:
             raise InputError("Dispersion template needs at least 4 radial bins for cubic interpolation")
 
@@ -314,6 +316,12 @@ class CCFModel:
             apar = params.get("apar", 1)
         iaH_true = self.iaH * apar
         delta_r, int_delta_r = self.delta_profiles(r, params, **kwargs)
+        if model["mean_model"] == "template":
+            growth = (params["fsigma8"] / self.template_fsigma8) * self.template_hubble_ratio * \
+                (1 + self.z_sim) / (1 + self.z_eff) / apar
+            rg = np.linspace(0.1, self.r.max(), 100)
+            vr = self.radial_velocity(r) * growth
+            return vr, T.notaknot(rg, np.gradient(self.radial_velocity(rg) * growth, rg))(r)
         if model["matter_model"] == "linear_bias" and model["realspace_ccf_from_data"]:
             growth = params["beta"] * params.get("bias", model["bias"])
         else:
@@ -338,6 +346,13 @@ class CCFModel:
         V2 = r*Delta*delta, Ge1, Ge2; beta-dependent -> (2, n_beta-1, n_r, 4, 4) for V1, Da.
         """
         r_ext = np.append([0.01], self.r)
+        if matter_model == "velocity_template":
+            # v_r = growth_t * V_t(r/c); its derivative by the reference's numerical gradient (ccf_model.py:486-490)
+            rg = np.linspace(0.1, self.r.max(), 100)
+            gt = T.notaknot(rg, np.gradient(self.radial_velocity(rg), rg))(r_ext)
+            zero = np.zeros_like(r_ext)
+            nodal = np.stack([self.radial_velocity(r_ext), gt / 3, zero, zero, zero], axis=1)
+            return np.moveaxis(T.notaknot_coefficients(r_ext, nodal), 2, 0), False
         if matter_model == "linear_bias" and not self.fixed_real_input:
             Bd, Td = self._linear_bias_maps(r_ext)
             ypoly = T.pchip_coefficients(self.beta, self.real_multipoles["0"])      # (n_beta-1, 4, n_r)
@@ -380,9 +395,13 @@ class CCFModel:
             raise InputError("matter_model 'template' requested but no matter ccf template was loaded")
         if model["matter_model"] == "linear_bias" and not model["realspace_ccf_from_data"] and not self.template_sigma8:
             raise InputError("template_sigma8 must be provided for the linear_bias matter model")
-        if model["mean_model"] != "linear":
+        if model["mean_model"] == "template":
+            if not self.has_velocity_template:
+                raise InputError("velocity_terms: Cannot use template option as no template has been supplied.")
+        elif model["mean_model"] != "linear":
             problems.append(f"velocity mean model '{model['mean_model']}'")
-        if model["empirical_corr"] and model["matter_model"] == "linear_bias" and not self.fixed_real_input:
+        if (model["empirical_corr"] and model["mean_model"] == "linear" and model["matter_model"] == "linear_bias"
+                and not self.fixed_real_input):
             problems.append("empirical_corr together with linear_bias on a beta-dependent real-space ccf")
         if model["rsd_model"] not in N.RSD:
             raise InputError(f"theory_xi: Unrecognised choice of model {model['rsd_model']}")
@@ -442,10 +461,14 @@ class CCFModel:
         # growth term: beta*bias for linear_bias on a measured real-space ccf, fsigma8/sigma8 otherwise
         return not (model["matter_model"] == "linear_bias" and model["realspace_ccf_from_data"])
 
+    def _engine_key(self, model):
+        """Which table set a call needs: the velocity template replaces the matter-model based profile."""
+        return "velocity_template" if model["mean_model"] == "template" else model["matter_model"]
+
     def _prepare(self, params, model):
         """(engine, opts, rows) for one call with merged options ``model``."""
         self._check_supported(model)
-        eng = self._get_engine(model["matter_model"])
+        eng = self._get_engine(self._engine_key(model))
         opts = eng.make_opts(model)
         rows = self._param_rows(params, self._needs_beta(model), self._needs_fsigma8(model))
         return eng, opts, rows

@@ -70,6 +70,12 @@ struct TheoryArgs {
   double iaH;
   double inv_sigma8;
   int rescale_from_ap;
+  int matter_vt;          // velocity-template mean model: amplitude = -3 iaH vt_amp fsigma8
+  double vt_amp;
+  int sv_n_mu;            // > 0: anisotropic sigma_v(r, mu) template, bicubic patches in global memory
+  double sv_mu_inv_h;
+  const double* sv_mu;
+  const double* sv2d;
   int matter_lb;          // linear_bias matter model: amplitudes carry 1/bias (ccf_model.py:358-370,426-435)
   int vr_beta_dep;        // velocity tables are PCHIP-in-beta polynomials (rebuilt per point)
   int from_data;          // ccf_model.py:618-619,675-679
@@ -218,6 +224,36 @@ __device__ __forceinline__ double vel_shape(const PPLds& vr, const PointScalars&
   return V;
 }
 
+// Normalised dispersion sigma_v(r/c, mu_r)/sigma_v: the 1-D table, or the bicubic patches of the anisotropic
+// template with both arguments clamped to the table box (FITPACK bispeu; a negative mu_r therefore reads mu = 0).
+__device__ __forceinline__ double sv_shape(const PPLds& sv, const TheoryArgs& a, double u, double mu_r) {
+  const double usv = clampd(u, sv.lo, sv.hi);
+  const int i = pp_interval(sv, usv);
+  if (a.sv_n_mu == 0) return pp_eval_at(sv, 0, i, usv);
+  const int nm = a.sv_n_mu - 1;
+  const double m = clampd(mu_r, a.sv_mu[0], a.sv_mu[nm]);
+  int j;
+  if (a.sv_mu_inv_h > 0.0) {
+    j = min(max((int)((m - a.sv_mu[0]) * a.sv_mu_inv_h), 0), nm - 1);
+  } else {
+    int lo = 0, hi = nm;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (m >= a.sv_mu[mid]) lo = mid; else hi = mid;
+    }
+    j = lo;
+  }
+  const double du = usv - sv.knots[i], dm = m - a.sv_mu[j];
+  const double* c = a.sv2d + ((size_t)i * nm + j) * 16;
+  double acc = 0.0;
+#pragma unroll
+  for (int p = 3; p >= 0; --p) {
+    const double cp = fma(fma(fma(c[4 * p + 3], dm, c[4 * p + 2]), dm, c[4 * p + 1]), dm, c[4 * p]);
+    acc = fma(acc, du, cp);
+  }
+  return acc;
+}
+
 // One integrand point of the streaming model (ccf_model.py:648-657, 681-690), already multiplied by the
 // Simpson weight.  NLR = number of real-space multipoles summed (1 = assume_isotropic).
 template <int NLR>
@@ -229,8 +265,7 @@ __device__ __forceinline__ double streaming_integrand(const PPLds& sv, const PPL
   const double mu_r = r_par / r;
   const double u = r * ps.inv_c;
 
-  const double usv = clampd(u, sv.lo, sv.hi);
-  const double SV = pp_eval_at(sv, 0, pp_interval(sv, usv), usv);
+  const double SV = sv_shape(sv, a, u, mu_r);
   const double uv = clampd(u, vr.lo, vr.hi);
   const double V = vel_shape(vr, ps, a, pp_interval(vr, uv), uv);
   const double xir = xi_real<NLR>(xi, ps, a, u, mu_r, r_par, s_perp);
@@ -279,8 +314,7 @@ __device__ __forceinline__ double rsd_integrand(const PPLds& sv, const PPLds& vr
   const double m2 = mu_r * mu_r;
   const double xir = xi_real<NLR>(xi, ps, a, u, mu_r, r_par, s_perp);
   if (RSD == VK_RSD_DISPERSION) {
-    const double usv = clampd(u, sv.lo, sv.hi);
-    const double SV = pp_eval_at(sv, 0, pp_interval(sv, usv), usv);
+    const double SV = sv_shape(sv, a, u, mu_r);
     const double inv_sv = 1.0 / SV;
     const double z = xk * inv_sv;
     const double jac = 1.0 / (1.0 + q + m2 * (dq - q));
@@ -310,7 +344,7 @@ __device__ void stage_tables(const TheoryArgs& a, const LdsPlan& pl, double* lds
     lds[pl.wx + i] = a.w_x[i];
   }
   for (int i = tid; i <= a.sv.n_int; i += kBlock) lds[pl.svk + i] = a.sv.knots[i];
-  for (int i = tid; i < a.sv.n_int * 4; i += kBlock) lds[pl.svc + i] = a.sv.coef[i];
+  for (int i = tid; i < a.sv.n_int * 4; i += kBlock) lds[pl.svc + i] = a.sv_n_mu ? 0.0 : a.sv.coef[i];
   for (int i = tid; i <= a.vr.n_int; i += kBlock) lds[pl.vrk + i] = a.vr.knots[i];
   for (int i = tid; i < kVrVars * a.vr.n_int * 4; i += kBlock)
     lds[pl.vrc + i] = a.vr_beta_dep ? 0.0 : a.vr.coef[i];
@@ -397,9 +431,11 @@ __device__ __forceinline__ PointScalars point_scalars(const TheoryArgs& a, const
     binv = 1.0 / bias;
     extra += bias;
   }
+  // velocity template: v_r = growth_t V_t(r/c), growth_t = fsigma8 vt_amp / apar  ==  -gb V_t / (3 aH_true)
+  if (a.matter_vt) growth = -3.0 * a.iaH * a.vt_amp * fs8;
   const double gb = growth * binv;
   ps.av = 0.0;
-  if (a.empirical) {
+  if (a.empirical && !a.matter_vt) {
     ps.av = row[VK_P_AV] * binv;
     extra += ps.av;
   }
@@ -1137,7 +1173,9 @@ struct vk_ctx {
                *d_eig = nullptr;
   PPView xi{}, vr{}, sv{};
   bool fast_ok = false;      // tables qualify for vk_theory_fast_kernel
-  int matter_lb = 0, vr_beta_dep = 0;
+  int matter_lb = 0, vr_beta_dep = 0, matter_vt = 0, sv_n_mu = 0;
+  double vt_amp = 0, sv_mu_inv_h = 0;
+  const double *d_sv_mu = nullptr, *d_sv2d = nullptr;
   const char* last_kernel = "none";  // theory kernel variant of the most recent launch
   // scratch for the host-buffer entry points
   double* d_scratch = nullptr;
@@ -1282,9 +1320,15 @@ int theory_args(vk_ctx* ctx, const vk_eval_opts* o, TheoryArgs* a, int* nlr) {
   a->inv_sigma8 = 1.0 / ctx->template_sigma8;
   a->rescale_from_ap = o->rescale_from_ap;
   a->matter_lb = ctx->matter_lb;
+  a->matter_vt = ctx->matter_vt;
+  a->vt_amp = ctx->vt_amp;
+  a->sv_n_mu = ctx->sv_n_mu;
+  a->sv_mu_inv_h = ctx->sv_mu_inv_h;
+  a->sv_mu = ctx->d_sv_mu;
+  a->sv2d = ctx->d_sv2d;
   a->vr_beta_dep = ctx->vr_beta_dep;
   a->from_data = o->from_data ? 1 : 0;
-  a->empirical = o->empirical_corr ? 1 : 0;
+  a->empirical = (o->empirical_corr && !ctx->matter_vt) ? 1 : 0;   // the template-mean branch ignores Av (ccf_model.py:483-490)
   if (a->empirical && a->vr_beta_dep)
     return fail(ctx, VK_E_ARG, "empirical_corr with a beta-dependent linear_bias velocity profile is not implemented");
   a->rsd = o->rsd_model;
@@ -1486,7 +1530,8 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
   if (t->n_beta_r == 1 || t->n_beta_d == 1 || t->n_beta_c == 1) return bail("beta grids need at least 2 nodes");
   if (t->n_beta_r > 0 && !t->beta_r) return bail("beta_r missing");
   if (t->vr_beta_dep && t->n_beta_r < 2) return bail("beta-dependent velocity tables need the beta_r grid");
-  if (t->matter_model != VK_MATTER_TEMPLATE && t->matter_model != VK_MATTER_LINEAR_BIAS) return bail("unknown matter_model");
+  if (t->matter_model < VK_MATTER_TEMPLATE || t->matter_model > VK_MATTER_VELOCITY_TEMPLATE) return bail("unknown matter_model");
+  if (t->sv_n_mu != 0 && (t->sv_n_mu < 4 || !t->sv_mu || !t->sv2d)) return bail("anisotropic dispersion template needs >= 4 mu nodes and its patches");
   const int N = t->n_ell * t->n_s;
   if (t->data || t->prec) {
     if (!t->data || !t->prec) return bail("data and prec must be given together");
@@ -1528,7 +1573,9 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
       for (int i = 0; i <= t->xi.n_int && ok; ++i) ok = fabs(t->vr.knots[i + 1] - t->xi.knots[i]) <= tol;
       ok = ok && fabs(t->vr.inv_h - t->xi.inv_h) <= 1e-12 * t->xi.inv_h;
     }
-    ctx->fast_ok = ok && !t->vr_beta_dep;
+    ctx->fast_ok = ok && !t->vr_beta_dep && t->sv_n_mu == 0;
+    ctx->matter_vt = t->matter_model == VK_MATTER_VELOCITY_TEMPLATE;
+    ctx->vt_amp = t->vt_amp;
     ctx->matter_lb = t->matter_model == VK_MATTER_LINEAR_BIAS;
     ctx->vr_beta_dep = t->vr_beta_dep ? 1 : 0;
   }
@@ -1544,7 +1591,13 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
   const size_t o_xik = up.add(t->xi.knots, t->xi.n_int + 1), o_xic = up.add(t->xi.coef, xi_coef_n);
   const size_t vr_coef_n = t->vr_beta_dep ? (size_t)2 * (t->n_beta_r - 1) * t->vr.n_int * 16 : (size_t)kVrVars * t->vr.n_int * 4;
   const size_t o_vrk = up.add(t->vr.knots, t->vr.n_int + 1), o_vrc = up.add(t->vr.coef, vr_coef_n);
-  const size_t o_svk = up.add(t->sv.knots, t->sv.n_int + 1), o_svc = up.add(t->sv.coef, (size_t)t->sv.n_int * 4);
+  const size_t o_svk = up.add(t->sv.knots, t->sv.n_int + 1),
+               o_svc = up.add(t->sv.coef, t->sv_n_mu ? 4 : (size_t)t->sv.n_int * 4);   // 1-D coefficients unused with sv2d
+  size_t o_svmu = 0, o_sv2d = 0;
+  if (t->sv_n_mu) {
+    o_svmu = up.add(t->sv_mu, t->sv_n_mu);
+    o_sv2d = up.add(t->sv2d, (size_t)t->sv.n_int * (t->sv_n_mu - 1) * 16);
+  }
   size_t o_bd = 0, o_data = 0, o_bc = 0, o_prec = 0, o_ld = 0, o_eig = 0;
   if (t->data) {
     if (t->n_beta_d > 0) {
@@ -1578,6 +1631,12 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
   ctx->xi = view(t->xi, o_xik, o_xic);
   ctx->vr = view(t->vr, o_vrk, o_vrc);
   ctx->sv = view(t->sv, o_svk, o_svc);
+  ctx->sv_n_mu = t->sv_n_mu;
+  ctx->sv_mu_inv_h = t->sv_mu_inv_h;
+  if (t->sv_n_mu) {
+    ctx->d_sv_mu = base + o_svmu;
+    ctx->d_sv2d = base + o_sv2d;
+  }
   if (t->data) {
     ctx->d_beta_d = t->n_beta_d > 0 ? base + o_bd : nullptr;
     ctx->d_data = base + o_data;

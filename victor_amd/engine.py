@@ -86,11 +86,25 @@ def build_tables(model, fit=None, matter_model=None):
     t.vr, k = _pp(r_ext, vr_coef, lead=1)
     keep.append(k)
 
-    # dispersion template (isotropic): the bicubic RectBivariateSpline of ccf_model.py:654 through
-    # mu-independent data is the 1-D not-a-knot spline in r
-    sv_r = model.sv_rmu[0]
-    t.sv, k = _pp(model.r_for_sv, T.notaknot_coefficients(model.r_for_sv, sv_r)[None])
-    keep.append(k)
+    if matter_model == "velocity_template":
+        t.vt_amp = float(model.template_hubble_ratio * (1 + model.z_sim) / (1 + model.z_eff) / model.template_fsigma8)
+
+    # dispersion template.  Isotropic: the bicubic RectBivariateSpline of ccf_model.py:654 through mu-independent
+    # data is the 1-D not-a-knot spline in r.  Anisotropic (3 keys): bicubic patches, evaluated from global memory.
+    if model._sv_isotropic:
+        t.sv, k = _pp(model.r_for_sv, T.notaknot_coefficients(model.r_for_sv, model.sv_rmu[0])[None])
+        keep.append(k)
+        t.sv_n_mu = 0
+    else:
+        patches = arr(T.bicubic_patches(model.r_for_sv, model.mu_for_sv, model.sv_rmu.T))
+        mu_sv = arr(model.mu_for_sv)
+        t.sv, k = _pp(model.r_for_sv, patches)          # coef pointer unused by the kernels in this mode
+        keep.append(k)
+        t.sv_n_mu = len(mu_sv)
+        hmu = T.uniform_spacing(mu_sv)
+        t.sv_mu_inv_h = 1.0 / hmu if hmu is not None else 0.0
+        t.sv_mu = N.as_dp(mu_sv)
+        t.sv2d = N.as_dp(patches)
 
     t.iaH = float(model.iaH)
     # not used when the growth term is beta*bias (linear_bias on a measured real-space ccf)

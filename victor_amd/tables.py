@@ -285,3 +285,15 @@ def trapezoid_weights(x):
     w[:-1] += 0.5 * d
     w[1:] += 0.5 * d
     return w
+
+
+def bicubic_patches(x, y, z):
+    """Power-basis patches of the tensor-product not-a-knot spline through ``z`` (len(x), len(y)).
+
+    Returns (len(x)-1, len(y)-1, 4, 4): coefficient of (u - x_i)^p (v - y_j)^q.  This is what
+    ``RectBivariateSpline(x, y, z)`` (kx = ky = 3, s = 0) interpolates with: FITPACK places its knots on the data
+    points minus the 2nd and 2nd-last in each direction, i.e. the not-a-knot spline along each axis.
+    """
+    lx = notaknot_coefficients(x, np.eye(len(x)))      # (nx-1, 4, nx)
+    ly = notaknot_coefficients(y, np.eye(len(y)))      # (ny-1, 4, ny)
+    return np.einsum("ipn,jqm,nm->ijpq", lx, ly, np.asarray(z, dtype=np.float64))
