@@ -78,11 +78,6 @@ extern "C" {
 #define VK_LIKE_HARTLAP 2
 #define VK_LIKE_PERCIVAL 3
 
-/* 'want' bit mask for vk_eval_batch */
-#define VK_WANT_LNL 1u
-#define VK_WANT_CHI2 2u
-#define VK_WANT_THEORY 4u
-
 /*
  * A clamped piecewise-cubic table  f(u) = sum_p coef[i][p] * (u - knot_i)^p  on interval i.
  * Evaluation clamps u to [knots[0], knots[n_int]] first (FITPACK ext=3 / box clamp).

@@ -1369,13 +1369,23 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   // lanes-over-batch variant: batch-constant tables and enough points to fill the chip with n_s * n/64 waves
   const char* mapping = getenv("VICTOR_HIP_MAPPING");
   const bool lanes_ok = fast && a.n_beta_r == 0 && !a.matter_lb;
-  const bool lanes = lanes_ok && (mapping ? !strcmp(mapping, "lanes") : a.n >= 8192);
+  // One wave per (s bin, 64-point chunk).  The kernel is register-limited to 4 waves per SIMD, i.e. 16 per CU, so the
+  // chip holds n_cu*16 waves at a time; the last round of waves is only partly filled.  The lanes kernel is ~1.2x
+  // faster per integrand than the point-major one (81 vs 92 VALU instructions), so it wins once that fill
+  // efficiency exceeds ~0.85.
+  const long long waves = ((a.n + 63) >> 6) * (long long)a.n_s;
+  const long long slots = 16LL * ctx->n_cu;
+  const long long rounds = (waves + slots - 1) / slots;
+  const double fill = (double)waves / (double)(rounds * slots);
+  const bool lanes = lanes_ok && (mapping ? !strcmp(mapping, "lanes") : fill >= 0.85);
   if (lanes) {
     ctx->last_kernel = "vk_theory_lanes_kernel";
     const size_t lds_l = (size_t)make_lanes_plan(a.n_mu, a.n_x, a.sv.n_int, a.xi.n_int, nlr).total * sizeof(double);
-    const long long waves = ((a.n + 63) >> 6) * (long long)a.n_s;
     const long long blocks = (waves + kWaves - 1) / kWaves;
-    const long long capl = 16LL * ctx->n_cu;
+    // Many more workgroups than fit at once: letting the dispatcher refill CUs as workgroups retire measured
+    // 38.1 / 36.0 / 34.6 / 33.8 ms at 4 / 8 / 16 / 64 workgroups per CU on the bench workload (4 are resident)
+    const char* cap_env = getenv("VICTOR_HIP_LANES_CAP");          // tuning knob: workgroups per CU in the launch
+    const long long capl = (cap_env ? atoll(cap_env) : 64LL) * ctx->n_cu;
     const int grid_l = (int)(blocks < capl ? blocks : capl);
     switch (nlr) {
       case 1: return launch_lanes_nl<1>(ctx, a, grid_l, lds_l);
