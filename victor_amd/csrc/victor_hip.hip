@@ -1364,7 +1364,9 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   if (lds > 160 * 1024) return fail(ctx, VK_E_ARG, "tables need %zu bytes of LDS (> 160 KiB)", lds);
   const long long groups = (a.n_s + a.sbins_per_item - 1) / a.sbins_per_item;
   const long long items = a.n * groups;
-  const long long cap = 8LL * ctx->n_cu;
+  // over-subscribe: 27.9 / 25.9 / 24.8 / 24.0 ms at 4 / 8 / 16 / 64 workgroups per CU on BOSS x 65536 (4 are resident)
+  const char* pcap_env = getenv("VICTOR_HIP_POINT_CAP");            // tuning knob: workgroups per CU in the launch
+  const long long cap = (pcap_env ? atoll(pcap_env) : 64LL) * ctx->n_cu;
   const int grid = (int)(items < cap ? items : cap);
   // lanes-over-batch variant: batch-constant tables and enough points to fill the chip with n_s * n/64 waves
   const char* mapping = getenv("VICTOR_HIP_MAPPING");
