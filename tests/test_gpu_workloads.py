@@ -86,3 +86,24 @@ def test_density_split_joint_fit():
     assert np.max(np.abs(lnl + 0.5 * chi2)) < 1e-9 * np.max(chi2)
     parts = sum(f.log_likelihood_batch({k: v[:64] for k, v in hp.items()})[1] for f in joint.fits)
     assert np.max(np.abs(parts / chi2[:64] - 1)) < 1e-12      # sub-batches use a different work split / summation order
+
+
+def test_walker_example_under_torchrun_single_rank():
+    """examples/run_walkers.py as one rank of a torch.distributed.run launch: exercises the RCCL communicator
+    (unique id broadcast, ncclCommInitRank, ncclAllGather on the context's stream) end to end."""
+    import json
+    import socket
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "examples", "run_walkers.py"), "--steps", "40"]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    res = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    assert res["walkers_total"] == 8 and res["gathered_shape"] == [40, 8]
+    assert 0.02 < res["acceptance"] < 0.95
+    assert 0.2 <= res["mean"]["beta"] <= 0.6 and 100 <= res["mean"]["sigma_v"] <= 500
+    assert res["best_lnl_over_all_ranks"] > 250          # the reference point alone gives lnL = 284.8

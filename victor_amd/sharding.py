@@ -145,3 +145,29 @@ class ShardedLikelihood:
             eng.free(d_send)
             eng.free(d_recv)
         return out[:, 0].reshape(-1), out[:, 1].reshape(-1)
+
+
+class RcclGather:
+    """All-gather of equal-size double arrays through RCCL on the engine's stream (device staging buffers are
+    allocated once).  ``uid`` comes from rank 0's ``Engine.comm_unique_id()`` broadcast over the host process group."""
+
+    def __init__(self, engine, dist, count):
+        self.engine, self.dist, self.count = engine, dist, int(count)
+        uid = engine.comm_unique_id() if dist.rank == 0 else None
+        uid = dist.broadcast_bytes(uid, src=0, nbytes=128)
+        engine.comm_init(uid, dist.rank, dist.world)
+        self.d_send = engine.alloc(self.count)
+        self.d_recv = engine.alloc(self.count * dist.world)
+
+    def __call__(self, local):
+        local = np.ascontiguousarray(local, dtype=np.float64)
+        assert local.shape == (self.count,)
+        self.engine.upload(self.d_send, local)
+        self.engine.comm_allgather_async(self.d_send, self.d_recv, self.count)
+        self.engine.sync()
+        return self.engine.download(self.d_recv, self.count * self.dist.world)
+
+    def close(self):
+        self.engine.free(self.d_send)
+        self.engine.free(self.d_recv)
+        self.engine.comm_destroy()
