@@ -314,3 +314,67 @@ def test_lanes_over_batch_mapping_matches_point_major(synth_fit, gold):
             assert np.max(np.abs(chi2 / g[f"synth{config}_chi2"] - 1)) < RTOL, (config, mapping)
         assert np.max(np.abs(out["point"][1] / out["lanes"][1] - 1)) < 1e-11
         assert not np.array_equal(out["point"][1], out["lanes"][1])
+
+
+# --------------------------------------------------------------------------- edge cases
+def test_empty_and_ragged_batches(synth_fit):
+    fit = synth_fit[3]
+    hp = cases.halton_params(200)
+    lnl, chi2 = fit.log_likelihood_batch({k: v[:0] for k, v in hp.items()})
+    assert lnl.shape == (0,) and chi2.shape == (0,)
+    assert fit.theory_vector_batch({k: v[:0] for k, v in hp.items()}).shape == (0, 120)
+    full = fit.log_likelihood_batch(hp)
+    for n in (1, 2, 63, 64, 65, 127, 129):
+        for mapping in ("point", "lanes"):
+            os.environ["VICTOR_HIP_MAPPING"] = mapping
+            try:
+                lnl, chi2 = fit.log_likelihood_batch({k: v[:n] for k, v in hp.items()})
+            finally:
+                del os.environ["VICTOR_HIP_MAPPING"]
+            assert lnl.shape == (n,)
+            assert np.max(np.abs(chi2 / full[1][:n] - 1)) < 1e-11, (n, mapping)
+
+
+def test_bad_rows_do_not_contaminate_neighbours(synth_fit, boss_fit):
+    """A NaN / inf parameter row yields (-inf, +inf) for that row only (ccf_fit.py:477-481), in both mappings."""
+    fit = synth_fit[3]
+    hp = cases.halton_params(9000)
+    good = fit.log_likelihood_batch(hp)
+    bad = {k: v.copy() for k, v in hp.items()}
+    bad["fsigma8"][5] = np.nan
+    bad["sigma_v"][77] = np.inf
+    bad["aperp"][8999] = np.nan
+    for mapping in ("point", "lanes"):
+        os.environ["VICTOR_HIP_MAPPING"] = mapping
+        try:
+            lnl, chi2 = fit.log_likelihood_batch(bad)
+        finally:
+            del os.environ["VICTOR_HIP_MAPPING"]
+        for i in (5, 77, 8999):
+            assert lnl[i] == -np.inf and chi2[i] == np.inf, (mapping, i)
+        keep = np.ones(9000, bool)
+        keep[[5, 77, 8999]] = False
+        assert np.max(np.abs(chi2[keep] / good[1][keep] - 1)) < 1e-11
+    rows = boss_fit["config"]._fit_rows(cases.halton_params(50, with_beta=True), boss_fit["config"].model)
+    rows[7, 5] = np.nan                                   # beta
+    lnl, chi2 = boss_fit["config"].log_likelihood_batch(rows)
+    assert lnl[7] == -np.inf and np.all(np.isfinite(np.delete(lnl, 7)))
+
+
+def test_extreme_but_valid_parameters_vs_oracle(synth_fit, oracle):
+    """Corners of parameter space that push the integrand into its clamps: tiny dispersion (pdf far in the tails,
+    exp underflow), strong AP distortion (r beyond every table), very large growth rate."""
+    fit = synth_fit[3]
+    ora = oracle.OracleFit(*cases.synth_options(3))
+    pts = [{"fsigma8": 1.5, "sigma_v": 40.0, "aperp": 0.8, "apar": 1.2},
+           {"fsigma8": 0.05, "sigma_v": 900.0, "aperp": 1.35, "apar": 0.7},
+           {"fsigma8": 3.0, "sigma_v": 100.0, "aperp": 1.0, "apar": 1.0},
+           {"fsigma8": 0.0, "sigma_v": 250.0, "aperp": 0.6, "apar": 1.5}]
+    for p in pts:
+        got = fit.log_likelihood(dict(p))
+        want = ora.log_likelihood(dict(p))
+        assert np.isfinite(want[1])
+        assert abs(got[1] / want[1] - 1) < RTOL and abs(got[0] / want[0] - 1) < RTOL, p
+        t = fit.theory_multipole_vector(fit.s, dict(p), fit.poles_s)
+        to = ora.theory_multipole_vector(ora.s, dict(p), ora.poles_s)
+        assert vec_close(t, to), p

@@ -416,10 +416,10 @@ class CCFModel:
                 raise InputError(f"parameter array must have shape (n, {N.VK_NPAR})")
             return rows
         get = params.get
-        n = 1
-        for v in params.values():
-            if np.ndim(v) > 0:
-                n = max(n, len(v))
+        lengths = {len(v) for v in params.values() if np.ndim(v) > 0}
+        if len(lengths) > 1:
+            raise InputError(f"parameter arrays have different lengths: {sorted(lengths)}")
+        n = lengths.pop() if lengths else 1           # an empty batch (length 0) is legal
         rows = np.empty((n, N.VK_NPAR))
 
         def col(v):
