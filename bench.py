@@ -58,6 +58,22 @@ def cpu_worker(args):
     return idx, busy, out, theory
 
 
+class stdout_to_stderr:
+    """Route file descriptor 1 to stderr while native libraries (gloo, RCCL) print their banners, so that the only thing
+    this program ever writes to stdout is rank 0's JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def host_cores():
     """Cores this job may really use: affinity mask, capped by the cgroup CPU quota and by 16 (the GPU box's
     documented share per GPU; the visible 256 hardware threads are not ours - 256 workers ran at 0.6 evals/s each
@@ -196,7 +212,8 @@ def main():
     from victor_amd.sharding import Dist
     dist = Dist()
     if launched:
-        dist.init_process_group("gloo")
+        with stdout_to_stderr():
+            dist.init_process_group("gloo")
     rank, world = dist.rank, dist.world
     if launched and world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
@@ -236,15 +253,21 @@ def main():
     eng.upload(d_rows, rows)
     use_comm = launched
     if use_comm:
-        uid = eng.comm_unique_id() if rank == 0 else None
-        uid = dist.broadcast_bytes(uid, src=0, nbytes=128)
-        eng.comm_init(uid, rank, world)
+        # RCCL logs (version banner, topology warnings) go to stdout by default; stdout is reserved for the JSON line
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
+        with stdout_to_stderr():
+            uid = eng.comm_unique_id() if rank == 0 else None
+            uid = dist.broadcast_bytes(uid, src=0, nbytes=128)
+            eng.comm_init(uid, rank, world)
+            eng.comm_allgather_async(d_lnl, d_all, B)      # first collective builds the rings (and logs) here
+            eng.sync()
 
     def step():
         eng.eval_device_async(opts, d_rows, B, d_lnl, d_chi, d_ws)
         if use_comm:
             eng.comm_allgather_async(d_lnl, d_all, B)
 
+    warm_up(eng, step)                 # untimed pre-warm (runtime's one-off post-allocation stall), then the W steps
     for _ in range(args.warmup):
         step()
     eng.sync()
@@ -338,6 +361,8 @@ def main():
     if use_comm:
         eng.comm_destroy()
     dist.barrier()
+    if dist.pg is not None:
+        dist.pg.destroy_process_group()
     if not ok:
         sys.exit(1)
 

@@ -35,6 +35,7 @@ def main():
     from victor_amd.sampler import DistributedEnsemble, gelman_rubin, parse_cobaya_params
     from victor_amd.sharding import Dist, RcclGather
 
+    os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")      # keep RCCL's log lines off stdout
     dist = Dist()
     if dist.launched:
         dist.init_process_group("gloo")
