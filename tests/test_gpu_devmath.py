@@ -1,0 +1,29 @@
+"""Accuracy of the FP64 building blocks of the fast kernels (vk_devmath.h) measured on the hardware itself."""
+
+import json
+import os
+import shutil
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_device_math_within_two_ulp(tmp_path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = os.path.join(ROOT, "tools", "devmath_check")
+    src = os.path.join(ROOT, "tools", "devmath_check.hip")
+    hdr = os.path.join(ROOT, "victor_amd", "csrc", "vk_devmath.h")
+    if not os.path.isfile(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        exe = str(tmp_path / "devmath_check")
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-I", os.path.join(ROOT, "victor_amd", "csrc"),
+                               src, "-o", exe], stderr=subprocess.DEVNULL)
+    out = subprocess.check_output([exe]).decode().strip().splitlines()[-1]
+    res = json.loads(out)
+    # 4M samples each: sqrt/rsqrt over x in [2e-9, 5e8], recip likewise, exp over [-760, 0]
+    assert res["sqrt_ulp"] <= 2.0 and res["rsqrt_ulp"] <= 2.0 and res["recip_ulp"] <= 1.0
+    assert res["exp_ulp_normal"] <= 2.5
+    # the raw hardware seeds are only ~2^-24, which is why each gets a third-order correction step
+    assert 1e-9 < res["raw_v_rsq_f64_rel"] < 1e-6 and 1e-9 < res["raw_v_rcp_f64_rel"] < 1e-6
