@@ -295,10 +295,12 @@ def test_lanes_over_batch_mapping_matches_point_major(synth_fit, gold):
     hp = cases.halton_params(8192 + 37)              # not a multiple of 64: exercises the ragged last chunk
     for config in (2, 3):
         fit = synth_fit[config]
-        for mapping in ("point", "lanes"):
+        for mapping in ("point", "lanes", "cells"):
             os.environ["VICTOR_HIP_MAPPING"] = mapping
             try:
                 out[mapping] = fit.log_likelihood_batch(hp)
+                assert fit._get_engine().last_kernel() == {"point": "vk_theory_fast_kernel", "lanes": "vk_theory_lanes_kernel",
+                                                           "cells": "vk_theory_cells_kernel"}[mapping]
             finally:
                 del os.environ["VICTOR_HIP_MAPPING"]
             # golden points through each mapping as well
@@ -313,6 +315,7 @@ def test_lanes_over_batch_mapping_matches_point_major(synth_fit, gold):
                 del os.environ["VICTOR_HIP_MAPPING"]
             assert np.max(np.abs(chi2 / g[f"synth{config}_chi2"] - 1)) < RTOL, (config, mapping)
         assert np.max(np.abs(out["point"][1] / out["lanes"][1] - 1)) < 1e-11
+        assert np.max(np.abs(out["point"][1] / out["cells"][1] - 1)) < 1e-11
         assert not np.array_equal(out["point"][1], out["lanes"][1])
 
 
@@ -325,7 +328,7 @@ def test_empty_and_ragged_batches(synth_fit):
     assert fit.theory_vector_batch({k: v[:0] for k, v in hp.items()}).shape == (0, 120)
     full = fit.log_likelihood_batch(hp)
     for n in (1, 2, 63, 64, 65, 127, 129):
-        for mapping in ("point", "lanes"):
+        for mapping in ("point", "lanes", "cells"):
             os.environ["VICTOR_HIP_MAPPING"] = mapping
             try:
                 lnl, chi2 = fit.log_likelihood_batch({k: v[:n] for k, v in hp.items()})
@@ -344,7 +347,7 @@ def test_bad_rows_do_not_contaminate_neighbours(synth_fit, boss_fit):
     bad["fsigma8"][5] = np.nan
     bad["sigma_v"][77] = np.inf
     bad["aperp"][8999] = np.nan
-    for mapping in ("point", "lanes"):
+    for mapping in ("point", "lanes", "cells"):
         os.environ["VICTOR_HIP_MAPPING"] = mapping
         try:
             lnl, chi2 = fit.log_likelihood_batch(bad)
@@ -378,3 +381,33 @@ def test_extreme_but_valid_parameters_vs_oracle(synth_fit, oracle):
         t = fit.theory_multipole_vector(fit.s, dict(p), fit.poles_s)
         to = ora.theory_multipole_vector(ora.s, dict(p), ora.poles_s)
         assert vec_close(t, to), p
+
+
+def test_cells_mapping_on_beta_dependent_tables(boss_fit, gold):
+    """BOSS (per-point xi^r tables): the cells kernel against the point-major kernel and the reference goldens."""
+    g, meta = gold
+    for variant in ("config", "cobaya"):
+        fit = boss_fit[variant]
+        rows = np.concatenate([fit._fit_rows(dict(p), fit.model) for p in meta["boss_points"]])
+        res = {}
+        for mapping in ("point", "cells"):
+            os.environ["VICTOR_HIP_MAPPING"] = mapping
+            try:
+                res[mapping] = fit.log_likelihood_batch(rows)
+                th = fit.theory_vector_batch(rows, assume_isotropic=False)
+            finally:
+                del os.environ["VICTOR_HIP_MAPPING"]
+            assert np.max(np.abs(res[mapping][1] / g[f"boss_{variant}_chi2"] - 1)) < RTOL, (variant, mapping)
+            if variant == "config":
+                assert vec_close(th[:3], g["boss_aniso_theory"]), mapping
+        assert np.max(np.abs(res["point"][1] / res["cells"][1] - 1)) < 1e-11
+    hb = cases.halton_params(3000, with_beta=True)
+    fit = boss_fit["config"]
+    a = fit.log_likelihood_batch(hb)                      # default choice at this size: cells
+    assert fit._get_engine().last_kernel() == "vk_theory_cells_kernel"
+    os.environ["VICTOR_HIP_MAPPING"] = "point"
+    try:
+        b = fit.log_likelihood_batch(hb)
+    finally:
+        del os.environ["VICTOR_HIP_MAPPING"]
+    assert np.max(np.abs(a[0] / b[0] - 1)) < 1e-11

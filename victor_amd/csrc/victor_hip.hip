@@ -994,6 +994,197 @@ __global__ __launch_bounds__(kBlock) void vk_theory_lanes_kernel(TheoryArgs a) {
 }
 
 // --------------------------------------------------------------------------------------------------
+// K1 "cells" variant: the lanes kernel's inner loop for per-point tables (reconstruction beta, BOSS).
+// One workgroup owns one parameter point (its xi^r records are rebuilt in LDS as in the point-major kernel); each
+// of its four waves owns the s bins j = wave, wave+4, ... and spreads the (s bin, mu) cells of those bins over its
+// lanes, with the 50 velocity nodes as the inner, wave-uniform loop.  Like the lanes kernel this forms s_perp and
+// s_par once per cell, reads x_k, w_k as LDS broadcasts and closes the v sum before the projection, so the
+// integrand costs the same ~80 instructions; the projection sum over mu is a two-segment wave reduction per trip
+// (a wave's 64 cells straddle at most two s bins when n_mu >= 64), accumulated by lane 0 in wave-private LDS.
+// --------------------------------------------------------------------------------------------------
+struct CellsPlan {
+  int mu, w, xw, s, svrec, vxrec, lead, etab, betar, acc, total, vx_stride;
+};
+
+__host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s, int n_ell, int sv_int, int xi_int,
+                                                    int nlr, int n_beta_r) {
+  CellsPlan p;
+  int o = 0;
+  p.vx_stride = 4 * (1 + nlr) + 2;
+  p.mu = o;    o += 2 * n_mu;                      // {mu_i, sqrt(1 - mu_i^2)}
+  p.w = o;     o += kMaxEll * n_mu;                // W_l[i]
+  p.xw = o;    o += 2 * n_x;                       // {x_k, w_k}
+  p.s = o;     o += (n_s + 1) & ~1;
+  p.svrec = o; o += sv_int * kSvRec;
+  p.vxrec = o; o += xi_int * p.vx_stride;
+  p.lead = o;  o += 4;
+  p.etab = o;  o += 32;
+  p.betar = o; o += (n_beta_r + 1) & ~1;
+  p.acc = o;   o += kMaxEll * ((n_s + kWaves - 1) / kWaves) * kWaves;   // [l][slot][wave]
+  p.total = o;
+  return p;
+}
+
+// (130 VGPRs -> 3 waves per SIMD; forcing 4 with __launch_bounds__(256, 4) spills and measured 1.5 % slower)
+template <int NLR, int NL>
+__global__ __launch_bounds__(kBlock) void vk_theory_cells_kernel(TheoryArgs a) {
+  extern __shared__ double lds[];
+  constexpr int vx_stride = 4 * (1 + NLR) + 2;
+  const CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.n_ell, a.sv.n_int, a.xi.n_int, NLR, a.n_beta_r);
+  const int tid = threadIdx.x;
+  const double hs = 1.0 / a.sv.inv_h, hx = 1.0 / a.xi.inv_h;
+  const double hl = a.vr.knots[1] - a.vr.knots[0];
+  for (int i = tid; i < a.n_mu; i += kBlock) {
+    const double m = a.mu[i];
+    lds[pl.mu + 2 * i] = m;
+    lds[pl.mu + 2 * i + 1] = sqrt(1.0 - m * m);
+#pragma unroll
+    for (int l = 0; l < kMaxEll; ++l) lds[pl.w + l * a.n_mu + i] = (l < NL) ? a.w_ell[l * a.n_mu + i] : 0.0;
+  }
+  for (int k = tid; k < a.n_x; k += kBlock) {
+    lds[pl.xw + 2 * k] = a.x[k];
+    lds[pl.xw + 2 * k + 1] = a.w_x[k];
+  }
+  for (int j = tid; j < a.n_s; j += kBlock) lds[pl.s + j] = a.s[j];
+  for (int e = tid; e < a.sv.n_int * 4; e += kBlock)
+    lds[pl.svrec + (e >> 2) * kSvRec + (e & 3)] = a.sv.coef[e] * hpow(hs, e & 3);
+  for (int e = tid; e < a.xi.n_int * 4; e += kBlock)
+    lds[pl.vxrec + (e >> 2) * vx_stride + (e & 3)] = a.vr.coef[4 + e] * hpow(hx, e & 3);
+  if (a.n_beta_r == 0) {
+    const int per_l = a.xi.n_int * 4;
+    for (int e = tid; e < NLR * per_l; e += kBlock) {
+      const int l = e / per_l, iq = e - l * per_l;
+      lds[pl.vxrec + (iq >> 2) * vx_stride + 4 * (1 + l) + (iq & 3)] = a.xi.coef[e] * hpow(hx, iq & 3);
+    }
+  } else {
+    for (int i = tid; i < a.n_beta_r; i += kBlock) lds[pl.betar + i] = a.beta_r[i];
+  }
+  if (tid < 4) lds[pl.lead + tid] = a.vr.coef[tid] * hpow(hl, tid);
+  if (tid < 32) lds[pl.etab + tid] = vkm::exp2_frac32(tid);
+  FastConsts fc;
+  fc.inv_hs = a.sv.inv_h;
+  fc.off_s = -a.sv.knots[0] * a.sv.inv_h;
+  fc.ns_eps = (double)a.sv.n_int * (1.0 - 0x1p-52);
+  fc.inv_hx = a.xi.inv_h;
+  fc.off_x = -a.xi.knots[0] * a.xi.inv_h;
+  fc.nx_eps = (double)a.xi.n_int * (1.0 - 0x1p-52);
+  fc.inv_hl = 1.0 / hl;
+  fc.off_l = -a.vr.knots[0] * fc.inv_hl;
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const double* l_mu = lds + pl.mu;
+  const double* l_w = lds + pl.w;
+  const double* l_xw = lds + pl.xw;
+  const double* l_s = lds + pl.s;
+  const double* svrec = lds + pl.svrec;
+  const double* vxrec = lds + pl.vxrec;
+  const double* leadrec = lds + pl.lead;
+  const double* etab = lds + pl.etab;
+  const int slots = (a.n_s + kWaves - 1) / kWaves;        // s bins per wave (upper bound)
+  double* l_acc = lds + pl.acc;                            // [l][slot][wave]: each entry touched by one wave only
+  const int my_bins = (a.n_s - wave + kWaves - 1) / kWaves;  // bins j = wave + 4*jj, jj < my_bins
+  const int cells = my_bins * a.n_mu;
+
+  double wsum[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    double t = 0.0;
+    for (int i = lane; i < a.n_mu; i += 64) t += l_w[l * a.n_mu + i];
+    wsum[l] = wave_sum(t);
+  }
+
+  for (long long point = blockIdx.x; point < a.n; point += gridDim.x) {
+    const double* row = a.params + point * VK_NPAR;
+    const PointScalars ps = point_scalars(a, row);
+    if (a.n_beta_r > 0) {
+      __syncthreads();
+      const double* bg = lds + pl.betar;
+      const double beta = row[VK_P_BETA];
+      int kb = 0;
+      for (int i = 1; i < a.n_beta_r - 1; ++i) kb = (beta >= bg[i]) ? i : kb;
+      const double db = beta - bg[kb];
+      const int per_l = a.xi.n_int * 4;
+      const size_t stride_l = (size_t)(a.n_beta_r - 1) * per_l * 4;
+      for (int e = tid; e < NLR * per_l; e += kBlock) {
+        const int l = e / per_l, iq = e - l * per_l;
+        const double* c = a.xi.coef + l * stride_l + ((size_t)kb * per_l + iq) * 4;
+        lds[pl.vxrec + (iq >> 2) * vx_stride + 4 * (1 + l) + (iq & 3)] =
+            fma(fma(fma(c[3], db, c[2]), db, c[1]), db, c[0]) * hpow(hx, iq & 3);
+      }
+      __syncthreads();
+    }
+    for (int e = lane; e < kMaxEll * slots; e += 64) l_acc[e * kWaves + wave] = 0.0;
+    const double AV = ps.A;
+    for (int base = 0; base < cells; base += 64) {
+      const int e = base + lane;
+      const bool live = e < cells;
+      const int ec = live ? e : cells - 1;
+      const int jj = ec / a.n_mu;
+      const int i = ec - jj * a.n_mu;
+      const double sj = l_s[wave + kWaves * jj];
+      const vk_d2 mm = *reinterpret_cast<const vk_d2*>(l_mu + 2 * i);
+      const double s_perp = sj * ps.aperp * mm.y;
+      const double sperp2 = s_perp * s_perp;
+      const double s_par = sj * ps.apar * mm.x;
+      double g = 0.0;
+      for (int k = 0; k < a.n_x; ++k) {
+        const vk_d2 xw = *reinterpret_cast<const vk_d2*>(l_xw + 2 * k);
+        const double xk = xw.x;
+        const double r_par = fma(-xk, ps.B, s_par);
+        const double r2 = fma(r_par, r_par, sperp2);
+        double r, inv_r;
+        vkm::sqrt_rsqrt(r2, r, inv_r);
+        const double mu_r = r_par * inv_r;
+        const double u = r * ps.inv_c;
+        const double ts = vmin_f64(fmax(fma(u, fc.inv_hs, fc.off_s), 0.0), fc.ns_eps);
+        const double SV = cubic_b128(lds_at(svrec, __mul24((int)ts, kSvRec * 8)), __builtin_amdgcn_fract(ts));
+        const double tr = fma(u, fc.inv_hx, fc.off_x);
+        const double tx = vmin_f64(fmax(tr, 0.0), fc.nx_eps);
+        const double tq = __builtin_amdgcn_fract(tx);
+        const double* rec = lds_at(vxrec, __mul24((int)tx, vx_stride * 8));
+        double V = cubic_b128(rec, tq);
+        if (tr < 0.0) V = cubic_b128(leadrec, fmax(fma(u, fc.inv_hl, fc.off_l), 0.0));
+        double xir = cubic_b128(rec + 4, tq);
+        if (NLR > 1) {
+          const double m2 = mu_r * mu_r;
+          xir = fma(cubic_b128(rec + 8, tq), fma(1.5, m2, -0.5), xir);
+          if (NLR > 2) xir = fma(cubic_b128(rec + 12, tq), vkm::fma3(vkm::fma3(m2, 4.375, -3.75), m2, 0.375), xir);
+        }
+        const double inv_sv = vkm::recip(SV);
+        const double z = fma(AV * V, mu_r, xk) * inv_sv;
+        const double ex = vkm::exp_nonpos((-0.5 * z) * z, etab);
+        g = fma(xw.y * inv_sv, fma(ex, xir, ex), g);
+      }
+      if (!live) g = 0.0;
+      // projection: this trip's cells belong to s bin jj0 or jj0 + 1
+      const int jj0 = __builtin_amdgcn_readfirstlane(jj);
+      const bool first = (jj == jj0);
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        const double v = l_w[l * a.n_mu + i] * g;
+        const double s0 = wave_sum(first ? v : 0.0);
+        const double s1 = wave_sum(first ? 0.0 : v);
+        if (lane == 0) {
+          l_acc[(l * slots + jj0) * kWaves + wave] += s0;
+          if (jj0 + 1 < my_bins) l_acc[(l * slots + jj0 + 1) * kWaves + wave] += s1;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < NL * my_bins; e += 64) {
+      const int l = e / my_bins, jj = e - l * my_bins;
+      double ws = wsum[0];
+#pragma unroll
+      for (int q = 1; q < NL; ++q) ws = (l == q) ? wsum[q] : ws;
+      a.out[point * (long long)(a.n_ell * a.n_s) + (long long)l * a.n_s + wave + kWaves * jj] =
+          l_acc[(l * slots + jj) * kWaves + wave] - ws + ps.poison;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
 // K1x: xi^s(mu_i, s_j), one wave per (point, mu, s) cell, lanes over the velocity nodes
 // --------------------------------------------------------------------------------------------------
 template <int RSD, int NLR>
@@ -1297,6 +1488,18 @@ int launch_lanes_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   return VK_OK;
 }
 
+template <int NLR>
+int launch_cells_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
+  switch (a.n_ell) {
+    case 1: hipLaunchKernelGGL((vk_theory_cells_kernel<NLR, 1>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+    case 2: hipLaunchKernelGGL((vk_theory_cells_kernel<NLR, 2>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+    case 3: hipLaunchKernelGGL((vk_theory_cells_kernel<NLR, 3>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+    default: return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
+  }
+  VK_HIP(ctx, hipGetLastError());
+  return VK_OK;
+}
+
 template <int RSD>
 int launch_xi_smu(vk_ctx* ctx, const TheoryArgs& a, int nlr, int grid, size_t lds) {
   switch (nlr) {
@@ -1393,6 +1596,23 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
       case 1: return launch_lanes_nl<1>(ctx, a, grid_l, lds_l);
       case 2: return launch_lanes_nl<2>(ctx, a, grid_l, lds_l);
       case 3: return launch_lanes_nl<3>(ctx, a, grid_l, lds_l);
+    }
+  }
+  // cells variant: one workgroup per point with the velocity loop innermost; needs enough points to fill the chip
+  // and n_mu >= 64 (a wave's 64 cells must not straddle more than two s bins)
+  const bool cells_ok = fast && a.n_mu >= 64 && a.n_mu <= 4096 && a.n_x <= 2048;
+  const bool cells = cells_ok && (mapping ? !strcmp(mapping, "cells") : a.n >= 4LL * ctx->n_cu);
+  if (cells) {
+    ctx->last_kernel = "vk_theory_cells_kernel";
+    const size_t lds_c =
+        (size_t)make_cells_plan(a.n_mu, a.n_x, a.n_s, a.n_ell, a.sv.n_int, a.xi.n_int, nlr, a.n_beta_r).total * sizeof(double);
+    if (lds_c > 160 * 1024) return fail(ctx, VK_E_ARG, "tables need %zu bytes of LDS (> 160 KiB)", lds_c);
+    const long long capc = (pcap_env ? atoll(pcap_env) : 64LL) * ctx->n_cu;
+    const int grid_c = (int)(a.n < capc ? a.n : capc);
+    switch (nlr) {
+      case 1: return launch_cells_nl<1>(ctx, a, grid_c, lds_c);
+      case 2: return launch_cells_nl<2>(ctx, a, grid_c, lds_c);
+      case 3: return launch_cells_nl<3>(ctx, a, grid_c, lds_c);
     }
   }
   ctx->last_kernel = fast ? "vk_theory_fast_kernel" : "vk_theory_kernel";
