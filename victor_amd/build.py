@@ -18,7 +18,8 @@ def hipcc_path():
 
 
 def build_native(force=False, verbose=False):
-    deps = [SRC, os.path.join(INCLUDE, "victor_hip.h")]
+    import glob
+    deps = [SRC, os.path.join(INCLUDE, "victor_hip.h")] + glob.glob(os.path.join(HERE, "csrc", "*.h"))
     if not force and os.path.isfile(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",

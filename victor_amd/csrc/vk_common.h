@@ -1,0 +1,191 @@
+// vk_common.h: device-side views, table evaluation helpers, per-point scalars - part of libvictor_hip.so (see victor_hip.hip for the overview and DESIGN.md section 5).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "victor_hip.h"
+#include "vk_devmath.h"
+
+namespace vk {
+
+constexpr int kBlock = 256;               // 4 wavefronts
+constexpr int kWaves = kBlock / 64;
+constexpr int kMaxEll = 3;
+constexpr int kVrVars = 5;               // V1, Da, V2, Ge1, Ge2 (see vk_tables.vr)
+
+// --------------------------------------------------------------------------------------------------
+// device-side views
+// --------------------------------------------------------------------------------------------------
+struct PPView {           // a vk_pp living in global memory (device pointers)
+  int n_int;
+  int lead;
+  double inv_h;
+  const double* knots;
+  const double* coef;
+};
+
+struct TheoryArgs {
+  const double* params;   // [n][VK_NPAR]
+  long long n;
+  int n_s, n_mu, n_x, n_ell;
+  const double* s;        // [n_s]
+  const double* mu;       // [n_mu]
+  const double* w_ell;    // [n_ell][n_mu]
+  const double* x;        // [n_x]
+  const double* w_x;      // [n_x]
+  int n_beta_r;           // 0 = fixed xi tables
+  const double* beta_r;
+  PPView xi, vr, sv;
+  double iaH;
+  double inv_sigma8;
+  int rescale_from_ap;
+  int matter_vt;          // velocity-template mean model: amplitude = -3 iaH vt_amp fsigma8
+  double vt_amp;
+  int sv_n_mu;            // > 0: anisotropic sigma_v(r, mu) template, bicubic patches in global memory
+  double sv_mu_inv_h;
+  const double* sv_mu;
+  const double* sv2d;
+  int matter_lb;          // linear_bias matter model: amplitudes carry 1/bias (ccf_model.py:358-370,426-435)
+  int vr_beta_dep;        // velocity tables are PCHIP-in-beta polynomials (rebuilt per point)
+  int from_data;          // ccf_model.py:618-619,675-679
+  int empirical;          // ccf_model.py:451-459
+  int rsd;                // VK_RSD_*
+  int niter;              // fixed-point iterations of the dispersion / Kaiser coordinate shift
+  int kaiser_approx;      // ccf_model.py:730-738
+  int coord_shift;        // ccf_model.py:698-707
+  int sbins_per_item;     // s bins handled by one workgroup visit
+  int team;               // waves cooperating on one s bin (1, 2 or 4)
+  double* out;            // theory: [n][n_ell*n_s];  xi_smu: [n][n_mu][n_s]
+};
+
+struct LikeArgs {
+  const double* params;
+  const double* theory;   // [n][N]
+  long long n;
+  int N;
+  int n_beta_d;
+  const double* beta_d;
+  const double* data;
+  int n_beta_c;
+  const double* beta_c;
+  const double* prec;
+  const double* logdet;
+  const double* eig;
+  int like_form;
+  double nmocks, nparams;
+  double* lnl;
+  double* chi2;
+};
+
+// piecewise-cubic table resident in LDS
+struct PPLds {
+  const double* knots;
+  const double* coef;
+  int n_int;
+  int lead;
+  double inv_h;
+  double lo, hi, x_u0;
+};
+
+__device__ __forceinline__ int pp_interval(const PPLds& t, double u) {
+  int i;
+  if (t.inv_h > 0.0) {
+    const int n_uniform = t.n_int - t.lead;
+    double tt = (u - t.x_u0) * t.inv_h;
+    i = (int)tt;
+    i = min(max(i, 0), n_uniform - 1) + t.lead;
+    if (t.lead && u < t.x_u0) i = 0;
+  } else {
+    // general knots: largest i with knots[i] <= u
+    int lo = 0, hi = t.n_int;
+    while (hi - lo > 1) {
+      int mid = (lo + hi) >> 1;
+      if (u >= t.knots[mid]) lo = mid; else hi = mid;
+    }
+    i = lo;
+  }
+  return i;
+}
+
+__device__ __forceinline__ double pp_eval_at(const PPLds& t, int var, int i, double u) {
+  const double dx = u - t.knots[i];
+  const double* c = t.coef + ((size_t)var * t.n_int + i) * 4;
+  return fma(fma(fma(c[3], dx, c[2]), dx, c[1]), dx, c[0]);
+}
+
+__device__ __forceinline__ double clampd(double u, double lo, double hi) { return fmin(fmax(u, lo), hi); }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// per-point, wave-uniform quantities (ccf_model.py:589-613, 432-450, 638)
+struct PointScalars {
+  double aperp, apar, inv_c, A, B;
+  double G;       // fsigma8/(3 sigma8_tmpl):  aH^-1 v_r(r)/r = -G V(r/c)/r
+  double gD;      // fsigma8/(sigma8_tmpl c):   aH^-1 v_r'(r)  = -gD D(r/c)
+  double M, Q;    // Kaiser nuisance parameters (ccf_model.py:695-696)
+  double av;      // Av (divided by bias for linear_bias) when empirical_corr is on, else 0
+  double inv_aperp, inv_apar;
+  double poison;  // 0, or NaN when any input of the point is NaN/inf: added to every output so that a bad
+                  // parameter can never be masked by a clamp (the reference propagates NaN, ccf_fit.py:477)
+};
+
+
+
+__device__ __forceinline__ PointScalars point_scalars(const TheoryArgs& a, const double* row) {
+  PointScalars ps;
+  const double fs8 = row[VK_P_FSIGMA8];
+  const double sigv = row[VK_P_SIGMAV];
+  ps.aperp = row[VK_P_APERP];
+  ps.apar = row[VK_P_APAR];
+  const double eps = row[VK_P_EPSILON];
+  double c;
+  if (a.rescale_from_ap) {
+    // ccf_model.py:609-611: trapz over mu = linspace(1e-10, 1, 50) of apar*sqrt(1+(1-mu^2)(eps^2-1))
+    const int lane = threadIdx.x & 63;
+    const double e2 = eps * eps - 1.0;
+    const double h = (1.0 - 1e-10) / 49.0;
+    double v = 0.0;
+    if (lane < 50) {
+      const double m = (lane == 49) ? 1.0 : fma((double)lane, h, 1e-10);
+      v = ps.apar * sqrt(fma(1.0 - m * m, e2, 1.0));
+      if (lane == 0 || lane == 49) v *= 0.5;
+    }
+    c = wave_sum(v) * h;
+  } else {
+    c = row[VK_P_ASTAR];
+  }
+  ps.inv_c = 1.0 / c;
+  const double iaH_true = a.iaH * ps.apar;
+  // growth term and powers of the bias (ccf_model.py:426-435, 358-370): v_r = -gb [V1 + av V2](r/c) / (3 aH)
+  double growth = fs8 * a.inv_sigma8;
+  double binv = 1.0, extra = 0.0;
+  if (a.matter_lb) {
+    const double bias = row[VK_P_BIAS];
+    if (a.from_data) growth = row[VK_P_BETA] * bias;
+    binv = 1.0 / bias;
+    extra += bias;
+  }
+  // velocity template: v_r = growth_t V_t(r/c), growth_t = fsigma8 vt_amp / apar  ==  -gb V_t / (3 aH_true)
+  if (a.matter_vt) growth = -3.0 * a.iaH * a.vt_amp * fs8;
+  const double gb = growth * binv;
+  ps.av = 0.0;
+  if (a.empirical && !a.matter_vt) {
+    ps.av = row[VK_P_AV] * binv;
+    extra += ps.av;
+  }
+  ps.B = sigv * iaH_true;
+  ps.A = gb / (3.0 * iaH_true * sigv);
+  ps.G = gb / 3.0;
+  ps.gD = gb * ps.inv_c;
+  ps.M = row[VK_P_M];
+  ps.Q = row[VK_P_Q];
+  ps.inv_aperp = 1.0 / ps.aperp;
+  ps.inv_apar = 1.0 / ps.apar;
+  ps.poison = 0.0 * (gb + sigv + ps.aperp + ps.apar + eps + c + ps.A + extra + (a.n_beta_r > 0 ? row[VK_P_BETA] : 0.0));
+  return ps;
+}
+
+}  // namespace vk

@@ -1,0 +1,176 @@
+// vk_kernel_cells.h: cells theory kernel (per-point tables, velocity loop innermost) - part of libvictor_hip.so (see victor_hip.hip for the overview and DESIGN.md section 5).
+#pragma once
+#include "vk_kernel_fast.h"
+
+namespace vk {
+
+// --------------------------------------------------------------------------------------------------
+// K1 "cells" variant: the lanes kernel's inner loop for per-point tables (reconstruction beta, BOSS).
+// One workgroup owns one parameter point (its xi^r records are rebuilt in LDS as in the point-major kernel); each
+// of its four waves owns the s bins j = wave, wave+4, ... and spreads the (s bin, mu) cells of those bins over its
+// lanes, with the 50 velocity nodes as the inner, wave-uniform loop.  Like the lanes kernel this forms s_perp and
+// s_par once per cell, reads x_k, w_k as LDS broadcasts and closes the v sum before the projection, so the
+// integrand costs the same ~80 instructions; the projection sum over mu is a two-segment wave reduction per trip
+// (a wave's 64 cells straddle at most two s bins when n_mu >= 64), accumulated by lane 0 in wave-private LDS.
+// --------------------------------------------------------------------------------------------------
+struct CellsPlan {
+  int mu, w, xw, s, svrec, vxrec, lead, etab, betar, acc, total, vx_stride;
+};
+
+__host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s, int n_ell, int sv_int, int xi_int,
+                                                    int nlr, int n_beta_r) {
+  CellsPlan p;
+  int o = 0;
+  p.vx_stride = 4 * (1 + nlr) + 2;
+  p.mu = o;    o += 2 * n_mu;                      // {mu_i, sqrt(1 - mu_i^2)}
+  p.w = o;     o += kMaxEll * n_mu;                // W_l[i]
+  p.xw = o;    o += 2 * n_x;                       // {x_k, w_k}
+  p.s = o;     o += (n_s + 1) & ~1;
+  p.svrec = o; o += sv_int * kSvRec;
+  p.vxrec = o; o += xi_int * p.vx_stride;
+  p.lead = o;  o += 4;
+  p.etab = o;  o += 32;
+  p.betar = o; o += (n_beta_r + 1) & ~1;
+  p.acc = o;   o += kMaxEll * ((n_s + kWaves - 1) / kWaves) * kWaves;   // [l][slot][wave]
+  p.total = o;
+  return p;
+}
+
+// (130 VGPRs -> 3 waves per SIMD; forcing 4 with __launch_bounds__(256, 4) spills and measured 1.5 % slower)
+template <int NLR, int NL>
+__global__ __launch_bounds__(kBlock) void vk_theory_cells_kernel(TheoryArgs a) {
+  extern __shared__ double lds[];
+  constexpr int vx_stride = 4 * (1 + NLR) + 2;
+  const CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.n_ell, a.sv.n_int, a.xi.n_int, NLR, a.n_beta_r);
+  const int tid = threadIdx.x;
+  const double hs = 1.0 / a.sv.inv_h, hx = 1.0 / a.xi.inv_h;
+  const double hl = a.vr.knots[1] - a.vr.knots[0];
+  for (int i = tid; i < a.n_mu; i += kBlock) {
+    const double m = a.mu[i];
+    lds[pl.mu + 2 * i] = m;
+    lds[pl.mu + 2 * i + 1] = sqrt(1.0 - m * m);
+#pragma unroll
+    for (int l = 0; l < kMaxEll; ++l) lds[pl.w + l * a.n_mu + i] = (l < NL) ? a.w_ell[l * a.n_mu + i] : 0.0;
+  }
+  for (int k = tid; k < a.n_x; k += kBlock) {
+    lds[pl.xw + 2 * k] = a.x[k];
+    lds[pl.xw + 2 * k + 1] = a.w_x[k];
+  }
+  for (int j = tid; j < a.n_s; j += kBlock) lds[pl.s + j] = a.s[j];
+  for (int e = tid; e < a.sv.n_int * 4; e += kBlock)
+    lds[pl.svrec + (e >> 2) * kSvRec + (e & 3)] = a.sv.coef[e] * hpow(hs, e & 3);
+  for (int e = tid; e < a.xi.n_int * 4; e += kBlock)
+    lds[pl.vxrec + (e >> 2) * vx_stride + (e & 3)] = a.vr.coef[4 + e] * hpow(hx, e & 3);
+  if (a.n_beta_r == 0) {
+    const int per_l = a.xi.n_int * 4;
+    for (int e = tid; e < NLR * per_l; e += kBlock) {
+      const int l = e / per_l, iq = e - l * per_l;
+      lds[pl.vxrec + (iq >> 2) * vx_stride + 4 * (1 + l) + (iq & 3)] = a.xi.coef[e] * hpow(hx, iq & 3);
+    }
+  } else {
+    for (int i = tid; i < a.n_beta_r; i += kBlock) lds[pl.betar + i] = a.beta_r[i];
+  }
+  if (tid < 4) lds[pl.lead + tid] = a.vr.coef[tid] * hpow(hl, tid);
+  if (tid < 32) lds[pl.etab + tid] = vkm::exp2_frac32(tid);
+  FastConsts fc;
+  fc.inv_hs = a.sv.inv_h;
+  fc.off_s = -a.sv.knots[0] * a.sv.inv_h;
+  fc.ns_eps = (double)a.sv.n_int * (1.0 - 0x1p-52);
+  fc.inv_hx = a.xi.inv_h;
+  fc.off_x = -a.xi.knots[0] * a.xi.inv_h;
+  fc.nx_eps = (double)a.xi.n_int * (1.0 - 0x1p-52);
+  fc.inv_hl = 1.0 / hl;
+  fc.off_l = -a.vr.knots[0] * fc.inv_hl;
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const double* l_mu = lds + pl.mu;
+  const double* l_w = lds + pl.w;
+  const double* l_xw = lds + pl.xw;
+  const double* l_s = lds + pl.s;
+  const double* svrec = lds + pl.svrec;
+  const double* vxrec = lds + pl.vxrec;
+  const double* leadrec = lds + pl.lead;
+  const double* etab = lds + pl.etab;
+  const int slots = (a.n_s + kWaves - 1) / kWaves;        // s bins per wave (upper bound)
+  double* l_acc = lds + pl.acc;                            // [l][slot][wave]: each entry touched by one wave only
+  const int my_bins = (a.n_s - wave + kWaves - 1) / kWaves;  // bins j = wave + 4*jj, jj < my_bins
+  const int cells = my_bins * a.n_mu;
+
+  double wsum[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    double t = 0.0;
+    for (int i = lane; i < a.n_mu; i += 64) t += l_w[l * a.n_mu + i];
+    wsum[l] = wave_sum(t);
+  }
+
+  for (long long point = blockIdx.x; point < a.n; point += gridDim.x) {
+    const double* row = a.params + point * VK_NPAR;
+    const PointScalars ps = point_scalars(a, row);
+    if (a.n_beta_r > 0) {
+      __syncthreads();
+      const double* bg = lds + pl.betar;
+      const double beta = row[VK_P_BETA];
+      int kb = 0;
+      for (int i = 1; i < a.n_beta_r - 1; ++i) kb = (beta >= bg[i]) ? i : kb;
+      const double db = beta - bg[kb];
+      const int per_l = a.xi.n_int * 4;
+      const size_t stride_l = (size_t)(a.n_beta_r - 1) * per_l * 4;
+      for (int e = tid; e < NLR * per_l; e += kBlock) {
+        const int l = e / per_l, iq = e - l * per_l;
+        const double* c = a.xi.coef + l * stride_l + ((size_t)kb * per_l + iq) * 4;
+        lds[pl.vxrec + (iq >> 2) * vx_stride + 4 * (1 + l) + (iq & 3)] =
+            fma(fma(fma(c[3], db, c[2]), db, c[1]), db, c[0]) * hpow(hx, iq & 3);
+      }
+      __syncthreads();
+    }
+    for (int e = lane; e < kMaxEll * slots; e += 64) l_acc[e * kWaves + wave] = 0.0;
+    const double AV = ps.A;
+    for (int base = 0; base < cells; base += 64) {
+      const int e = base + lane;
+      const bool live = e < cells;
+      const int ec = live ? e : cells - 1;
+      const int jj = ec / a.n_mu;
+      const int i = ec - jj * a.n_mu;
+      const double sj = l_s[wave + kWaves * jj];
+      const vk_d2 mm = *reinterpret_cast<const vk_d2*>(l_mu + 2 * i);
+      const double s_perp = sj * ps.aperp * mm.y;
+      const double sperp2 = s_perp * s_perp;
+      const double s_par = sj * ps.apar * mm.x;
+      double g = 0.0;
+      for (int k = 0; k < a.n_x; ++k) {
+        const vk_d2 xw = *reinterpret_cast<const vk_d2*>(l_xw + 2 * k);
+        const double xk = xw.x;
+        g = fma(xw.y, node_value<NLR>(svrec, vxrec, leadrec, etab, fc, ps.B, ps.inv_c, AV, s_par, sperp2, xk), g);
+      }
+      if (!live) g = 0.0;
+      // projection: this trip's cells belong to s bin jj0 or jj0 + 1
+      const int jj0 = __builtin_amdgcn_readfirstlane(jj);
+      const bool first = (jj == jj0);
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        const double v = l_w[l * a.n_mu + i] * g;
+        const double s0 = wave_sum(first ? v : 0.0);
+        const double s1 = wave_sum(first ? 0.0 : v);
+        if (lane == 0) {
+          l_acc[(l * slots + jj0) * kWaves + wave] += s0;
+          if (jj0 + 1 < my_bins) l_acc[(l * slots + jj0 + 1) * kWaves + wave] += s1;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < NL * my_bins; e += 64) {
+      const int l = e / my_bins, jj = e - l * my_bins;
+      double ws = wsum[0];
+#pragma unroll
+      for (int q = 1; q < NL; ++q) ws = (l == q) ? wsum[q] : ws;
+      a.out[point * (long long)(a.n_ell * a.n_s) + (long long)l * a.n_s + wave + kWaves * jj] =
+          l_acc[(l * slots + jj) * kWaves + wave] - ws + ps.poison;
+    }
+  }
+}
+
+
+}  // namespace vk

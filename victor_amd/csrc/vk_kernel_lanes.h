@@ -1,0 +1,171 @@
+// vk_kernel_lanes.h: lanes-over-the-batch theory kernel - part of libvictor_hip.so (see victor_hip.hip for the overview and DESIGN.md section 5).
+#pragma once
+#include "vk_kernel_fast.h"
+
+namespace vk {
+
+// --------------------------------------------------------------------------------------------------
+// K1 "lanes over the batch" variant (the mapping BASELINE.json's north star sketches): one wavefront owns one s bin
+// of 64 consecutive parameter points, lane = point.  Everything that depends only on the (mu, v) node - mu_i,
+// sqrt(1-mu_i^2), x_k, w_k, W_l[i], the loop counters - is wave-uniform and lives in SGPRs / scalar loads, the
+// per-point factors live in VGPRs, no cross-lane reduction is needed and all 64 lanes are busy on every trip.
+// Per integrand point this saves the node-table read, two multiplies (s_perp, s_par are formed once per mu row),
+// two of the three projection FMAs (the v sum is closed per mu row first) and five LDS reads.
+// Needs batch-constant tables (no reconstruction beta) and a batch large enough to fill the chip with
+// n_s * n/64 wavefronts; the point-major kernel above serves every other case.
+// --------------------------------------------------------------------------------------------------
+struct LanesPlan {
+  int smu, xw, svrec, vxrec, lead, etab, total, vx_stride;
+};
+
+__host__ __device__ inline LanesPlan make_lanes_plan(int n_mu, int n_x, int sv_int, int xi_int, int nlr) {
+  LanesPlan p;
+  int o = 0;
+  p.vx_stride = 4 * (1 + nlr) + 2;
+  p.smu = o;   o += 2 * n_mu;           // {mu_i, sqrt(1 - mu_i^2)}
+  p.xw = o;    o += 2 * n_x;            // {x_k, w_k}: read with a wave-uniform address (LDS broadcast)
+  p.svrec = o; o += sv_int * kSvRec;
+  p.vxrec = o; o += xi_int * p.vx_stride;
+  p.lead = o;  o += 4;
+  p.etab = o;  o += 32;
+  p.total = o;
+  return p;
+}
+
+// per-lane version of point_scalars (each lane integrates its own AP rescaling factor, ccf_model.py:609-611)
+__device__ __forceinline__ PointScalars point_scalars_lane(const TheoryArgs& a, const double* row) {
+  PointScalars ps;
+  const double fs8 = row[VK_P_FSIGMA8];
+  const double sigv = row[VK_P_SIGMAV];
+  ps.aperp = row[VK_P_APERP];
+  ps.apar = row[VK_P_APAR];
+  const double eps = row[VK_P_EPSILON];
+  double c;
+  if (a.rescale_from_ap) {
+    const double e2 = eps * eps - 1.0;
+    const double h = (1.0 - 1e-10) / 49.0;
+    double acc = 0.0;
+    for (int m = 0; m < 50; ++m) {
+      const double mm = (m == 49) ? 1.0 : fma((double)m, h, 1e-10);
+      const double v = sqrt(fma(1.0 - mm * mm, e2, 1.0));
+      acc += (m == 0 || m == 49) ? 0.5 * v : v;
+    }
+    c = ps.apar * acc * h;
+  } else {
+    c = row[VK_P_ASTAR];
+  }
+  ps.inv_c = 1.0 / c;
+  const double iaH_true = a.iaH * ps.apar;
+  double growth = fs8 * a.inv_sigma8;
+  double binv = 1.0, extra = 0.0;
+  if (a.matter_lb) {
+    const double bias = row[VK_P_BIAS];
+    binv = 1.0 / bias;
+    extra = bias;
+  }
+  const double gb = growth * binv;
+  ps.av = 0.0;
+  ps.B = sigv * iaH_true;
+  ps.A = gb / (3.0 * iaH_true * sigv);
+  ps.G = gb / 3.0;
+  ps.gD = gb * ps.inv_c;
+  ps.M = row[VK_P_M];
+  ps.Q = row[VK_P_Q];
+  ps.inv_aperp = 1.0 / ps.aperp;
+  ps.inv_apar = 1.0 / ps.apar;
+  ps.poison = 0.0 * (gb + sigv + ps.aperp + ps.apar + eps + c + ps.A + extra);
+  return ps;
+}
+
+template <int NLR, int NL>
+__global__ __launch_bounds__(kBlock) void vk_theory_lanes_kernel(TheoryArgs a) {
+  extern __shared__ double lds[];
+  constexpr int vx_stride = 4 * (1 + NLR) + 2;
+  const LanesPlan pl = make_lanes_plan(a.n_mu, a.n_x, a.sv.n_int, a.xi.n_int, NLR);
+  const int tid = threadIdx.x;
+  const double hs = 1.0 / a.sv.inv_h, hx = 1.0 / a.xi.inv_h;
+  const double hl = a.vr.knots[1] - a.vr.knots[0];
+  for (int i = tid; i < a.n_mu; i += kBlock) {
+    const double m = a.mu[i];
+    lds[pl.smu + 2 * i] = m;
+    lds[pl.smu + 2 * i + 1] = sqrt(1.0 - m * m);
+  }
+  for (int k = tid; k < a.n_x; k += kBlock) {
+    lds[pl.xw + 2 * k] = a.x[k];
+    lds[pl.xw + 2 * k + 1] = a.w_x[k];
+  }
+  for (int e = tid; e < a.sv.n_int * 4; e += kBlock)
+    lds[pl.svrec + (e >> 2) * kSvRec + (e & 3)] = a.sv.coef[e] * hpow(hs, e & 3);
+  for (int e = tid; e < a.xi.n_int * 4; e += kBlock)
+    lds[pl.vxrec + (e >> 2) * vx_stride + (e & 3)] = a.vr.coef[4 + e] * hpow(hx, e & 3);
+  {
+    const int per_l = a.xi.n_int * 4;
+    for (int e = tid; e < NLR * per_l; e += kBlock) {
+      const int l = e / per_l, iq = e - l * per_l;
+      lds[pl.vxrec + (iq >> 2) * vx_stride + 4 * (1 + l) + (iq & 3)] = a.xi.coef[e] * hpow(hx, iq & 3);
+    }
+  }
+  if (tid < 4) lds[pl.lead + tid] = a.vr.coef[tid] * hpow(hl, tid);
+  if (tid < 32) lds[pl.etab + tid] = vkm::exp2_frac32(tid);
+  FastConsts fc;
+  fc.inv_hs = a.sv.inv_h;
+  fc.off_s = -a.sv.knots[0] * a.sv.inv_h;
+  fc.ns_eps = (double)a.sv.n_int * (1.0 - 0x1p-52);
+  fc.inv_hx = a.xi.inv_h;
+  fc.off_x = -a.xi.knots[0] * a.xi.inv_h;
+  fc.nx_eps = (double)a.xi.n_int * (1.0 - 0x1p-52);
+  fc.inv_hl = 1.0 / hl;
+  fc.off_l = -a.vr.knots[0] * fc.inv_hl;
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const double* l_smu = lds + pl.smu;
+  const double* l_xw = lds + pl.xw;
+  const double* svrec = lds + pl.svrec;
+  const double* vxrec = lds + pl.vxrec;
+  const double* leadrec = lds + pl.lead;
+  const double* etab = lds + pl.etab;
+  const long long chunks = (a.n + 63) >> 6;
+  const long long items = chunks * a.n_s;
+  for (long long item = (long long)blockIdx.x * kWaves + wave; item < items; item += (long long)gridDim.x * kWaves) {
+    const long long chunk = item / a.n_s;
+    const int j = (int)(item - chunk * a.n_s);
+    long long point = chunk * 64 + lane;
+    const bool valid = point < a.n;
+    if (!valid) point = a.n - 1;
+    const PointScalars ps = point_scalars_lane(a, a.params + point * VK_NPAR);
+    const double sj = a.s[j];
+    const double sa = sj * ps.aperp, sp = sj * ps.apar;
+    const double AV = ps.A;
+    double acc[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) acc[l] = 0.0;
+    for (int i = 0; i < a.n_mu; ++i) {
+      const vk_d2 mm = *reinterpret_cast<const vk_d2*>(l_smu + 2 * i);
+      const double s_perp = sa * mm.y;
+      const double sperp2 = s_perp * s_perp;
+      const double s_par = sp * mm.x;
+      double g = 0.0;
+      for (int k = 0; k < a.n_x; ++k) {
+        const vk_d2 xw = *reinterpret_cast<const vk_d2*>(l_xw + 2 * k);
+        const double xk = xw.x;
+        g = fma(xw.y, node_value<NLR>(svrec, vxrec, leadrec, etab, fc, ps.B, ps.inv_c, AV, s_par, sperp2, xk), g);
+      }
+#pragma unroll
+      for (int l = 0; l < NL; ++l) acc[l] = fma(a.w_ell[l * a.n_mu + i], g, acc[l]);
+    }
+    if (valid) {
+      double* o = a.out + point * (long long)(a.n_ell * a.n_s) + j;
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        double ws = 0.0;
+        for (int i = 0; i < a.n_mu; ++i) ws += a.w_ell[l * a.n_mu + i];
+        o[(long long)l * a.n_s] = acc[l] - ws + ps.poison;
+      }
+    }
+  }
+}
+
+
+}  // namespace vk

@@ -1,0 +1,124 @@
+// vk_kernel_like.h: chi-square / log-likelihood kernel - part of libvictor_hip.so (see victor_hip.hip for the overview and DESIGN.md section 5).
+#pragma once
+#include "vk_common.h"
+
+namespace vk {
+
+// --------------------------------------------------------------------------------------------------
+// K2: chi-square and log-likelihood, one wave per parameter point
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void vk_like_kernel(LikeArgs a) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  double* res = lds + (size_t)wave * a.N;
+  const double inf = __longlong_as_double(0x7ff0000000000000LL);
+  for (long long point = (long long)blockIdx.x * kWaves + wave; point < a.n;
+       point += (long long)gridDim.x * kWaves) {
+    const double beta = a.params[point * VK_NPAR + VK_P_BETA];
+    const double* th = a.theory + point * a.N;
+    // residual against the (beta-interpolated) data vector, ccf_fit.py:166-193,323
+    if (a.n_beta_d > 0) {
+      int k = 0;
+      for (int i = 1; i < a.n_beta_d - 1; ++i) k = (beta >= a.beta_d[i]) ? i : k;
+      const double db = beta - a.beta_d[k];
+      const double* piece = a.data + (size_t)k * a.N * 4;
+      for (int e = lane; e < a.N; e += 64) {
+        const double* c = piece + (size_t)e * 4;
+        res[e] = th[e] - fma(fma(fma(c[3], db, c[2]), db, c[1]), db, c[0]);
+      }
+    } else {
+      for (int e = lane; e < a.N; e += 64) res[e] = th[e] - a.data[e];
+    }
+    // precision / covariance bracket, ccf_fit.py:213-228,245-260 (upper bracket = LAST grid entry)
+    int lo = 0;
+    double t = 0.0;
+    const double* P0 = a.prec;
+    const double* P1 = a.prec;
+    if (a.n_beta_c > 0) {
+      const int last = a.n_beta_c - 1;
+      if (beta < a.beta_c[0]) {
+        lo = 0;
+      } else if (beta > a.beta_c[last]) {
+        lo = last;
+      } else {
+        int exact = -1, below = 0;
+        for (int i = 0; i <= last; ++i) {
+          const double g = a.beta_c[i];
+          if (g == beta && exact < 0) exact = i;
+          if (g < beta) below = i;
+        }
+        if (exact >= 0) {
+          lo = exact;
+        } else {
+          lo = below;
+          t = (beta - a.beta_c[lo]) / (a.beta_c[last] - a.beta_c[lo]);
+        }
+      }
+      P0 = a.prec + (size_t)lo * a.N * a.N;
+      P1 = a.prec + (size_t)last * a.N * a.N;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // chi2 = sum_b (sum_a r_a P_ab) r_b with lanes over b (coalesced rows of P), ccf_fit.py:354
+    double part = 0.0;
+    const double omt = 1.0 - t;
+    for (int b = lane; b < a.N; b += 64) {
+      double y = 0.0;
+      if (t != 0.0) {
+        for (int r = 0; r < a.N; ++r) {
+          const double p = omt * P0[(size_t)r * a.N + b] + t * P1[(size_t)r * a.N + b];
+          y = fma(res[r], p, y);
+        }
+      } else {
+        for (int r = 0; r < a.N; ++r) y = fma(res[r], P0[(size_t)r * a.N + b], y);
+      }
+      part = fma(y, res[b], part);
+    }
+    const double chisq = wave_sum(part);
+    // -1/2 log det of the blended covariance, ccf_fit.py:445-451
+    double factor = 0.0;
+    bool singular = false;
+    if (a.n_beta_c > 0) {
+      double ld = 0.0;
+      int bad = 0;
+      if (t != 0.0) {
+        const double* ev = a.eig + (size_t)lo * a.N;
+        for (int e = lane; e < a.N; e += 64) {
+          const double fct = fma(t, ev[e], omt);
+          bad |= !(fct > 0.0);
+          ld += log(fct);
+        }
+        ld = wave_sum(ld);
+      }
+      singular = __any(bad) || !(fabs(a.logdet[lo]) < inf);
+      factor = -0.5 * (a.logdet[lo] + ld);
+    }
+    double lnl;
+    const double nm = a.nmocks;
+    if (a.like_form == VK_LIKE_SELLENTIN) {
+      lnl = -nm * log(1.0 + chisq / (nm - 1.0)) / 2.0 + factor;
+    } else if (a.like_form == VK_LIKE_HARTLAP) {
+      lnl = -0.5 * chisq * ((nm - a.N - 2.0) / (nm - 1.0)) + factor;
+    } else if (a.like_form == VK_LIKE_PERCIVAL) {
+      const double nd = (double)a.N;
+      const double B = (nm - nd - 2.0) / ((nm - nd - 1.0) * (nm - nd - 4.0));
+      const double m = a.nparams + 2.0 + (nm - 1.0 + B * (nd - a.nparams)) / (1.0 + B * (nd - a.nparams));
+      lnl = -m * log(1.0 + chisq / (nm - 1.0)) / 2.0 + factor;
+    } else {
+      lnl = -0.5 * chisq + factor;
+    }
+    double chi_out = chisq;
+    if (singular || lnl != lnl) {  // ccf_fit.py:448-450, 477-481
+      lnl = -inf;
+      chi_out = inf;
+    }
+    if (lane == 0) {
+      if (a.lnl) a.lnl[point] = lnl;
+      if (a.chi2) a.chi2[point] = chi_out;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+
+}  // namespace vk
