@@ -411,3 +411,23 @@ def test_cells_mapping_on_beta_dependent_tables(boss_fit, gold):
     finally:
         del os.environ["VICTOR_HIP_MAPPING"]
     assert np.max(np.abs(a[0] / b[0] - 1)) < 1e-11
+
+
+def test_odd_multipoles_use_the_full_mu_range(synth_fit, oracle):
+    """poles containing an odd l switch the mu grid to [-1, 1] and halve the prefactor (ccf_model.py:816-819)."""
+    fit = synth_fit[3]
+    ora = oracle.OracleModel(cases.synth_options(3)[0])
+    s = np.array([6.0, 20.0, 41.0, 77.0])
+    p = {"fsigma8": 0.6, "sigma_v": 300, "aperp": 1.04, "apar": 0.95}
+    got = fit.theory_multipoles(s, dict(p), poles=[0, 1, 2])
+    want, _ = ora.theory_multipoles(s, dict(p), poles=[0, 1, 2])
+    assert set(got) == {"0", "1", "2"}
+    scale = max(np.max(np.abs(want[k])) for k in want)
+    for key in want:
+        assert np.max(np.abs(got[key] - want[key])) < RTOL * scale, key
+    assert np.max(np.abs(got["1"])) < 1e-6 * scale          # xi(s, mu) is even in mu, so the dipole vanishes
+    # theory_xi on an unsorted grid with duplicates sorts and de-duplicates 2-D inputs (np.unique, ccf_model.py:577)
+    S, M = np.meshgrid([20.0, 6.0, 20.0], [0.9, 0.1, 0.5])
+    xi = fit.theory_xi(S, M, dict(p))
+    xo = ora.theory_xi(np.array([6.0, 20.0]), np.array([0.1, 0.5, 0.9]), dict(p))
+    assert xi.shape == (3, 2) and np.max(np.abs(xi - xo)) < RTOL * np.max(np.abs(xo))
