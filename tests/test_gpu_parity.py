@@ -431,3 +431,26 @@ def test_odd_multipoles_use_the_full_mu_range(synth_fit, oracle):
     xi = fit.theory_xi(S, M, dict(p))
     xo = ora.theory_xi(np.array([6.0, 20.0]), np.array([0.1, 0.5, 0.9]), dict(p))
     assert xi.shape == (3, 2) and np.max(np.abs(xi - xo)) < RTOL * np.max(np.abs(xo))
+
+
+def test_tiled_likelihood_kernel_matches_per_point_kernel(synth_fit):
+    """Fixed covariance: the 8-points-per-wave chi-square kernel vs the one-point-per-wave kernel."""
+    for config in (2, 3):
+        fit = synth_fit[config]
+        hp = cases.halton_params(1003)                       # not a multiple of the tile
+        a = fit.log_likelihood_batch(hp)
+        os.environ["VICTOR_HIP_LIKE_UNTILED"] = "1"
+        try:
+            b = fit.log_likelihood_batch(hp)
+        finally:
+            del os.environ["VICTOR_HIP_LIKE_UNTILED"]
+        assert np.max(np.abs(a[1] / b[1] - 1)) < 1e-12 and np.max(np.abs(a[0] / b[0] - 1)) < 1e-12
+        for form in ("sellentin", "hartlap", "percival"):
+            kw = {"likelihood": {"form": form, "nmocks": 800, "nparams": 4}}
+            a = fit.log_likelihood_batch({k: v[:200] for k, v in hp.items()}, **kw)
+            os.environ["VICTOR_HIP_LIKE_UNTILED"] = "1"
+            try:
+                b = fit.log_likelihood_batch({k: v[:200] for k, v in hp.items()}, **kw)
+            finally:
+                del os.environ["VICTOR_HIP_LIKE_UNTILED"]
+            assert np.max(np.abs(a[0] / b[0] - 1)) < 1e-12, form

@@ -349,10 +349,22 @@ int launch_like(vk_ctx* ctx, const vk_eval_opts* o, const double* d_params, cons
   a.nparams = o->nparams;
   a.lnl = d_lnl;
   a.chi2 = d_chi2;
-  const long long blocks = (n + kWaves - 1) / kWaves;
   const long long cap = 16LL * ctx->n_cu;
+  // fixed covariance: 8 points per wave share the loads of the precision matrix (LDS: 4 waves x 8 x N doubles)
+  constexpr int kTile = 8;
+  const size_t lds_tiled = (size_t)kWaves * kTile * ctx->N * sizeof(double);
+  if (ctx->n_beta_c == 0 && n >= 4 * kTile * kWaves && lds_tiled <= 64 * 1024 && !getenv("VICTOR_HIP_LIKE_UNTILED")) {
+    const long long tiles = (n + kTile - 1) / kTile;
+    const long long blocks = (tiles + kWaves - 1) / kWaves;
+    const int grid = (int)(blocks < cap ? blocks : cap);
+    hipLaunchKernelGGL((vk_like_tiled_kernel<kTile>), dim3(grid), dim3(kBlock), lds_tiled, ctx->stream, a);
+    VK_HIP(ctx, hipGetLastError());
+    return VK_OK;
+  }
+  const long long blocks = (n + kWaves - 1) / kWaves;
   const int grid = (int)(blocks < cap ? blocks : cap);
   const size_t lds = (size_t)kWaves * ctx->N * sizeof(double);
+  if (lds > 160 * 1024) return fail(ctx, VK_E_ARG, "data vector of %d bins needs %zu bytes of LDS (> 160 KiB)", ctx->N, lds);
   hipLaunchKernelGGL(vk_like_kernel, dim3(grid), dim3(kBlock), lds, ctx->stream, a);
   VK_HIP(ctx, hipGetLastError());
   return VK_OK;

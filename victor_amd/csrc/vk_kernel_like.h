@@ -121,4 +121,90 @@ __global__ __launch_bounds__(kBlock) void vk_like_kernel(LikeArgs a) {
 }
 
 
+// --------------------------------------------------------------------------------------------------
+// K2 for a fixed covariance: T points per wave share every load of the precision matrix.
+// The per-point kernel above reads all N^2 elements of P from L2 for every point (115 KB at N = 120: 7.5 GB per 65536
+// batch, which is what bounds it); here a wave keeps the residuals of T points in LDS as res[a][p], streams each row of
+// P once (lanes over columns, coalesced) and feeds T accumulators from it.
+// --------------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(kBlock) void vk_like_tiled_kernel(LikeArgs a) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  double* res = lds + (size_t)wave * a.N * T;          // res[a * T + p]
+  const double inf = __longlong_as_double(0x7ff0000000000000LL);
+  const long long tiles = (a.n + T - 1) / T;
+  for (long long tile = (long long)blockIdx.x * kWaves + wave; tile < tiles; tile += (long long)gridDim.x * kWaves) {
+    const long long p0 = tile * T;
+    // residuals of the tile's points (data vector possibly PCHIP-interpolated in beta, ccf_fit.py:166-193)
+    for (int p = 0; p < T; ++p) {
+      const long long point = (p0 + p < a.n) ? p0 + p : a.n - 1;
+      const double* th = a.theory + point * a.N;
+      if (a.n_beta_d > 0) {
+        const double beta = a.params[point * VK_NPAR + VK_P_BETA];
+        int k = 0;
+        for (int i = 1; i < a.n_beta_d - 1; ++i) k = (beta >= a.beta_d[i]) ? i : k;
+        const double db = beta - a.beta_d[k];
+        const double* piece = a.data + (size_t)k * a.N * 4;
+        for (int e = lane; e < a.N; e += 64) {
+          const double* c = piece + (size_t)e * 4;
+          res[e * T + p] = th[e] - fma(fma(fma(c[3], db, c[2]), db, c[1]), db, c[0]);
+        }
+      } else {
+        for (int e = lane; e < a.N; e += 64) res[e * T + p] = th[e] - a.data[e];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    double part[T];
+#pragma unroll
+    for (int p = 0; p < T; ++p) part[p] = 0.0;
+    for (int b = lane; b < a.N; b += 64) {
+      double y[T];
+#pragma unroll
+      for (int p = 0; p < T; ++p) y[p] = 0.0;
+      for (int r = 0; r < a.N; ++r) {
+        const double pab = a.prec[(size_t)r * a.N + b];
+        const double* rr = res + r * T;
+#pragma unroll
+        for (int p = 0; p < T; ++p) y[p] = fma(rr[p], pab, y[p]);
+      }
+      const double* rb = res + b * T;
+#pragma unroll
+      for (int p = 0; p < T; ++p) part[p] = fma(y[p], rb[p], part[p]);
+    }
+    double mine = 0.0;                                 // lane p keeps the chi-square of point p0 + p
+#pragma unroll
+    for (int p = 0; p < T; ++p) {
+      const double c = wave_sum(part[p]);
+      mine = (lane == p) ? c : mine;
+    }
+    if (lane < T && p0 + lane < a.n) {
+      const double chisq = mine;
+      double lnl;
+      const double nm = a.nmocks;
+      if (a.like_form == VK_LIKE_SELLENTIN) {
+        lnl = -nm * log(1.0 + chisq / (nm - 1.0)) / 2.0;
+      } else if (a.like_form == VK_LIKE_HARTLAP) {
+        lnl = -0.5 * chisq * ((nm - a.N - 2.0) / (nm - 1.0));
+      } else if (a.like_form == VK_LIKE_PERCIVAL) {
+        const double nd = (double)a.N;
+        const double B = (nm - nd - 2.0) / ((nm - nd - 1.0) * (nm - nd - 4.0));
+        const double m = a.nparams + 2.0 + (nm - 1.0 + B * (nd - a.nparams)) / (1.0 + B * (nd - a.nparams));
+        lnl = -m * log(1.0 + chisq / (nm - 1.0)) / 2.0;
+      } else {
+        lnl = -0.5 * chisq;
+      }
+      double chi_out = chisq;
+      if (lnl != lnl) {  // ccf_fit.py:477-481
+        lnl = -inf;
+        chi_out = inf;
+      }
+      if (a.lnl) a.lnl[p0 + lane] = lnl;
+      if (a.chi2) a.chi2[p0 + lane] = chi_out;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 }  // namespace vk
