@@ -8,8 +8,8 @@
 
 __global__ void run(const double* x, const double* a, double* g, double* ir, double* rc, double* ex, double* raw_rsq,
                     double* raw_rcp, int n) {
-  __shared__ double tab[32];
-  if (threadIdx.x < 32) tab[threadIdx.x] = vkm::exp2_frac32(threadIdx.x);
+  __shared__ double tab[vkm::kExpTab];
+  for (int j = threadIdx.x; j < vkm::kExpTab; j += blockDim.x) tab[j] = vkm::exp2_frac(j);
   __syncthreads();
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

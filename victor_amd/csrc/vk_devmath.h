@@ -30,8 +30,9 @@ __device__ __forceinline__ double recip(double x) {
   return fma(y, fma(e, e, e), y);
 }
 
-// 2^(j/32), j = 0..31, to be staged in LDS by the caller (256 B)
-__device__ __forceinline__ double exp2_frac32(int j) { return exp2((double)j * 0.03125); }
+// 2^(j/256), j = 0..255, to be staged in LDS by the caller (2 KB)
+constexpr int kExpTab = 256;
+__device__ __forceinline__ double exp2_frac(int j) { return exp2((double)j * (1.0 / kExpTab)); }
 
 // p*f + c as ONE v_fma_f64.  hipcc prefers the two-address v_fmac_f64 and then needs a v_mov_b64 per step to
 // re-materialise the constant addend it overwrites; naming the three-address form keeps Horner steps at one
@@ -42,25 +43,23 @@ __device__ __forceinline__ double fma3(double p, double f, double c) {
   return r;
 }
 
-// exp(a) for a <= 0.  a is split as a = (32 m + j) ln2/32 + f with |f| <= ln2/64, so
-// exp(a) = 2^m * T[j] * exp(f) and a degree-6 Taylor polynomial in f is exact to 4e-18.
+// exp(a) for a <= 0.  a is split as a = (256 m + j) ln2/256 + f with |f| <= ln2/512, so
+// exp(a) = 2^m * T[j] * exp(f) and a degree-4 Taylor polynomial in f is exact to 4e-17.
 // The clamp keeps the range reduction exact for absurdly negative arguments (exp(-750) already underflows
 // to 0); v_max_f64 returns the bound for a NaN argument, so callers that must propagate NaN inputs add
 // their own poison term (the theory kernels do).
-__device__ __forceinline__ double exp_nonpos(double a, const double* __restrict__ tab32) {
+__device__ __forceinline__ double exp_nonpos(double a, const double* __restrict__ tab) {
   a = fmax(a, -750.0);
-  const double n = rint(a * 46.166241308446828);                 // 32 / ln 2
-  double f = fma(n, -0x1.62e42fef80000p-6, a);                   // ln2/32, high 34 bits: n*hi is exact
-  f = fma(n, -0x1.1cf79abc9e3b4p-41, f);                         //         remainder
+  const double n = rint(a * 369.3299304675746);                  // 256 / ln 2
+  double f = fma(n, -0x1.62e42fee00000p-9, a);                   // ln2/256, high 32 bits: n*hi is exact
+  f = fma(n, -0x1.a39ef35793c76p-41, f);                         //          remainder
   const int ni = (int)n;
-  const double t = tab32[ni & 31];
-  double p = fma3(f, 1.0 / 720.0, 1.0 / 120.0);
-  p = fma3(p, f, 1.0 / 24.0);
-  p = fma3(p, f, 1.0 / 6.0);
+  const double t = tab[ni & (kExpTab - 1)];
+  double p = fma3(f, 1.0 / 24.0, 1.0 / 6.0);
   p = fma(p, f, 0.5);
   p = fma(p, f, 1.0);
   p = fma(p, f, 1.0);
-  return ldexp(t * p, ni >> 5);
+  return ldexp(t * p, ni >> 8);
 }
 
 }  // namespace vkm

@@ -29,7 +29,7 @@ __host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s,
   p.svrec = o; o += sv_int * kSvRec;
   p.vxrec = o; o += xi_int * p.vx_stride;
   p.lead = o;  o += 4;
-  p.etab = o;  o += 32;
+  p.etab = o;  o += vkm::kExpTab;
   p.betar = o; o += (n_beta_r + 1) & ~1;
   p.acc = o;   o += kMaxEll * ((n_s + kWaves - 1) / kWaves) * kWaves;   // [l][slot][wave]
   p.total = o;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_cells_kernel(TheoryArgs a) {
     for (int i = tid; i < a.n_beta_r; i += kBlock) lds[pl.betar + i] = a.beta_r[i];
   }
   if (tid < 4) lds[pl.lead + tid] = a.vr.coef[tid] * hpow(hl, tid);
-  if (tid < 32) lds[pl.etab + tid] = vkm::exp2_frac32(tid);
+  for (int j = tid; j < vkm::kExpTab; j += kBlock) lds[pl.etab + j] = vkm::exp2_frac(j);
   FastConsts fc;
   fc.inv_hs = a.sv.inv_h;
   fc.off_s = -a.sv.knots[0] * a.sv.inv_h;

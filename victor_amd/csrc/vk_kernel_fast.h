@@ -31,7 +31,7 @@ __host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int sv_int
   p.svrec = o; o += sv_int * kSvRec;
   p.vxrec = o; o += xi_int * p.vx_stride;
   p.lead = o;  o += 4;
-  p.etab = o;  o += 32;
+  p.etab = o;  o += vkm::kExpTab;
   p.betar = o; o += n_beta_r;
   o = (o + 1) & ~1;
   p.red = o;   o += kWaves * kMaxEll;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
     for (int i = tid; i < a.n_beta_r; i += kBlock) lds[pl.betar + i] = a.beta_r[i];
   }
   if (tid < 4) lds[pl.lead + tid] = a.vr.coef[tid] * hpow(hl, tid);
-  if (tid < 32) lds[pl.etab + tid] = vkm::exp2_frac32(tid);
+  for (int j = tid; j < vkm::kExpTab; j += kBlock) lds[pl.etab + j] = vkm::exp2_frac(j);
   // byte offsets of the mu record (low 16 bits) and the (x, w) record (high 16 bits) of every plane node, so the
   // hot loop needs no index arithmetic: one ds_read_b32 per trip
   unsigned* node = reinterpret_cast<unsigned*>(lds + pl.node);

@@ -27,7 +27,7 @@ __host__ __device__ inline LanesPlan make_lanes_plan(int n_mu, int n_x, int sv_i
   p.svrec = o; o += sv_int * kSvRec;
   p.vxrec = o; o += xi_int * p.vx_stride;
   p.lead = o;  o += 4;
-  p.etab = o;  o += 32;
+  p.etab = o;  o += vkm::kExpTab;
   p.total = o;
   return p;
 }
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_lanes_kernel(TheoryArgs a) {
     }
   }
   if (tid < 4) lds[pl.lead + tid] = a.vr.coef[tid] * hpow(hl, tid);
-  if (tid < 32) lds[pl.etab + tid] = vkm::exp2_frac32(tid);
+  for (int j = tid; j < vkm::kExpTab; j += kBlock) lds[pl.etab + j] = vkm::exp2_frac(j);
   FastConsts fc;
   fc.inv_hs = a.sv.inv_h;
   fc.off_s = -a.sv.knots[0] * a.sv.inv_h;
