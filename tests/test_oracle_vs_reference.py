@@ -96,3 +96,38 @@ def test_oracle_anisotropic_dispersion_and_velocity_template_equal_reference(ref
             a = rm.log_likelihood(dict(p), **kw)
             b = om.log_likelihood(dict(p), **kw)
             assert abs(a[0] - b[0]) <= 1e-11 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-11 * abs(a[1]), (mean, kw)
+
+
+def _flatten(keep):
+    out = []
+    for item in keep:
+        if isinstance(item, tuple):
+            out.extend(_flatten(item))
+        else:
+            out.append(np.asarray(item))
+    return out
+
+
+@pytest.mark.parametrize("case", ["boss_config", "boss_cobaya", "synth3"])
+def test_device_tables_compile_from_reference_objects(ref, case):
+    """INTEGRATION.md route B: victor_amd.engine.build_tables fed with the REFERENCE's own CCFFit object gives the
+    same device tables as with this package's CCFFit (no GPU needed to check that)."""
+    import victor_amd
+    from victor_amd.engine import build_tables
+    opts = {"boss_config": cases.boss_options("config"), "boss_cobaya": cases.boss_options("cobaya"),
+            "synth3": cases.synth_options(3)}[case]
+    rfit = ref.CCFFit(cases.clone(opts[0]), cases.clone(opts[1]))
+    mfit = victor_amd.CCFFit(*opts)
+    for matter in ("template", "linear_bias"):
+        ta, ka = build_tables(rfit, rfit, matter)
+        tb, kb = build_tables(mfit, mfit, matter)
+        for name in ("n_s", "n_mu", "n_x", "n_ell", "n_ell_r", "n_beta_r", "n_beta_d", "n_beta_c", "matter_model",
+                     "vr_beta_dep", "sv_n_mu"):
+            assert getattr(ta, name) == getattr(tb, name), name
+        assert ta.iaH == tb.iaH and ta.template_sigma8 == tb.template_sigma8
+        fa, fb = _flatten(ka), _flatten(kb)
+        assert len(fa) == len(fb)
+        for x, y in zip(fa, fb):
+            assert x.shape == y.shape
+            scale = max(1e-300, float(np.max(np.abs(y))))
+            assert np.max(np.abs(x - y)) <= 1e-11 * scale

@@ -15,6 +15,7 @@ import numpy as np
 from . import _native as N
 from . import tables as T
 from . import utils
+from . import velocity_tables
 from .utils import InputError
 
 EXTENSIONS = {"npy": [".npy"],
@@ -258,30 +259,8 @@ class CCFModel:
         return np.atleast_2d(T.pchip(self.beta, np.moveaxis(stack, 1, 0))(beta))
 
     # ------------------------------------------------------------------ matter / velocity profiles ---
-    def _linear_bias_maps(self, r_nodes):
-        """Matrices (Bd, Td) with  b*delta(r_nodes) = Bd @ y  and  b*Delta(r_nodes) = Td @ y  for nodal values
-        y of the real-space monopole on ``self.r``: the reference's spline of xi^r_0 and its 100-point
-        trapezoid integral 3/(b r^3) int_0^r xi x^2 dx (ccf_model.py:358-370) are both linear in y."""
-        r_nodes = np.asarray(r_nodes, dtype=float)
-        basis = T.notaknot(self.r, np.eye(len(self.r)))
-        Bd = basis(r_nodes)
-        Td = np.empty_like(Bd)
-        for n, rn in enumerate(r_nodes):
-            x = np.linspace(0, rn, 100)
-            Td[n] = 3.0 / rn ** 3 * ((T.trapezoid_weights(x) * x ** 2) @ basis(x))
-        return Bd, Td
-
     def _matter_nodal(self, matter_model, r_nodes, beta=None):
-        """(delta, Delta) at ``r_nodes`` with the 1/bias factors left out (they are per-point amplitudes)."""
-        if matter_model == "template":
-            return self.delta(r_nodes), self.integrated_delta(r_nodes)
-        if matter_model == "linear_bias":
-            y = self.get_interpolated_real_multipoles(beta)[0]
-            Bd, Td = self._linear_bias_maps(r_nodes)
-            return Bd @ y, Td @ y
-        if matter_model == "excursion_set":
-            raise InputError("matter_model 'excursion_set' is not implemented in victor_amd")
-        raise InputError(f"Invalid choice of matter_model {matter_model}")
+        return velocity_tables.matter_nodal(self, matter_model, r_nodes, beta)
 
     def delta_profiles(self, r, params, **kwargs):
         """delta(r) and its volume average Delta(r) (reference: ccf_model.py:328-383).  Host-side accessor (used
@@ -293,16 +272,6 @@ class CCFModel:
             bias = params.get("bias", model["bias"])
             return d / bias, D / bias
         return d, D
-
-    def _empirical_gradient_tables(self, r_ext, delta_ext, int_delta_ext):
-        """Nodal values (at r_ext) of the two numerical-derivative pieces of the empirical_corr branch
-        (ccf_model.py:455-459): d/dr of r*Delta and of r*Delta*delta on linspace(0.1, r_max, 100)."""
-        rg = np.linspace(0.1, self.r.max(), 100)
-        Ds = T.notaknot(r_ext, int_delta_ext)(rg)
-        ds = T.notaknot(r_ext, delta_ext)(rg)
-        g1 = T.notaknot(rg, np.gradient(rg * Ds, rg))(r_ext)
-        g2 = T.notaknot(rg, np.gradient(rg * Ds * ds, rg))(r_ext)
-        return g1, g2
 
     def velocity_terms(self, r, params, **kwargs):
         """Mean radial velocity v_r(r) and its derivative (reference: ccf_model.py:385-492).  Host-side accessor
@@ -338,33 +307,6 @@ class CCFModel:
             vg = -growth * rg * Ds * (1 + Av * ds) / (3 * iaH_true)
             dvr = T.notaknot(rg, np.gradient(vg, rg))(r)
         return vr, dvr
-
-    def _velocity_tables(self, matter_model):
-        """Coefficient arrays of the velocity tables on r_ext = [0.01, r...] for one matter model.
-
-        Returns ``(coef, beta_dependent)``: fixed -> (5, n_r, 4) for V1 = r*Delta, Da = delta - 2 Delta/3,
-        V2 = r*Delta*delta, Ge1, Ge2; beta-dependent -> (2, n_beta-1, n_r, 4, 4) for V1, Da.
-        """
-        r_ext = np.append([0.01], self.r)
-        if matter_model == "velocity_template":
-            # v_r = growth_t * V_t(r/c); its derivative by the reference's numerical gradient (ccf_model.py:486-490)
-            rg = np.linspace(0.1, self.r.max(), 100)
-            gt = T.notaknot(rg, np.gradient(self.radial_velocity(rg), rg))(r_ext)
-            zero = np.zeros_like(r_ext)
-            nodal = np.stack([self.radial_velocity(r_ext), gt / 3, zero, zero, zero], axis=1)
-            return np.moveaxis(T.notaknot_coefficients(r_ext, nodal), 2, 0), False
-        if matter_model == "linear_bias" and not self.fixed_real_input:
-            Bd, Td = self._linear_bias_maps(r_ext)
-            ypoly = T.pchip_coefficients(self.beta, self.real_multipoles["0"])      # (n_beta-1, 4, n_r)
-            d_poly = np.einsum("nm,kpm->kpn", Bd, ypoly)
-            D_poly = np.einsum("nm,kpm->kpn", Td, ypoly)
-            V1 = T.spline_table_from_beta_poly(r_ext, r_ext * D_poly)
-            Da = T.spline_table_from_beta_poly(r_ext, d_poly - 2 * D_poly / 3)
-            return np.stack([V1, Da]), True
-        d, D = self._matter_nodal(matter_model, r_ext)
-        g1, g2 = self._empirical_gradient_tables(r_ext, d, D)
-        nodal = np.stack([r_ext * D, d - 2 * D / 3, r_ext * D * d, g1 / 3, g2 / 3], axis=1)   # (n_ext, 5)
-        return np.moveaxis(T.notaknot_coefficients(r_ext, nodal), 2, 0), False              # (5, n_r, 4)
 
     # ------------------------------------------------------------------ device plumbing -------
     def _merged(self, kwargs):

@@ -12,6 +12,7 @@ import numpy as np
 
 from . import _native as N
 from . import tables as T
+from . import velocity_tables as VT
 from .utils import InputError
 
 
@@ -30,9 +31,10 @@ def _pp(knots, coef, lead=0):
 
 
 def build_tables(model, fit=None, matter_model=None):
-    """Compile a :class:`CCFModel` (and optionally the data side of a :class:`CCFFit`) into vk_tables.
+    """Compile a ``CCFModel`` (and optionally the data side of a ``CCFFit``) into vk_tables.
 
-    Returns ``(tables, keepalive)``.
+    Only plain attributes are read (see :mod:`victor_amd.velocity_tables`), so ``model`` / ``fit`` may equally be
+    objects of the reference package.  Returns ``(tables, keepalive)``.
     """
     keep = []
 
@@ -77,10 +79,12 @@ def build_tables(model, fit=None, matter_model=None):
 
     # velocity profile tables on r_ext = [0.01, r...] (ccf_model.py:625, 449-459) for the chosen matter model
     matter_model = matter_model or model.matter_model
+    if matter_model == "excursion_set":
+        raise InputError("matter_model 'excursion_set' is not implemented on the HIP path")
     if matter_model not in N.MATTER:
         raise InputError(f"matter_model '{matter_model}' is not implemented on the HIP path")
     r_ext = np.append([0.01], r)
-    vr_coef, vr_beta_dep = model._velocity_tables(matter_model)
+    vr_coef, vr_beta_dep = VT.velocity_tables(model, matter_model)
     t.matter_model = N.MATTER[matter_model]
     t.vr_beta_dep = 1 if vr_beta_dep else 0
     t.vr, k = _pp(r_ext, vr_coef, lead=1)
@@ -91,7 +95,7 @@ def build_tables(model, fit=None, matter_model=None):
 
     # dispersion template.  Isotropic: the bicubic RectBivariateSpline of ccf_model.py:654 through mu-independent
     # data is the 1-D not-a-knot spline in r.  Anisotropic (3 keys): bicubic patches, evaluated from global memory.
-    if model._sv_isotropic:
+    if VT.dispersion_is_isotropic(model):
         t.sv, k = _pp(model.r_for_sv, T.notaknot_coefficients(model.r_for_sv, model.sv_rmu[0])[None])
         keep.append(k)
         t.sv_n_mu = 0
