@@ -151,3 +151,84 @@ def test_velocity_template_mean_model_on_gpu(tmp_path):
     t = fit.theory_multipole_vector(fit.s, cases.point(hp, 5), fit.poles_s, mean_model="linear")
     to = ora.theory_multipole_vector(ora.s, cases.point(hp, 5), ora.poles_s, mean_model="linear")
     assert np.max(np.abs(t - to)) < RTOL * np.max(np.abs(to))
+
+
+def test_example_void_model_hdf5_non_uniform_grids():
+    """The reference's example model file (HDF5, distances in units of the void radius, NON-uniform r grid): the
+    generic kernel with knot search, for the parameter sets of notebooks/model_options_demo.ipynb."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import victor_amd
+    import victor_oracle as vo
+    from victor_amd import h5lite
+    model = {"dir": cases.GOLDEN, "input_model_data_file": "h5/void_model_example.h5", "rsd_model": "streaming",
+             "z_eff": 0.50, "cosmology": {"Omega_m": 0.31},
+             "realspace_ccf": {"reconstruction": False, "format": "multipoles", "ccf_keys": ["r", "monopole"]},
+             "matter_ccf": {"model": "template", "integrated": False, "template_keys": ["rdelta", "delta"],
+                            "template_sigma8": 0.628, "bias": 1.9},
+             "velocity_pdf": {"mean": {"model": "linear"},
+                              "dispersion": {"model": "template", "template_keys": ["rsv", "sigmav"]}}}
+    m = victor_amd.CCFModel(model)
+    o = vo.OracleModel(model, h5lite.read_all(os.path.join(cases.GOLDEN, "h5", "void_model_example.h5")))
+    assert np.ptp(np.diff(m.r)) > 1e-3                      # the grid really is non-uniform
+    s = np.linspace(0.01, 3, 100)                           # as in the notebook
+    for p, kw in (({"fsigma8": 0.47, "sigma_v": 7, "epsilon": 1.0}, {}),
+                  ({"fsigma8": 0.47, "sigma_v": 7, "epsilon": 1.0}, {"rsd_model": "dispersion"}),
+                  ({"fsigma8": 0.47, "sigma_v": 7, "epsilon": 1.0, "M": 1.0, "Q": 1.0},
+                   {"rsd_model": "kaiser", "kaiser_approximation": True, "kaiser_coord_shift": False}),
+                  ({"beta": 0.4, "epsilon": 1.0, "fsigma8": 0.47}, {"rsd_model": "kaiser", "matter_model": "linear_bias"}),
+                  ({"fsigma8": 0.47, "sigma_v": 7, "epsilon": 1.0, "Av": 1},
+                   {"rsd_model": "dispersion", "empirical_corr": True})):
+        got = m.theory_multipoles(s, dict(p), poles=[0, 2], **kw)
+        want, _ = o.theory_multipoles(s, dict(p), poles=[0, 2], **kw)
+        for key in ("0", "2"):
+            assert np.max(np.abs(got[key] - want[key])) < RTOL * np.max(np.abs(want[key])), (kw, key)
+    assert m._get_engine().last_kernel() == "vk_theory_kernel"
+
+
+def test_special_amplitudes_in_every_fast_mapping(tmp_path, gold):
+    """linear_bias on fixed tables and the velocity-template mean model change only the per-point amplitude, so they run
+    on the fast kernels; all three mappings must agree with each other and with the reference / oracle."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import victor_amd
+    import victor_oracle as vo
+    from tests.test_host import _aniso_inputs
+    g, meta = gold
+    hp = cases.halton_params(8192 + 11)
+    # linear_bias, fixed real-space input: golden rows first, then a large batch through each mapping
+    fit = victor_amd.CCFFit(*cases.synth_options(3))
+    pts = [dict(q, beta=0.4, bias=1.7) for q in meta["synth_points"][:3]]
+    batch = dict({k: np.concatenate([[p[k] for p in pts], v]) for k, v in hp.items()}, beta=0.4, bias=1.7)
+    res = {}
+    for mapping in ("point", "cells", "lanes"):
+        os.environ["VICTOR_HIP_MAPPING"] = mapping
+        try:
+            th = fit.theory_vector_batch(batch, matter_model="linear_bias")
+        finally:
+            del os.environ["VICTOR_HIP_MAPPING"]
+        assert close(th[:3], g["opt_synth_lb_stream"]), mapping
+        res[mapping] = th
+    assert close(res["cells"], res["point"]) and close(res["lanes"], res["point"])
+    # velocity template mean model
+    model, data = _aniso_inputs(tmp_path)
+    model["velocity_pdf"]["mean"]["model"] = "template"
+    model["velocity_pdf"]["dispersion"] = {"model": "template", "template_keys": ["rsv", "sigmav"]}
+    fit = victor_amd.CCFFit(model, data)
+    ora = vo.OracleFit(model, data)
+    res = {}
+    for mapping in ("point", "cells", "lanes"):
+        os.environ["VICTOR_HIP_MAPPING"] = mapping
+        try:
+            res[mapping] = fit.log_likelihood_batch(hp)
+            assert fit._get_engine("velocity_template").last_kernel().endswith(
+                {"point": "fast_kernel", "cells": "cells_kernel", "lanes": "lanes_kernel"}[mapping])
+        finally:
+            del os.environ["VICTOR_HIP_MAPPING"]
+    for i in (0, 4000, 8202):
+        want = ora.log_likelihood(cases.point(hp, i))
+        for mapping in res:
+            assert abs(res[mapping][1][i] / want[1] - 1) < RTOL, (mapping, i)
+    assert np.max(np.abs(res["lanes"][1] / res["point"][1] - 1)) < 1e-11

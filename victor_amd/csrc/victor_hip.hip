@@ -268,7 +268,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   const int grid = (int)(items < cap ? items : cap);
   // lanes-over-batch variant: batch-constant tables and enough points to fill the chip with n_s * n/64 waves
   const char* mapping = getenv("VICTOR_HIP_MAPPING");
-  const bool lanes_ok = fast && a.n_beta_r == 0 && !a.matter_lb;
+  const bool lanes_ok = fast && a.n_beta_r == 0;
   // One wave per (s bin, 64-point chunk).  The kernel is register-limited to 4 waves per SIMD, i.e. 16 per CU, so the
   // chip holds n_cu*16 waves at a time; the last round of waves is only partly filled.  The lanes kernel is ~1.2x
   // faster per integrand than the point-major one (81 vs 92 VALU instructions), so it wins once that fill

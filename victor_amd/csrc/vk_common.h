@@ -120,6 +120,28 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// Growth term and powers of the bias (ccf_model.py:426-443, 358-370): v_r(r) = -gb [V1 + av V2](r/c) / (3 aH_true).
+// `extra` collects the inputs that must poison the outputs when they are NaN/inf.
+__device__ __forceinline__ double growth_amplitude(const TheoryArgs& a, const double* row, double fs8, double* av,
+                                                   double* extra) {
+  double growth = fs8 * a.inv_sigma8;
+  double binv = 1.0;
+  if (a.matter_lb) {
+    const double bias = row[VK_P_BIAS];
+    if (a.from_data) growth = row[VK_P_BETA] * bias;
+    binv = 1.0 / bias;
+    *extra += bias;
+  }
+  // velocity template: v_r = growth_t V_t(r/c), growth_t = fsigma8 vt_amp / apar  ==  -gb V_t / (3 aH_true)
+  if (a.matter_vt) growth = -3.0 * a.iaH * a.vt_amp * fs8;
+  *av = 0.0;
+  if (a.empirical && !a.matter_vt) {
+    *av = row[VK_P_AV] * binv;
+    *extra += *av;
+  }
+  return growth * binv;
+}
+
 // per-point, wave-uniform quantities (ccf_model.py:589-613, 432-450, 638)
 struct PointScalars {
   double aperp, apar, inv_c, A, B;
@@ -159,23 +181,8 @@ __device__ __forceinline__ PointScalars point_scalars(const TheoryArgs& a, const
   }
   ps.inv_c = 1.0 / c;
   const double iaH_true = a.iaH * ps.apar;
-  // growth term and powers of the bias (ccf_model.py:426-435, 358-370): v_r = -gb [V1 + av V2](r/c) / (3 aH)
-  double growth = fs8 * a.inv_sigma8;
-  double binv = 1.0, extra = 0.0;
-  if (a.matter_lb) {
-    const double bias = row[VK_P_BIAS];
-    if (a.from_data) growth = row[VK_P_BETA] * bias;
-    binv = 1.0 / bias;
-    extra += bias;
-  }
-  // velocity template: v_r = growth_t V_t(r/c), growth_t = fsigma8 vt_amp / apar  ==  -gb V_t / (3 aH_true)
-  if (a.matter_vt) growth = -3.0 * a.iaH * a.vt_amp * fs8;
-  const double gb = growth * binv;
-  ps.av = 0.0;
-  if (a.empirical && !a.matter_vt) {
-    ps.av = row[VK_P_AV] * binv;
-    extra += ps.av;
-  }
+  double extra = 0.0;
+  const double gb = growth_amplitude(a, row, fs8, &ps.av, &extra);
   ps.B = sigv * iaH_true;
   ps.A = gb / (3.0 * iaH_true * sigv);
   ps.G = gb / 3.0;

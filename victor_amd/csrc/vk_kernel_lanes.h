@@ -56,15 +56,8 @@ __device__ __forceinline__ PointScalars point_scalars_lane(const TheoryArgs& a, 
   }
   ps.inv_c = 1.0 / c;
   const double iaH_true = a.iaH * ps.apar;
-  double growth = fs8 * a.inv_sigma8;
-  double binv = 1.0, extra = 0.0;
-  if (a.matter_lb) {
-    const double bias = row[VK_P_BIAS];
-    binv = 1.0 / bias;
-    extra = bias;
-  }
-  const double gb = growth * binv;
-  ps.av = 0.0;
+  double extra = 0.0;
+  const double gb = growth_amplitude(a, row, fs8, &ps.av, &extra);
   ps.B = sigv * iaH_true;
   ps.A = gb / (3.0 * iaH_true * sigv);
   ps.G = gb / 3.0;
