@@ -81,13 +81,15 @@ extern "C" {
 /*
  * A clamped piecewise-cubic table  f(u) = sum_p coef[i][p] * (u - knot_i)^p  on interval i.
  * Evaluation clamps u to [knots[0], knots[n_int]] first (FITPACK ext=3 / box clamp).
- * Interval search: the first `lead` intervals are irregular (searched linearly), the rest
- * lie on a uniform grid starting at knots[lead] with spacing 1/inv_h.
+ * Interval search: the first `lead` intervals are irregular, the rest start at knots[lead].
+ * inv_h > 0: those knots are exactly uniform with spacing 1/inv_h; inv_h < 0: nearly uniform (every knot within
+ * 0.4 spacings of the uniform position, mean spacing 1/|inv_h|; the estimate is corrected against the knots);
+ * inv_h == 0: arbitrary knots, binary search.
  */
 typedef struct vk_pp {
   int32_t n_int;        /* number of intervals; knots has n_int+1 entries      */
   int32_t lead;         /* 0 or 1 leading irregular interval                   */
-  double inv_h;         /* 1/spacing of the uniform part                       */
+  double inv_h;         /* see above                                           */
   const double* knots;  /* [n_int+1]                                           */
   const double* coef;   /* [n_var][n_int][4]; n_var is table specific          */
 } vk_pp;

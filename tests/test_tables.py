@@ -127,3 +127,12 @@ def test_uniform_spacing_detection():
     assert T.uniform_spacing(2.0 + 4.0 * np.arange(30)) == pytest.approx(4.0)
     assert T.uniform_spacing(np.append([0.01], 2.0 + 4.0 * np.arange(30))) is None
     assert T.uniform_spacing(np.append([0.01], 2.0 + 4.0 * np.arange(30)), lead=1) == pytest.approx(4.0)
+
+
+def test_near_uniform_spacing_detection():
+    k = 0.05 + 0.12 * np.arange(25) + 0.01 * np.sin(np.arange(25))
+    assert T.uniform_spacing(k) is None
+    assert T.near_uniform_spacing(k) == pytest.approx((k[-1] - k[0]) / 24)
+    assert T.near_uniform_spacing(np.array([0.0, 1.0, 2.0, 3.9, 4.0])) is None          # too irregular
+    kk = np.append([0.001], k)
+    assert T.near_uniform_spacing(kk, lead=1) == pytest.approx((k[-1] - k[0]) / 24)

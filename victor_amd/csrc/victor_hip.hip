@@ -435,7 +435,7 @@ const char* vk_last_kernel(const vk_ctx* ctx) { return ctx ? ctx->last_kernel : 
 
 static int check_pp(const vk_pp* p, const char* name, std::string* err) {
   char buf[256];
-  if (p->n_int < 1 || !p->knots || !p->coef || p->lead < 0 || p->lead > 1 || p->lead >= p->n_int + (p->inv_h > 0 ? 0 : 1)) {
+  if (p->n_int < 1 || !p->knots || !p->coef || p->lead < 0 || p->lead > 1 || p->lead >= p->n_int + (p->inv_h != 0 ? 0 : 1)) {
     snprintf(buf, sizeof buf, "table '%s' is malformed", name);
     *err = buf;
     return VK_E_ARG;

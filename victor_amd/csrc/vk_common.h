@@ -86,14 +86,25 @@ struct PPLds {
   double lo, hi, x_u0;
 };
 
+// Interval of u (already clamped to the table range): exact for uniform knots (inv_h > 0); for nearly uniform knots
+// (inv_h < 0: |inv_h| is the mean spacing, every knot within 0.4 spacings of the uniform position - e.g. bin centres
+// that are mean pair separations) the uniform estimate is corrected by at most one interval against the knots;
+// arbitrary knots (inv_h == 0) use a binary search.
 __device__ __forceinline__ int pp_interval(const PPLds& t, double u) {
   int i;
-  if (t.inv_h > 0.0) {
+  if (t.inv_h != 0.0) {
     const int n_uniform = t.n_int - t.lead;
-    double tt = (u - t.x_u0) * t.inv_h;
+    const double tt = (u - t.x_u0) * fabs(t.inv_h);
     i = (int)tt;
     i = min(max(i, 0), n_uniform - 1) + t.lead;
     if (t.lead && u < t.x_u0) i = 0;
+    if (t.inv_h < 0.0) {
+      if (u < t.knots[i]) {
+        i = max(i - 1, 0);
+      } else if (u >= t.knots[i + 1]) {
+        i = min(i + 1, t.n_int - 1);
+      }
+    }
   } else {
     // general knots: largest i with knots[i] <= u
     int lo = 0, hi = t.n_int;

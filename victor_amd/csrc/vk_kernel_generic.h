@@ -5,7 +5,7 @@
 namespace vk {
 
 struct LdsPlan {
-  int mu, smu, w, x, wx, svk, svc, vrk, vrc, xik, xic, betar, red, total;
+  int mu, smu, w, x, wx, svk, svc, vrk, vrc, xik, xic, betar, red, etab, total;
 };
 
 __host__ __device__ inline LdsPlan make_plan(int n_mu, int n_x, int n_ell, int sv_int, int vr_int, int xi_int,
@@ -28,6 +28,8 @@ __host__ __device__ inline LdsPlan make_plan(int n_mu, int n_x, int n_ell, int s
   p.xic = o;  o += n_ell_r * xi_int * 4;
   p.betar = o; o += n_beta_r;
   p.red = o;  o += kWaves * kMaxEll;
+  o = (o + 1) & ~1;
+  p.etab = o; o += vkm::kExpTab;
   p.total = o;
   return p;
 }
@@ -97,21 +99,23 @@ __device__ __forceinline__ double sv_shape(const PPLds& sv, const TheoryArgs& a,
 // Simpson weight.  NLR = number of real-space multipoles summed (1 = assume_isotropic).
 template <int NLR>
 __device__ __forceinline__ double streaming_integrand(const PPLds& sv, const PPLds& vr, const PPLds& xi,
-                                                      const PointScalars& ps, const TheoryArgs& a, double s_perp,
-                                                      double s_par, double xk, double wk) {
+                                                      const PointScalars& ps, const TheoryArgs& a,
+                                                      const double* __restrict__ etab, double s_perp, double s_par,
+                                                      double xk, double wk) {
   const double r_par = fma(-xk, ps.B, s_par);
-  const double r = sqrt(fma(s_perp, s_perp, r_par * r_par));
-  const double mu_r = r_par / r;
+  double r, inv_r;
+  vkm::sqrt_rsqrt(fma(s_perp, s_perp, r_par * r_par), r, inv_r);
+  const double mu_r = r_par * inv_r;
   const double u = r * ps.inv_c;
 
   const double SV = sv_shape(sv, a, u, mu_r);
   const double uv = clampd(u, vr.lo, vr.hi);
   const double V = vel_shape(vr, ps, a, pp_interval(vr, uv), uv);
   const double xir = xi_real<NLR>(xi, ps, a, u, mu_r, r_par, s_perp);
-  const double inv_sv = 1.0 / SV;
+  const double inv_sv = vkm::recip(SV);
   const double z = fma(ps.A * V, mu_r, xk) * inv_sv;
-  const double e = exp(-0.5 * z * z);
-  return wk * (1.0 + xir) * e * inv_sv;
+  const double e = vkm::exp_nonpos((-0.5 * z) * z, etab);
+  return wk * inv_sv * fma(e, xir, e);
 }
 
 // The other RSD mappings of the reference on the same tables:
@@ -123,8 +127,9 @@ __device__ __forceinline__ double streaming_integrand(const PPLds& sv, const PPL
 // Returns f such that xi^s = sum_v f - 1 (for kaiser/euclid the "plane" has the single node x = 0, weight 1).
 template <int RSD, int NLR>
 __device__ __forceinline__ double rsd_integrand(const PPLds& sv, const PPLds& vr, const PPLds& xi, const PointScalars& ps,
-                                                const TheoryArgs& a, double s_perp, double s_par, double xk, double wk) {
-  if (RSD == VK_RSD_STREAMING) return streaming_integrand<NLR>(sv, vr, xi, ps, a, s_perp, s_par, xk, wk);
+                                                const TheoryArgs& a, const double* __restrict__ etab, double s_perp,
+                                                double s_par, double xk, double wk) {
+  if (RSD == VK_RSD_STREAMING) return streaming_integrand<NLR>(sv, vr, xi, ps, a, etab, s_perp, s_par, xk, wk);
   const double mfac = (RSD == VK_RSD_DISPERSION) ? 1.0 : ps.M;
   const double num = (RSD == VK_RSD_DISPERSION) ? fma(-xk, ps.B, s_par) : s_par;
   const double sp2 = s_perp * s_perp;
@@ -182,6 +187,7 @@ __device__ void stage_tables(const TheoryArgs& a, const LdsPlan& pl, double* lds
     lds[pl.x + i] = a.x[i];
     lds[pl.wx + i] = a.w_x[i];
   }
+  for (int j = tid; j < vkm::kExpTab; j += kBlock) lds[pl.etab + j] = vkm::exp2_frac(j);
   for (int i = tid; i <= a.sv.n_int; i += kBlock) lds[pl.svk + i] = a.sv.knots[i];
   for (int i = tid; i < a.sv.n_int * 4; i += kBlock) lds[pl.svc + i] = a.sv_n_mu ? 0.0 : a.sv.coef[i];
   for (int i = tid; i <= a.vr.n_int; i += kBlock) lds[pl.vrk + i] = a.vr.knots[i];
@@ -264,6 +270,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_kernel(TheoryArgs a) {
   const double* l_x = lds + pl.x;
   const double* l_wx = lds + pl.wx;
   double* l_red = lds + pl.red;
+  const double* l_etab = lds + pl.etab;
 
   double wsum[NL];
 #pragma unroll
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_kernel(TheoryArgs a) {
         int i = idx / a.n_x;
         int k = idx - i * a.n_x;
         for (; idx < plane; idx += step) {
-          const double f = rsd_integrand<RSD, NLR>(sv, vr, xi, ps, a, s_aperp * l_smu[i], s_apar * l_mu[i],
+          const double f = rsd_integrand<RSD, NLR>(sv, vr, xi, ps, a, l_etab, s_aperp * l_smu[i], s_apar * l_mu[i],
                                                    l_x[k], l_wx[k]);
 #pragma unroll
           for (int l = 0; l < NL; ++l) acc[l] = fma(l_w[l * a.n_mu + i], f, acc[l]);
@@ -351,6 +358,7 @@ __global__ __launch_bounds__(kBlock) void vk_xi_smu_kernel(TheoryArgs a) {
   const double* l_smu = lds + pl.smu;
   const double* l_x = lds + pl.x;
   const double* l_wx = lds + pl.wx;
+  const double* l_etab = lds + pl.etab;
   const int cells = a.n_mu * a.n_s;
   const int rounds = (cells + kWaves - 1) / kWaves;
   for (long long point = blockIdx.x; point < a.n; point += gridDim.x) {
@@ -371,7 +379,7 @@ __global__ __launch_bounds__(kBlock) void vk_xi_smu_kernel(TheoryArgs a) {
       const double s_par = sj * l_mu[i] * ps.apar;
       double acc = 0.0;
       for (int k = lane; k < a.n_x; k += 64)
-        acc += rsd_integrand<RSD, NLR>(sv, vr, xi, ps, a, s_perp, s_par, l_x[k], l_wx[k]);
+        acc += rsd_integrand<RSD, NLR>(sv, vr, xi, ps, a, l_etab, s_perp, s_par, l_x[k], l_wx[k]);
       acc = wave_sum(acc);
       if (lane == 0) a.out[(point * a.n_mu + i) * (long long)a.n_s + j] = acc - 1.0 + ps.poison;
     }

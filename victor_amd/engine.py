@@ -20,11 +20,17 @@ def _pp(knots, coef, lead=0):
     """Build a vk_pp (plus the arrays that must stay alive while it is used)."""
     knots = N.f64(knots)
     coef = N.f64(coef)
-    h = T.uniform_spacing(knots, lead=lead)
     pp = N.vk_pp()
     pp.n_int = len(knots) - 1
-    pp.lead = lead if h is not None else 0
-    pp.inv_h = 1.0 / h if h is not None else 0.0
+    h = T.uniform_spacing(knots, lead=lead)
+    if h is not None:
+        pp.lead, pp.inv_h = lead, 1.0 / h                    # exactly uniform
+    else:
+        hm = T.near_uniform_spacing(knots, lead=lead)
+        if hm is not None:
+            pp.lead, pp.inv_h = lead, -1.0 / hm              # nearly uniform: estimate + one-step correction
+        else:
+            pp.lead, pp.inv_h = 0, 0.0                       # arbitrary knots: binary search
     pp.knots = N.as_dp(knots)
     pp.coef = N.as_dp(coef)
     return pp, (knots, coef)

@@ -269,6 +269,17 @@ def spline_table_from_beta_poly(r, nodal_poly):
     return np.einsum("iqn,kpn->kiqp", lin, np.asarray(nodal_poly, dtype=np.float64))
 
 
+def near_uniform_spacing(knots, lead=0, tol=0.4):
+    """Mean spacing of knots[lead:] if every knot lies within ``tol`` spacings of its uniform position, else None."""
+    k = np.asarray(knots, dtype=np.float64)[lead:]
+    if len(k) < 2:
+        return None
+    h = (k[-1] - k[0]) / (len(k) - 1)
+    if np.all(np.abs(k - (k[0] + h * np.arange(len(k)))) <= tol * h):
+        return h
+    return None
+
+
 def beta_dependent_spline_table(r, beta, values):
     """Coefficients of the r-spline of PCHIP-in-beta nodal values, as polynomials in beta.
 
