@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 3
+#define VK_ABI_VERSION 4
 
 /* error codes */
 #define VK_OK 0
@@ -136,6 +136,16 @@ typedef struct vk_tables {
   const double* sv_mu;  /* [sv_n_mu] mu nodes                                                           */
   const double* sv2d;   /* [sv.n_int][sv_n_mu-1][4][4] bicubic patches: coefficient of du^p dmu^q of the
                            tensor-product not-a-knot spline (RectBivariateSpline, ccf_model.py:654)     */
+
+  /* ---- optional unified grid: one interval index for sigma_v, V1 and every xi^r_l -------------------- */
+  /* When the r grid and the sigma_v grid are uniform and commensurate, the host re-expresses all tables on
+   * their common refinement (u0 + q/inv_h, q < uni_n) in interval units; the fast theory kernels need it.  */
+  int32_t uni_n;        /* 0: not available (only the generic theory kernel is used)                    */
+  double uni_u0;        /* left end of the refined grid                                                  */
+  double uni_inv_h;     /* 1/spacing of the refined grid                                                 */
+  const double* uni_sv_v; /* [uni_n][2][4]: sigma_v shape and V1 = r*Delta, coefficients of tau^p        */
+  const double* uni_xi; /* fixed: [n_ell_r][uni_n][4]; beta-dependent: [n_ell_r][n_beta_r-1][uni_n][4][4]
+                           (last index = power of beta - beta_r[k])                                       */
 
   double iaH;           /* (1+z)/(100 E(z)) (ccf_model.py:43-45)               */
   double template_sigma8; /* ccf_model.py:432-435                              */

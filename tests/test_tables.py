@@ -136,3 +136,35 @@ def test_near_uniform_spacing_detection():
     assert T.near_uniform_spacing(np.array([0.0, 1.0, 2.0, 3.9, 4.0])) is None          # too irregular
     kk = np.append([0.001], k)
     assert T.near_uniform_spacing(kk, lead=1) == pytest.approx((k[-1] - k[0]) / 24)
+
+
+def test_common_refinement_and_refined_tables():
+    r = 2.0 + 4.0 * np.arange(30)            # BOSS-like xi grid
+    rsv = 3.0 + 6.0 * np.arange(25)          # and dispersion grid
+    u0, h, n = T.common_refinement(r, rsv)
+    assert (u0, h, n) == (2.0, 1.0, 145)
+    u0s, hs, ns = T.common_refinement(1.5 + 3.0 * np.arange(40), 3.0 + 6.0 * np.arange(25))
+    assert (u0s, hs, ns) == (1.5, 1.5, 97)
+    assert T.common_refinement(r, 3.3 + 6.1 * np.arange(25)) is None                 # incommensurate
+    assert T.common_refinement(r + 0.01 * np.sin(np.arange(30)), rsv) is None        # not uniform
+    rng = np.random.default_rng(0)
+    for knots in (r, rsv, np.append([0.01], r)):
+        y = rng.normal(size=(len(knots), 2))
+        pc = T.notaknot(knots, y)
+        ref = T.refine_pp(knots, pc.coef, u0, h, n)
+        assert ref.shape == (n, 4, 2)
+        u = rng.uniform(u0, u0 + n * h, 4000)
+        q = np.minimum(((u - u0) / h).astype(int), n - 1)
+        tau = (u - u0) / h - q
+        val = ((ref[q, 3] * tau[:, None] + ref[q, 2]) * tau[:, None] + ref[q, 1]) * tau[:, None] + ref[q, 0]
+        assert np.max(np.abs(val - pc(u))) < 1e-12 * max(1.0, np.max(np.abs(y)))     # incl. the clamped ranges
+    # beta-polynomial coefficient arrays refine the same way (the shift is linear in the coefficients)
+    beta = np.linspace(0.16, 0.65, 7)
+    vals = rng.normal(size=(7, 30))
+    tab = T.beta_dependent_spline_table(r, beta, vals)                   # (6, 29, 4, 4)
+    ref = T.refine_pp(r, np.moveaxis(tab, 0, -1), u0, h, n)              # (n, 4, 4[p_beta], 6)
+    k, db = 2, 0.03
+    coef_r = ((tab[k, :, :, 3] * db + tab[k, :, :, 2]) * db + tab[k, :, :, 1]) * db + tab[k, :, :, 0]
+    want = T.refine_pp(r, coef_r, u0, h, n)
+    got = ((ref[:, :, 3, k] * db + ref[:, :, 2, k]) * db + ref[:, :, 1, k]) * db + ref[:, :, 0, k]
+    assert np.max(np.abs(got - want)) < 1e-13

@@ -62,6 +62,9 @@ struct vk_ctx {
   int matter_lb = 0, vr_beta_dep = 0, matter_vt = 0, sv_n_mu = 0;
   double vt_amp = 0, sv_mu_inv_h = 0;
   const double *d_sv_mu = nullptr, *d_sv2d = nullptr;
+  int uni_n = 0;             // unified refined grid (fast kernels need it)
+  double uni_u0 = 0, uni_inv_h = 0;
+  const double *d_uni_sv_v = nullptr, *d_uni_xi = nullptr;
   const char* last_kernel = "none";  // theory kernel variant of the most recent launch
   // scratch for the host-buffer entry points
   double* d_scratch = nullptr;
@@ -224,6 +227,11 @@ int theory_args(vk_ctx* ctx, const vk_eval_opts* o, TheoryArgs* a, int* nlr) {
   a->sv_mu_inv_h = ctx->sv_mu_inv_h;
   a->sv_mu = ctx->d_sv_mu;
   a->sv2d = ctx->d_sv2d;
+  a->uni_n = ctx->uni_n;
+  a->uni_u0 = ctx->uni_u0;
+  a->uni_inv_h = ctx->uni_inv_h;
+  a->uni_sv_v = ctx->d_uni_sv_v;
+  a->uni_xi = ctx->d_uni_xi;
   a->vr_beta_dep = ctx->vr_beta_dep;
   a->from_data = o->from_data ? 1 : 0;
   a->empirical = (o->empirical_corr && !ctx->matter_vt) ? 1 : 0;   // the template-mean branch ignores Av (ccf_model.py:483-490)
@@ -254,7 +262,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
                     a.n_mu <= 1024 && a.n_x <= 2048 && !getenv("VICTOR_HIP_FORCE_GENERIC");
   size_t lds;
   if (fast) {
-    lds = (size_t)make_fast_plan(a.n_mu, a.n_x, a.sv.n_int, a.xi.n_int, nlr, a.n_beta_r).total * sizeof(double);
+    lds = (size_t)make_fast_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.n_beta_r).total * sizeof(double);
   } else {
     lds = (size_t)make_plan(a.n_mu, a.n_x, a.n_ell, a.sv.n_int, a.vr.n_int, a.xi.n_int, nlr, a.n_beta_r).total *
           sizeof(double);
@@ -280,7 +288,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   const bool lanes = lanes_ok && (mapping ? !strcmp(mapping, "lanes") : fill >= 0.85);
   if (lanes) {
     ctx->last_kernel = "vk_theory_lanes_kernel";
-    const size_t lds_l = (size_t)make_lanes_plan(a.n_mu, a.n_x, a.sv.n_int, a.xi.n_int, nlr).total * sizeof(double);
+    const size_t lds_l = (size_t)make_lanes_plan(a.n_mu, a.n_x, a.uni_n, nlr).total * sizeof(double);
     const long long blocks = (waves + kWaves - 1) / kWaves;
     // Many more workgroups than fit at once: letting the dispatcher refill CUs as workgroups retire measured
     // 38.1 / 36.0 / 34.6 / 33.8 ms at 4 / 8 / 16 / 64 workgroups per CU on the bench workload (4 are resident)
@@ -300,7 +308,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   if (cells) {
     ctx->last_kernel = "vk_theory_cells_kernel";
     const size_t lds_c =
-        (size_t)make_cells_plan(a.n_mu, a.n_x, a.n_s, a.n_ell, a.sv.n_int, a.xi.n_int, nlr, a.n_beta_r).total * sizeof(double);
+        (size_t)make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, nlr, a.n_beta_r).total * sizeof(double);
     if (lds_c > 160 * 1024) return fail(ctx, VK_E_ARG, "tables need %zu bytes of LDS (> 160 KiB)", lds_c);
     const long long capc = (pcap_env ? atoll(pcap_env) : 64LL) * ctx->n_cu;
     const int grid_c = (int)(a.n < capc ? a.n : capc);
@@ -512,7 +520,8 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
       for (int i = 0; i <= t->xi.n_int && ok; ++i) ok = fabs(t->vr.knots[i + 1] - t->xi.knots[i]) <= tol;
       ok = ok && fabs(t->vr.inv_h - t->xi.inv_h) <= 1e-12 * t->xi.inv_h;
     }
-    ctx->fast_ok = ok && !t->vr_beta_dep && t->sv_n_mu == 0;
+    ctx->fast_ok = ok && !t->vr_beta_dep && t->sv_n_mu == 0 && t->uni_n > 0 && t->uni_sv_v && t->uni_xi &&
+                   t->uni_inv_h > 0 && t->uni_u0 >= t->vr.knots[0];
     ctx->matter_vt = t->matter_model == VK_MATTER_VELOCITY_TEMPLATE;
     ctx->vt_amp = t->vt_amp;
     ctx->matter_lb = t->matter_model == VK_MATTER_LINEAR_BIAS;
@@ -536,6 +545,12 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
   if (t->sv_n_mu) {
     o_svmu = up.add(t->sv_mu, t->sv_n_mu);
     o_sv2d = up.add(t->sv2d, (size_t)t->sv.n_int * (t->sv_n_mu - 1) * 16);
+  }
+  size_t o_usv = 0, o_uxi = 0;
+  if (t->uni_n > 0 && t->uni_sv_v && t->uni_xi) {
+    o_usv = up.add(t->uni_sv_v, (size_t)t->uni_n * 8);
+    o_uxi = up.add(t->uni_xi, t->n_beta_r > 0 ? (size_t)t->n_ell_r * (t->n_beta_r - 1) * t->uni_n * 16
+                                              : (size_t)t->n_ell_r * t->uni_n * 4);
   }
   size_t o_bd = 0, o_data = 0, o_bc = 0, o_prec = 0, o_ld = 0, o_eig = 0;
   if (t->data) {
@@ -570,6 +585,13 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
   ctx->xi = view(t->xi, o_xik, o_xic);
   ctx->vr = view(t->vr, o_vrk, o_vrc);
   ctx->sv = view(t->sv, o_svk, o_svc);
+  if (t->uni_n > 0 && t->uni_sv_v && t->uni_xi) {
+    ctx->uni_n = t->uni_n;
+    ctx->uni_u0 = t->uni_u0;
+    ctx->uni_inv_h = t->uni_inv_h;
+    ctx->d_uni_sv_v = base + o_usv;
+    ctx->d_uni_xi = base + o_uxi;
+  }
   ctx->sv_n_mu = t->sv_n_mu;
   ctx->sv_mu_inv_h = t->sv_mu_inv_h;
   if (t->sv_n_mu) {

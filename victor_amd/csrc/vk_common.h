@@ -44,6 +44,10 @@ struct TheoryArgs {
   double sv_mu_inv_h;
   const double* sv_mu;
   const double* sv2d;
+  int uni_n;              // unified refined grid (vk_tables.uni_*): one interval index for sigma_v, V1, xi^r_l
+  double uni_u0, uni_inv_h;
+  const double* uni_sv_v;
+  const double* uni_xi;
   int matter_lb;          // linear_bias matter model: amplitudes carry 1/bias (ccf_model.py:358-370,426-435)
   int vr_beta_dep;        // velocity tables are PCHIP-in-beta polynomials (rebuilt per point)
   int from_data;          // ccf_model.py:618-619,675-679

@@ -14,20 +14,17 @@ namespace vk {
 // (a wave's 64 cells straddle at most two s bins when n_mu >= 64), accumulated by lane 0 in wave-private LDS.
 // --------------------------------------------------------------------------------------------------
 struct CellsPlan {
-  int mu, w, xw, s, svrec, vxrec, lead, etab, betar, acc, total, vx_stride;
+  int mu, w, xw, s, recs, lead, etab, betar, acc, total;
 };
 
-__host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s, int n_ell, int sv_int, int xi_int,
-                                                    int nlr, int n_beta_r) {
+__host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s, int uni_n, int nlr, int n_beta_r) {
   CellsPlan p;
   int o = 0;
-  p.vx_stride = 4 * (1 + nlr) + 2;
   p.mu = o;    o += 2 * n_mu;                      // {mu_i, sqrt(1 - mu_i^2)}
   p.w = o;     o += kMaxEll * n_mu;                // W_l[i]
   p.xw = o;    o += 2 * n_x;                       // {x_k, w_k}
   p.s = o;     o += (n_s + 1) & ~1;
-  p.svrec = o; o += sv_int * kSvRec;
-  p.vxrec = o; o += xi_int * p.vx_stride;
+  p.recs = o;  o += uni_n * uni_stride(nlr);
   p.lead = o;  o += 4;
   p.etab = o;  o += vkm::kExpTab;
   p.betar = o; o += (n_beta_r + 1) & ~1;
@@ -40,11 +37,8 @@ __host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s,
 template <int NLR, int NL>
 __global__ __launch_bounds__(kBlock) void vk_theory_cells_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
-  constexpr int vx_stride = 4 * (1 + NLR) + 2;
-  const CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.n_ell, a.sv.n_int, a.xi.n_int, NLR, a.n_beta_r);
+  const CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r);
   const int tid = threadIdx.x;
-  const double hs = 1.0 / a.sv.inv_h, hx = 1.0 / a.xi.inv_h;
-  const double hl = a.vr.knots[1] - a.vr.knots[0];
   for (int i = tid; i < a.n_mu; i += kBlock) {
     const double m = a.mu[i];
     lds[pl.mu + 2 * i] = m;
@@ -57,30 +51,10 @@ __global__ __launch_bounds__(kBlock) void vk_theory_cells_kernel(TheoryArgs a) {
     lds[pl.xw + 2 * k + 1] = a.w_x[k];
   }
   for (int j = tid; j < a.n_s; j += kBlock) lds[pl.s + j] = a.s[j];
-  for (int e = tid; e < a.sv.n_int * 4; e += kBlock)
-    lds[pl.svrec + (e >> 2) * kSvRec + (e & 3)] = a.sv.coef[e] * hpow(hs, e & 3);
-  for (int e = tid; e < a.xi.n_int * 4; e += kBlock)
-    lds[pl.vxrec + (e >> 2) * vx_stride + (e & 3)] = a.vr.coef[4 + e] * hpow(hx, e & 3);
-  if (a.n_beta_r == 0) {
-    const int per_l = a.xi.n_int * 4;
-    for (int e = tid; e < NLR * per_l; e += kBlock) {
-      const int l = e / per_l, iq = e - l * per_l;
-      lds[pl.vxrec + (iq >> 2) * vx_stride + 4 * (1 + l) + (iq & 3)] = a.xi.coef[e] * hpow(hx, iq & 3);
-    }
-  } else {
+  stage_uni_records<NLR>(a, lds + pl.recs, lds + pl.lead, lds + pl.etab);
+  if (a.n_beta_r > 0)
     for (int i = tid; i < a.n_beta_r; i += kBlock) lds[pl.betar + i] = a.beta_r[i];
-  }
-  if (tid < 4) lds[pl.lead + tid] = a.vr.coef[tid] * hpow(hl, tid);
-  for (int j = tid; j < vkm::kExpTab; j += kBlock) lds[pl.etab + j] = vkm::exp2_frac(j);
-  FastConsts fc;
-  fc.inv_hs = a.sv.inv_h;
-  fc.off_s = -a.sv.knots[0] * a.sv.inv_h;
-  fc.ns_eps = (double)a.sv.n_int * (1.0 - 0x1p-52);
-  fc.inv_hx = a.xi.inv_h;
-  fc.off_x = -a.xi.knots[0] * a.xi.inv_h;
-  fc.nx_eps = (double)a.xi.n_int * (1.0 - 0x1p-52);
-  fc.inv_hl = 1.0 / hl;
-  fc.off_l = -a.vr.knots[0] * fc.inv_hl;
+  const FastConsts fc = make_fast_consts(a);
   __syncthreads();
 
   const int lane = tid & 63;
@@ -89,8 +63,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_cells_kernel(TheoryArgs a) {
   const double* l_w = lds + pl.w;
   const double* l_xw = lds + pl.xw;
   const double* l_s = lds + pl.s;
-  const double* svrec = lds + pl.svrec;
-  const double* vxrec = lds + pl.vxrec;
+  const double* recs = lds + pl.recs;
   const double* leadrec = lds + pl.lead;
   const double* etab = lds + pl.etab;
   const int slots = (a.n_s + kWaves - 1) / kWaves;        // s bins per wave (upper bound)
@@ -110,20 +83,8 @@ __global__ __launch_bounds__(kBlock) void vk_theory_cells_kernel(TheoryArgs a) {
     const double* row = a.params + point * VK_NPAR;
     const PointScalars ps = point_scalars(a, row);
     if (a.n_beta_r > 0) {
-      __syncthreads();
-      const double* bg = lds + pl.betar;
-      const double beta = row[VK_P_BETA];
-      int kb = 0;
-      for (int i = 1; i < a.n_beta_r - 1; ++i) kb = (beta >= bg[i]) ? i : kb;
-      const double db = beta - bg[kb];
-      const int per_l = a.xi.n_int * 4;
-      const size_t stride_l = (size_t)(a.n_beta_r - 1) * per_l * 4;
-      for (int e = tid; e < NLR * per_l; e += kBlock) {
-        const int l = e / per_l, iq = e - l * per_l;
-        const double* c = a.xi.coef + l * stride_l + ((size_t)kb * per_l + iq) * 4;
-        lds[pl.vxrec + (iq >> 2) * vx_stride + 4 * (1 + l) + (iq & 3)] =
-            fma(fma(fma(c[3], db, c[2]), db, c[1]), db, c[0]) * hpow(hx, iq & 3);
-      }
+      __syncthreads();  // every wave is done with the previous point's records
+      rebuild_uni_xi<NLR>(a, lds + pl.recs, lds + pl.betar, row[VK_P_BETA]);
       __syncthreads();
     }
     for (int e = lane; e < kMaxEll * slots; e += 64) l_acc[e * kWaves + wave] = 0.0;
@@ -143,7 +104,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_cells_kernel(TheoryArgs a) {
       for (int k = 0; k < a.n_x; ++k) {
         const vk_d2 xw = *reinterpret_cast<const vk_d2*>(l_xw + 2 * k);
         const double xk = xw.x;
-        g = fma(xw.y, node_value<NLR>(svrec, vxrec, leadrec, etab, fc, ps.B, ps.inv_c, AV, s_par, sperp2, xk), g);
+        g = fma(xw.y, node_value<NLR>(recs, leadrec, etab, fc, ps.B, ps.inv_c, AV, s_par, sperp2, xk), g);
       }
       if (!live) g = 0.0;
       // projection: this trip's cells belong to s bin jj0 or jj0 + 1

@@ -5,44 +5,26 @@
 namespace vk {
 
 // --------------------------------------------------------------------------------------------------
-// K1 fast path: all three tables on uniform grids, and the velocity table shares the xi^r knots behind its
-// extra leading node at 0.01 (always true for tables built by the reference's own recipe, ccf_model.py:625).
-//   * coefficients are re-expressed in interval units (tau = (u - knot_i)/h in [0,1)) when they are staged,
-//     so one fma + clamp + v_cvt + v_fract yields interval and local coordinate, with no knot read;
-//   * V, xi_0, xi_2, xi_4 of one r interval sit in one LDS record (one index for four cubics), records are
-//     padded to 4*(1+NLR)+2 doubles so that the ds_read_b128 of 16 consecutive intervals hit distinct banks;
-//   * sqrt and 1/r come from one refined v_rsq_f64, 1/sigma_v from a refined v_rcp_f64, exp from a 32-entry
-//     2^(j/32) table and a degree-6 polynomial (vk_devmath.h; all within 2 ulp).
+// Shared building blocks of the fast theory kernels (point-major, lanes, cells).
+// They run on the UNIFIED GRID the host prepares when the r grid and the sigma_v grid are uniform and commensurate
+// (vk_tables.uni_*): every table is re-expressed on the common refinement of the two grids, in interval units, so
+//   * one fma + clamp + v_cvt + v_fract yields THE interval and local coordinate for all five cubics
+//     (sigma_v, V, xi_0, xi_2, xi_4), with no knot read and no second index;
+//   * the five cubics of a refined interval sit in one LDS record, padded to 4*(2+NLR)+2 doubles so that the
+//     ds_read_b128 of 16 consecutive intervals hit distinct banks;
+//   * refined intervals outside a table's range hold its (constant) boundary value, which reproduces the
+//     clamped spline evaluation of the reference (FITPACK ext=3) exactly; only V below the first r node needs the
+//     extra leading interval [0.01, r_0] of ccf_model.py:625 and takes a (rare, divergent) branch;
+//   * sqrt and 1/r come from one refined v_rsq_f64, 1/sigma_v from a refined v_rcp_f64, exp from a 256-entry
+//     2^(j/256) table and a degree-4 polynomial (vk_devmath.h; all within ~2 ulp).
 // --------------------------------------------------------------------------------------------------
 typedef double vk_d2 __attribute__((ext_vector_type(2)));
 constexpr int kMuRec = 6;   // {mu, sqrt(1-mu^2), W_0, W_1, W_2, pad}
-constexpr int kSvRec = 6;   // {c0..c3, pad, pad}
 
-struct FastPlan {
-  int murec, xrec, svrec, vxrec, lead, etab, betar, red, node, total, vx_stride;
-};
-
-__host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int sv_int, int xi_int, int nlr, int n_beta_r) {
-  FastPlan p;
-  int o = 0;
-  p.vx_stride = 4 * (1 + nlr) + 2;
-  p.murec = o; o += n_mu * kMuRec;
-  p.xrec = o;  o += n_x * 2;
-  p.svrec = o; o += sv_int * kSvRec;
-  p.vxrec = o; o += xi_int * p.vx_stride;
-  p.lead = o;  o += 4;
-  p.etab = o;  o += vkm::kExpTab;
-  p.betar = o; o += n_beta_r;
-  o = (o + 1) & ~1;
-  p.red = o;   o += kWaves * kMaxEll;
-  p.node = o;  o += (n_mu * n_x + 1) / 2;   // one packed u32 per (mu, v) node
-  p.total = o;
-  return p;
-}
+__host__ __device__ constexpr int uni_stride(int nlr) { return 4 * (2 + nlr) + 2; }   // doubles per refined interval
 
 struct FastConsts {
-  double inv_hs, off_s, ns_eps;   // sigma_v table
-  double inv_hx, off_x, nx_eps;   // xi / V table (uniform part)
+  double inv_h, off, n_eps;       // unified grid: t = u*inv_h + off, clamped to [0, n_eps]
   double inv_hl, off_l;           // V leading interval [0.01, r_0]
 };
 
@@ -64,69 +46,79 @@ __device__ __forceinline__ double cubic_b128(const double* rec, double t) {
   return fma(fma(fma(hi.y, t, hi.x), t, lo.y), t, lo.x);
 }
 
-template <int NLR>
-__device__ __forceinline__ double fast_integrand(const double* __restrict__ svrec, const double* __restrict__ vxrec,
-                                                 const double* __restrict__ leadrec, const double* __restrict__ etab,
-                                                 const FastConsts& fc, const PointScalars& ps,
-                                                 double s_perp, double s_par, double xk, double wk) {
-  constexpr int vx_stride = 4 * (1 + NLR) + 2;
-  const double r_par = fma(-xk, ps.B, s_par);
-  const double r2 = fma(s_perp, s_perp, r_par * r_par);
-  double r, inv_r;
-  vkm::sqrt_rsqrt(r2, r, inv_r);
-  const double mu_r = r_par * inv_r;
-  const double u = r * ps.inv_c;
-
-  const double ts = vmin_f64(fmax(fma(u, fc.inv_hs, fc.off_s), 0.0), fc.ns_eps);
-  const double SV = cubic_b128(lds_at(svrec, __mul24((int)ts, kSvRec * 8)), __builtin_amdgcn_fract(ts));
-
-  const double tr = fma(u, fc.inv_hx, fc.off_x);
-  const double tx = vmin_f64(fmax(tr, 0.0), fc.nx_eps);
-  const double tq = __builtin_amdgcn_fract(tx);
-  const double* rec = lds_at(vxrec, __mul24((int)tx, vx_stride * 8));
-  double V = cubic_b128(rec, tq);
-  if (tr < 0.0) V = cubic_b128(leadrec, fmax(fma(u, fc.inv_hl, fc.off_l), 0.0));
-  double xir = cubic_b128(rec + 4, tq);
-  if (NLR > 1) {
-    const double m2 = mu_r * mu_r;
-    xir = fma(cubic_b128(rec + 8, tq), fma(1.5, m2, -0.5), xir);
-    if (NLR > 2) xir = fma(cubic_b128(rec + 12, tq), vkm::fma3(vkm::fma3(m2, 4.375, -3.75), m2, 0.375), xir);
-  }
-  const double inv_sv = vkm::recip(SV);
-  const double z = fma(ps.A * V, mu_r, xk) * inv_sv;
-  const double e = vkm::exp_nonpos((-0.5 * z) * z, etab);
-  const double t1 = wk * inv_sv;
-  return fma(t1, xir, t1) * e;
+__device__ __forceinline__ double hpow(double h, int q) {
+  return q == 0 ? 1.0 : (q == 1 ? h : (q == 2 ? h * h : h * h * h));
 }
 
-// The same integrand for the kernels that loop over the velocity nodes with a wave-uniform x_k (lanes, cells):
-// s_par and s_perp^2 of the cell are formed once outside the loop, the Simpson weight is applied by the caller.
-// Returns (1 + xi^r) * exp(-z^2/2) / SV.
+__device__ __forceinline__ FastConsts make_fast_consts(const TheoryArgs& a) {
+  FastConsts fc;
+  fc.inv_h = a.uni_inv_h;
+  fc.off = -a.uni_u0 * a.uni_inv_h;
+  fc.n_eps = (double)a.uni_n * (1.0 - 0x1p-52);
+  const double hl = a.vr.knots[1] - a.vr.knots[0];
+  fc.inv_hl = 1.0 / hl;
+  fc.off_l = -a.vr.knots[0] * fc.inv_hl;
+  return fc;
+}
+
+// Stage the batch-constant parts of the records: sigma_v and V always, xi^r_l when it does not depend on beta;
+// also the leading V cubic (in units of its own interval) and the exp table.  All threads of the workgroup.
 template <int NLR>
-__device__ __forceinline__ double node_value(const double* __restrict__ svrec, const double* __restrict__ vxrec,
-                                             const double* __restrict__ leadrec, const double* __restrict__ etab,
-                                             const FastConsts& fc, double B, double inv_c, double AV, double s_par,
-                                             double sperp2, double xk) {
-  constexpr int vx_stride = 4 * (1 + NLR) + 2;
-  const double r_par = fma(-xk, B, s_par);
-  const double r2 = fma(r_par, r_par, sperp2);
+__device__ __forceinline__ void stage_uni_records(const TheoryArgs& a, double* recs, double* lead, double* etab) {
+  constexpr int stride = uni_stride(NLR);
+  const int tid = threadIdx.x;
+  for (int e = tid; e < a.uni_n * 8; e += kBlock) recs[(e >> 3) * stride + (e & 7)] = a.uni_sv_v[e];
+  if (a.n_beta_r == 0) {
+    const int per_l = a.uni_n * 4;
+    for (int e = tid; e < NLR * per_l; e += kBlock) {
+      const int l = e / per_l, iq = e - l * per_l;
+      recs[(iq >> 2) * stride + 8 + 4 * l + (iq & 3)] = a.uni_xi[e];
+    }
+  }
+  const double hl = a.vr.knots[1] - a.vr.knots[0];
+  if (tid < 4) lead[tid] = a.vr.coef[tid] * hpow(hl, tid);
+  for (int j = tid; j < vkm::kExpTab; j += kBlock) etab[j] = vkm::exp2_frac(j);
+}
+
+// Per-point xi^r records when the real-space input depends on the reconstruction beta (PCHIP piece kb, extrapolating
+// with the end pieces as PchipInterpolator does; ccf_model.py:323-326).  `bg` = beta grid in LDS.
+template <int NLR>
+__device__ __forceinline__ void rebuild_uni_xi(const TheoryArgs& a, double* recs, const double* bg, double beta) {
+  constexpr int stride = uni_stride(NLR);
+  int kb = 0;
+  for (int i = 1; i < a.n_beta_r - 1; ++i) kb = (beta >= bg[i]) ? i : kb;
+  const double db = beta - bg[kb];
+  const int per_l = a.uni_n * 4;
+  const size_t stride_l = (size_t)(a.n_beta_r - 1) * per_l * 4;
+  for (int e = threadIdx.x; e < NLR * per_l; e += kBlock) {
+    const int l = e / per_l, iq = e - l * per_l;
+    const double* c = a.uni_xi + l * stride_l + ((size_t)kb * per_l + iq) * 4;
+    recs[(iq >> 2) * stride + 8 + 4 * l + (iq & 3)] = fma(fma(fma(c[3], db, c[2]), db, c[1]), db, c[0]);
+  }
+}
+
+// (1 + xi^r) * exp(-z^2/2) / SV at one integrand point, given r_par and s_perp^2 (ccf_model.py:648-657, 681-690)
+template <int NLR>
+__device__ __forceinline__ double uni_value(const double* __restrict__ recs, const double* __restrict__ leadrec,
+                                            const double* __restrict__ etab, const FastConsts& fc, double inv_c,
+                                            double AV, double r_par, double sperp2, double xk) {
+  constexpr int stride = uni_stride(NLR);
   double r, inv_r;
-  vkm::sqrt_rsqrt(r2, r, inv_r);
+  vkm::sqrt_rsqrt(fma(r_par, r_par, sperp2), r, inv_r);
   const double mu_r = r_par * inv_r;
   const double u = r * inv_c;
-  const double ts = vmin_f64(fmax(fma(u, fc.inv_hs, fc.off_s), 0.0), fc.ns_eps);
-  const double SV = cubic_b128(lds_at(svrec, __mul24((int)ts, kSvRec * 8)), __builtin_amdgcn_fract(ts));
-  const double tr = fma(u, fc.inv_hx, fc.off_x);
-  const double tx = vmin_f64(fmax(tr, 0.0), fc.nx_eps);
-  const double tq = __builtin_amdgcn_fract(tx);
-  const double* rec = lds_at(vxrec, __mul24((int)tx, vx_stride * 8));
-  double V = cubic_b128(rec, tq);
+  const double tr = fma(u, fc.inv_h, fc.off);
+  const double t = vmin_f64(fmax(tr, 0.0), fc.n_eps);
+  const double tq = __builtin_amdgcn_fract(t);
+  const double* rec = lds_at(recs, __mul24((int)t, stride * 8));
+  const double SV = cubic_b128(rec, tq);
+  double V = cubic_b128(rec + 4, tq);
   if (tr < 0.0) V = cubic_b128(leadrec, fmax(fma(u, fc.inv_hl, fc.off_l), 0.0));
-  double xir = cubic_b128(rec + 4, tq);
+  double xir = cubic_b128(rec + 8, tq);
   if (NLR > 1) {
     const double m2 = mu_r * mu_r;
-    xir = fma(cubic_b128(rec + 8, tq), fma(1.5, m2, -0.5), xir);
-    if (NLR > 2) xir = fma(cubic_b128(rec + 12, tq), vkm::fma3(vkm::fma3(m2, 4.375, -3.75), m2, 0.375), xir);
+    xir = fma(cubic_b128(rec + 12, tq), fma(1.5, m2, -0.5), xir);
+    if (NLR > 2) xir = fma(cubic_b128(rec + 16, tq), vkm::fma3(vkm::fma3(m2, 4.375, -3.75), m2, 0.375), xir);
   }
   const double inv_sv = vkm::recip(SV);
   const double z = fma(AV * V, mu_r, xk) * inv_sv;
@@ -134,17 +126,41 @@ __device__ __forceinline__ double node_value(const double* __restrict__ svrec, c
   return inv_sv * fma(e, xir, e);
 }
 
-__device__ __forceinline__ double hpow(double h, int q) {
-  return q == 0 ? 1.0 : (q == 1 ? h : (q == 2 ? h * h : h * h * h));
+// the same for the kernels that loop over the velocity nodes with a wave-uniform x_k (lanes, cells)
+template <int NLR>
+__device__ __forceinline__ double node_value(const double* __restrict__ recs, const double* __restrict__ leadrec,
+                                             const double* __restrict__ etab, const FastConsts& fc, double B,
+                                             double inv_c, double AV, double s_par, double sperp2, double xk) {
+  return uni_value<NLR>(recs, leadrec, etab, fc, inv_c, AV, fma(-xk, B, s_par), sperp2, xk);
+}
+
+// --------------------------------------------------------------------------------------------------
+// K1 point-major fast kernel: one wave owns one (point, s bin); lanes sweep the flattened (mu, v) plane.
+// --------------------------------------------------------------------------------------------------
+struct FastPlan {
+  int murec, xrec, recs, lead, etab, betar, red, node, total;
+};
+
+__host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int uni_n, int nlr, int n_beta_r) {
+  FastPlan p;
+  int o = 0;
+  p.murec = o; o += n_mu * kMuRec;
+  p.xrec = o;  o += n_x * 2;
+  p.recs = o;  o += uni_n * uni_stride(nlr);
+  p.lead = o;  o += 4;
+  p.etab = o;  o += vkm::kExpTab;
+  p.betar = o; o += (n_beta_r + 1) & ~1;
+  p.red = o;   o += kWaves * kMaxEll;
+  p.node = o;  o += (n_mu * n_x + 1) / 2;   // one packed u32 per (mu, v) node
+  p.total = o;
+  return p;
 }
 
 template <int NLR, int NL>
 __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
-  const FastPlan pl = make_fast_plan(a.n_mu, a.n_x, a.sv.n_int, a.xi.n_int, NLR, a.n_beta_r);
+  const FastPlan pl = make_fast_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.n_beta_r);
   const int tid = threadIdx.x;
-  const double hs = 1.0 / a.sv.inv_h, hx = 1.0 / a.xi.inv_h;
-  const double hl = a.vr.knots[1] - a.vr.knots[0];
   // ---- stage batch-constant tables -------------------------------------------------------------
   for (int i = tid; i < a.n_mu; i += kBlock) {
     const double m = a.mu[i];
@@ -159,21 +175,9 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
     lds[pl.xrec + 2 * i] = a.x[i];
     lds[pl.xrec + 2 * i + 1] = a.w_x[i];
   }
-  for (int e = tid; e < a.sv.n_int * 4; e += kBlock)
-    lds[pl.svrec + (e >> 2) * kSvRec + (e & 3)] = a.sv.coef[e] * hpow(hs, e & 3);
-  for (int e = tid; e < a.xi.n_int * 4; e += kBlock)   // V lives one interval further in its own table
-    lds[pl.vxrec + (e >> 2) * pl.vx_stride + (e & 3)] = a.vr.coef[4 + e] * hpow(hx, e & 3);
-  if (a.n_beta_r == 0) {
-    const int per_l = a.xi.n_int * 4;
-    for (int e = tid; e < NLR * per_l; e += kBlock) {
-      const int l = e / per_l, iq = e - l * per_l;
-      lds[pl.vxrec + (iq >> 2) * pl.vx_stride + 4 * (1 + l) + (iq & 3)] = a.xi.coef[e] * hpow(hx, iq & 3);
-    }
-  } else {
+  stage_uni_records<NLR>(a, lds + pl.recs, lds + pl.lead, lds + pl.etab);
+  if (a.n_beta_r > 0)
     for (int i = tid; i < a.n_beta_r; i += kBlock) lds[pl.betar + i] = a.beta_r[i];
-  }
-  if (tid < 4) lds[pl.lead + tid] = a.vr.coef[tid] * hpow(hl, tid);
-  for (int j = tid; j < vkm::kExpTab; j += kBlock) lds[pl.etab + j] = vkm::exp2_frac(j);
   // byte offsets of the mu record (low 16 bits) and the (x, w) record (high 16 bits) of every plane node, so the
   // hot loop needs no index arithmetic: one ds_read_b32 per trip
   unsigned* node = reinterpret_cast<unsigned*>(lds + pl.node);
@@ -181,15 +185,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
     const int i = idx / a.n_x, k = idx - i * a.n_x;
     node[idx] = (unsigned)(i * kMuRec * 8) | ((unsigned)(k * 16) << 16);
   }
-  FastConsts fc;
-  fc.inv_hs = a.sv.inv_h;
-  fc.off_s = -a.sv.knots[0] * a.sv.inv_h;
-  fc.ns_eps = __builtin_canonicalize((double)a.sv.n_int * (1.0 - 0x1p-52));
-  fc.inv_hx = a.xi.inv_h;
-  fc.off_x = -a.xi.knots[0] * a.xi.inv_h;
-  fc.nx_eps = __builtin_canonicalize((double)a.xi.n_int * (1.0 - 0x1p-52));
-  fc.inv_hl = 1.0 / hl;
-  fc.off_l = -a.vr.knots[0] * fc.inv_hl;
+  const FastConsts fc = make_fast_consts(a);
   __syncthreads();
 
   const int lane = tid & 63;
@@ -205,8 +201,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
   const int rounds = (a.sbins_per_item + nteams - 1) / nteams;
   const double* murec = lds + pl.murec;
   const double* xrec = lds + pl.xrec;
-  const double* svrec = lds + pl.svrec;
-  const double* vxrec = lds + pl.vxrec;
+  const double* recs = lds + pl.recs;
   const double* leadrec = lds + pl.lead;
   const double* etab = lds + pl.etab;
   double* l_red = lds + pl.red;
@@ -225,20 +220,8 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
     const double* row = a.params + point * VK_NPAR;
     const PointScalars ps = point_scalars(a, row);
     if (a.n_beta_r > 0) {
-      __syncthreads();
-      const double* bg = lds + pl.betar;
-      const double beta = row[VK_P_BETA];
-      int kb = 0;
-      for (int i = 1; i < a.n_beta_r - 1; ++i) kb = (beta >= bg[i]) ? i : kb;
-      const double db = beta - bg[kb];
-      const int per_l = a.xi.n_int * 4;
-      const size_t stride_l = (size_t)(a.n_beta_r - 1) * per_l * 4;
-      for (int e = tid; e < NLR * per_l; e += kBlock) {
-        const int l = e / per_l, iq = e - l * per_l;
-        const double* c = a.xi.coef + l * stride_l + ((size_t)kb * per_l + iq) * 4;
-        lds[pl.vxrec + (iq >> 2) * pl.vx_stride + 4 * (1 + l) + (iq & 3)] =
-            fma(fma(fma(c[3], db, c[2]), db, c[1]), db, c[0]) * hpow(hx, iq & 3);
-      }
+      __syncthreads();  // previous item's readers are done with the per-point records
+      rebuild_uni_xi<NLR>(a, lds + pl.recs, lds + pl.betar, row[VK_P_BETA]);
       __syncthreads();
     }
     for (int rd = 0; rd < rounds; ++rd) {
@@ -259,8 +242,9 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
           const double* mr = reinterpret_cast<const double*>(mu_bytes + (pk & 0xffffu));
           const vk_d2 m01 = *reinterpret_cast<const vk_d2*>(mr);
           const vk_d2 xw = *reinterpret_cast<const vk_d2*>(x_bytes + (pk >> 16));
-          const double f = fast_integrand<NLR>(svrec, vxrec, leadrec, etab, fc, ps, s_aperp * m01.y,
-                                               s_apar * m01.x, xw.x, xw.y);
+          const double s_perp = s_aperp * m01.y;
+          const double f = xw.y * uni_value<NLR>(recs, leadrec, etab, fc, ps.inv_c, ps.A, fma(-xw.x, ps.B, s_apar * m01.x),
+                                                 s_perp * s_perp, xw.x);
           const vk_d2 w01 = *reinterpret_cast<const vk_d2*>(mr + 2);
           acc[0] = fma(w01.x, f, acc[0]);
           if (NL > 1) acc[1] = fma(w01.y, f, acc[1]);

@@ -15,17 +15,15 @@ namespace vk {
 // n_s * n/64 wavefronts; the point-major kernel above serves every other case.
 // --------------------------------------------------------------------------------------------------
 struct LanesPlan {
-  int smu, xw, svrec, vxrec, lead, etab, total, vx_stride;
+  int smu, xw, recs, lead, etab, total;
 };
 
-__host__ __device__ inline LanesPlan make_lanes_plan(int n_mu, int n_x, int sv_int, int xi_int, int nlr) {
+__host__ __device__ inline LanesPlan make_lanes_plan(int n_mu, int n_x, int uni_n, int nlr) {
   LanesPlan p;
   int o = 0;
-  p.vx_stride = 4 * (1 + nlr) + 2;
   p.smu = o;   o += 2 * n_mu;           // {mu_i, sqrt(1 - mu_i^2)}
   p.xw = o;    o += 2 * n_x;            // {x_k, w_k}: read with a wave-uniform address (LDS broadcast)
-  p.svrec = o; o += sv_int * kSvRec;
-  p.vxrec = o; o += xi_int * p.vx_stride;
+  p.recs = o;  o += uni_n * uni_stride(nlr);
   p.lead = o;  o += 4;
   p.etab = o;  o += vkm::kExpTab;
   p.total = o;
@@ -73,11 +71,8 @@ __device__ __forceinline__ PointScalars point_scalars_lane(const TheoryArgs& a, 
 template <int NLR, int NL>
 __global__ __launch_bounds__(kBlock) void vk_theory_lanes_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
-  constexpr int vx_stride = 4 * (1 + NLR) + 2;
-  const LanesPlan pl = make_lanes_plan(a.n_mu, a.n_x, a.sv.n_int, a.xi.n_int, NLR);
+  const LanesPlan pl = make_lanes_plan(a.n_mu, a.n_x, a.uni_n, NLR);
   const int tid = threadIdx.x;
-  const double hs = 1.0 / a.sv.inv_h, hx = 1.0 / a.xi.inv_h;
-  const double hl = a.vr.knots[1] - a.vr.knots[0];
   for (int i = tid; i < a.n_mu; i += kBlock) {
     const double m = a.mu[i];
     lds[pl.smu + 2 * i] = m;
@@ -87,36 +82,15 @@ __global__ __launch_bounds__(kBlock) void vk_theory_lanes_kernel(TheoryArgs a) {
     lds[pl.xw + 2 * k] = a.x[k];
     lds[pl.xw + 2 * k + 1] = a.w_x[k];
   }
-  for (int e = tid; e < a.sv.n_int * 4; e += kBlock)
-    lds[pl.svrec + (e >> 2) * kSvRec + (e & 3)] = a.sv.coef[e] * hpow(hs, e & 3);
-  for (int e = tid; e < a.xi.n_int * 4; e += kBlock)
-    lds[pl.vxrec + (e >> 2) * vx_stride + (e & 3)] = a.vr.coef[4 + e] * hpow(hx, e & 3);
-  {
-    const int per_l = a.xi.n_int * 4;
-    for (int e = tid; e < NLR * per_l; e += kBlock) {
-      const int l = e / per_l, iq = e - l * per_l;
-      lds[pl.vxrec + (iq >> 2) * vx_stride + 4 * (1 + l) + (iq & 3)] = a.xi.coef[e] * hpow(hx, iq & 3);
-    }
-  }
-  if (tid < 4) lds[pl.lead + tid] = a.vr.coef[tid] * hpow(hl, tid);
-  for (int j = tid; j < vkm::kExpTab; j += kBlock) lds[pl.etab + j] = vkm::exp2_frac(j);
-  FastConsts fc;
-  fc.inv_hs = a.sv.inv_h;
-  fc.off_s = -a.sv.knots[0] * a.sv.inv_h;
-  fc.ns_eps = (double)a.sv.n_int * (1.0 - 0x1p-52);
-  fc.inv_hx = a.xi.inv_h;
-  fc.off_x = -a.xi.knots[0] * a.xi.inv_h;
-  fc.nx_eps = (double)a.xi.n_int * (1.0 - 0x1p-52);
-  fc.inv_hl = 1.0 / hl;
-  fc.off_l = -a.vr.knots[0] * fc.inv_hl;
+  stage_uni_records<NLR>(a, lds + pl.recs, lds + pl.lead, lds + pl.etab);
+  const FastConsts fc = make_fast_consts(a);
   __syncthreads();
 
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const double* l_smu = lds + pl.smu;
   const double* l_xw = lds + pl.xw;
-  const double* svrec = lds + pl.svrec;
-  const double* vxrec = lds + pl.vxrec;
+  const double* recs = lds + pl.recs;
   const double* leadrec = lds + pl.lead;
   const double* etab = lds + pl.etab;
   const long long chunks = (a.n + 63) >> 6;
@@ -143,7 +117,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_lanes_kernel(TheoryArgs a) {
       for (int k = 0; k < a.n_x; ++k) {
         const vk_d2 xw = *reinterpret_cast<const vk_d2*>(l_xw + 2 * k);
         const double xk = xw.x;
-        g = fma(xw.y, node_value<NLR>(svrec, vxrec, leadrec, etab, fc, ps.B, ps.inv_c, AV, s_par, sperp2, xk), g);
+        g = fma(xw.y, node_value<NLR>(recs, leadrec, etab, fc, ps.B, ps.inv_c, AV, s_par, sperp2, xk), g);
       }
 #pragma unroll
       for (int l = 0; l < NL; ++l) acc[l] = fma(a.w_ell[l * a.n_mu + i], g, acc[l]);

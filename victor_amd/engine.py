@@ -116,6 +116,27 @@ def build_tables(model, fit=None, matter_model=None):
         t.sv_mu = N.as_dp(mu_sv)
         t.sv2d = N.as_dp(patches)
 
+    # unified refined grid for the fast kernels: r and r_sv grids uniform and commensurate, fixed velocity tables
+    t.uni_n = 0
+    if (t.sv_n_mu == 0 and not vr_beta_dep and t.xi.inv_h > 0 and t.xi.lead == 0 and t.sv.inv_h > 0
+            and t.sv.lead == 0 and t.vr.inv_h > 0 and t.vr.lead == 1):
+        cr = T.common_refinement(r, model.r_for_sv)
+        if cr is not None and cr[0] >= r_ext[0]:
+            u0, h, n = cr
+            sv_ref = T.refine_pp(model.r_for_sv, T.notaknot_coefficients(model.r_for_sv, model.sv_rmu[0]), u0, h, n)
+            v_ref = T.refine_pp(r_ext, vr_coef[0], u0, h, n)
+            uni_sv_v = arr(np.stack([sv_ref, v_ref], axis=1))                         # (n, 2, 4)
+            if model.fixed_real_input:
+                uni_xi = arr(np.stack([T.refine_pp(r, coef[l], u0, h, n) for l in range(n_ell_r)]))   # (L, n, 4)
+            else:
+                parts = []
+                for l in range(n_ell_r):                                              # coef[l]: (n_beta-1, n_int, 4, 4)
+                    ref = T.refine_pp(r, np.moveaxis(coef[l], 0, -1), u0, h, n)       # (n, 4, 4, n_beta-1)
+                    parts.append(np.moveaxis(ref, -1, 0))                              # (n_beta-1, n, 4, 4)
+                uni_xi = arr(np.stack(parts))
+            t.uni_n, t.uni_u0, t.uni_inv_h = n, u0, 1.0 / h
+            t.uni_sv_v, t.uni_xi = N.as_dp(uni_sv_v), N.as_dp(uni_xi)
+
     t.iaH = float(model.iaH)
     # not used when the growth term is beta*bias (linear_bias on a measured real-space ccf)
     t.template_sigma8 = float(model.template_sigma8) if model.template_sigma8 else 1.0

@@ -308,3 +308,70 @@ def bicubic_patches(x, y, z):
     lx = notaknot_coefficients(x, np.eye(len(x)))      # (nx-1, 4, nx)
     ly = notaknot_coefficients(y, np.eye(len(y)))      # (ny-1, 4, ny)
     return np.einsum("ipn,jqm,nm->ijpq", lx, ly, np.asarray(z, dtype=np.float64))
+
+
+# --------------------------------------------------------------------------- #
+# one refined grid for several piecewise-cubic tables (single interval index on the device)
+# --------------------------------------------------------------------------- #
+def common_refinement(knots_a, knots_b, max_intervals=512, max_den=64, tol=1e-9):
+    """A uniform grid (u0, h, n) that contains every knot of two uniform knot sets, or None.
+
+    Both sets must be uniform and commensurate (spacings and offset in small integer ratios, e.g. r = 2, 6, 10, ...
+    with r_sv = 3, 9, 15, ... -> h = 1).  Every interval of the refined grid then lies inside exactly one interval
+    of each table (or outside its range), so one index serves both tables.
+    """
+    from fractions import Fraction
+    ka, kb = np.asarray(knots_a, dtype=np.float64), np.asarray(knots_b, dtype=np.float64)
+    ha, hb = uniform_spacing(ka), uniform_spacing(kb)
+    if ha is None or hb is None:
+        return None
+    fb = Fraction(hb / ha).limit_denominator(max_den)
+    fo = Fraction((kb[0] - ka[0]) / ha).limit_denominator(max_den)
+    if abs(float(fb) - hb / ha) > tol or abs(float(fo) - (kb[0] - ka[0]) / ha) > tol:
+        return None
+    den = np.lcm(fb.denominator, fo.denominator)
+    num = np.gcd(np.gcd(den, int(fb * den)), int(abs(fo) * den)) if fo != 0 else np.gcd(den, int(fb * den))
+    h = ha * float(num) / float(den)
+    u0 = min(ka[0], kb[0])
+    u1 = max(ka[-1], kb[-1])
+    n = int(round((u1 - u0) / h))
+    if n < 1 or n > max_intervals:
+        return None
+    for k in (ka, kb):                                  # every knot must sit on the refined grid
+        pos = (k - u0) / h
+        if np.max(np.abs(pos - np.round(pos))) > 1e-7:
+            return None
+    return float(u0), float(h), n
+
+
+def refine_pp(knots, coef, u0, h, n):
+    """Re-express a clamped piecewise cubic on the refined grid, in interval units.
+
+    ``coef`` (n_int, 4, ...) about the left knots of ``knots``.  Returns (n, 4, ...): on refined interval q the
+    function is sum_p out[q, p] tau^p with tau = (u - u0 - q h)/h in [0, 1).  Refined intervals outside the table's
+    range hold the (constant) boundary value, which reproduces the clamped evaluation exactly.
+    """
+    knots = np.asarray(knots, dtype=np.float64)
+    coef = np.asarray(coef, dtype=np.float64)
+    left = u0 + h * np.arange(n)
+    mid = left + 0.5 * h
+    i = np.clip(np.searchsorted(knots, mid, side="right") - 1, 0, len(knots) - 2)
+    d = left - knots[i]
+    extra = (1,) * (coef.ndim - 2)
+    dd = d.reshape(d.shape + extra)
+    c0, c1, c2, c3 = coef[i, 0], coef[i, 1], coef[i, 2], coef[i, 3]
+    out = np.stack([((c3 * dd + c2) * dd + c1) * dd + c0,
+                    ((3 * c3 * dd + 2 * c2) * dd + c1) * h,
+                    (3 * c3 * dd + c2) * h ** 2,
+                    c3 * h ** 3], axis=1)
+    below = mid < knots[0]
+    above = mid > knots[-1]
+    if np.any(below):
+        out[below] = 0.0
+        out[below, 0] = coef[0, 0]
+    if np.any(above):
+        hl = knots[-1] - knots[-2]
+        end = ((coef[-1, 3] * hl + coef[-1, 2]) * hl + coef[-1, 1]) * hl + coef[-1, 0]
+        out[above] = 0.0
+        out[above, 0] = end
+    return out
