@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 4
+#define VK_ABI_VERSION 5
 
 /* error codes */
 #define VK_OK 0
@@ -146,6 +146,9 @@ typedef struct vk_tables {
   const double* uni_sv_v; /* [uni_n][2][4]: sigma_v shape and V1 = r*Delta, coefficients of tau^p        */
   const double* uni_xi; /* fixed: [n_ell_r][uni_n][4]; beta-dependent: [n_ell_r][n_beta_r-1][uni_n][4][4]
                            (last index = power of beta - beta_r[k])                                       */
+  const double* uni_xic;/* same shape, the Legendre sum regrouped in powers of m = mu_r^2 (n_ell_r >= 2 only):
+                           sum_l xi_l P_l(mu_r) = A + m B + m^2 C with A = xi_0 - xi_2/2 + 3 xi_4/8,
+                           B = 3 xi_2/2 - 15 xi_4/4, C = 35 xi_4/8; used when the anisotropic sum is asked for  */
 
   double iaH;           /* (1+z)/(100 E(z)) (ccf_model.py:43-45)               */
   double template_sigma8; /* ccf_model.py:432-435                              */

@@ -64,7 +64,7 @@ struct vk_ctx {
   const double *d_sv_mu = nullptr, *d_sv2d = nullptr;
   int uni_n = 0;             // unified refined grid (fast kernels need it)
   double uni_u0 = 0, uni_inv_h = 0;
-  const double *d_uni_sv_v = nullptr, *d_uni_xi = nullptr;
+  const double *d_uni_sv_v = nullptr, *d_uni_xi = nullptr, *d_uni_xic = nullptr;
   const char* last_kernel = "none";  // theory kernel variant of the most recent launch
   // scratch for the host-buffer entry points
   double* d_scratch = nullptr;
@@ -232,6 +232,7 @@ int theory_args(vk_ctx* ctx, const vk_eval_opts* o, TheoryArgs* a, int* nlr) {
   a->uni_inv_h = ctx->uni_inv_h;
   a->uni_sv_v = ctx->d_uni_sv_v;
   a->uni_xi = ctx->d_uni_xi;
+  a->uni_xic = ctx->d_uni_xic;
   a->vr_beta_dep = ctx->vr_beta_dep;
   a->from_data = o->from_data ? 1 : 0;
   a->empirical = (o->empirical_corr && !ctx->matter_vt) ? 1 : 0;   // the template-mean branch ignores Av (ccf_model.py:483-490)
@@ -520,7 +521,7 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
       for (int i = 0; i <= t->xi.n_int && ok; ++i) ok = fabs(t->vr.knots[i + 1] - t->xi.knots[i]) <= tol;
       ok = ok && fabs(t->vr.inv_h - t->xi.inv_h) <= 1e-12 * t->xi.inv_h;
     }
-    ctx->fast_ok = ok && !t->vr_beta_dep && t->sv_n_mu == 0 && t->uni_n > 0 && t->uni_sv_v && t->uni_xi &&
+    ctx->fast_ok = ok && !t->vr_beta_dep && t->sv_n_mu == 0 && t->uni_n > 0 && t->uni_sv_v && t->uni_xi && t->uni_xic &&
                    t->uni_inv_h > 0 && t->uni_u0 >= t->vr.knots[0];
     ctx->matter_vt = t->matter_model == VK_MATTER_VELOCITY_TEMPLATE;
     ctx->vt_amp = t->vt_amp;
@@ -546,11 +547,13 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
     o_svmu = up.add(t->sv_mu, t->sv_n_mu);
     o_sv2d = up.add(t->sv2d, (size_t)t->sv.n_int * (t->sv_n_mu - 1) * 16);
   }
-  size_t o_usv = 0, o_uxi = 0;
-  if (t->uni_n > 0 && t->uni_sv_v && t->uni_xi) {
+  size_t o_usv = 0, o_uxi = 0, o_uxc = 0;
+  if (t->uni_n > 0 && t->uni_sv_v && t->uni_xi && t->uni_xic) {
     o_usv = up.add(t->uni_sv_v, (size_t)t->uni_n * 8);
     o_uxi = up.add(t->uni_xi, t->n_beta_r > 0 ? (size_t)t->n_ell_r * (t->n_beta_r - 1) * t->uni_n * 16
                                               : (size_t)t->n_ell_r * t->uni_n * 4);
+    o_uxc = up.add(t->uni_xic, t->n_beta_r > 0 ? (size_t)t->n_ell_r * (t->n_beta_r - 1) * t->uni_n * 16
+                                               : (size_t)t->n_ell_r * t->uni_n * 4);
   }
   size_t o_bd = 0, o_data = 0, o_bc = 0, o_prec = 0, o_ld = 0, o_eig = 0;
   if (t->data) {
@@ -585,12 +588,13 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
   ctx->xi = view(t->xi, o_xik, o_xic);
   ctx->vr = view(t->vr, o_vrk, o_vrc);
   ctx->sv = view(t->sv, o_svk, o_svc);
-  if (t->uni_n > 0 && t->uni_sv_v && t->uni_xi) {
+  if (t->uni_n > 0 && t->uni_sv_v && t->uni_xi && t->uni_xic) {
     ctx->uni_n = t->uni_n;
     ctx->uni_u0 = t->uni_u0;
     ctx->uni_inv_h = t->uni_inv_h;
     ctx->d_uni_sv_v = base + o_usv;
     ctx->d_uni_xi = base + o_uxi;
+    ctx->d_uni_xic = base + o_uxc;
   }
   ctx->sv_n_mu = t->sv_n_mu;
   ctx->sv_mu_inv_h = t->sv_mu_inv_h;

@@ -48,6 +48,7 @@ struct TheoryArgs {
   double uni_u0, uni_inv_h;
   const double* uni_sv_v;
   const double* uni_xi;
+  const double* uni_xic;  // Legendre sum regrouped in powers of mu_r^2 (anisotropic sum)
   int matter_lb;          // linear_bias matter model: amplitudes carry 1/bias (ccf_model.py:358-370,426-435)
   int vr_beta_dep;        // velocity tables are PCHIP-in-beta polynomials (rebuilt per point)
   int from_data;          // ccf_model.py:618-619,675-679

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_cells_kernel(TheoryArgs a) {
     }
     for (int e = lane; e < kMaxEll * slots; e += 64) l_acc[e * kWaves + wave] = 0.0;
     const double AV = ps.A;
+    const double kidx = ps.inv_c * fc.inv_h;
     for (int base = 0; base < cells; base += 64) {
       const int e = base + lane;
       const bool live = e < cells;
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_cells_kernel(TheoryArgs a) {
       for (int k = 0; k < a.n_x; ++k) {
         const vk_d2 xw = *reinterpret_cast<const vk_d2*>(l_xw + 2 * k);
         const double xk = xw.x;
-        g = fma(xw.y, node_value<NLR>(recs, leadrec, etab, fc, ps.B, ps.inv_c, AV, s_par, sperp2, xk), g);
+        g = fma(xw.y, node_value<NLR>(recs, leadrec, etab, fc, ps.B, kidx, ps.inv_c, AV, s_par, sperp2, xk), g);
       }
       if (!live) g = 0.0;
       // projection: this trip's cells belong to s bin jj0 or jj0 + 1

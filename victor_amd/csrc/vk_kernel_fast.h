@@ -25,6 +25,7 @@ __host__ __device__ constexpr int uni_stride(int nlr) { return 4 * (2 + nlr) + 2
 
 struct FastConsts {
   double inv_h, off, n_eps;       // unified grid: t = u*inv_h + off, clamped to [0, n_eps]
+                                  // (callers pass k = inv_h/c per point, so that t = r*k + off needs no u)
   double inv_hl, off_l;           // V leading interval [0.01, r_0]
 };
 
@@ -69,10 +70,11 @@ __device__ __forceinline__ void stage_uni_records(const TheoryArgs& a, double* r
   const int tid = threadIdx.x;
   for (int e = tid; e < a.uni_n * 8; e += kBlock) recs[(e >> 3) * stride + (e & 7)] = a.uni_sv_v[e];
   if (a.n_beta_r == 0) {
+    const double* src = (NLR > 1) ? a.uni_xic : a.uni_xi;      // anisotropic sum: the mu_r^2-power regrouping
     const int per_l = a.uni_n * 4;
     for (int e = tid; e < NLR * per_l; e += kBlock) {
       const int l = e / per_l, iq = e - l * per_l;
-      recs[(iq >> 2) * stride + 8 + 4 * l + (iq & 3)] = a.uni_xi[e];
+      recs[(iq >> 2) * stride + 8 + 4 * l + (iq & 3)] = src[e];
     }
   }
   const double hl = a.vr.knots[1] - a.vr.knots[0];
@@ -92,33 +94,37 @@ __device__ __forceinline__ void rebuild_uni_xi(const TheoryArgs& a, double* recs
   const size_t stride_l = (size_t)(a.n_beta_r - 1) * per_l * 4;
   for (int e = threadIdx.x; e < NLR * per_l; e += kBlock) {
     const int l = e / per_l, iq = e - l * per_l;
-    const double* c = a.uni_xi + l * stride_l + ((size_t)kb * per_l + iq) * 4;
+    const double* c = ((NLR > 1) ? a.uni_xic : a.uni_xi) + l * stride_l + ((size_t)kb * per_l + iq) * 4;
     recs[(iq >> 2) * stride + 8 + 4 * l + (iq & 3)] = fma(fma(fma(c[3], db, c[2]), db, c[1]), db, c[0]);
   }
 }
 
-// (1 + xi^r) * exp(-z^2/2) / SV at one integrand point, given r_par and s_perp^2 (ccf_model.py:648-657, 681-690)
+// (1 + xi^r) * exp(-z^2/2) / SV at one integrand point, given r_par and s_perp^2 (ccf_model.py:648-657, 681-690).
+// `kidx` = inv_h / c of the point: the interval coordinate is t = r * kidx + off.  For NLR > 1 the records hold the
+// Legendre sum regrouped in powers of m = mu_r^2 (A, B, C of vk_tables.uni_xic), so xi^r = A + m (B + m C).
 template <int NLR>
 __device__ __forceinline__ double uni_value(const double* __restrict__ recs, const double* __restrict__ leadrec,
-                                            const double* __restrict__ etab, const FastConsts& fc, double inv_c,
-                                            double AV, double r_par, double sperp2, double xk) {
+                                            const double* __restrict__ etab, const FastConsts& fc, double kidx,
+                                            double inv_c, double AV, double r_par, double sperp2, double xk) {
   constexpr int stride = uni_stride(NLR);
   double r, inv_r;
   vkm::sqrt_rsqrt(fma(r_par, r_par, sperp2), r, inv_r);
   const double mu_r = r_par * inv_r;
-  const double u = r * inv_c;
-  const double tr = fma(u, fc.inv_h, fc.off);
+  const double tr = fma(r, kidx, fc.off);
   const double t = vmin_f64(fmax(tr, 0.0), fc.n_eps);
   const double tq = __builtin_amdgcn_fract(t);
   const double* rec = lds_at(recs, __mul24((int)t, stride * 8));
   const double SV = cubic_b128(rec, tq);
   double V = cubic_b128(rec + 4, tq);
-  if (tr < 0.0) V = cubic_b128(leadrec, fmax(fma(u, fc.inv_hl, fc.off_l), 0.0));
+  if (tr < 0.0) V = cubic_b128(leadrec, fmax(fma(r * inv_c, fc.inv_hl, fc.off_l), 0.0));
   double xir = cubic_b128(rec + 8, tq);
   if (NLR > 1) {
     const double m2 = mu_r * mu_r;
-    xir = fma(cubic_b128(rec + 12, tq), fma(1.5, m2, -0.5), xir);
-    if (NLR > 2) xir = fma(cubic_b128(rec + 16, tq), vkm::fma3(vkm::fma3(m2, 4.375, -3.75), m2, 0.375), xir);
+    if (NLR == 2) {
+      xir = fma(cubic_b128(rec + 12, tq), m2, xir);
+    } else {
+      xir = fma(fma(cubic_b128(rec + 16, tq), m2, cubic_b128(rec + 12, tq)), m2, xir);
+    }
   }
   const double inv_sv = vkm::recip(SV);
   const double z = fma(AV * V, mu_r, xk) * inv_sv;
@@ -130,8 +136,9 @@ __device__ __forceinline__ double uni_value(const double* __restrict__ recs, con
 template <int NLR>
 __device__ __forceinline__ double node_value(const double* __restrict__ recs, const double* __restrict__ leadrec,
                                              const double* __restrict__ etab, const FastConsts& fc, double B,
-                                             double inv_c, double AV, double s_par, double sperp2, double xk) {
-  return uni_value<NLR>(recs, leadrec, etab, fc, inv_c, AV, fma(-xk, B, s_par), sperp2, xk);
+                                             double kidx, double inv_c, double AV, double s_par, double sperp2,
+                                             double xk) {
+  return uni_value<NLR>(recs, leadrec, etab, fc, kidx, inv_c, AV, fma(-xk, B, s_par), sperp2, xk);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -235,6 +242,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
         const double sj = a.s[j];
         const double s_aperp = sj * ps.aperp;
         const double s_apar = sj * ps.apar;
+        const double kidx = ps.inv_c * fc.inv_h;
         const char* mu_bytes = reinterpret_cast<const char*>(murec);
         const char* x_bytes = reinterpret_cast<const char*>(xrec);
         for (int idx = lane + 64 * my_rank; idx < plane; idx += step) {
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
           const vk_d2 m01 = *reinterpret_cast<const vk_d2*>(mr);
           const vk_d2 xw = *reinterpret_cast<const vk_d2*>(x_bytes + (pk >> 16));
           const double s_perp = s_aperp * m01.y;
-          const double f = xw.y * uni_value<NLR>(recs, leadrec, etab, fc, ps.inv_c, ps.A, fma(-xw.x, ps.B, s_apar * m01.x),
+          const double f = xw.y * uni_value<NLR>(recs, leadrec, etab, fc, kidx, ps.inv_c, ps.A, fma(-xw.x, ps.B, s_apar * m01.x),
                                                  s_perp * s_perp, xw.x);
           const vk_d2 w01 = *reinterpret_cast<const vk_d2*>(mr + 2);
           acc[0] = fma(w01.x, f, acc[0]);

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_lanes_kernel(TheoryArgs a) {
     const double sj = a.s[j];
     const double sa = sj * ps.aperp, sp = sj * ps.apar;
     const double AV = ps.A;
+    const double kidx = ps.inv_c * fc.inv_h;
     double acc[NL];
 #pragma unroll
     for (int l = 0; l < NL; ++l) acc[l] = 0.0;
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_lanes_kernel(TheoryArgs a) {
       for (int k = 0; k < a.n_x; ++k) {
         const vk_d2 xw = *reinterpret_cast<const vk_d2*>(l_xw + 2 * k);
         const double xk = xw.x;
-        g = fma(xw.y, node_value<NLR>(recs, leadrec, etab, fc, ps.B, ps.inv_c, AV, s_par, sperp2, xk), g);
+        g = fma(xw.y, node_value<NLR>(recs, leadrec, etab, fc, ps.B, kidx, ps.inv_c, AV, s_par, sperp2, xk), g);
       }
 #pragma unroll
       for (int l = 0; l < NL; ++l) acc[l] = fma(a.w_ell[l * a.n_mu + i], g, acc[l]);

@@ -134,8 +134,16 @@ def build_tables(model, fit=None, matter_model=None):
                     ref = T.refine_pp(r, np.moveaxis(coef[l], 0, -1), u0, h, n)       # (n, 4, 4, n_beta-1)
                     parts.append(np.moveaxis(ref, -1, 0))                              # (n_beta-1, n, 4, 4)
                 uni_xi = arr(np.stack(parts))
+            # Legendre sum regrouped in powers of mu_r^2 (exact: linear combinations of the coefficient sets)
+            if n_ell_r == 1:
+                uni_xic = uni_xi
+            else:
+                x0, x2 = uni_xi[0], uni_xi[1]
+                x4 = uni_xi[2] if n_ell_r == 3 else np.zeros_like(x0)
+                comb = [x0 - 0.5 * x2 + 0.375 * x4, 1.5 * x2 - 3.75 * x4, 4.375 * x4]
+                uni_xic = arr(np.stack(comb[:n_ell_r]))
             t.uni_n, t.uni_u0, t.uni_inv_h = n, u0, 1.0 / h
-            t.uni_sv_v, t.uni_xi = N.as_dp(uni_sv_v), N.as_dp(uni_xi)
+            t.uni_sv_v, t.uni_xi, t.uni_xic = N.as_dp(uni_sv_v), N.as_dp(uni_xi), N.as_dp(uni_xic)
 
     t.iaH = float(model.iaH)
     # not used when the growth term is beta*bias (linear_bias on a measured real-space ccf)
