@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 5
+#define VK_ABI_VERSION 6
 
 /* error codes */
 #define VK_OK 0
@@ -139,9 +139,12 @@ typedef struct vk_tables {
 
   /* ---- optional unified grid: one interval index for sigma_v, V1 and every xi^r_l -------------------- */
   /* When the r grid and the sigma_v grid are uniform and commensurate, the host re-expresses all tables on
-   * their common refinement (u0 + q/inv_h, q < uni_n) in interval units; the fast theory kernels need it.  */
+   * their common refinement (u0 + q/inv_h, q < uni_n) in interval units; the fast theory kernels need it.
+   * The grid starts at or below the first knot of vr (u = 0.01): refined intervals below a table's first knot hold
+   * its boundary value, the interval that contains 0.01 holds the leading V cubic (the kernels never evaluate
+   * below u = 0.01: V is clamped there, ccf_model.py:625 with ext=3, and every other table is constant).       */
   int32_t uni_n;        /* 0: not available (only the generic theory kernel is used)                    */
-  double uni_u0;        /* left end of the refined grid                                                  */
+  double uni_u0;        /* left end of the refined grid, <= vr.knots[0]                                  */
   double uni_inv_h;     /* 1/spacing of the refined grid                                                 */
   const double* uni_sv_v; /* [uni_n][2][4]: sigma_v shape and V1 = r*Delta, coefficients of tau^p        */
   const double* uni_xi; /* fixed: [n_ell_r][uni_n][4]; beta-dependent: [n_ell_r][n_beta_r-1][uni_n][4][4]

@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-VK_ABI_VERSION = 5
+VK_ABI_VERSION = 6
 VK_NPAR = 12
 (P_FSIGMA8, P_SIGMAV, P_APERP, P_APAR, P_EPSILON, P_BETA, P_ASTAR, P_M, P_Q, P_BIAS, P_AV, P_SPARE) = range(12)
 MATTER = {"template": 0, "linear_bias": 1, "velocity_template": 2}

@@ -522,7 +522,7 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
       ok = ok && fabs(t->vr.inv_h - t->xi.inv_h) <= 1e-12 * t->xi.inv_h;
     }
     ctx->fast_ok = ok && !t->vr_beta_dep && t->sv_n_mu == 0 && t->uni_n > 0 && t->uni_sv_v && t->uni_xi && t->uni_xic &&
-                   t->uni_inv_h > 0 && t->uni_u0 >= t->vr.knots[0];
+                   t->uni_inv_h > 0 && t->uni_u0 <= t->vr.knots[0] && t->sv.knots[0] >= t->vr.knots[0];
     ctx->matter_vt = t->matter_model == VK_MATTER_VELOCITY_TEMPLATE;
     ctx->vt_amp = t->vt_amp;
     ctx->matter_lb = t->matter_model == VK_MATTER_LINEAR_BIAS;

@@ -23,6 +23,14 @@ __device__ __forceinline__ void sqrt_rsqrt(double x, double& g, double& ir) {
   g = x * ir;
 }
 
+// 1/sqrt(x) alone, same scheme (callers that need sqrt(x) fold x * ir into their next fma)
+__device__ __forceinline__ double rsqrt3(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(-(x * y), y, 1.0);
+  const double p = fma(0.375, e, 0.5);
+  return fma(y * e, p, y);
+}
+
 // 1/x for a positive normal x (the velocity dispersion): y' = y (1 + e + e^2), e = 1 - x y, error ~ e^3
 __device__ __forceinline__ double recip(double x) {
   const double y = __builtin_amdgcn_rcp(x);   // v_rcp_f64
@@ -60,6 +68,38 @@ __device__ __forceinline__ double exp_nonpos(double a, const double* __restrict_
   p = fma(p, f, 1.0);
   p = fma(p, f, 1.0);
   return ldexp(t * p, ni >> 8);
+}
+
+// p*f + c with the constant addend in a scalar register pair (one constant-bus operand is allowed per VALU
+// instruction on gfx9): no v_mov to re-materialise constants inside the hot loop.
+__device__ __forceinline__ double fma_s(double p, double f, double c) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(f), "s"(c));
+  return r;
+}
+
+// exp(-z^2/2) for callers that carry y = kExpScale * z instead of z (kExpScale^2 = 128/ln2, folded into their
+// per-point and per-node constants): with yn = -y*y = -(z^2/2) * 256/ln2 the range reduction is n = rint(yn),
+// d = yn - n (exact), exp = 2^(n/256) * exp(d ln2/256).  The degree-4 Taylor polynomial in f = d ln2/256 is
+// evaluated in d with every coefficient divided by the leading one, c4 = (ln2/256)^4/24, so the Horner addends
+// are scalar constants and c4 lives in the table: `tab_c4[j]` = c4 * 2^(j/256) (exp2_frac_c4 below).
+// No clamp is needed: an fma-free exact d keeps the polynomial in [0.998, 1.002] for every finite argument, a huge
+// |yn| saturates v_cvt_i32 and v_ldexp then underflows to 0, and a NaN propagates.
+constexpr double kExpScale = 13.589148804608305;                 // sqrt(128/ln 2)
+constexpr double kExpC1 = 0.0027076061740622863;                 // ln2/256
+constexpr double kExpC4 = kExpC1 * kExpC1 * kExpC1 * kExpC1 / 24.0;
+__device__ __forceinline__ double exp2_frac_c4(int j) { return kExpC4 * exp2((double)j * (1.0 / kExpTab)); }
+
+__device__ __forceinline__ double exp_scaled(double yn, const double* __restrict__ tab_c4) {
+  const double n = rint(yn);
+  const double d = yn - n;
+  const int ni = (int)n;
+  const double t = tab_c4[ni & (kExpTab - 1)];
+  double q = d + 4.0 / kExpC1;                                   // (c3/c4)
+  q = fma_s(q, d, 12.0 / (kExpC1 * kExpC1));                     // c2/c4
+  q = fma_s(q, d, 24.0 / (kExpC1 * kExpC1 * kExpC1));            // c1/c4
+  q = fma_s(q, d, 24.0 / (kExpC1 * kExpC1 * kExpC1 * kExpC1));   // 1/c4
+  return ldexp(t * q, ni >> 8);
 }
 
 }  // namespace vkm

@@ -14,19 +14,17 @@ namespace vk {
 // (a wave's 64 cells straddle at most two s bins when n_mu >= 64), accumulated by lane 0 in wave-private LDS.
 // --------------------------------------------------------------------------------------------------
 struct CellsPlan {
-  int mu, w, xw, s, recs, lead, etab, betar, acc, total;
+  int mu, w, xw, s, betar, acc, total;
 };
 
 __host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s, int uni_n, int nlr, int n_beta_r) {
   CellsPlan p;
-  int o = 0;
+  int o = fast_fixed_doubles(uni_n, nlr);          // exp table + records first (fixed offsets)
+  o = (o + 1) & ~1;
   p.mu = o;    o += 2 * n_mu;                      // {mu_i, sqrt(1 - mu_i^2)}
   p.w = o;     o += kMaxEll * n_mu;                // W_l[i]
-  p.xw = o;    o += 2 * n_x;                       // {x_k, w_k}
+  p.xw = o;    o += 2 * n_x;                       // {kExpScale x_k, w_k}
   p.s = o;     o += (n_s + 1) & ~1;
-  p.recs = o;  o += uni_n * uni_stride(nlr);
-  p.lead = o;  o += 4;
-  p.etab = o;  o += vkm::kExpTab;
   p.betar = o; o += (n_beta_r + 1) & ~1;
   p.acc = o;   o += kMaxEll * ((n_s + kWaves - 1) / kWaves) * kWaves;   // [l][slot][wave]
   p.total = o;
@@ -47,11 +45,11 @@ __global__ __launch_bounds__(kBlock) void vk_theory_cells_kernel(TheoryArgs a) {
     for (int l = 0; l < kMaxEll; ++l) lds[pl.w + l * a.n_mu + i] = (l < NL) ? a.w_ell[l * a.n_mu + i] : 0.0;
   }
   for (int k = tid; k < a.n_x; k += kBlock) {
-    lds[pl.xw + 2 * k] = a.x[k];
+    lds[pl.xw + 2 * k] = a.x[k] * vkm::kExpScale;
     lds[pl.xw + 2 * k + 1] = a.w_x[k];
   }
   for (int j = tid; j < a.n_s; j += kBlock) lds[pl.s + j] = a.s[j];
-  stage_uni_records<NLR>(a, lds + pl.recs, lds + pl.lead, lds + pl.etab);
+  stage_uni_records<NLR>(a, lds);
   if (a.n_beta_r > 0)
     for (int i = tid; i < a.n_beta_r; i += kBlock) lds[pl.betar + i] = a.beta_r[i];
   const FastConsts fc = make_fast_consts(a);
@@ -63,9 +61,6 @@ __global__ __launch_bounds__(kBlock) void vk_theory_cells_kernel(TheoryArgs a) {
   const double* l_w = lds + pl.w;
   const double* l_xw = lds + pl.xw;
   const double* l_s = lds + pl.s;
-  const double* recs = lds + pl.recs;
-  const double* leadrec = lds + pl.lead;
-  const double* etab = lds + pl.etab;
   const int slots = (a.n_s + kWaves - 1) / kWaves;        // s bins per wave (upper bound)
   double* l_acc = lds + pl.acc;                            // [l][slot][wave]: each entry touched by one wave only
   const int my_bins = (a.n_s - wave + kWaves - 1) / kWaves;  // bins j = wave + 4*jj, jj < my_bins
@@ -84,12 +79,11 @@ __global__ __launch_bounds__(kBlock) void vk_theory_cells_kernel(TheoryArgs a) {
     const PointScalars ps = point_scalars(a, row);
     if (a.n_beta_r > 0) {
       __syncthreads();  // every wave is done with the previous point's records
-      rebuild_uni_xi<NLR>(a, lds + pl.recs, lds + pl.betar, row[VK_P_BETA]);
+      rebuild_uni_xi<NLR>(a, lds + kRecsOff, lds + pl.betar, row[VK_P_BETA]);
       __syncthreads();
     }
     for (int e = lane; e < kMaxEll * slots; e += 64) l_acc[e * kWaves + wave] = 0.0;
-    const double AV = ps.A;
-    const double kidx = ps.inv_c * fc.inv_h;
+    const FastPoint fp = make_fast_point(ps, fc);
     for (int base = 0; base < cells; base += 64) {
       const int e = base + lane;
       const bool live = e < cells;
@@ -98,14 +92,14 @@ __global__ __launch_bounds__(kBlock) void vk_theory_cells_kernel(TheoryArgs a) {
       const int i = ec - jj * a.n_mu;
       const double sj = l_s[wave + kWaves * jj];
       const vk_d2 mm = *reinterpret_cast<const vk_d2*>(l_mu + 2 * i);
-      const double s_perp = sj * ps.aperp * mm.y;
+      const double s_perp = sj * fp.k_perp * mm.y;
       const double sperp2 = s_perp * s_perp;
-      const double s_par = sj * ps.apar * mm.x;
+      const double s_par = sj * fp.k_par * mm.x;
       double g = 0.0;
       for (int k = 0; k < a.n_x; ++k) {
         const vk_d2 xw = *reinterpret_cast<const vk_d2*>(l_xw + 2 * k);
         const double xk = xw.x;
-        g = fma(xw.y, node_value<NLR>(recs, leadrec, etab, fc, ps.B, kidx, ps.inv_c, AV, s_par, sperp2, xk), g);
+        g = fma(xw.y, uni_value<NLR>(lds, fc, fp.AVk, fma(-xk, fp.Bk, s_par), sperp2, xk), g);
       }
       if (!live) g = 0.0;
       // projection: this trip's cells belong to s bin jj0 or jj0 + 1

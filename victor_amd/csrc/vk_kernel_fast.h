@@ -7,33 +7,45 @@ namespace vk {
 // --------------------------------------------------------------------------------------------------
 // Shared building blocks of the fast theory kernels (point-major, lanes, cells).
 // They run on the UNIFIED GRID the host prepares when the r grid and the sigma_v grid are uniform and commensurate
-// (vk_tables.uni_*): every table is re-expressed on the common refinement of the two grids, in interval units, so
-//   * one fma + clamp + v_cvt + v_fract yields THE interval and local coordinate for all five cubics
-//     (sigma_v, V, xi_0, xi_2, xi_4), with no knot read and no second index;
+// (vk_tables.uni_*): every table is re-expressed on the common refinement of the two grids, extended down to
+// u <= 0, in interval units, so
+//   * the kernels work in INDEX UNITS: every length of a point is multiplied by k = 1/(c h) once per point / mu row,
+//     and the interval coordinate of an integrand point is t = r2' * rsqrt(r2') + off - one fma on the refined
+//     1/sqrt, no separate r, no u = r/c; one clamp pair + v_cvt + v_fract then yields THE interval and local
+//     coordinate for all five cubics (sigma_v, V, xi_0, xi_2, xi_4), with no knot read and no second index;
 //   * the five cubics of a refined interval sit in one LDS record, padded to 4*(2+NLR)+2 doubles so that the
 //     ds_read_b128 of 16 consecutive intervals hit distinct banks;
 //   * refined intervals outside a table's range hold its (constant) boundary value, which reproduces the
-//     clamped spline evaluation of the reference (FITPACK ext=3) exactly; only V below the first r node needs the
-//     extra leading interval [0.01, r_0] of ccf_model.py:625 and takes a (rare, divergent) branch;
-//   * sqrt and 1/r come from one refined v_rsq_f64, 1/sigma_v from a refined v_rcp_f64, exp from a 256-entry
-//     2^(j/256) table and a degree-4 polynomial (vk_devmath.h; all within ~2 ulp).
+//     clamped spline evaluation of the reference (FITPACK ext=3) exactly; the V table's leading interval
+//     [0.01, r_0] of ccf_model.py:625 is part of the grid, and its clamp V(u < 0.01) = V(0.01) is the lower clamp
+//     of t itself (every other table is constant down there);
+//   * 1/r comes from one refined v_rsq_f64, 1/sigma_v from a refined v_rcp_f64, exp(-z^2/2) from a 256-entry
+//     2^(j/256) table and a degree-4 polynomial on the pre-scaled y = z sqrt(128/ln2) (vk_devmath.h; ~2 ulp).
+// The exp table and the records sit at fixed LDS offsets (0 and 2 KB) so their addresses are immediates.
 // --------------------------------------------------------------------------------------------------
 typedef double vk_d2 __attribute__((ext_vector_type(2)));
 constexpr int kMuRec = 6;   // {mu, sqrt(1-mu^2), W_0, W_1, W_2, pad}
+constexpr int kEtabOff = 0;                  // doubles
+constexpr int kRecsOff = vkm::kExpTab;
 
 __host__ __device__ constexpr int uni_stride(int nlr) { return 4 * (2 + nlr) + 2; }   // doubles per refined interval
+__host__ __device__ constexpr int fast_fixed_doubles(int uni_n, int nlr) { return kRecsOff + uni_n * uni_stride(nlr); }
 
 struct FastConsts {
-  double inv_h, off, n_eps;       // unified grid: t = u*inv_h + off, clamped to [0, n_eps]
-                                  // (callers pass k = inv_h/c per point, so that t = r*k + off needs no u)
-  double inv_hl, off_l;           // V leading interval [0.01, r_0]
+  double inv_h;                   // callers form k = inv_h / c per point and scale their lengths by it
+  double off, t_lo, n_eps;        // t = r' + off, clamped to [t_lo, n_eps]; t_lo is u = 0.01, the first V knot
 };
 
-// v_min_f64 without the canonicalising v_max hipcc puts in front of fmin() for a bound it cannot prove quiet
-// (the bound is a finite table size; the other operand comes out of an fma/max and is canonical already)
+// v_min_f64 / v_max_f64 without the canonicalising v_max hipcc puts in front of fmin()/fmax() for a bound it cannot
+// prove quiet (the bounds are finite table constants; a NaN first operand yields the bound, i.e. a valid index)
 __device__ __forceinline__ double vmin_f64(double a, double b) {
   double r;
   asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double vmax_f64(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
 
@@ -47,26 +59,21 @@ __device__ __forceinline__ double cubic_b128(const double* rec, double t) {
   return fma(fma(fma(hi.y, t, hi.x), t, lo.y), t, lo.x);
 }
 
-__device__ __forceinline__ double hpow(double h, int q) {
-  return q == 0 ? 1.0 : (q == 1 ? h : (q == 2 ? h * h : h * h * h));
-}
-
 __device__ __forceinline__ FastConsts make_fast_consts(const TheoryArgs& a) {
   FastConsts fc;
   fc.inv_h = a.uni_inv_h;
   fc.off = -a.uni_u0 * a.uni_inv_h;
+  fc.t_lo = (a.vr.knots[0] - a.uni_u0) * a.uni_inv_h;
   fc.n_eps = (double)a.uni_n * (1.0 - 0x1p-52);
-  const double hl = a.vr.knots[1] - a.vr.knots[0];
-  fc.inv_hl = 1.0 / hl;
-  fc.off_l = -a.vr.knots[0] * fc.inv_hl;
   return fc;
 }
 
 // Stage the batch-constant parts of the records: sigma_v and V always, xi^r_l when it does not depend on beta;
-// also the leading V cubic (in units of its own interval) and the exp table.  All threads of the workgroup.
+// also the exp table.  All threads of the workgroup; `lds` is the start of dynamic LDS.
 template <int NLR>
-__device__ __forceinline__ void stage_uni_records(const TheoryArgs& a, double* recs, double* lead, double* etab) {
+__device__ __forceinline__ void stage_uni_records(const TheoryArgs& a, double* lds) {
   constexpr int stride = uni_stride(NLR);
+  double* recs = lds + kRecsOff;
   const int tid = threadIdx.x;
   for (int e = tid; e < a.uni_n * 8; e += kBlock) recs[(e >> 3) * stride + (e & 7)] = a.uni_sv_v[e];
   if (a.n_beta_r == 0) {
@@ -77,9 +84,7 @@ __device__ __forceinline__ void stage_uni_records(const TheoryArgs& a, double* r
       recs[(iq >> 2) * stride + 8 + 4 * l + (iq & 3)] = src[e];
     }
   }
-  const double hl = a.vr.knots[1] - a.vr.knots[0];
-  if (tid < 4) lead[tid] = a.vr.coef[tid] * hpow(hl, tid);
-  for (int j = tid; j < vkm::kExpTab; j += kBlock) etab[j] = vkm::exp2_frac(j);
+  for (int j = tid; j < vkm::kExpTab; j += kBlock) lds[kEtabOff + j] = vkm::exp2_frac_c4(j);
 }
 
 // Per-point xi^r records when the real-space input depends on the reconstruction beta (PCHIP piece kb, extrapolating
@@ -99,24 +104,39 @@ __device__ __forceinline__ void rebuild_uni_xi(const TheoryArgs& a, double* recs
   }
 }
 
-// (1 + xi^r) * exp(-z^2/2) / SV at one integrand point, given r_par and s_perp^2 (ccf_model.py:648-657, 681-690).
-// `kidx` = inv_h / c of the point: the interval coordinate is t = r * kidx + off.  For NLR > 1 the records hold the
-// Legendre sum regrouped in powers of m = mu_r^2 (A, B, C of vk_tables.uni_xic), so xi^r = A + m (B + m C).
+// per-point factors of the index-unit formulation (wave-uniform in the point-major and cells kernels, per lane in
+// the lanes kernel)
+struct FastPoint {
+  double k_perp, k_par;   // aperp k, apar k: s_perp' = s sqrt(1-mu^2) k_perp, s_par' = s mu k_par
+  double Bk;              // sigma_v iaH_true k / kExpScale: r_par' = s_par' - x_k' Bk with x_k' = kExpScale x_k
+  double AVk;             // kExpScale g / (3 iaH_true sigma_v): y = (x_k' + AVk V mu_r) / SV
+};
+
+__device__ __forceinline__ FastPoint make_fast_point(const PointScalars& ps, const FastConsts& fc) {
+  FastPoint fp;
+  const double k = ps.inv_c * fc.inv_h;
+  fp.k_perp = ps.aperp * k;
+  fp.k_par = ps.apar * k;
+  fp.Bk = ps.B * k * (1.0 / vkm::kExpScale);
+  fp.AVk = ps.A * vkm::kExpScale;
+  return fp;
+}
+
+// (1 + xi^r) * exp(-z^2/2) / SV at one integrand point, given r_par' and s_perp'^2 in index units and the scaled
+// velocity node xk' (ccf_model.py:648-657, 681-690).  For NLR > 1 the records hold the Legendre sum regrouped in
+// powers of m = mu_r^2 (A, B, C of vk_tables.uni_xic), so xi^r = A + m (B + m C).
 template <int NLR>
-__device__ __forceinline__ double uni_value(const double* __restrict__ recs, const double* __restrict__ leadrec,
-                                            const double* __restrict__ etab, const FastConsts& fc, double kidx,
-                                            double inv_c, double AV, double r_par, double sperp2, double xk) {
+__device__ __forceinline__ double uni_value(const double* __restrict__ lds, const FastConsts& fc, double AVk,
+                                            double r_par, double sperp2, double xk) {
   constexpr int stride = uni_stride(NLR);
-  double r, inv_r;
-  vkm::sqrt_rsqrt(fma(r_par, r_par, sperp2), r, inv_r);
+  const double r2 = fma(r_par, r_par, sperp2);
+  const double inv_r = vkm::rsqrt3(r2);
   const double mu_r = r_par * inv_r;
-  const double tr = fma(r, kidx, fc.off);
-  const double t = vmin_f64(fmax(tr, 0.0), fc.n_eps);
+  const double t = vmin_f64(vmax_f64(fma(r2, inv_r, fc.off), fc.t_lo), fc.n_eps);
   const double tq = __builtin_amdgcn_fract(t);
-  const double* rec = lds_at(recs, __mul24((int)t, stride * 8));
+  const double* rec = lds_at(lds + kRecsOff, __mul24((int)t, stride * 8));
   const double SV = cubic_b128(rec, tq);
-  double V = cubic_b128(rec + 4, tq);
-  if (tr < 0.0) V = cubic_b128(leadrec, fmax(fma(r * inv_c, fc.inv_hl, fc.off_l), 0.0));
+  const double V = cubic_b128(rec + 4, tq);
   double xir = cubic_b128(rec + 8, tq);
   if (NLR > 1) {
     const double m2 = mu_r * mu_r;
@@ -127,35 +147,24 @@ __device__ __forceinline__ double uni_value(const double* __restrict__ recs, con
     }
   }
   const double inv_sv = vkm::recip(SV);
-  const double z = fma(AV * V, mu_r, xk) * inv_sv;
-  const double e = vkm::exp_nonpos((-0.5 * z) * z, etab);
+  const double y = fma(AVk * V, mu_r, xk) * inv_sv;
+  const double e = vkm::exp_scaled(-y * y, lds + kEtabOff);
   return inv_sv * fma(e, xir, e);
-}
-
-// the same for the kernels that loop over the velocity nodes with a wave-uniform x_k (lanes, cells)
-template <int NLR>
-__device__ __forceinline__ double node_value(const double* __restrict__ recs, const double* __restrict__ leadrec,
-                                             const double* __restrict__ etab, const FastConsts& fc, double B,
-                                             double kidx, double inv_c, double AV, double s_par, double sperp2,
-                                             double xk) {
-  return uni_value<NLR>(recs, leadrec, etab, fc, kidx, inv_c, AV, fma(-xk, B, s_par), sperp2, xk);
 }
 
 // --------------------------------------------------------------------------------------------------
 // K1 point-major fast kernel: one wave owns one (point, s bin); lanes sweep the flattened (mu, v) plane.
 // --------------------------------------------------------------------------------------------------
 struct FastPlan {
-  int murec, xrec, recs, lead, etab, betar, red, node, total;
+  int murec, xrec, betar, red, node, total;
 };
 
 __host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int uni_n, int nlr, int n_beta_r) {
   FastPlan p;
-  int o = 0;
+  int o = fast_fixed_doubles(uni_n, nlr);   // exp table + records first (fixed offsets)
+  o = (o + 1) & ~1;
   p.murec = o; o += n_mu * kMuRec;
   p.xrec = o;  o += n_x * 2;
-  p.recs = o;  o += uni_n * uni_stride(nlr);
-  p.lead = o;  o += 4;
-  p.etab = o;  o += vkm::kExpTab;
   p.betar = o; o += (n_beta_r + 1) & ~1;
   p.red = o;   o += kWaves * kMaxEll;
   p.node = o;  o += (n_mu * n_x + 1) / 2;   // one packed u32 per (mu, v) node
@@ -179,10 +188,10 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
     rec[5] = 0.0;
   }
   for (int i = tid; i < a.n_x; i += kBlock) {
-    lds[pl.xrec + 2 * i] = a.x[i];
+    lds[pl.xrec + 2 * i] = a.x[i] * vkm::kExpScale;
     lds[pl.xrec + 2 * i + 1] = a.w_x[i];
   }
-  stage_uni_records<NLR>(a, lds + pl.recs, lds + pl.lead, lds + pl.etab);
+  stage_uni_records<NLR>(a, lds);
   if (a.n_beta_r > 0)
     for (int i = tid; i < a.n_beta_r; i += kBlock) lds[pl.betar + i] = a.beta_r[i];
   // byte offsets of the mu record (low 16 bits) and the (x, w) record (high 16 bits) of every plane node, so the
@@ -208,9 +217,6 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
   const int rounds = (a.sbins_per_item + nteams - 1) / nteams;
   const double* murec = lds + pl.murec;
   const double* xrec = lds + pl.xrec;
-  const double* recs = lds + pl.recs;
-  const double* leadrec = lds + pl.lead;
-  const double* etab = lds + pl.etab;
   double* l_red = lds + pl.red;
 
   double wsum[NL];
@@ -228,9 +234,10 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
     const PointScalars ps = point_scalars(a, row);
     if (a.n_beta_r > 0) {
       __syncthreads();  // previous item's readers are done with the per-point records
-      rebuild_uni_xi<NLR>(a, lds + pl.recs, lds + pl.betar, row[VK_P_BETA]);
+      rebuild_uni_xi<NLR>(a, lds + kRecsOff, lds + pl.betar, row[VK_P_BETA]);
       __syncthreads();
     }
+    const FastPoint fp = make_fast_point(ps, fc);
     for (int rd = 0; rd < rounds; ++rd) {
       const int jl = rd * nteams + my_team;
       const int j = g * a.sbins_per_item + jl;
@@ -240,9 +247,8 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
       for (int l = 0; l < NL; ++l) acc[l] = 0.0;
       if (valid) {
         const double sj = a.s[j];
-        const double s_aperp = sj * ps.aperp;
-        const double s_apar = sj * ps.apar;
-        const double kidx = ps.inv_c * fc.inv_h;
+        const double s_aperp = sj * fp.k_perp;
+        const double s_apar = sj * fp.k_par;
         const char* mu_bytes = reinterpret_cast<const char*>(murec);
         const char* x_bytes = reinterpret_cast<const char*>(xrec);
         for (int idx = lane + 64 * my_rank; idx < plane; idx += step) {
@@ -251,8 +257,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
           const vk_d2 m01 = *reinterpret_cast<const vk_d2*>(mr);
           const vk_d2 xw = *reinterpret_cast<const vk_d2*>(x_bytes + (pk >> 16));
           const double s_perp = s_aperp * m01.y;
-          const double f = xw.y * uni_value<NLR>(recs, leadrec, etab, fc, kidx, ps.inv_c, ps.A, fma(-xw.x, ps.B, s_apar * m01.x),
-                                                 s_perp * s_perp, xw.x);
+          const double f = xw.y * uni_value<NLR>(lds, fc, fp.AVk, fma(-xw.x, fp.Bk, s_apar * m01.x), s_perp * s_perp, xw.x);
           const vk_d2 w01 = *reinterpret_cast<const vk_d2*>(mr + 2);
           acc[0] = fma(w01.x, f, acc[0]);
           if (NL > 1) acc[1] = fma(w01.y, f, acc[1]);

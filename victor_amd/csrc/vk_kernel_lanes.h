@@ -15,17 +15,15 @@ namespace vk {
 // n_s * n/64 wavefronts; the point-major kernel above serves every other case.
 // --------------------------------------------------------------------------------------------------
 struct LanesPlan {
-  int smu, xw, recs, lead, etab, total;
+  int smu, xw, total;
 };
 
 __host__ __device__ inline LanesPlan make_lanes_plan(int n_mu, int n_x, int uni_n, int nlr) {
   LanesPlan p;
-  int o = 0;
+  int o = fast_fixed_doubles(uni_n, nlr);   // exp table + records first (fixed offsets)
+  o = (o + 1) & ~1;
   p.smu = o;   o += 2 * n_mu;           // {mu_i, sqrt(1 - mu_i^2)}
-  p.xw = o;    o += 2 * n_x;            // {x_k, w_k}: read with a wave-uniform address (LDS broadcast)
-  p.recs = o;  o += uni_n * uni_stride(nlr);
-  p.lead = o;  o += 4;
-  p.etab = o;  o += vkm::kExpTab;
+  p.xw = o;    o += 2 * n_x;            // {kExpScale x_k, w_k}: read with a wave-uniform address (LDS broadcast)
   p.total = o;
   return p;
 }
@@ -79,10 +77,10 @@ __global__ __launch_bounds__(kBlock) void vk_theory_lanes_kernel(TheoryArgs a) {
     lds[pl.smu + 2 * i + 1] = sqrt(1.0 - m * m);
   }
   for (int k = tid; k < a.n_x; k += kBlock) {
-    lds[pl.xw + 2 * k] = a.x[k];
+    lds[pl.xw + 2 * k] = a.x[k] * vkm::kExpScale;
     lds[pl.xw + 2 * k + 1] = a.w_x[k];
   }
-  stage_uni_records<NLR>(a, lds + pl.recs, lds + pl.lead, lds + pl.etab);
+  stage_uni_records<NLR>(a, lds);
   const FastConsts fc = make_fast_consts(a);
   __syncthreads();
 
@@ -90,9 +88,6 @@ __global__ __launch_bounds__(kBlock) void vk_theory_lanes_kernel(TheoryArgs a) {
   const int wave = tid >> 6;
   const double* l_smu = lds + pl.smu;
   const double* l_xw = lds + pl.xw;
-  const double* recs = lds + pl.recs;
-  const double* leadrec = lds + pl.lead;
-  const double* etab = lds + pl.etab;
   const long long chunks = (a.n + 63) >> 6;
   const long long items = chunks * a.n_s;
   for (long long item = (long long)blockIdx.x * kWaves + wave; item < items; item += (long long)gridDim.x * kWaves) {
@@ -102,10 +97,9 @@ __global__ __launch_bounds__(kBlock) void vk_theory_lanes_kernel(TheoryArgs a) {
     const bool valid = point < a.n;
     if (!valid) point = a.n - 1;
     const PointScalars ps = point_scalars_lane(a, a.params + point * VK_NPAR);
+    const FastPoint fp = make_fast_point(ps, fc);
     const double sj = a.s[j];
-    const double sa = sj * ps.aperp, sp = sj * ps.apar;
-    const double AV = ps.A;
-    const double kidx = ps.inv_c * fc.inv_h;
+    const double sa = sj * fp.k_perp, sp = sj * fp.k_par;
     double acc[NL];
 #pragma unroll
     for (int l = 0; l < NL; ++l) acc[l] = 0.0;
@@ -118,7 +112,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_lanes_kernel(TheoryArgs a) {
       for (int k = 0; k < a.n_x; ++k) {
         const vk_d2 xw = *reinterpret_cast<const vk_d2*>(l_xw + 2 * k);
         const double xk = xw.x;
-        g = fma(xw.y, node_value<NLR>(recs, leadrec, etab, fc, ps.B, kidx, ps.inv_c, AV, s_par, sperp2, xk), g);
+        g = fma(xw.y, uni_value<NLR>(lds, fc, fp.AVk, fma(-xk, fp.Bk, s_par), sperp2, xk), g);
       }
 #pragma unroll
       for (int l = 0; l < NL; ++l) acc[l] = fma(a.w_ell[l * a.n_mu + i], g, acc[l]);

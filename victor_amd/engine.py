@@ -121,8 +121,14 @@ def build_tables(model, fit=None, matter_model=None):
     if (t.sv_n_mu == 0 and not vr_beta_dep and t.xi.inv_h > 0 and t.xi.lead == 0 and t.sv.inv_h > 0
             and t.sv.lead == 0 and t.vr.inv_h > 0 and t.vr.lead == 1):
         cr = T.common_refinement(r, model.r_for_sv)
-        if cr is not None and cr[0] >= r_ext[0]:
+        if cr is not None and cr[0] >= r_ext[0] and cr[2] + int(np.ceil(cr[0] / cr[1])) <= 640:
             u0, h, n = cr
+            # extend the grid down to u <= 0 so that the index-unit coordinate t = r/(c h) - u0/h is never negative
+            # and the leading V interval [0.01, r_0] is part of the same records (see vk_kernel_fast.h)
+            k0 = int(np.ceil(u0 / h - 1e-9))
+            u0, n = u0 - k0 * h, n + k0
+            if abs(u0) < 1e-9 * h:
+                u0 = 0.0
             sv_ref = T.refine_pp(model.r_for_sv, T.notaknot_coefficients(model.r_for_sv, model.sv_rmu[0]), u0, h, n)
             v_ref = T.refine_pp(r_ext, vr_coef[0], u0, h, n)
             uni_sv_v = arr(np.stack([sv_ref, v_ref], axis=1))                         # (n, 2, 4)
