@@ -54,6 +54,7 @@ struct vk_ctx {
   double* d_tables = nullptr;  // one allocation holding every table
   // device pointers into d_tables
   const double *d_x1 = nullptr, *d_w1 = nullptr;  // single velocity node for the Kaiser-type models
+  const double* d_xws = nullptr;                  // [n_x + 1][2]: {kExpScale x_k, w_k}, scalar-cache reads (fast kernels)
   const double *d_s = nullptr, *d_mu = nullptr, *d_w = nullptr, *d_x = nullptr, *d_wx = nullptr, *d_beta_r = nullptr,
                *d_beta_d = nullptr, *d_data = nullptr, *d_beta_c = nullptr, *d_prec = nullptr, *d_logdet = nullptr,
                *d_eig = nullptr;
@@ -251,6 +252,7 @@ int theory_args(vk_ctx* ctx, const vk_eval_opts* o, TheoryArgs* a, int* nlr) {
     a->x = ctx->d_x;
     a->w_x = ctx->d_wx;
   }
+  a->xw_scaled = ctx->d_xws;
   *nlr = o->assume_isotropic ? 1 : ctx->n_ell_r;
   return VK_OK;
 }
@@ -278,9 +280,9 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   // lanes-over-batch variant: batch-constant tables and enough points to fill the chip with n_s * n/64 waves
   const char* mapping = getenv("VICTOR_HIP_MAPPING");
   const bool lanes_ok = fast && a.n_beta_r == 0;
-  // One wave per (s bin, 64-point chunk).  The kernel is register-limited to 4 waves per SIMD, i.e. 16 per CU, so the
+  // One wave per (s bin, 64-point chunk).  LDS and registers hold 4-5 workgroups (16-20 waves) per CU, so the
   // chip holds n_cu*16 waves at a time; the last round of waves is only partly filled.  The lanes kernel is ~1.2x
-  // faster per integrand than the point-major one (81 vs 92 VALU instructions), so it wins once that fill
+  // faster per integrand than the point-major one (56 vs ~68 VALU instructions), so it wins once that fill
   // efficiency exceeds ~0.85.
   const long long waves = ((a.n + 63) >> 6) * (long long)a.n_s;
   const long long slots = 16LL * ctx->n_cu;
@@ -534,6 +536,13 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
                o_wx = up.add(t->w_x, t->n_x);
   const double zero_one[2] = {0.0, 1.0};
   const size_t o_x1 = up.add(zero_one, 2);
+  // {kExpScale x_k, w_k} pairs for the kernels that read the velocity nodes through the scalar cache; one pad pair
+  std::vector<double> xw_scaled(2 * ((size_t)t->n_x + 1), 0.0);
+  for (int k = 0; k < t->n_x; ++k) {
+    xw_scaled[2 * k] = t->x[k] * vkm::kExpScale;
+    xw_scaled[2 * k + 1] = t->w_x[k];
+  }
+  const size_t o_xws = up.add(xw_scaled.data(), xw_scaled.size());
   const size_t o_br = t->n_beta_r > 0 ? up.add(t->beta_r, t->n_beta_r) : 0;
   const size_t xi_coef_n = t->n_beta_r > 0 ? (size_t)t->n_ell_r * (t->n_beta_r - 1) * t->xi.n_int * 16
                                            : (size_t)t->n_ell_r * t->xi.n_int * 4;
@@ -578,6 +587,7 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
     return hip_bail(rc, "hipMemcpy(tables)");
   const double* base = ctx->d_tables;
   ctx->d_x1 = base + o_x1; ctx->d_w1 = base + o_x1 + 1;
+  ctx->d_xws = base + o_xws;
   ctx->d_s = base + o_s; ctx->d_mu = base + o_mu; ctx->d_w = base + o_w; ctx->d_x = base + o_x; ctx->d_wx = base + o_wx;
   ctx->d_beta_r = t->n_beta_r > 0 ? base + o_br : nullptr;
   auto view = [&](const vk_pp& p, size_t ok, size_t oc) {

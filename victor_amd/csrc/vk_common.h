@@ -32,6 +32,7 @@ struct TheoryArgs {
   const double* w_ell;    // [n_ell][n_mu]
   const double* x;        // [n_x]
   const double* w_x;      // [n_x]
+  const double* xw_scaled;  // [n_x + 1][2]: {kExpScale x_k, w_k} (streaming fast kernels; last pair is padding)
   int n_beta_r;           // 0 = fixed xi tables
   const double* beta_r;
   PPView xi, vr, sv;

@@ -10,11 +10,11 @@ namespace vk {
 // of its four waves owns the s bins j = wave, wave+4, ... and spreads the (s bin, mu) cells of those bins over its
 // lanes, with the 50 velocity nodes as the inner, wave-uniform loop.  Like the lanes kernel this forms s_perp and
 // s_par once per cell, reads x_k, w_k as LDS broadcasts and closes the v sum before the projection, so the
-// integrand costs the same ~80 instructions; the projection sum over mu is a two-segment wave reduction per trip
+// integrand costs the same ~56 instructions; the projection sum over mu is a two-segment wave reduction per trip
 // (a wave's 64 cells straddle at most two s bins when n_mu >= 64), accumulated by lane 0 in wave-private LDS.
 // --------------------------------------------------------------------------------------------------
 struct CellsPlan {
-  int mu, w, xw, s, betar, acc, total;
+  int mu, w, s, betar, acc, total;
 };
 
 __host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s, int uni_n, int nlr, int n_beta_r) {
@@ -23,7 +23,6 @@ __host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s,
   o = (o + 1) & ~1;
   p.mu = o;    o += 2 * n_mu;                      // {mu_i, sqrt(1 - mu_i^2)}
   p.w = o;     o += kMaxEll * n_mu;                // W_l[i]
-  p.xw = o;    o += 2 * n_x;                       // {kExpScale x_k, w_k}
   p.s = o;     o += (n_s + 1) & ~1;
   p.betar = o; o += (n_beta_r + 1) & ~1;
   p.acc = o;   o += kMaxEll * ((n_s + kWaves - 1) / kWaves) * kWaves;   // [l][slot][wave]
@@ -33,7 +32,7 @@ __host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s,
 
 // (130 VGPRs -> 3 waves per SIMD; forcing 4 with __launch_bounds__(256, 4) spills and measured 1.5 % slower)
 template <int NLR, int NL>
-__global__ __launch_bounds__(kBlock) void vk_theory_cells_kernel(TheoryArgs a) {
+__global__ __launch_bounds__(kBlock, 5) void vk_theory_cells_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
   const CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r);
   const int tid = threadIdx.x;
@@ -43,10 +42,6 @@ __global__ __launch_bounds__(kBlock) void vk_theory_cells_kernel(TheoryArgs a) {
     lds[pl.mu + 2 * i + 1] = sqrt(1.0 - m * m);
 #pragma unroll
     for (int l = 0; l < kMaxEll; ++l) lds[pl.w + l * a.n_mu + i] = (l < NL) ? a.w_ell[l * a.n_mu + i] : 0.0;
-  }
-  for (int k = tid; k < a.n_x; k += kBlock) {
-    lds[pl.xw + 2 * k] = a.x[k] * vkm::kExpScale;
-    lds[pl.xw + 2 * k + 1] = a.w_x[k];
   }
   for (int j = tid; j < a.n_s; j += kBlock) lds[pl.s + j] = a.s[j];
   stage_uni_records<NLR>(a, lds);
@@ -59,7 +54,8 @@ __global__ __launch_bounds__(kBlock) void vk_theory_cells_kernel(TheoryArgs a) {
   const int wave = tid >> 6;
   const double* l_mu = lds + pl.mu;
   const double* l_w = lds + pl.w;
-  const double* l_xw = lds + pl.xw;
+  typedef const vk_d2 __attribute__((address_space(4))) * cvec_ptr;
+  const cvec_ptr cxw = (cvec_ptr)(unsigned long long)a.xw_scaled;
   const double* l_s = lds + pl.s;
   const int slots = (a.n_s + kWaves - 1) / kWaves;        // s bins per wave (upper bound)
   double* l_acc = lds + pl.acc;                            // [l][slot][wave]: each entry touched by one wave only
@@ -97,7 +93,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_cells_kernel(TheoryArgs a) {
       const double s_par = sj * fp.k_par * mm.x;
       double g = 0.0;
       for (int k = 0; k < a.n_x; ++k) {
-        const vk_d2 xw = *reinterpret_cast<const vk_d2*>(l_xw + 2 * k);
+        const vk_d2 xw = cxw[k];             // scalar-cache read (wave-uniform), see vk_kernel_lanes.h
         const double xk = xw.x;
         g = fma(xw.y, uni_value<NLR>(lds, fc, fp.AVk, fma(-xk, fp.Bk, s_par), sperp2, xk), g);
       }

@@ -15,7 +15,7 @@ namespace vk {
 // n_s * n/64 wavefronts; the point-major kernel above serves every other case.
 // --------------------------------------------------------------------------------------------------
 struct LanesPlan {
-  int smu, xw, total;
+  int smu, total;
 };
 
 __host__ __device__ inline LanesPlan make_lanes_plan(int n_mu, int n_x, int uni_n, int nlr) {
@@ -23,7 +23,6 @@ __host__ __device__ inline LanesPlan make_lanes_plan(int n_mu, int n_x, int uni_
   int o = fast_fixed_doubles(uni_n, nlr);   // exp table + records first (fixed offsets)
   o = (o + 1) & ~1;
   p.smu = o;   o += 2 * n_mu;           // {mu_i, sqrt(1 - mu_i^2)}
-  p.xw = o;    o += 2 * n_x;            // {kExpScale x_k, w_k}: read with a wave-uniform address (LDS broadcast)
   p.total = o;
   return p;
 }
@@ -67,7 +66,7 @@ __device__ __forceinline__ PointScalars point_scalars_lane(const TheoryArgs& a, 
 }
 
 template <int NLR, int NL>
-__global__ __launch_bounds__(kBlock) void vk_theory_lanes_kernel(TheoryArgs a) {
+__global__ __launch_bounds__(kBlock, 5) void vk_theory_lanes_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
   const LanesPlan pl = make_lanes_plan(a.n_mu, a.n_x, a.uni_n, NLR);
   const int tid = threadIdx.x;
@@ -76,10 +75,6 @@ __global__ __launch_bounds__(kBlock) void vk_theory_lanes_kernel(TheoryArgs a) {
     lds[pl.smu + 2 * i] = m;
     lds[pl.smu + 2 * i + 1] = sqrt(1.0 - m * m);
   }
-  for (int k = tid; k < a.n_x; k += kBlock) {
-    lds[pl.xw + 2 * k] = a.x[k] * vkm::kExpScale;
-    lds[pl.xw + 2 * k + 1] = a.w_x[k];
-  }
   stage_uni_records<NLR>(a, lds);
   const FastConsts fc = make_fast_consts(a);
   __syncthreads();
@@ -87,7 +82,10 @@ __global__ __launch_bounds__(kBlock) void vk_theory_lanes_kernel(TheoryArgs a) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const double* l_smu = lds + pl.smu;
-  const double* l_xw = lds + pl.xw;
+  // velocity nodes through the scalar cache: wave-uniform, read-only for the whole launch (constant address space
+  // tells the compiler so), which keeps them out of the VALU and LDS pipes
+  typedef const vk_d2 __attribute__((address_space(4))) * cvec_ptr;
+  const cvec_ptr cxw = (cvec_ptr)(unsigned long long)a.xw_scaled;
   const long long chunks = (a.n + 63) >> 6;
   const long long items = chunks * a.n_s;
   for (long long item = (long long)blockIdx.x * kWaves + wave; item < items; item += (long long)gridDim.x * kWaves) {
@@ -110,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_lanes_kernel(TheoryArgs a) {
       const double s_par = sp * mm.x;
       double g = 0.0;
       for (int k = 0; k < a.n_x; ++k) {
-        const vk_d2 xw = *reinterpret_cast<const vk_d2*>(l_xw + 2 * k);
+        const vk_d2 xw = cxw[k];
         const double xk = xw.x;
         g = fma(xw.y, uni_value<NLR>(lds, fc, fp.AVk, fma(-xk, fp.Bk, s_par), sperp2, xk), g);
       }
