@@ -239,7 +239,11 @@ def main():
         sel = np.linspace(0, B - 1, ns).astype(int)
         base, vals, theory_o = cpu_baseline([cases.point(mine, int(i)) for i in sel])
 
-    fit = victor_amd.CCFFit(model, data, device=dist.local_rank if launched else 0)
+    # one rank per GPU; on a box with fewer GPUs than ranks (rehearsals) ranks share devices and the RCCL communicator
+    # cannot be built, which exercises the host-gather fallback below
+    from victor_amd import _native
+    n_dev = max(_native.load().vk_device_count(), 1)
+    fit = victor_amd.CCFFit(model, data, device=(dist.local_rank % n_dev) if launched else 0)
     eng = fit._get_engine()
     opts = eng.make_opts(fit.model, fit.fit_options)
     rows = fit._fit_rows(mine, fit.model)
@@ -252,20 +256,40 @@ def main():
     d_all = eng.alloc(B * world) if world > 1 or launched else None
     eng.upload(d_rows, rows)
     use_comm = launched
+    host_gather = False
     if use_comm:
         # RCCL logs (version banner, topology warnings) go to stdout by default; stdout is reserved for the JSON line
         os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
         with stdout_to_stderr():
-            uid = eng.comm_unique_id() if rank == 0 else None
+            rccl_ok = 1.0
+            try:
+                uid = eng.comm_unique_id() if rank == 0 else None
+            except Exception as exc:                        # librccl missing: every rank must learn about it
+                print(f"rank {rank}: RCCL unavailable ({exc})", file=sys.stderr)
+                uid, rccl_ok = bytes(128), 0.0
             uid = dist.broadcast_bytes(uid, src=0, nbytes=128)
-            eng.comm_init(uid, rank, world)
-            eng.comm_allgather_async(d_lnl, d_all, B)      # first collective builds the rings (and logs) here
-            eng.sync()
+            rccl_ok = dist.min_float(rccl_ok)
+            if rccl_ok:
+                try:
+                    eng.comm_init(uid, rank, world)
+                    eng.comm_allgather_async(d_lnl, d_all, B)  # first collective builds the rings (and logs) here
+                    eng.sync()
+                except Exception as exc:
+                    print(f"rank {rank}: RCCL communicator failed ({exc})", file=sys.stderr)
+                    rccl_ok = 0.0
+                rccl_ok = dist.min_float(rccl_ok)
+        if not rccl_ok:
+            # degraded mode, reported as such in the JSON line: gather lnL through the host process group
+            use_comm = False
+            host_gather = True
 
     def step():
         eng.eval_device_async(opts, d_rows, B, d_lnl, d_chi, d_ws)
         if use_comm:
             eng.comm_allgather_async(d_lnl, d_all, B)
+        elif host_gather:
+            eng.sync()
+            step.gathered = dist.allgather_host(eng.download(d_lnl, B), B)
 
     warm_up(eng, step)                 # untimed pre-warm (runtime's one-off post-allocation stall), then the W steps
     for _ in range(args.warmup):
@@ -291,6 +315,8 @@ def main():
     if use_comm:
         allv = eng.download(d_all, B * world)
         gathered_ok = bool(np.array_equal(allv[rank * B:(rank + 1) * B], lnl))
+    elif host_gather:
+        gathered_ok = bool(np.array_equal(step.gathered[rank * B:(rank + 1) * B], lnl))
     ok = bool(np.all(np.isfinite(lnl)) and np.all(chi2 > 0))
 
     if rank == 0:
@@ -317,7 +343,8 @@ def main():
             "config": {"workload": "BASELINE config 3: synthetic 40 s x 100 mu x 50 v grid, xi_r l=0,2,4, data l=0,2,4 "
                                    "(N=120), AP-dependent rescale, sigma_v(r) template, gaussian likelihood",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"batch-sharded x{world}",
-                       "gather": "rccl allgather of lnL" if use_comm else "none (single process)"},
+                       "gather": "rccl allgather of lnL" if use_comm else
+                       ("host allgather of lnL (RCCL unavailable)" if host_gather else "none (single process)")},
             "roofline": {"bound": "fp64-valu", "kernel": kernel_name + "<3,3>",
                          "achieved": achieved_tf, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / PEAK_FP64_VALU_TFLOPS if achieved_tf else None,

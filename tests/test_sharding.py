@@ -62,6 +62,7 @@ for n in (1, 2, 9, 1000, 1001):
     want_l, want_c = evaluate(rows)
     assert lnl.shape == (n,) and np.array_equal(lnl, want_l) and np.array_equal(chi2, want_c), n
 t = dist.max_float(1.0 + dist.rank)
+assert dist.min_float(1.0 + dist.rank) == 1.0
 assert t == 2.0
 payload = dist.broadcast_bytes(bytes(range(128)) if dist.rank == 0 else None, src=0, nbytes=128)
 assert payload == bytes(range(128))

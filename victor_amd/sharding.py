@@ -76,6 +76,14 @@ class Dist:
         self.pg.all_reduce(t, op=self.pg.ReduceOp.MAX)
         return float(t[0])
 
+    def min_float(self, x):
+        if self.pg is None or self.world == 1:
+            return float(x)
+        import torch
+        t = torch.tensor([float(x)], dtype=torch.float64)
+        self.pg.all_reduce(t, op=self.pg.ReduceOp.MIN)
+        return float(t[0])
+
     def allgather_host(self, local, chunk):
         """All-gather equal-size host arrays of ``chunk`` doubles per rank -> (world*chunk,)."""
         local = np.ascontiguousarray(local, dtype=np.float64)
