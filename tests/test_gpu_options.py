@@ -232,3 +232,43 @@ def test_special_amplitudes_in_every_fast_mapping(tmp_path, gold):
         for mapping in res:
             assert abs(res[mapping][1][i] / want[1] - 1) < RTOL, (mapping, i)
     assert np.max(np.abs(res["lanes"][1] / res["point"][1] - 1)) < 1e-11
+
+
+def test_offset_commensurate_grids_in_every_fast_mapping(tmp_path):
+    """r and sigma_v grids whose first knots are not multiples of the common spacing: the unified grid then starts
+    below zero (off != 0) and the leading V interval [0.01, r_0] spans a fraction of a refined interval."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import victor_amd
+    import victor_oracle as vo
+    src = np.load(os.path.join(cases.GOLDEN, "synth", "model.npy"), allow_pickle=True).item()
+    r = 1.3 + 3.0 * np.arange(40)
+    rsv = 2.8 + 4.5 * np.arange(26)
+    tab = dict(src, r=r, rsv=rsv, sigmav=np.interp(rsv, src["rsv"], src["sigmav"]))
+    for key in ("monopole", "quadrupole", "hexadecapole"):
+        tab[key] = np.interp(r, src["r"], src[key])
+    np.save(tmp_path / "model_offset.npy", tab, allow_pickle=True)
+    model, data = cases.synth_options(3)
+    model = dict(model, dir=str(tmp_path), input_model_data_file="model_offset.npy")
+    fit = victor_amd.CCFFit(model, data)
+    from victor_amd.engine import build_tables
+    tabs, _keep = build_tables(fit, fit)
+    assert tabs.uni_n > 0 and tabs.uni_u0 < 0 and abs(tabs.uni_u0 + 0.2) < 1e-12     # 1.3 - 1 * 1.5
+    ora = vo.OracleFit(model, data)
+    hp = cases.halton_params(4096 + 5)
+    res = {}
+    for mapping in ("point", "cells", "lanes"):
+        os.environ["VICTOR_HIP_MAPPING"] = mapping
+        try:
+            res[mapping] = fit.log_likelihood_batch(hp)
+            assert fit._get_engine().last_kernel().endswith(
+                {"point": "fast_kernel", "cells": "cells_kernel", "lanes": "lanes_kernel"}[mapping])
+        finally:
+            del os.environ["VICTOR_HIP_MAPPING"]
+    for i in (0, 1, 2047, 4100):
+        want = ora.log_likelihood(cases.point(hp, i))
+        for mapping in res:
+            assert abs(res[mapping][1][i] / want[1] - 1) < RTOL, (mapping, i)
+    assert np.max(np.abs(res["lanes"][1] / res["point"][1] - 1)) < 1e-11
+    assert np.max(np.abs(res["cells"][1] / res["point"][1] - 1)) < 1e-11
