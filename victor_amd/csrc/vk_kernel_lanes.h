@@ -88,7 +88,13 @@ __global__ __launch_bounds__(kBlock, 5) void vk_theory_lanes_kernel(TheoryArgs a
   const cvec_ptr cxw = (cvec_ptr)(unsigned long long)a.xw_scaled;
   const long long chunks = (a.n + 63) >> 6;
   const long long items = chunks * a.n_s;
-  for (long long item = (long long)blockIdx.x * kWaves + wave; item < items; item += (long long)gridDim.x * kWaves) {
+  // XCD-aware block order: the n_s waves of a 64-point chunk read the same 6 KB of parameter rows; consecutive
+  // workgroup ids round-robin over the 8 XCDs (each with a private L2), so give every XCD a contiguous range of
+  // logical ids (bijective for any grid size) and a chunk's rows are fetched from HBM once, not eight times
+  const unsigned nwg = gridDim.x, orig = blockIdx.x;
+  const unsigned xq = nwg >> 3, xr = nwg & 7, xcd = orig & 7;
+  const unsigned bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (orig >> 3);
+  for (long long item = (long long)bid * kWaves + wave; item < items; item += (long long)gridDim.x * kWaves) {
     const long long chunk = item / a.n_s;
     const int j = (int)(item - chunk * a.n_s);
     long long point = chunk * 64 + lane;
