@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 6
+#define VK_ABI_VERSION 7
 
 /* error codes */
 #define VK_OK 0
@@ -126,6 +126,9 @@ typedef struct vk_tables {
                                    V2 = r*Delta*delta, Ge1, Ge2 (numerical-gradient tables of the
                                    empirical_corr branch, ccf_model.py:455-459; /3 folded in)
                            beta-dependent: coef[2][n_beta_r-1][n_int][4][4] = V1, Da              */
+  const double* vr_emp; /* beta-dependent tables only, may be NULL (then empirical_corr is refused):
+                           [3][n_beta_r-1][vr.n_int][4][7] = V2, Ge1, Ge2 as polynomials of degree 6 in
+                           (beta - beta_r[k]) - V2 and Ge2 are products of two PCHIP cubics              */
   double vt_amp;        /* VK_MATTER_VELOCITY_TEMPLATE only: template_hubble_ratio * (1+z_sim)/(1+z_eff) /
                            template_fsigma8 (ccf_model.py:442-443); apar cancels against aH_true       */
   /* ---- velocity dispersion template (ccf_model.py:654-655) ----------------- */

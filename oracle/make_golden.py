@@ -281,7 +281,10 @@ def main():
         "emp_disp": dict(empirical_corr=True, rsd_model="dispersion"),
         "emp_kaiser": dict(empirical_corr=True, rsd_model="kaiser"),
     }
-    for tag, kw in opt_cases.items():
+    boss_extra = dict(lb_emp_stream=dict(matter_model="linear_bias", empirical_corr=True),
+                      lb_emp_disp=dict(matter_model="linear_bias", empirical_corr=True, rsd_model="dispersion"),
+                      lb_emp_kaiser=dict(matter_model="linear_bias", empirical_corr=True, rsd_model="kaiser"))
+    for tag, kw in dict(opt_cases, **boss_extra).items():
         out[f"opt_boss_{tag}"] = np.array([fit.theory_multipole_vector(fit.s, dict(q), fit.poles_s, **kw) for q in pts3])
     # fixed real-space input (synthetic tables): linear_bias with and without the empirical correction
     model, data = synth_options(3)

@@ -34,12 +34,25 @@ def test_boss_beta_dependent_tables(gold):
     g, meta = gold
     fit = victor_amd.CCFFit(*cases.boss_options("config"))
     pts = [dict(q, bias=2.1, Av=0.7, M=1.05, Q=0.95) for q in meta["boss_points"][:3]]
-    for tag, kw in OPT.items():
+    # linear_bias + empirical_corr on beta-dependent tables: V2 and Ge2 are degree-6 polynomials in beta (vr_emp)
+    opt = dict(OPT, lb_emp_stream=dict(matter_model="linear_bias", empirical_corr=True),
+               lb_emp_disp=dict(matter_model="linear_bias", empirical_corr=True, rsd_model="dispersion"),
+               lb_emp_kaiser=dict(matter_model="linear_bias", empirical_corr=True, rsd_model="kaiser"))
+    for tag, kw in opt.items():
         t = np.array([fit.theory_multipole_vector(fit.s, dict(q), fit.poles_s, **kw) for q in pts])
         assert close(t, g[f"opt_boss_{tag}"]), tag
-    from victor_amd import InputError
-    with pytest.raises(InputError):       # not implemented: needs products of beta polynomials
-        fit.theory_multipole_vector(fit.s, dict(pts[0]), fit.poles_s, matter_model="linear_bias", empirical_corr=True)
+    # beta outside the grid (PCHIP extrapolation with the end pieces) against the live oracle
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import victor_oracle as vo
+    ora = vo.OracleFit(*cases.boss_options("config"))
+    for beta in (0.12, 0.70):
+        q = dict(pts[1], beta=beta)
+        kw = dict(matter_model="linear_bias", empirical_corr=True)
+        want = ora.theory_multipole_vector(ora.s, dict(q), ora.poles_s, **kw)
+        got = fit.theory_multipole_vector(fit.s, dict(q), fit.poles_s, **kw)
+        assert close(got, want), beta
 
 
 def test_synthetic_fixed_tables(gold):

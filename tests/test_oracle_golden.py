@@ -124,3 +124,27 @@ def test_covariance_bracket_quirk(boss):
     assert np.array_equal(boss._interp_stack(boss.icov, 0.1), boss.icov[0])
     assert np.array_equal(boss._interp_stack(boss.icov, 0.7), boss.icov[-1])
     assert np.array_equal(boss._interp_stack(boss.icov, g[5]), boss.icov[5])
+
+
+def test_model_options_match_reference(boss, gold):
+    """SURVEY 8(f3) options on the oracle: linear_bias, empirical_corr and both together, every RSD branch
+    (reference outputs: 'opt_boss_*' / 'opt_synth_*' keys of ref_outputs.npz)."""
+    g, meta = gold
+    base = {"lb": dict(matter_model="linear_bias"), "emp": dict(empirical_corr=True),
+            "lb_emp": dict(matter_model="linear_bias", empirical_corr=True)}
+    rsd = {"stream": {}, "disp": dict(rsd_model="dispersion"), "kaiser": dict(rsd_model="kaiser")}
+    pts = [dict(q, bias=2.1, Av=0.7, M=1.05, Q=0.95) for q in meta["boss_points"][:3]]
+    synth = vo.OracleFit(*cases.synth_options(3))
+    spts = [dict(q, beta=0.4, bias=1.7, Av=-0.5, M=1.1, Q=0.9) for q in meta["synth_points"][:3]]
+    checked = 0
+    for b, bkw in base.items():
+        for r, rkw in rsd.items():
+            kw = dict(bkw, **rkw)
+            for fit, points, prefix in ((boss, pts, "opt_boss"), (synth, spts, "opt_synth")):
+                key = f"{prefix}_{b}_{r}"
+                if key not in g:
+                    continue
+                t = np.array([fit.theory_multipole_vector(fit.s, dict(q), fit.poles_s, **kw) for q in points])
+                assert np.max(np.abs(t - g[key])) <= TOL * np.max(np.abs(g[key])), key
+                checked += 1
+    assert checked >= 17

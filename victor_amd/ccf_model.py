@@ -342,9 +342,6 @@ class CCFModel:
                 raise InputError("velocity_terms: Cannot use template option as no template has been supplied.")
         elif model["mean_model"] != "linear":
             problems.append(f"velocity mean model '{model['mean_model']}'")
-        if (model["empirical_corr"] and model["mean_model"] == "linear" and model["matter_model"] == "linear_bias"
-                and not self.fixed_real_input):
-            problems.append("empirical_corr together with linear_bias on a beta-dependent real-space ccf")
         if model["rsd_model"] not in N.RSD:
             raise InputError(f"theory_xi: Unrecognised choice of model {model['rsd_model']}")
         if problems:

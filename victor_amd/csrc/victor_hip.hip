@@ -54,6 +54,7 @@ struct vk_ctx {
   double* d_tables = nullptr;  // one allocation holding every table
   // device pointers into d_tables
   const double *d_x1 = nullptr, *d_w1 = nullptr;  // single velocity node for the Kaiser-type models
+  const double* d_vr_emp = nullptr;               // beta-dependent V2, Ge1, Ge2 (degree 6 in beta), see vk_tables.vr_emp
   const double* d_xws = nullptr;                  // [n_x + 1][2]: {kExpScale x_k, w_k}, scalar-cache reads (fast kernels)
   const double *d_s = nullptr, *d_mu = nullptr, *d_w = nullptr, *d_x = nullptr, *d_wx = nullptr, *d_beta_r = nullptr,
                *d_beta_d = nullptr, *d_data = nullptr, *d_beta_c = nullptr, *d_prec = nullptr, *d_logdet = nullptr,
@@ -235,10 +236,11 @@ int theory_args(vk_ctx* ctx, const vk_eval_opts* o, TheoryArgs* a, int* nlr) {
   a->uni_xi = ctx->d_uni_xi;
   a->uni_xic = ctx->d_uni_xic;
   a->vr_beta_dep = ctx->vr_beta_dep;
+  a->vr_emp = ctx->d_vr_emp;
   a->from_data = o->from_data ? 1 : 0;
   a->empirical = (o->empirical_corr && !ctx->matter_vt) ? 1 : 0;   // the template-mean branch ignores Av (ccf_model.py:483-490)
-  if (a->empirical && a->vr_beta_dep)
-    return fail(ctx, VK_E_ARG, "empirical_corr with a beta-dependent linear_bias velocity profile is not implemented");
+  if (a->empirical && a->vr_beta_dep && !a->vr_emp)
+    return fail(ctx, VK_E_ARG, "empirical_corr with a beta-dependent velocity profile needs vk_tables.vr_emp");
   a->rsd = o->rsd_model;
   a->niter = o->niter;
   a->kaiser_approx = o->kaiser_approx;
@@ -549,6 +551,8 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
   const size_t o_xik = up.add(t->xi.knots, t->xi.n_int + 1), o_xic = up.add(t->xi.coef, xi_coef_n);
   const size_t vr_coef_n = t->vr_beta_dep ? (size_t)2 * (t->n_beta_r - 1) * t->vr.n_int * 16 : (size_t)kVrVars * t->vr.n_int * 4;
   const size_t o_vrk = up.add(t->vr.knots, t->vr.n_int + 1), o_vrc = up.add(t->vr.coef, vr_coef_n);
+  const bool have_vr_emp = t->vr_beta_dep && t->vr_emp;
+  const size_t o_vre = have_vr_emp ? up.add(t->vr_emp, (size_t)3 * (t->n_beta_r - 1) * t->vr.n_int * 28) : 0;
   const size_t o_svk = up.add(t->sv.knots, t->sv.n_int + 1),
                o_svc = up.add(t->sv.coef, t->sv_n_mu ? 4 : (size_t)t->sv.n_int * 4);   // 1-D coefficients unused with sv2d
   size_t o_svmu = 0, o_sv2d = 0;
@@ -597,6 +601,7 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
   };
   ctx->xi = view(t->xi, o_xik, o_xic);
   ctx->vr = view(t->vr, o_vrk, o_vrc);
+  ctx->d_vr_emp = have_vr_emp ? base + o_vre : nullptr;
   ctx->sv = view(t->sv, o_svk, o_svc);
   if (t->uni_n > 0 && t->uni_sv_v && t->uni_xi && t->uni_xic) {
     ctx->uni_n = t->uni_n;

@@ -52,6 +52,7 @@ struct TheoryArgs {
   const double* uni_xic;  // Legendre sum regrouped in powers of mu_r^2 (anisotropic sum)
   int matter_lb;          // linear_bias matter model: amplitudes carry 1/bias (ccf_model.py:358-370,426-435)
   int vr_beta_dep;        // velocity tables are PCHIP-in-beta polynomials (rebuilt per point)
+  const double* vr_emp;   // [3][n_beta_r-1][vr.n_int][4][7]: V2, Ge1, Ge2 of the empirical_corr branch, degree 6 in beta
   int from_data;          // ccf_model.py:618-619,675-679
   int empirical;          // ccf_model.py:451-459
   int rsd;                // VK_RSD_*

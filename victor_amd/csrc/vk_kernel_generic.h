@@ -239,6 +239,18 @@ __device__ void build_beta_tables(const TheoryArgs& a, const LdsPlan& pl, double
       const double* c = a.vr.coef + var * stride_v + ((size_t)k * per_v + iq) * 4;
       lds[pl.vrc + e] = fma(fma(fma(c[3], db, c[2]), db, c[1]), db, c[0]);
     }
+    if (a.empirical) {   // V2 = r Delta delta, Ge1, Ge2: products of PCHIP cubics -> degree 6 in beta (ccf_model.py:451-459)
+      const size_t stride_e = (size_t)(a.n_beta_r - 1) * per_v * 7;
+      for (int e = threadIdx.x; e < 3 * per_v; e += kBlock) {
+        const int var = e / per_v;
+        const int iq = e - var * per_v;
+        const double* c = a.vr_emp + var * stride_e + ((size_t)k * per_v + iq) * 7;
+        double v = c[6];
+#pragma unroll
+        for (int p = 5; p >= 0; --p) v = fma(v, db, c[p]);
+        lds[pl.vrc + 2 * per_v + e] = v;
+      }
+    }
   }
 }
 

@@ -95,6 +95,9 @@ def build_tables(model, fit=None, matter_model=None):
     t.vr_beta_dep = 1 if vr_beta_dep else 0
     t.vr, k = _pp(r_ext, vr_coef, lead=1)
     keep.append(k)
+    if vr_beta_dep:
+        vr_emp = arr(VT.empirical_beta_tables(model))
+        t.vr_emp = N.as_dp(vr_emp)
 
     if matter_model == "velocity_template":
         t.vt_amp = float(model.template_hubble_ratio * (1 + model.z_sim) / (1 + model.z_eff) / model.template_fsigma8)

@@ -51,11 +51,48 @@ def empirical_gradient_tables(model, r_ext, delta_ext, int_delta_ext):
     return g1, g2
 
 
+def _poly_mul(a, b):
+    """Product of polynomials stored along axis 1: (k, pa, n) x (k, pb, n) -> (k, pa + pb - 1, n)."""
+    out = np.zeros((a.shape[0], a.shape[1] + b.shape[1] - 1, a.shape[2]))
+    for i in range(a.shape[1]):
+        for j in range(b.shape[1]):
+            out[:, i + j] += a[:, i] * b[:, j]
+    return out
+
+
+def empirical_beta_tables(model):
+    """beta-dependent counterpart of V2, Ge1, Ge2 for linear_bias on a reconstructed real-space ccf.
+
+    delta and Delta at the nodes are PCHIP cubics in (beta - beta_k); every later step of ccf_model.py:451-459
+    (splines onto the gradient grid, np.gradient, splines back) is linear, so V2 = r Delta delta and Ge2 are
+    polynomials of degree 6 and Ge1 one of degree 3 (stored with zero high coefficients).
+    Returns (3, n_beta-1, n_r, 4, 7): spline coefficient of (u - r_i)^q times (beta - beta_k)^p.
+    """
+    r_ext = np.append([0.01], np.asarray(model.r, dtype=float))
+    Bd, Td = linear_bias_maps(model, r_ext)
+    ypoly = T.pchip_coefficients(model.beta, model.real_multipoles["0"])       # (n_beta-1, 4, n_r)
+    d_poly = np.einsum("nm,kpm->kpn", Bd, ypoly)
+    D_poly = np.einsum("nm,kpm->kpn", Td, ypoly)
+    rg = np.linspace(0.1, np.max(model.r), 100)
+    to_rg = T.notaknot(r_ext, np.eye(len(r_ext)))(rg)                          # (100, n_ext)
+    back = T.notaknot(rg, np.gradient(np.eye(len(rg)), rg, axis=0))(r_ext)     # (n_ext, 100): gradient, then spline
+    Ds = np.einsum("gn,kpn->kpg", to_rg, D_poly)
+    ds = np.einsum("gn,kpn->kpg", to_rg, d_poly)
+    g1 = np.einsum("ng,kpg->kpn", back, rg * Ds)                               # degree 3
+    g2 = np.einsum("ng,kpg->kpn", back, rg * _poly_mul(Ds, ds))                # degree 6
+    v2 = r_ext * _poly_mul(D_poly, d_poly)
+    g1 = np.concatenate([g1, np.zeros((g1.shape[0], 3, g1.shape[2]))], axis=1)
+    return np.stack([T.spline_table_from_beta_poly(r_ext, v2),
+                     T.spline_table_from_beta_poly(r_ext, g1 / 3),
+                     T.spline_table_from_beta_poly(r_ext, g2 / 3)])
+
+
 def velocity_tables(model, matter_model):
     """Coefficient arrays of the velocity tables on r_ext = [0.01, r...] for one matter model.
 
     Returns ``(coef, beta_dependent)``: fixed -> (5, n_r, 4) for V1 = r*Delta, Da = delta - 2 Delta/3,
-    V2 = r*Delta*delta, Ge1, Ge2; beta-dependent -> (2, n_beta-1, n_r, 4, 4) for V1, Da.
+    V2 = r*Delta*delta, Ge1, Ge2; beta-dependent -> (2, n_beta-1, n_r, 4, 4) for V1, Da (the other three:
+    ``empirical_beta_tables``).
     """
     r_ext = np.append([0.01], np.asarray(model.r, dtype=float))
     if matter_model == "velocity_template":
