@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 7
+#define VK_ABI_VERSION 8
 
 /* error codes */
 #define VK_OK 0
@@ -155,6 +155,15 @@ typedef struct vk_tables {
   const double* uni_xic;/* same shape, the Legendre sum regrouped in powers of m = mu_r^2 (n_ell_r >= 2 only):
                            sum_l xi_l P_l(mu_r) = A + m B + m^2 C with A = xi_0 - xi_2/2 + 3 xi_4/8,
                            B = 3 xi_2/2 - 15 xi_4/4, C = 35 xi_4/8; used when the anisotropic sum is asked for  */
+  /* Union-grid form of the same tables for knots that are not uniform or not commensurate: uni_n intervals between
+   * the sorted distinct knots uni_knots[0..uni_n] of vr (uni_knots[0] = vr.knots[0] = 0.01), xi and sv; the
+   * coefficient arrays above are then in units of each interval's own width.  A uniform look-up table of
+   * uni_lut_n cells over [0, uni_knots[uni_n]) locates the interval: every cell holds at most one interior knot and
+   * uni_lut[c] is the interval that contains the cell's left edge.  uni_u0 / uni_inv_h are unused in this form.   */
+  int32_t uni_lut_n;      /* 0: uniform-lattice form.  > 0: union-grid form, number of look-up cells (<= 4096)  */
+  double uni_lut_inv_g;   /* cells per unit length: uni_lut_n / uni_knots[uni_n]                                */
+  const uint16_t* uni_lut;/* [uni_lut_n]                                                                        */
+  const double* uni_knots;/* [uni_n + 1]                                                                        */
 
   double iaH;           /* (1+z)/(100 E(z)) (ccf_model.py:43-45)               */
   double template_sigma8; /* ccf_model.py:432-435                              */

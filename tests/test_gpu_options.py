@@ -285,3 +285,46 @@ def test_offset_commensurate_grids_in_every_fast_mapping(tmp_path):
             assert abs(res[mapping][1][i] / want[1] - 1) < RTOL, (mapping, i)
     assert np.max(np.abs(res["lanes"][1] / res["point"][1] - 1)) < 1e-11
     assert np.max(np.abs(res["cells"][1] / res["point"][1] - 1)) < 1e-11
+
+
+def test_non_uniform_grids_in_every_fast_mapping(tmp_path):
+    """Jittered r and sigma_v grids (neither uniform nor commensurate): the unified tables take their union-grid form
+    (look-up table + one knot comparison) and every fast mapping must agree with the oracle and the generic kernel."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import victor_amd
+    import victor_oracle as vo
+    from victor_amd.engine import build_tables
+    src = np.load(os.path.join(cases.GOLDEN, "synth", "model.npy"), allow_pickle=True).item()
+    rng = np.random.default_rng(11)
+    r = src["r"] + rng.uniform(-0.9, 0.9, len(src["r"]))
+    rsv = src["rsv"] + rng.uniform(-2.0, 2.0, len(src["rsv"]))
+    tab = dict(src, r=r, rsv=rsv, sigmav=np.interp(rsv, src["rsv"], src["sigmav"]))
+    for key in ("monopole", "quadrupole", "hexadecapole"):
+        tab[key] = np.interp(r, src["r"], src[key])
+    np.save(tmp_path / "model_jitter.npy", tab, allow_pickle=True)
+    model, data = cases.synth_options(3)
+    model = dict(model, dir=str(tmp_path), input_model_data_file="model_jitter.npy")
+    fit = victor_amd.CCFFit(model, data)
+    tabs, _keep = build_tables(fit, fit)
+    assert tabs.uni_n == len(r) + len(rsv) and tabs.uni_lut_n >= 64
+    ora = vo.OracleFit(model, data)
+    hp = cases.halton_params(4096 + 5)
+    res = {}
+    for mapping in ("point", "cells", "lanes", "generic"):
+        env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
+        os.environ[env] = "1" if mapping == "generic" else mapping
+        try:
+            res[mapping] = fit.log_likelihood_batch(hp)
+            assert fit._get_engine().last_kernel().endswith(
+                {"point": "fast_kernel", "cells": "cells_kernel", "lanes": "lanes_kernel",
+                 "generic": "vk_theory_kernel"}[mapping])
+        finally:
+            del os.environ[env]
+    for i in (0, 1, 2047, 4100):
+        want = ora.log_likelihood(cases.point(hp, i))
+        for mapping in res:
+            assert abs(res[mapping][1][i] / want[1] - 1) < RTOL, (mapping, i)
+    for mapping in ("cells", "lanes", "generic"):
+        assert np.max(np.abs(res[mapping][1] / res["point"][1] - 1)) < 1e-10, mapping

@@ -42,4 +42,8 @@ for k in ("data_file",):
 dd["dir"] = ""
 m["dir"] = tmp; m["input_model_data_file"] = "jitter.npy"
 fitj = victor_amd.CCFFit(m, dd)
-run(fitj, "config 3, jittered r grid (nearly uniform)")
+a = run(fitj, "config 3, jittered r grid: union-grid fast path")
+os.environ["VICTOR_HIP_FORCE_GENERIC"] = "1"
+b = run(fitj, "config 3, jittered r grid: generic kernel")
+del os.environ["VICTOR_HIP_FORCE_GENERIC"]
+print("max rel diff", np.max(np.abs(a / b - 1)))

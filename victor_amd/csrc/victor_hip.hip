@@ -67,6 +67,10 @@ struct vk_ctx {
   int uni_n = 0;             // unified refined grid (fast kernels need it)
   double uni_u0 = 0, uni_inv_h = 0;
   const double *d_uni_sv_v = nullptr, *d_uni_xi = nullptr, *d_uni_xic = nullptr;
+  int uni_lut_n = 0;         // > 0: union-grid form of the unified tables
+  double uni_lut_inv_g = 0;
+  const unsigned short* d_uni_lut = nullptr;
+  const double* d_uni_knots = nullptr;
   const char* last_kernel = "none";  // theory kernel variant of the most recent launch
   // scratch for the host-buffer entry points
   double* d_scratch = nullptr;
@@ -164,12 +168,29 @@ int launch_generic(vk_ctx* ctx, const TheoryArgs& a, int nlr, int grid, size_t l
   return fail(ctx, VK_E_ARG, "bad number of real-space multipoles %d", nlr);
 }
 
+template <int NLR, int GRID>
+int launch_fast_ng(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
+  switch (a.n_ell) {
+    case 1: hipLaunchKernelGGL((vk_theory_fast_kernel<NLR, 1, GRID>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+    case 2: hipLaunchKernelGGL((vk_theory_fast_kernel<NLR, 2, GRID>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+    case 3: hipLaunchKernelGGL((vk_theory_fast_kernel<NLR, 3, GRID>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+    default: return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
+  }
+  VK_HIP(ctx, hipGetLastError());
+  return VK_OK;
+}
+
 template <int NLR>
 int launch_fast_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
+  return a.uni_lut_n > 0 ? launch_fast_ng<NLR, 1>(ctx, a, grid, lds) : launch_fast_ng<NLR, 0>(ctx, a, grid, lds);
+}
+
+template <int NLR, int GRID>
+int launch_lanes_ng(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: hipLaunchKernelGGL((vk_theory_fast_kernel<NLR, 1>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-    case 2: hipLaunchKernelGGL((vk_theory_fast_kernel<NLR, 2>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-    case 3: hipLaunchKernelGGL((vk_theory_fast_kernel<NLR, 3>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+    case 1: hipLaunchKernelGGL((vk_theory_lanes_kernel<NLR, 1, GRID>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+    case 2: hipLaunchKernelGGL((vk_theory_lanes_kernel<NLR, 2, GRID>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+    case 3: hipLaunchKernelGGL((vk_theory_lanes_kernel<NLR, 3, GRID>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
     default: return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
   }
   VK_HIP(ctx, hipGetLastError());
@@ -178,10 +199,15 @@ int launch_fast_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
 
 template <int NLR>
 int launch_lanes_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
+  return a.uni_lut_n > 0 ? launch_lanes_ng<NLR, 1>(ctx, a, grid, lds) : launch_lanes_ng<NLR, 0>(ctx, a, grid, lds);
+}
+
+template <int NLR, int GRID>
+int launch_cells_ng(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: hipLaunchKernelGGL((vk_theory_lanes_kernel<NLR, 1>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-    case 2: hipLaunchKernelGGL((vk_theory_lanes_kernel<NLR, 2>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-    case 3: hipLaunchKernelGGL((vk_theory_lanes_kernel<NLR, 3>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+    case 1: hipLaunchKernelGGL((vk_theory_cells_kernel<NLR, 1, GRID>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+    case 2: hipLaunchKernelGGL((vk_theory_cells_kernel<NLR, 2, GRID>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
+    case 3: hipLaunchKernelGGL((vk_theory_cells_kernel<NLR, 3, GRID>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
     default: return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
   }
   VK_HIP(ctx, hipGetLastError());
@@ -190,14 +216,7 @@ int launch_lanes_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
 
 template <int NLR>
 int launch_cells_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
-  switch (a.n_ell) {
-    case 1: hipLaunchKernelGGL((vk_theory_cells_kernel<NLR, 1>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-    case 2: hipLaunchKernelGGL((vk_theory_cells_kernel<NLR, 2>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-    case 3: hipLaunchKernelGGL((vk_theory_cells_kernel<NLR, 3>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-    default: return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
-  }
-  VK_HIP(ctx, hipGetLastError());
-  return VK_OK;
+  return a.uni_lut_n > 0 ? launch_cells_ng<NLR, 1>(ctx, a, grid, lds) : launch_cells_ng<NLR, 0>(ctx, a, grid, lds);
 }
 
 template <int RSD>
@@ -235,6 +254,10 @@ int theory_args(vk_ctx* ctx, const vk_eval_opts* o, TheoryArgs* a, int* nlr) {
   a->uni_sv_v = ctx->d_uni_sv_v;
   a->uni_xi = ctx->d_uni_xi;
   a->uni_xic = ctx->d_uni_xic;
+  a->uni_lut_n = ctx->uni_lut_n;
+  a->uni_lut_inv_g = ctx->uni_lut_inv_g;
+  a->uni_lut = ctx->d_uni_lut;
+  a->uni_knots = ctx->d_uni_knots;
   a->vr_beta_dep = ctx->vr_beta_dep;
   a->vr_emp = ctx->d_vr_emp;
   a->from_data = o->from_data ? 1 : 0;
@@ -267,7 +290,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
                     a.n_mu <= 1024 && a.n_x <= 2048 && !getenv("VICTOR_HIP_FORCE_GENERIC");
   size_t lds;
   if (fast) {
-    lds = (size_t)make_fast_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.n_beta_r).total * sizeof(double);
+    lds = (size_t)make_fast_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n).total * sizeof(double);
   } else {
     lds = (size_t)make_plan(a.n_mu, a.n_x, a.n_ell, a.sv.n_int, a.vr.n_int, a.xi.n_int, nlr, a.n_beta_r).total *
           sizeof(double);
@@ -293,7 +316,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   const bool lanes = lanes_ok && (mapping ? !strcmp(mapping, "lanes") : fill >= 0.85);
   if (lanes) {
     ctx->last_kernel = "vk_theory_lanes_kernel";
-    const size_t lds_l = (size_t)make_lanes_plan(a.n_mu, a.n_x, a.uni_n, nlr).total * sizeof(double);
+    const size_t lds_l = (size_t)make_lanes_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.uni_lut_n).total * sizeof(double);
     const long long blocks = (waves + kWaves - 1) / kWaves;
     // Many more workgroups than fit at once: letting the dispatcher refill CUs as workgroups retire measured
     // 38.1 / 36.0 / 34.6 / 33.8 ms at 4 / 8 / 16 / 64 workgroups per CU on the bench workload (4 are resident)
@@ -313,7 +336,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   if (cells) {
     ctx->last_kernel = "vk_theory_cells_kernel";
     const size_t lds_c =
-        (size_t)make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, nlr, a.n_beta_r).total * sizeof(double);
+        (size_t)make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n).total * sizeof(double);
     if (lds_c > 160 * 1024) return fail(ctx, VK_E_ARG, "tables need %zu bytes of LDS (> 160 KiB)", lds_c);
     const long long capc = (pcap_env ? atoll(pcap_env) : 64LL) * ctx->n_cu;
     const int grid_c = (int)(a.n < capc ? a.n : capc);
@@ -518,15 +541,20 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
   ctx->n_beta_c = t->data ? t->n_beta_c : 0;
 
   {
-    bool ok = t->xi.inv_h > 0 && t->xi.lead == 0 && t->sv.inv_h > 0 && t->sv.lead == 0 && t->vr.inv_h > 0 &&
-              t->vr.lead == 1 && t->vr.n_int == t->xi.n_int + 1;
-    if (ok) {
-      const double tol = 1e-12 * fabs(t->xi.knots[t->xi.n_int]);
-      for (int i = 0; i <= t->xi.n_int && ok; ++i) ok = fabs(t->vr.knots[i + 1] - t->xi.knots[i]) <= tol;
-      ok = ok && fabs(t->vr.inv_h - t->xi.inv_h) <= 1e-12 * t->xi.inv_h;
+    // the fast theory kernels need the unified tables: either the uniform-lattice form (uniform, commensurate knot
+    // sets sharing the r grid between xi and V) or the union-grid form (any knots) located through a look-up table
+    bool ok = !t->vr_beta_dep && t->sv_n_mu == 0 && t->uni_n > 0 && t->uni_sv_v && t->uni_xi && t->uni_xic &&
+              t->xi.knots[0] > t->vr.knots[0] && t->sv.knots[0] >= t->vr.knots[0];
+    if (ok && t->uni_lut_n > 0) {
+      ok = t->uni_lut && t->uni_knots && t->uni_lut_n <= 4096 && t->uni_n < 4096 && t->uni_lut_inv_g > 0 &&
+           t->uni_knots[0] == t->vr.knots[0];
+      for (int q = 0; q < t->uni_n && ok; ++q) ok = t->uni_knots[q + 1] > t->uni_knots[q];
+      for (int c = 0; c < t->uni_lut_n && ok; ++c) ok = t->uni_lut[c] < t->uni_n;
+    } else if (ok) {
+      ok = t->xi.inv_h > 0 && t->xi.lead == 0 && t->sv.inv_h > 0 && t->sv.lead == 0 && t->vr.inv_h > 0 &&
+           t->vr.lead == 1 && t->vr.n_int == t->xi.n_int + 1 && t->uni_inv_h > 0 && t->uni_u0 <= t->vr.knots[0];
     }
-    ctx->fast_ok = ok && !t->vr_beta_dep && t->sv_n_mu == 0 && t->uni_n > 0 && t->uni_sv_v && t->uni_xi && t->uni_xic &&
-                   t->uni_inv_h > 0 && t->uni_u0 <= t->vr.knots[0] && t->sv.knots[0] >= t->vr.knots[0];
+    ctx->fast_ok = ok;
     ctx->matter_vt = t->matter_model == VK_MATTER_VELOCITY_TEMPLATE;
     ctx->vt_amp = t->vt_amp;
     ctx->matter_lb = t->matter_model == VK_MATTER_LINEAR_BIAS;
@@ -560,7 +588,14 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
     o_svmu = up.add(t->sv_mu, t->sv_n_mu);
     o_sv2d = up.add(t->sv2d, (size_t)t->sv.n_int * (t->sv_n_mu - 1) * 16);
   }
-  size_t o_usv = 0, o_uxi = 0, o_uxc = 0;
+  size_t o_usv = 0, o_uxi = 0, o_uxc = 0, o_ulut = 0, o_uk = 0;
+  const bool have_lut = t->uni_n > 0 && t->uni_lut_n > 0 && t->uni_lut && t->uni_knots;
+  if (have_lut) {
+    std::vector<double> packed(((size_t)t->uni_lut_n + 3) / 4, 0.0);        // u16 cells travel inside the double arena
+    memcpy(packed.data(), t->uni_lut, (size_t)t->uni_lut_n * sizeof(uint16_t));
+    o_ulut = up.add(packed.data(), packed.size());
+    o_uk = up.add(t->uni_knots, (size_t)t->uni_n + 1);
+  }
   if (t->uni_n > 0 && t->uni_sv_v && t->uni_xi && t->uni_xic) {
     o_usv = up.add(t->uni_sv_v, (size_t)t->uni_n * 8);
     o_uxi = up.add(t->uni_xi, t->n_beta_r > 0 ? (size_t)t->n_ell_r * (t->n_beta_r - 1) * t->uni_n * 16
@@ -610,6 +645,12 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
     ctx->d_uni_sv_v = base + o_usv;
     ctx->d_uni_xi = base + o_uxi;
     ctx->d_uni_xic = base + o_uxc;
+    if (have_lut) {
+      ctx->uni_lut_n = t->uni_lut_n;
+      ctx->uni_lut_inv_g = t->uni_lut_inv_g;
+      ctx->d_uni_lut = reinterpret_cast<const unsigned short*>(base + o_ulut);
+      ctx->d_uni_knots = base + o_uk;
+    }
   }
   ctx->sv_n_mu = t->sv_n_mu;
   ctx->sv_mu_inv_h = t->sv_mu_inv_h;

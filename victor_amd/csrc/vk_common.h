@@ -50,6 +50,10 @@ struct TheoryArgs {
   const double* uni_sv_v;
   const double* uni_xi;
   const double* uni_xic;  // Legendre sum regrouped in powers of mu_r^2 (anisotropic sum)
+  int uni_lut_n;          // > 0: union-grid form (arbitrary knots), cells of the look-up table
+  double uni_lut_inv_g;
+  const unsigned short* uni_lut;
+  const double* uni_knots;  // [uni_n + 1]
   int matter_lb;          // linear_bias matter model: amplitudes carry 1/bias (ccf_model.py:358-370,426-435)
   int vr_beta_dep;        // velocity tables are PCHIP-in-beta polynomials (rebuilt per point)
   const double* vr_emp;   // [3][n_beta_r-1][vr.n_int][4][7]: V2, Ge1, Ge2 of the empirical_corr branch, degree 6 in beta

@@ -17,9 +17,10 @@ struct CellsPlan {
   int mu, w, s, betar, acc, total;
 };
 
-__host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s, int uni_n, int nlr, int n_beta_r) {
+__host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s, int uni_n, int nlr, int n_beta_r,
+                                                     int lut_n) {
   CellsPlan p;
-  int o = fast_fixed_doubles(uni_n, nlr);          // exp table + records first (fixed offsets)
+  int o = fast_fixed_doubles(uni_n, nlr, lut_n);          // exp table + records first (fixed offsets)
   o = (o + 1) & ~1;
   p.mu = o;    o += 2 * n_mu;                      // {mu_i, sqrt(1 - mu_i^2)}
   p.w = o;     o += kMaxEll * n_mu;                // W_l[i]
@@ -31,10 +32,10 @@ __host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s,
 }
 
 // (130 VGPRs -> 3 waves per SIMD; forcing 4 with __launch_bounds__(256, 4) spills and measured 1.5 % slower)
-template <int NLR, int NL>
+template <int NLR, int NL, int GRID>
 __global__ __launch_bounds__(kBlock, 5) void vk_theory_cells_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
-  const CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r);
+  const CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n);
   const int tid = threadIdx.x;
   for (int i = tid; i < a.n_mu; i += kBlock) {
     const double m = a.mu[i];
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(kBlock, 5) void vk_theory_cells_kernel(TheoryArgs a
   stage_uni_records<NLR>(a, lds);
   if (a.n_beta_r > 0)
     for (int i = tid; i < a.n_beta_r; i += kBlock) lds[pl.betar + i] = a.beta_r[i];
-  const FastConsts fc = make_fast_consts(a);
+  const FastConsts fc = make_fast_consts<NLR>(a);
   __syncthreads();
 
   const int lane = tid & 63;
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(kBlock, 5) void vk_theory_cells_kernel(TheoryArgs a
       for (int k = 0; k < a.n_x; ++k) {
         const vk_d2 xw = cxw[k];             // scalar-cache read (wave-uniform), see vk_kernel_lanes.h
         const double xk = xw.x;
-        g = fma(xw.y, uni_value<NLR>(lds, fc, fp.AVk, fma(-xk, fp.Bk, s_par), sperp2, xk), g);
+        g = fma(xw.y, uni_value<NLR, GRID>(lds, fc, fp.AVk, fma(-xk, fp.Bk, s_par), sperp2, xk), g);
       }
       if (!live) g = 0.0;
       // projection: this trip's cells belong to s bin jj0 or jj0 + 1

@@ -29,11 +29,21 @@ constexpr int kEtabOff = 0;                  // doubles
 constexpr int kRecsOff = vkm::kExpTab;
 
 __host__ __device__ constexpr int uni_stride(int nlr) { return 4 * (2 + nlr) + 2; }   // doubles per refined interval
-__host__ __device__ constexpr int fast_fixed_doubles(int uni_n, int nlr) { return kRecsOff + uni_n * uni_stride(nlr); }
+// exp table + records (+ one sentinel record and the u16 look-up table of the union-grid mode), at fixed offsets
+__host__ __device__ constexpr int fast_fixed_doubles(int uni_n, int nlr, int lut_n) {
+  return kRecsOff + (uni_n + (lut_n > 0 ? 1 : 0)) * uni_stride(nlr) + (lut_n + 3) / 4;
+}
 
+// GRID = 0: the unified grid is a uniform lattice (index arithmetic).  GRID = 1: it is the union of arbitrary knot
+// sets (vk_tables.uni_lut_n > 0): a u16 look-up table gives the interval of the cell's left edge, one comparison with
+// the next knot (kept in the pad slot of the next record) corrects it, and the record's own pad holds its left knot
+// and 1/width for the local coordinate.  Costs 6 more VALU instructions and two more LDS reads per integrand point.
 struct FastConsts {
-  double inv_h;                   // callers form k = inv_h / c per point and scale their lengths by it
-  double off, t_lo, n_eps;        // t = r' + off, clamped to [t_lo, n_eps]; t_lo is u = 0.01, the first V knot
+  double inv_h;                   // callers form k = inv_h / c per point and scale their lengths by it (GRID 1: 1)
+  double off, t_lo, n_eps;        // GRID 0: t = r' + off, clamped to [t_lo, n_eps]; t_lo is u = 0.01, the first V knot
+                                  // GRID 1: u = r' clamped to [t_lo, n_eps] = [first knot, last knot)
+  double inv_g;                   // GRID 1: cells of the look-up table per unit length
+  int lut_off;                    // GRID 1: byte offset of the look-up table in LDS
 };
 
 // v_min_f64 / v_max_f64 without the canonicalising v_max hipcc puts in front of fmin()/fmax() for a bound it cannot
@@ -59,12 +69,24 @@ __device__ __forceinline__ double cubic_b128(const double* rec, double t) {
   return fma(fma(fma(hi.y, t, hi.x), t, lo.y), t, lo.x);
 }
 
+template <int NLR>
 __device__ __forceinline__ FastConsts make_fast_consts(const TheoryArgs& a) {
   FastConsts fc;
-  fc.inv_h = a.uni_inv_h;
-  fc.off = -a.uni_u0 * a.uni_inv_h;
-  fc.t_lo = (a.vr.knots[0] - a.uni_u0) * a.uni_inv_h;
-  fc.n_eps = (double)a.uni_n * (1.0 - 0x1p-52);
+  if (a.uni_lut_n > 0) {
+    fc.inv_h = 1.0;
+    fc.off = 0.0;
+    fc.t_lo = a.uni_knots[0];
+    fc.n_eps = a.uni_knots[a.uni_n] * (1.0 - 0x1p-52);
+    fc.inv_g = a.uni_lut_inv_g;
+    fc.lut_off = (kRecsOff + (a.uni_n + 1) * uni_stride(NLR)) * 8;
+  } else {
+    fc.inv_h = a.uni_inv_h;
+    fc.off = -a.uni_u0 * a.uni_inv_h;
+    fc.t_lo = (a.vr.knots[0] - a.uni_u0) * a.uni_inv_h;
+    fc.n_eps = (double)a.uni_n * (1.0 - 0x1p-52);
+    fc.inv_g = 0.0;
+    fc.lut_off = 0;
+  }
   return fc;
 }
 
@@ -85,6 +107,18 @@ __device__ __forceinline__ void stage_uni_records(const TheoryArgs& a, double* l
     }
   }
   for (int j = tid; j < vkm::kExpTab; j += kBlock) lds[kEtabOff + j] = vkm::exp2_frac_c4(j);
+  if (a.uni_lut_n > 0) {
+    // union-grid mode: pad slots {left knot, 1/width}; a sentinel record whose left knot is the last knot; the table
+    for (int q = tid; q <= a.uni_n; q += kBlock) {
+      const double left = a.uni_knots[q];
+      recs[q * stride + stride - 2] = left;
+      recs[q * stride + stride - 1] = (q < a.uni_n) ? 1.0 / (a.uni_knots[q + 1] - left) : 0.0;
+      if (q == a.uni_n)
+        for (int e = 0; e < stride - 2; ++e) recs[q * stride + e] = 0.0;
+    }
+    unsigned short* lut = reinterpret_cast<unsigned short*>(recs + (a.uni_n + 1) * stride);
+    for (int c = tid; c < a.uni_lut_n; c += kBlock) lut[c] = a.uni_lut[c];
+  }
 }
 
 // Per-point xi^r records when the real-space input depends on the reconstruction beta (PCHIP piece kb, extrapolating
@@ -125,16 +159,28 @@ __device__ __forceinline__ FastPoint make_fast_point(const PointScalars& ps, con
 // (1 + xi^r) * exp(-z^2/2) / SV at one integrand point, given r_par' and s_perp'^2 in index units and the scaled
 // velocity node xk' (ccf_model.py:648-657, 681-690).  For NLR > 1 the records hold the Legendre sum regrouped in
 // powers of m = mu_r^2 (A, B, C of vk_tables.uni_xic), so xi^r = A + m (B + m C).
-template <int NLR>
+template <int NLR, int GRID>
 __device__ __forceinline__ double uni_value(const double* __restrict__ lds, const FastConsts& fc, double AVk,
                                             double r_par, double sperp2, double xk) {
   constexpr int stride = uni_stride(NLR);
   const double r2 = fma(r_par, r_par, sperp2);
   const double inv_r = vkm::rsqrt3(r2);
   const double mu_r = r_par * inv_r;
-  const double t = vmin_f64(vmax_f64(fma(r2, inv_r, fc.off), fc.t_lo), fc.n_eps);
-  const double tq = __builtin_amdgcn_fract(t);
-  const double* rec = lds_at(lds + kRecsOff, __mul24((int)t, stride * 8));
+  const double* rec;
+  double tq;
+  if (GRID == 0) {
+    const double t = vmin_f64(vmax_f64(fma(r2, inv_r, fc.off), fc.t_lo), fc.n_eps);
+    tq = __builtin_amdgcn_fract(t);
+    rec = lds_at(lds + kRecsOff, __mul24((int)t, stride * 8));
+  } else {
+    const double u = vmin_f64(vmax_f64(r2 * inv_r, fc.t_lo), fc.n_eps);
+    const int cell = (int)(u * fc.inv_g);
+    const int q0 = *reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(lds) + fc.lut_off + 2 * cell);
+    const double* rec0 = lds_at(lds + kRecsOff, __mul24(q0, stride * 8));
+    rec = (u >= rec0[2 * stride - 2]) ? rec0 + stride : rec0;      // next record's left knot
+    const vk_d2 kw = *reinterpret_cast<const vk_d2*>(rec + stride - 2);
+    tq = (u - kw.x) * kw.y;
+  }
   const double SV = cubic_b128(rec, tq);
   const double V = cubic_b128(rec + 4, tq);
   double xir = cubic_b128(rec + 8, tq);
@@ -159,9 +205,9 @@ struct FastPlan {
   int murec, xrec, betar, red, node, total;
 };
 
-__host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int uni_n, int nlr, int n_beta_r) {
+__host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int uni_n, int nlr, int n_beta_r, int lut_n) {
   FastPlan p;
-  int o = fast_fixed_doubles(uni_n, nlr);   // exp table + records first (fixed offsets)
+  int o = fast_fixed_doubles(uni_n, nlr, lut_n);   // exp table + records first (fixed offsets)
   o = (o + 1) & ~1;
   p.murec = o; o += n_mu * kMuRec;
   p.xrec = o;  o += n_x * 2;
@@ -172,10 +218,10 @@ __host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int uni_n,
   return p;
 }
 
-template <int NLR, int NL>
+template <int NLR, int NL, int GRID>
 __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
-  const FastPlan pl = make_fast_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.n_beta_r);
+  const FastPlan pl = make_fast_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n);
   const int tid = threadIdx.x;
   // ---- stage batch-constant tables -------------------------------------------------------------
   for (int i = tid; i < a.n_mu; i += kBlock) {
@@ -201,7 +247,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
     const int i = idx / a.n_x, k = idx - i * a.n_x;
     node[idx] = (unsigned)(i * kMuRec * 8) | ((unsigned)(k * 16) << 16);
   }
-  const FastConsts fc = make_fast_consts(a);
+  const FastConsts fc = make_fast_consts<NLR>(a);
   __syncthreads();
 
   const int lane = tid & 63;
@@ -257,7 +303,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
           const vk_d2 m01 = *reinterpret_cast<const vk_d2*>(mr);
           const vk_d2 xw = *reinterpret_cast<const vk_d2*>(x_bytes + (pk >> 16));
           const double s_perp = s_aperp * m01.y;
-          const double f = xw.y * uni_value<NLR>(lds, fc, fp.AVk, fma(-xw.x, fp.Bk, s_apar * m01.x), s_perp * s_perp, xw.x);
+          const double f = xw.y * uni_value<NLR, GRID>(lds, fc, fp.AVk, fma(-xw.x, fp.Bk, s_apar * m01.x), s_perp * s_perp, xw.x);
           const vk_d2 w01 = *reinterpret_cast<const vk_d2*>(mr + 2);
           acc[0] = fma(w01.x, f, acc[0]);
           if (NL > 1) acc[1] = fma(w01.y, f, acc[1]);

@@ -18,9 +18,9 @@ struct LanesPlan {
   int smu, total;
 };
 
-__host__ __device__ inline LanesPlan make_lanes_plan(int n_mu, int n_x, int uni_n, int nlr) {
+__host__ __device__ inline LanesPlan make_lanes_plan(int n_mu, int n_x, int uni_n, int nlr, int lut_n) {
   LanesPlan p;
-  int o = fast_fixed_doubles(uni_n, nlr);   // exp table + records first (fixed offsets)
+  int o = fast_fixed_doubles(uni_n, nlr, lut_n);   // exp table + records first (fixed offsets)
   o = (o + 1) & ~1;
   p.smu = o;   o += 2 * n_mu;           // {mu_i, sqrt(1 - mu_i^2)}
   p.total = o;
@@ -65,10 +65,10 @@ __device__ __forceinline__ PointScalars point_scalars_lane(const TheoryArgs& a, 
   return ps;
 }
 
-template <int NLR, int NL>
+template <int NLR, int NL, int GRID>
 __global__ __launch_bounds__(kBlock, 5) void vk_theory_lanes_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
-  const LanesPlan pl = make_lanes_plan(a.n_mu, a.n_x, a.uni_n, NLR);
+  const LanesPlan pl = make_lanes_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.uni_lut_n);
   const int tid = threadIdx.x;
   for (int i = tid; i < a.n_mu; i += kBlock) {
     const double m = a.mu[i];
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kBlock, 5) void vk_theory_lanes_kernel(TheoryArgs a
     lds[pl.smu + 2 * i + 1] = sqrt(1.0 - m * m);
   }
   stage_uni_records<NLR>(a, lds);
-  const FastConsts fc = make_fast_consts(a);
+  const FastConsts fc = make_fast_consts<NLR>(a);
   __syncthreads();
 
   const int lane = tid & 63;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kBlock, 5) void vk_theory_lanes_kernel(TheoryArgs a
       for (int k = 0; k < a.n_x; ++k) {
         const vk_d2 xw = cxw[k];
         const double xk = xw.x;
-        g = fma(xw.y, uni_value<NLR>(lds, fc, fp.AVk, fma(-xk, fp.Bk, s_par), sperp2, xk), g);
+        g = fma(xw.y, uni_value<NLR, GRID>(lds, fc, fp.AVk, fma(-xk, fp.Bk, s_par), sperp2, xk), g);
       }
 #pragma unroll
       for (int l = 0; l < NL; ++l) acc[l] = fma(a.w_ell[l * a.n_mu + i], g, acc[l]);

@@ -119,28 +119,47 @@ def build_tables(model, fit=None, matter_model=None):
         t.sv_mu = N.as_dp(mu_sv)
         t.sv2d = N.as_dp(patches)
 
-    # unified refined grid for the fast kernels: r and r_sv grids uniform and commensurate, fixed velocity tables
+    # unified tables for the fast kernels (fixed velocity tables, isotropic sigma_v template).  Uniform, commensurate
+    # r and r_sv grids: the lattice form (index arithmetic).  Anything else: the union-grid form (look-up table).
     t.uni_n = 0
-    if (t.sv_n_mu == 0 and not vr_beta_dep and t.xi.inv_h > 0 and t.xi.lead == 0 and t.sv.inv_h > 0
-            and t.sv.lead == 0 and t.vr.inv_h > 0 and t.vr.lead == 1):
-        cr = T.common_refinement(r, model.r_for_sv)
-        if cr is not None and cr[0] >= r_ext[0] and cr[2] + int(np.ceil(cr[0] / cr[1])) <= 640:
-            u0, h, n = cr
-            # extend the grid down to u <= 0 so that the index-unit coordinate t = r/(c h) - u0/h is never negative
-            # and the leading V interval [0.01, r_0] is part of the same records (see vk_kernel_fast.h)
-            k0 = int(np.ceil(u0 / h - 1e-9))
-            u0, n = u0 - k0 * h, n + k0
-            if abs(u0) < 1e-9 * h:
-                u0 = 0.0
-            sv_ref = T.refine_pp(model.r_for_sv, T.notaknot_coefficients(model.r_for_sv, model.sv_rmu[0]), u0, h, n)
-            v_ref = T.refine_pp(r_ext, vr_coef[0], u0, h, n)
+    t.uni_lut_n = 0
+    if t.sv_n_mu == 0 and not vr_beta_dep and r[0] > r_ext[0] and model.r_for_sv[0] >= r_ext[0]:
+        grid = None
+        if t.xi.inv_h > 0 and t.sv.inv_h > 0 and t.vr.inv_h > 0:
+            cr = T.common_refinement(r, model.r_for_sv)
+            if cr is not None and cr[2] + int(np.ceil(cr[0] / cr[1])) <= 640:
+                u0, h, n = cr
+                # extend the grid down to u <= 0 so that the index-unit coordinate t = r/(c h) - u0/h is never
+                # negative and the leading V interval [0.01, r_0] is part of the same records (vk_kernel_fast.h)
+                k0 = int(np.ceil(u0 / h - 1e-9))
+                u0, n = u0 - k0 * h, n + k0
+                if abs(u0) < 1e-9 * h:
+                    u0 = 0.0
+                grid = (u0 + h * np.arange(n), np.full(n, h))
+                t.uni_n, t.uni_u0, t.uni_inv_h = n, u0, 1.0 / h
+        if grid is None:
+            ug = T.union_grid(r_ext, model.r_for_sv)
+            if ug is not None and len(ug[0]) - 1 <= 512:
+                U, lut, inv_g = ug
+                grid = (U[:-1], np.diff(U))
+                lut = np.ascontiguousarray(lut, dtype=np.uint16)
+                knots_u = arr(U)
+                keep.append(lut)
+                t.uni_n, t.uni_u0, t.uni_inv_h = len(U) - 1, float(U[0]), 0.0
+                t.uni_lut_n, t.uni_lut_inv_g = len(lut), float(inv_g)
+                t.uni_lut = lut.ctypes.data_as(C.POINTER(C.c_uint16))
+                t.uni_knots = N.as_dp(knots_u)
+        if grid is not None:
+            left, width = grid
+            sv_ref = T.refine_pp_on(model.r_for_sv, T.notaknot_coefficients(model.r_for_sv, model.sv_rmu[0]), left, width)
+            v_ref = T.refine_pp_on(r_ext, vr_coef[0], left, width)
             uni_sv_v = arr(np.stack([sv_ref, v_ref], axis=1))                         # (n, 2, 4)
             if model.fixed_real_input:
-                uni_xi = arr(np.stack([T.refine_pp(r, coef[l], u0, h, n) for l in range(n_ell_r)]))   # (L, n, 4)
+                uni_xi = arr(np.stack([T.refine_pp_on(r, coef[l], left, width) for l in range(n_ell_r)]))   # (L, n, 4)
             else:
                 parts = []
                 for l in range(n_ell_r):                                              # coef[l]: (n_beta-1, n_int, 4, 4)
-                    ref = T.refine_pp(r, np.moveaxis(coef[l], 0, -1), u0, h, n)       # (n, 4, 4, n_beta-1)
+                    ref = T.refine_pp_on(r, np.moveaxis(coef[l], 0, -1), left, width)  # (n, 4, 4, n_beta-1)
                     parts.append(np.moveaxis(ref, -1, 0))                              # (n_beta-1, n, 4, 4)
                 uni_xi = arr(np.stack(parts))
             # Legendre sum regrouped in powers of mu_r^2 (exact: linear combinations of the coefficient sets)
@@ -151,7 +170,6 @@ def build_tables(model, fit=None, matter_model=None):
                 x4 = uni_xi[2] if n_ell_r == 3 else np.zeros_like(x0)
                 comb = [x0 - 0.5 * x2 + 0.375 * x4, 1.5 * x2 - 3.75 * x4, 4.375 * x4]
                 uni_xic = arr(np.stack(comb[:n_ell_r]))
-            t.uni_n, t.uni_u0, t.uni_inv_h = n, u0, 1.0 / h
             t.uni_sv_v, t.uni_xi, t.uni_xic = N.as_dp(uni_sv_v), N.as_dp(uni_xi), N.as_dp(uni_xic)
 
     t.iaH = float(model.iaH)

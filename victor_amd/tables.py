@@ -351,19 +351,28 @@ def refine_pp(knots, coef, u0, h, n):
     function is sum_p out[q, p] tau^p with tau = (u - u0 - q h)/h in [0, 1).  Refined intervals outside the table's
     range hold the (constant) boundary value, which reproduces the clamped evaluation exactly.
     """
+    left = u0 + h * np.arange(n)
+    return refine_pp_on(knots, coef, left, np.full(n, float(h)))
+
+
+def refine_pp_on(knots, coef, left, width):
+    """``refine_pp`` for arbitrary target intervals [left_q, left_q + width_q], each inside one interval of ``knots``
+    (or outside its range): coefficients of tau^p, tau = (u - left_q)/width_q."""
     knots = np.asarray(knots, dtype=np.float64)
     coef = np.asarray(coef, dtype=np.float64)
-    left = u0 + h * np.arange(n)
-    mid = left + 0.5 * h
+    left = np.asarray(left, dtype=np.float64)
+    width = np.asarray(width, dtype=np.float64)
+    mid = left + 0.5 * width
     i = np.clip(np.searchsorted(knots, mid, side="right") - 1, 0, len(knots) - 2)
     d = left - knots[i]
     extra = (1,) * (coef.ndim - 2)
     dd = d.reshape(d.shape + extra)
+    w = width.reshape(width.shape + extra)
     c0, c1, c2, c3 = coef[i, 0], coef[i, 1], coef[i, 2], coef[i, 3]
     out = np.stack([((c3 * dd + c2) * dd + c1) * dd + c0,
-                    ((3 * c3 * dd + 2 * c2) * dd + c1) * h,
-                    (3 * c3 * dd + c2) * h ** 2,
-                    c3 * h ** 3], axis=1)
+                    ((3 * c3 * dd + 2 * c2) * dd + c1) * w,
+                    (3 * c3 * dd + c2) * w ** 2,
+                    c3 * w ** 3], axis=1)
     below = mid < knots[0]
     above = mid > knots[-1]
     if np.any(below):
@@ -375,3 +384,35 @@ def refine_pp(knots, coef, u0, h, n):
         out[above] = 0.0
         out[above, 0] = end
     return out
+
+
+def union_grid(*knot_sets, max_cells=4096):
+    """Union of several knot sets plus a uniform look-up table that locates its intervals with one comparison.
+
+    Returns ``(U, lut, inv_g)`` or None.  ``U`` (n+1,) are the sorted distinct knots.  The table has G cells of width
+    1/inv_g over [0, U[-1]); every cell holds at most one interior knot of U, and ``lut[c]`` (uint16) is the index of
+    the interval that contains the cell's left edge, so the interval of u in [U[0], U[-1]) is
+    ``q = lut[int(u * inv_g)];  q += (u >= U[q + 1])``.
+    """
+    U = np.unique(np.concatenate([np.asarray(k, dtype=np.float64) for k in knot_sets]))
+    n = len(U) - 1
+    if n < 1 or n > 4000 or U[0] < 0:
+        return None
+    inner = U[1:-1]
+    span = U[-1]
+    G = 64
+    if len(inner) > 1:
+        gap = np.min(np.diff(inner))
+        while G < max_cells and span / G >= gap:
+            G *= 2
+    while True:
+        edges = span * np.arange(G + 1) / G
+        # knots sitting exactly on a cell's left edge belong to the index, not to the cell
+        count = np.searchsorted(inner, edges[1:], side="left") - np.searchsorted(inner, edges[:-1], side="right")
+        if np.all(count <= 1):
+            break
+        G *= 2
+        if G > max_cells:
+            return None
+    lut = np.searchsorted(inner, edges[:-1], side="right").astype(np.uint16)
+    return U, lut, G / span
