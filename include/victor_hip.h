@@ -158,10 +158,11 @@ typedef struct vk_tables {
   /* Union-grid form of the same tables for knots that are not uniform or not commensurate: uni_n intervals between
    * the sorted distinct knots uni_knots[0..uni_n] of vr (uni_knots[0] = vr.knots[0] = 0.01), xi and sv; the
    * coefficient arrays above are then in units of each interval's own width.  A uniform look-up table of
-   * uni_lut_n cells over [0, uni_knots[uni_n]) locates the interval: every cell holds at most one interior knot and
-   * uni_lut[c] is the interval that contains the cell's left edge.  uni_u0 / uni_inv_h are unused in this form.   */
-  int32_t uni_lut_n;      /* 0: uniform-lattice form.  > 0: union-grid form, number of look-up cells (<= 4096)  */
-  double uni_lut_inv_g;   /* cells per unit length: uni_lut_n / uni_knots[uni_n]                                */
+   * uni_lut_n - 1 cells over [0, uni_knots[uni_n]) plus one guard cell locates the interval: every cell holds at most
+   * TWO interior knots and uni_lut[c] is the interval that contains the cell's left edge (guard cell: the last
+   * interval); the kernels add (u >= next knot) + (u >= the one after).  uni_u0 / uni_inv_h are unused here.     */
+  int32_t uni_lut_n;      /* 0: uniform-lattice form.  > 0: union-grid form, entries of the table (<= 4097)     */
+  double uni_lut_inv_g;   /* cells per unit length: (uni_lut_n - 1) / uni_knots[uni_n]                          */
   const uint16_t* uni_lut;/* [uni_lut_n]                                                                        */
   const double* uni_knots;/* [uni_n + 1]                                                                        */
 

@@ -168,3 +168,33 @@ def test_common_refinement_and_refined_tables():
     want = T.refine_pp(r, coef_r, u0, h, n)
     got = ((ref[:, :, 3, k] * db + ref[:, :, 2, k]) * db + ref[:, :, 1, k]) * db + ref[:, :, 0, k]
     assert np.max(np.abs(got - want)) < 1e-13
+
+
+def test_union_grid_lookup_and_refinement():
+    """Union-grid form of the unified tables: the u16 look-up table plus one comparison finds the interval of every
+    u (knots and the clamped upper end included), and the re-expanded records reproduce the clamped splines."""
+    from victor_amd import tables as T
+    rng = np.random.default_rng(4)
+    for trial in range(5):
+        r = np.sort(np.append([0.01], 1.5 + 3 * np.arange(40) + rng.uniform(-0.9, 0.9, 40)))
+        sv = 3 + 6 * np.arange(25) + rng.uniform(-2, 2, 25)
+        U, lut, inv_g = T.union_grid(r, sv)
+        assert len(U) == 66 and lut.dtype == np.uint16 and len(lut) <= 257
+        top = U[-1] * (1 - 2.0 ** -52)
+        u = np.concatenate([rng.uniform(U[0], top, 50000), U[:-1], [top], np.nextafter(U[1:-1], 0)])
+        cell = (u * inv_g).astype(int)
+        assert cell.max() < len(lut)
+        q = lut[cell].astype(int)
+        Up = np.append(U, U[-1])
+        q = q + (u >= Up[q + 1]) + (u >= Up[q + 2])
+        assert np.array_equal(q, np.searchsorted(U, u, side="right") - 1)
+        y = rng.normal(size=len(sv))
+        rec = T.refine_pp_on(sv, T.notaknot_coefficients(sv, y), U[:-1], np.diff(U))
+        tau = (u - U[q]) / (U[q + 1] - U[q])
+        got = ((rec[q, 3] * tau + rec[q, 2]) * tau + rec[q, 1]) * tau + rec[q, 0]
+        want = T.notaknot(sv, y)(np.clip(u, sv[0], sv[-1]))
+        assert np.max(np.abs(got - want)) < 1e-13 * np.max(np.abs(want))
+    # commensurate uniform grids need few cells; coincident knots are merged
+    U, lut, inv_g = T.union_grid(np.append([0.01], 2 + 4.0 * np.arange(30)), 3 + 6.0 * np.arange(25), [2.0, 6.0])
+    assert len(U) == 56 and len(lut) <= 257
+    assert T.union_grid([0.01, 1.0, 1.0 + 1e-7, 1.0 + 2e-7, 200.0], [5.0]) is None     # would need > 4096 cells

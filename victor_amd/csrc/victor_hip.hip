@@ -546,7 +546,7 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
     bool ok = !t->vr_beta_dep && t->sv_n_mu == 0 && t->uni_n > 0 && t->uni_sv_v && t->uni_xi && t->uni_xic &&
               t->xi.knots[0] > t->vr.knots[0] && t->sv.knots[0] >= t->vr.knots[0];
     if (ok && t->uni_lut_n > 0) {
-      ok = t->uni_lut && t->uni_knots && t->uni_lut_n <= 4096 && t->uni_n < 4096 && t->uni_lut_inv_g > 0 &&
+      ok = t->uni_lut && t->uni_knots && t->uni_lut_n <= 4097 && t->uni_n < 4096 && t->uni_lut_inv_g > 0 &&
            t->uni_knots[0] == t->vr.knots[0];
       for (int q = 0; q < t->uni_n && ok; ++q) ok = t->uni_knots[q + 1] > t->uni_knots[q];
       for (int c = 0; c < t->uni_lut_n && ok; ++c) ok = t->uni_lut[c] < t->uni_n;

@@ -29,15 +29,16 @@ constexpr int kEtabOff = 0;                  // doubles
 constexpr int kRecsOff = vkm::kExpTab;
 
 __host__ __device__ constexpr int uni_stride(int nlr) { return 4 * (2 + nlr) + 2; }   // doubles per refined interval
-// exp table + records (+ one sentinel record and the u16 look-up table of the union-grid mode), at fixed offsets
+// exp table + records (+ two sentinel records and the u16 look-up table of the union-grid mode), at fixed offsets
 __host__ __device__ constexpr int fast_fixed_doubles(int uni_n, int nlr, int lut_n) {
-  return kRecsOff + (uni_n + (lut_n > 0 ? 1 : 0)) * uni_stride(nlr) + (lut_n + 3) / 4;
+  return kRecsOff + (uni_n + (lut_n > 0 ? 2 : 0)) * uni_stride(nlr) + (lut_n + 3) / 4;
 }
 
 // GRID = 0: the unified grid is a uniform lattice (index arithmetic).  GRID = 1: it is the union of arbitrary knot
-// sets (vk_tables.uni_lut_n > 0): a u16 look-up table gives the interval of the cell's left edge, one comparison with
-// the next knot (kept in the pad slot of the next record) corrects it, and the record's own pad holds its left knot
-// and 1/width for the local coordinate.  Costs 6 more VALU instructions and two more LDS reads per integrand point.
+// sets (vk_tables.uni_lut_n > 0): a u16 look-up table gives the interval of the cell's left edge, comparisons with
+// the next two knots (kept in the pad slots of the next two records; a cell holds at most two knots) correct it, and
+// the record's own pad holds its left knot and 1/width for the local coordinate.  Costs 8 more VALU instructions and
+// three more LDS reads per integrand point.
 struct FastConsts {
   double inv_h;                   // callers form k = inv_h / c per point and scale their lengths by it (GRID 1: 1)
   double off, t_lo, n_eps;        // GRID 0: t = r' + off, clamped to [t_lo, n_eps]; t_lo is u = 0.01, the first V knot
@@ -78,7 +79,7 @@ __device__ __forceinline__ FastConsts make_fast_consts(const TheoryArgs& a) {
     fc.t_lo = a.uni_knots[0];
     fc.n_eps = a.uni_knots[a.uni_n] * (1.0 - 0x1p-52);
     fc.inv_g = a.uni_lut_inv_g;
-    fc.lut_off = (kRecsOff + (a.uni_n + 1) * uni_stride(NLR)) * 8;
+    fc.lut_off = (kRecsOff + (a.uni_n + 2) * uni_stride(NLR)) * 8;
   } else {
     fc.inv_h = a.uni_inv_h;
     fc.off = -a.uni_u0 * a.uni_inv_h;
@@ -108,15 +109,15 @@ __device__ __forceinline__ void stage_uni_records(const TheoryArgs& a, double* l
   }
   for (int j = tid; j < vkm::kExpTab; j += kBlock) lds[kEtabOff + j] = vkm::exp2_frac_c4(j);
   if (a.uni_lut_n > 0) {
-    // union-grid mode: pad slots {left knot, 1/width}; a sentinel record whose left knot is the last knot; the table
-    for (int q = tid; q <= a.uni_n; q += kBlock) {
-      const double left = a.uni_knots[q];
+    // union-grid mode: pad slots {left knot, 1/width}; two sentinel records whose left knot is the last knot; the table
+    for (int q = tid; q <= a.uni_n + 1; q += kBlock) {
+      const double left = a.uni_knots[q < a.uni_n ? q : a.uni_n];
       recs[q * stride + stride - 2] = left;
       recs[q * stride + stride - 1] = (q < a.uni_n) ? 1.0 / (a.uni_knots[q + 1] - left) : 0.0;
-      if (q == a.uni_n)
+      if (q >= a.uni_n)
         for (int e = 0; e < stride - 2; ++e) recs[q * stride + e] = 0.0;
     }
-    unsigned short* lut = reinterpret_cast<unsigned short*>(recs + (a.uni_n + 1) * stride);
+    unsigned short* lut = reinterpret_cast<unsigned short*>(recs + (a.uni_n + 2) * stride);
     for (int c = tid; c < a.uni_lut_n; c += kBlock) lut[c] = a.uni_lut[c];
   }
 }
@@ -177,7 +178,9 @@ __device__ __forceinline__ double uni_value(const double* __restrict__ lds, cons
     const int cell = (int)(u * fc.inv_g);
     const int q0 = *reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(lds) + fc.lut_off + 2 * cell);
     const double* rec0 = lds_at(lds + kRecsOff, __mul24(q0, stride * 8));
-    rec = (u >= rec0[2 * stride - 2]) ? rec0 + stride : rec0;      // next record's left knot
+    const double k1 = rec0[2 * stride - 2], k2 = rec0[3 * stride - 2];      // left knots of the next two records
+    const int q = q0 + (u >= k1) + (u >= k2);
+    rec = lds_at(lds + kRecsOff, __mul24(q, stride * 8));
     const vk_d2 kw = *reinterpret_cast<const vk_d2*>(rec + stride - 2);
     tq = (u - kw.x) * kw.y;
   }

@@ -387,12 +387,13 @@ def refine_pp_on(knots, coef, left, width):
 
 
 def union_grid(*knot_sets, max_cells=4096):
-    """Union of several knot sets plus a uniform look-up table that locates its intervals with one comparison.
+    """Union of several knot sets plus a uniform look-up table that locates its intervals with two comparisons.
 
     Returns ``(U, lut, inv_g)`` or None.  ``U`` (n+1,) are the sorted distinct knots.  The table has G cells of width
-    1/inv_g over [0, U[-1]); every cell holds at most one interior knot of U, and ``lut[c]`` (uint16) is the index of
-    the interval that contains the cell's left edge, so the interval of u in [U[0], U[-1]) is
-    ``q = lut[int(u * inv_g)];  q += (u >= U[q + 1])``.
+    1/inv_g over [0, U[-1]) plus one guard cell; every cell holds at most TWO interior knots of U (two families of
+    knots may interleave arbitrarily closely; a cell narrower than the spacing within each family never sees three),
+    and ``lut[c]`` (uint16) is the index of the interval that contains the cell's left edge, so the interval of u in
+    [U[0], U[-1]) is ``q = lut[int(u * inv_g)];  q += (u >= U[q + 1]) + (u >= U[q + 2])`` (U padded with U[-1]).
     """
     U = np.unique(np.concatenate([np.asarray(k, dtype=np.float64) for k in knot_sets]))
     n = len(U) - 1
@@ -401,18 +402,15 @@ def union_grid(*knot_sets, max_cells=4096):
     inner = U[1:-1]
     span = U[-1]
     G = 64
-    if len(inner) > 1:
-        gap = np.min(np.diff(inner))
-        while G < max_cells and span / G >= gap:
-            G *= 2
     while True:
         edges = span * np.arange(G + 1) / G
         # knots sitting exactly on a cell's left edge belong to the index, not to the cell
         count = np.searchsorted(inner, edges[1:], side="left") - np.searchsorted(inner, edges[:-1], side="right")
-        if np.all(count <= 1):
+        if np.all(count <= 2):
             break
         G *= 2
         if G > max_cells:
             return None
-    lut = np.searchsorted(inner, edges[:-1], side="right").astype(np.uint16)
+    # one extra cell: u is clamped just below U[-1], but the rounded product u * inv_g can still reach G
+    lut = np.searchsorted(inner, edges, side="right").astype(np.uint16)
     return U, lut, G / span
