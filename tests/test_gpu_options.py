@@ -328,3 +328,42 @@ def test_non_uniform_grids_in_every_fast_mapping(tmp_path):
             assert abs(res[mapping][1][i] / want[1] - 1) < RTOL, (mapping, i)
     for mapping in ("cells", "lanes", "generic"):
         assert np.max(np.abs(res[mapping][1] / res["point"][1] - 1)) < 1e-10, mapping
+
+
+def test_fine_grids_need_more_than_64k_of_lds(tmp_path):
+    """300 r bins and 150 sigma_v bins: the tables of every theory kernel exceed the 64 KiB default of dynamic LDS (the
+    launcher opts in to the 160 KiB of gfx950); all mappings against the oracle."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import victor_amd
+    import victor_oracle as vo
+    from victor_amd.engine import build_tables
+    src = np.load(os.path.join(cases.GOLDEN, "synth", "model.npy"), allow_pickle=True).item()
+    r = 0.5 + 0.4 * np.arange(300)
+    rsv = 1.0 + 0.8 * np.arange(150)
+    tab = dict(src, r=r, rsv=rsv, sigmav=np.interp(rsv, src["rsv"], src["sigmav"]))
+    for key in ("monopole", "quadrupole", "hexadecapole"):
+        tab[key] = np.interp(r, src["r"], src[key])
+    np.save(tmp_path / "model_fine.npy", tab, allow_pickle=True)
+    model, data = cases.synth_options(3)
+    model = dict(model, dir=str(tmp_path), input_model_data_file="model_fine.npy")
+    fit = victor_amd.CCFFit(model, data)
+    tabs, _keep = build_tables(fit, fit)
+    assert tabs.uni_n == 450 and tabs.uni_lut_n > 0          # 450 records x 176 B = 79 KB
+    ora = vo.OracleFit(model, data)
+    hp = cases.halton_params(1024 + 3)
+    res = {}
+    for mapping in ("point", "cells", "lanes", "generic"):
+        env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
+        os.environ[env] = "1" if mapping == "generic" else mapping
+        try:
+            res[mapping] = fit.log_likelihood_batch(hp)
+        finally:
+            del os.environ[env]
+    for i in (0, 1026):
+        want = ora.log_likelihood(cases.point(hp, i))
+        for mapping in res:
+            assert abs(res[mapping][1][i] / want[1] - 1) < RTOL, (mapping, i)
+    for mapping in ("cells", "lanes", "generic"):
+        assert np.max(np.abs(res[mapping][1] / res["point"][1] - 1)) < 1e-10, mapping

@@ -137,6 +137,17 @@ int check_opts(vk_ctx* ctx, const vk_eval_opts* o) {
   return VK_OK;
 }
 
+// Launch on the context's stream.  Dynamic LDS above the 64 KiB default needs an explicit per-kernel opt-in
+// (gfx950 has 160 KiB per CU).
+template <typename Kern, typename Args>
+int launch_on_stream(vk_ctx* ctx, Kern kern, int grid, size_t lds, const Args& a) {
+  if (lds > 64 * 1024)
+    VK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, ctx->stream, a);
+  VK_HIP(ctx, hipGetLastError());
+  return VK_OK;
+}
+
 void choose_split(const vk_ctx* ctx, long long n, int n_s, int* spi, int* team) {
   // enough workgroups to fill 256 CUs several times over, otherwise split finer
   const long long want = 4LL * ctx->n_cu;
@@ -149,13 +160,11 @@ void choose_split(const vk_ctx* ctx, long long n, int n_s, int* spi, int* team) 
 template <int RSD, int NLR>
 int launch_generic_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: hipLaunchKernelGGL((vk_theory_kernel<RSD, NLR, 1>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-    case 2: hipLaunchKernelGGL((vk_theory_kernel<RSD, NLR, 2>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-    case 3: hipLaunchKernelGGL((vk_theory_kernel<RSD, NLR, 3>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-    default: return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
+    case 1: return launch_on_stream(ctx, vk_theory_kernel<RSD, NLR, 1>, grid, lds, a);
+    case 2: return launch_on_stream(ctx, vk_theory_kernel<RSD, NLR, 2>, grid, lds, a);
+    case 3: return launch_on_stream(ctx, vk_theory_kernel<RSD, NLR, 3>, grid, lds, a);
   }
-  VK_HIP(ctx, hipGetLastError());
-  return VK_OK;
+  return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
 }
 
 template <int RSD>
@@ -171,13 +180,11 @@ int launch_generic(vk_ctx* ctx, const TheoryArgs& a, int nlr, int grid, size_t l
 template <int NLR, int GRID>
 int launch_fast_ng(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: hipLaunchKernelGGL((vk_theory_fast_kernel<NLR, 1, GRID>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-    case 2: hipLaunchKernelGGL((vk_theory_fast_kernel<NLR, 2, GRID>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-    case 3: hipLaunchKernelGGL((vk_theory_fast_kernel<NLR, 3, GRID>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-    default: return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
+    case 1: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 1, GRID>, grid, lds, a);
+    case 2: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 2, GRID>, grid, lds, a);
+    case 3: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 3, GRID>, grid, lds, a);
   }
-  VK_HIP(ctx, hipGetLastError());
-  return VK_OK;
+  return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
 }
 
 template <int NLR>
@@ -188,13 +195,11 @@ int launch_fast_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
 template <int NLR, int GRID>
 int launch_lanes_ng(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: hipLaunchKernelGGL((vk_theory_lanes_kernel<NLR, 1, GRID>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-    case 2: hipLaunchKernelGGL((vk_theory_lanes_kernel<NLR, 2, GRID>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-    case 3: hipLaunchKernelGGL((vk_theory_lanes_kernel<NLR, 3, GRID>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-    default: return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
+    case 1: return launch_on_stream(ctx, vk_theory_lanes_kernel<NLR, 1, GRID>, grid, lds, a);
+    case 2: return launch_on_stream(ctx, vk_theory_lanes_kernel<NLR, 2, GRID>, grid, lds, a);
+    case 3: return launch_on_stream(ctx, vk_theory_lanes_kernel<NLR, 3, GRID>, grid, lds, a);
   }
-  VK_HIP(ctx, hipGetLastError());
-  return VK_OK;
+  return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
 }
 
 template <int NLR>
@@ -205,13 +210,11 @@ int launch_lanes_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
 template <int NLR, int GRID>
 int launch_cells_ng(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: hipLaunchKernelGGL((vk_theory_cells_kernel<NLR, 1, GRID>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-    case 2: hipLaunchKernelGGL((vk_theory_cells_kernel<NLR, 2, GRID>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-    case 3: hipLaunchKernelGGL((vk_theory_cells_kernel<NLR, 3, GRID>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-    default: return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
+    case 1: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 1, GRID>, grid, lds, a);
+    case 2: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 2, GRID>, grid, lds, a);
+    case 3: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 3, GRID>, grid, lds, a);
   }
-  VK_HIP(ctx, hipGetLastError());
-  return VK_OK;
+  return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
 }
 
 template <int NLR>
@@ -222,13 +225,11 @@ int launch_cells_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
 template <int RSD>
 int launch_xi_smu(vk_ctx* ctx, const TheoryArgs& a, int nlr, int grid, size_t lds) {
   switch (nlr) {
-    case 1: hipLaunchKernelGGL((vk_xi_smu_kernel<RSD, 1>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-    case 2: hipLaunchKernelGGL((vk_xi_smu_kernel<RSD, 2>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-    case 3: hipLaunchKernelGGL((vk_xi_smu_kernel<RSD, 3>), dim3(grid), dim3(kBlock), lds, ctx->stream, a); break;
-    default: return fail(ctx, VK_E_ARG, "bad number of real-space multipoles %d", nlr);
+    case 1: return launch_on_stream(ctx, vk_xi_smu_kernel<RSD, 1>, grid, lds, a);
+    case 2: return launch_on_stream(ctx, vk_xi_smu_kernel<RSD, 2>, grid, lds, a);
+    case 3: return launch_on_stream(ctx, vk_xi_smu_kernel<RSD, 3>, grid, lds, a);
   }
-  VK_HIP(ctx, hipGetLastError());
-  return VK_OK;
+  return fail(ctx, VK_E_ARG, "bad number of real-space multipoles %d", nlr);
 }
 
 // fills the grid-independent part of TheoryArgs
@@ -393,17 +394,13 @@ int launch_like(vk_ctx* ctx, const vk_eval_opts* o, const double* d_params, cons
     const long long tiles = (n + kTile - 1) / kTile;
     const long long blocks = (tiles + kWaves - 1) / kWaves;
     const int grid = (int)(blocks < cap ? blocks : cap);
-    hipLaunchKernelGGL((vk_like_tiled_kernel<kTile>), dim3(grid), dim3(kBlock), lds_tiled, ctx->stream, a);
-    VK_HIP(ctx, hipGetLastError());
-    return VK_OK;
+    return launch_on_stream(ctx, vk_like_tiled_kernel<kTile>, grid, lds_tiled, a);
   }
   const long long blocks = (n + kWaves - 1) / kWaves;
   const int grid = (int)(blocks < cap ? blocks : cap);
   const size_t lds = (size_t)kWaves * ctx->N * sizeof(double);
   if (lds > 160 * 1024) return fail(ctx, VK_E_ARG, "data vector of %d bins needs %zu bytes of LDS (> 160 KiB)", ctx->N, lds);
-  hipLaunchKernelGGL(vk_like_kernel, dim3(grid), dim3(kBlock), lds, ctx->stream, a);
-  VK_HIP(ctx, hipGetLastError());
-  return VK_OK;
+  return launch_on_stream(ctx, vk_like_kernel, grid, lds, a);
 }
 
 void harvest_timing(vk_ctx* ctx) {
