@@ -1,0 +1,33 @@
+"""Throughput of the other RSD branches (generic kernel) on the config-3 and BOSS tables."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import victor_amd
+from tests import cases
+
+def run(fit, label, batch, beta, **kw):
+    model = fit._merged(kw)
+    eng = fit._get_engine(fit._engine_key(model))
+    o = eng.make_opts(model, fit.fit_options)
+    hp = cases.halton_params(batch, with_beta=beta)
+    if not beta:
+        hp = dict(hp, beta=0.4)          # required key for linear_bias on fixed tables, value unused
+    rows = fit._fit_rows(hp, model)
+    bufs = [eng.alloc(rows.size), eng.alloc(batch), eng.alloc(batch), eng.alloc(batch * eng.n_data)]
+    eng.upload(bufs[0], rows)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.3:
+        eng.eval_device_async(o, bufs[0], batch, bufs[1], bufs[2], bufs[3]); eng.sync()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        eng.eval_device_async(o, bufs[0], batch, bufs[1], bufs[2], bufs[3])
+    eng.sync()
+    dt = (time.perf_counter() - t0) / 4
+    print(f"{label}: {dt*1e3:.2f} ms/batch {batch/dt:.0f} evals/s ({eng.last_kernel()})", flush=True)
+    for b in bufs: eng.free(b)
+
+for name, opts, beta in (("config3", cases.synth_options(3), False), ("boss", cases.boss_options("config"), True)):
+    fit = victor_amd.CCFFit(*opts)
+    for kw in ({}, {"rsd_model": "dispersion"}, {"rsd_model": "kaiser"}, {"rsd_model": "euclid_special"},
+               {"empirical_corr": True}, {"matter_model": "linear_bias"}):
+        run(fit, f"{name} {kw}", 16384, beta, **kw)

@@ -27,6 +27,7 @@
 #include <cstring>
 #include <limits>
 #include <new>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -306,18 +307,19 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   // lanes-over-batch variant: batch-constant tables and enough points to fill the chip with n_s * n/64 waves
   const char* mapping = getenv("VICTOR_HIP_MAPPING");
   const bool lanes_ok = fast && a.n_beta_r == 0;
-  // One wave per (s bin, 64-point chunk).  LDS and registers hold 4-5 workgroups (16-20 waves) per CU, so the
-  // chip holds n_cu*16 waves at a time; the last round of waves is only partly filled.  The lanes kernel is ~1.2x
+  // One wave per (s bin, 64-point chunk).  LDS and registers hold up to 5 workgroups (20 waves) per CU, so the
+  // chip holds `slots` waves at a time; the last round of waves is only partly filled.  The lanes kernel is ~1.2x
   // faster per integrand than the point-major one (56 vs ~68 VALU instructions), so it wins once that fill
   // efficiency exceeds ~0.85.
   const long long waves = ((a.n + 63) >> 6) * (long long)a.n_s;
-  const long long slots = 16LL * ctx->n_cu;
+  const size_t lds_l = (size_t)make_lanes_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.uni_lut_n).total * sizeof(double);
+  const long long wg_per_cu = std::max<long long>(1, std::min<long long>(5, (160 * 1024) / (lds_l ? lds_l : 1)));
+  const long long slots = kWaves * wg_per_cu * ctx->n_cu;
   const long long rounds = (waves + slots - 1) / slots;
   const double fill = (double)waves / (double)(rounds * slots);
-  const bool lanes = lanes_ok && (mapping ? !strcmp(mapping, "lanes") : fill >= 0.85);
+  const bool lanes = lanes_ok && lds_l <= 160 * 1024 && (mapping ? !strcmp(mapping, "lanes") : fill >= 0.85);
   if (lanes) {
     ctx->last_kernel = "vk_theory_lanes_kernel";
-    const size_t lds_l = (size_t)make_lanes_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.uni_lut_n).total * sizeof(double);
     const long long blocks = (waves + kWaves - 1) / kWaves;
     // Many more workgroups than fit at once: letting the dispatcher refill CUs as workgroups retire measured
     // 38.1 / 36.0 / 34.6 / 33.8 ms at 4 / 8 / 16 / 64 workgroups per CU on the bench workload (4 are resident)

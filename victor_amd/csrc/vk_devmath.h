@@ -31,7 +31,7 @@ __device__ __forceinline__ double rsqrt3(double x) {
   return fma(y * e, p, y);
 }
 
-// 1/x for a positive normal x (the velocity dispersion): y' = y (1 + e + e^2), e = 1 - x y, error ~ e^3
+// 1/x for a normal x of either sign (velocity dispersion, Jacobians): y' = y (1 + e + e^2), e = 1 - x y, error ~ e^3
 __device__ __forceinline__ double recip(double x) {
   const double y = __builtin_amdgcn_rcp(x);   // v_rcp_f64
   const double e = fma(-x, y, 1.0);

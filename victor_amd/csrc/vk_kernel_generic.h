@@ -133,25 +133,26 @@ __device__ __forceinline__ double rsd_integrand(const PPLds& sv, const PPLds& vr
   const double mfac = (RSD == VK_RSD_DISPERSION) ? 1.0 : ps.M;
   const double num = (RSD == VK_RSD_DISPERSION) ? fma(-xk, ps.B, s_par) : s_par;
   const double sp2 = s_perp * s_perp;
-  auto q_of = [&](double r) {
+  // square roots, 1/r and the divisions by 1 + q, the Jacobian and sigma_v through the refined v_rsq / v_rcp forms
+  // of vk_devmath.h (<= 2 ulp), as in the streaming branch: the fixed-point iteration alone has 6 of each
+  auto q_of = [&](double r2) {     // aH^-1 v_r(r) / r at r = sqrt(r2)
+    double r, inv_r;
+    vkm::sqrt_rsqrt(r2, r, inv_r);
     const double uv = clampd(r * ps.inv_c, vr.lo, vr.hi);
-    return -ps.G * vel_shape(vr, ps, a, pp_interval(vr, uv), uv) / r;
+    return -ps.G * vel_shape(vr, ps, a, pp_interval(vr, uv), uv) * inv_r;
   };
   double r_par = s_par;
   if (RSD == VK_RSD_DISPERSION || a.coord_shift) {
-    const double s_true = sqrt(fma(s_par, s_par, sp2));
-    r_par = num / (1.0 + mfac * q_of(s_true));
-    for (int it = 0; it < a.niter; ++it) {
-      const double r = sqrt(fma(r_par, r_par, sp2));
-      r_par = num / (1.0 + mfac * q_of(r));
-    }
+    r_par = num * vkm::recip(fma(mfac, q_of(fma(s_par, s_par, sp2)), 1.0));
+    for (int it = 0; it < a.niter; ++it) r_par = num * vkm::recip(fma(mfac, q_of(fma(r_par, r_par, sp2)), 1.0));
   }
-  const double r = sqrt(fma(r_par, r_par, sp2));
-  const double mu_r = r_par / r;
+  double r, inv_r;
+  vkm::sqrt_rsqrt(fma(r_par, r_par, sp2), r, inv_r);
+  const double mu_r = r_par * inv_r;
   const double u = r * ps.inv_c;
   const double uv = clampd(u, vr.lo, vr.hi);
   const int iv = pp_interval(vr, uv);
-  const double q = -ps.G * vel_shape(vr, ps, a, iv, uv) / r;
+  const double q = -ps.G * vel_shape(vr, ps, a, iv, uv) * inv_r;
   // derivative table: analytic delta - 2 Delta/3, or the numerical-gradient tables of the empirical branch
   const double Dq = a.empirical ? fma(ps.av, pp_eval_at(vr, 4, iv, uv), pp_eval_at(vr, 3, iv, uv)) : pp_eval_at(vr, 1, iv, uv);
   const double dq = -ps.gD * Dq;
@@ -159,15 +160,15 @@ __device__ __forceinline__ double rsd_integrand(const PPLds& sv, const PPLds& vr
   const double xir = xi_real<NLR>(xi, ps, a, u, mu_r, r_par, s_perp);
   if (RSD == VK_RSD_DISPERSION) {
     const double SV = sv_shape(sv, a, u, mu_r);
-    const double inv_sv = 1.0 / SV;
+    const double inv_sv = vkm::recip(SV);
     const double z = xk * inv_sv;
-    const double jac = 1.0 / (1.0 + q + m2 * (dq - q));
-    return wk * (1.0 + xir) * jac * exp(-0.5 * z * z) * inv_sv;
+    const double jac = vkm::recip(1.0 + q + m2 * (dq - q));
+    return wk * (1.0 + xir) * jac * vkm::exp_nonpos((-0.5 * z) * z, etab) * inv_sv;
   }
   if (RSD == VK_RSD_KAISER) {
     const double J = ps.M * q + ps.M * ps.Q * m2 * (dq - q);
     if (a.kaiser_approx) return 1.0 + (ps.M * xir - J);
-    return (1.0 + ps.M * xir) / (1.0 + J);
+    return (1.0 + ps.M * xir) * vkm::recip(1.0 + J);
   }
   const double J = 3.0 * ps.M * q + 2.0 * ps.M * ps.Q * m2 * (dq - q);
   return 1.0 + (ps.M * xir - J);
