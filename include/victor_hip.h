@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 8
+#define VK_ABI_VERSION 9
 
 /* error codes */
 #define VK_OK 0
@@ -155,6 +155,8 @@ typedef struct vk_tables {
   const double* uni_xic;/* same shape, the Legendre sum regrouped in powers of m = mu_r^2 (n_ell_r >= 2 only):
                            sum_l xi_l P_l(mu_r) = A + m B + m^2 C with A = xi_0 - xi_2/2 + 3 xi_4/8,
                            B = 3 xi_2/2 - 15 xi_4/4, C = 35 xi_4/8; used when the anisotropic sum is asked for  */
+  const double* uni_vb; /* vr_beta_dep only (else NULL): V1 on the unified grid as beta polynomials,
+                           [n_beta_r-1][uni_n][4][4]; the V half of uni_sv_v is then rebuilt per point            */
   /* Union-grid form of the same tables for knots that are not uniform or not commensurate: uni_n intervals between
    * the sorted distinct knots uni_knots[0..uni_n] of vr (uni_knots[0] = vr.knots[0] = 0.01), xi and sv; the
    * coefficient arrays above are then in units of each interval's own width.  A uniform look-up table of

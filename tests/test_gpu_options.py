@@ -367,3 +367,29 @@ def test_fine_grids_need_more_than_64k_of_lds(tmp_path):
             assert abs(res[mapping][1][i] / want[1] - 1) < RTOL, (mapping, i)
     for mapping in ("cells", "lanes", "generic"):
         assert np.max(np.abs(res[mapping][1] / res["point"][1] - 1)) < 1e-10, mapping
+
+
+def test_boss_linear_bias_runs_on_the_fast_kernels(gold):
+    """linear_bias on the reconstructed BOSS tables: V1 = r Delta follows xi^r_0(beta), rebuilt per point in the fast
+    kernels (vk_tables.uni_vb); golden rows from the reference, then a batch through every mapping."""
+    import os
+    import victor_amd
+    g, meta = gold
+    fit = victor_amd.CCFFit(*cases.boss_options("config"))
+    pts = [dict(q, bias=2.1, Av=0.7, M=1.05, Q=0.95) for q in meta["boss_points"][:3]]
+    hp = cases.halton_params(2048 + 7, with_beta=True)
+    lb_model = fit._merged({"matter_model": "linear_bias"})
+    batch = np.vstack([fit._fit_rows(dict(p), lb_model) for p in pts] + [fit._fit_rows(dict(hp, bias=2.1), lb_model)])
+    res = {}
+    for mapping in ("point", "cells", "generic"):
+        env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
+        os.environ[env] = "1" if mapping == "generic" else mapping
+        try:
+            res[mapping] = fit.theory_vector_batch(batch, matter_model="linear_bias")
+            assert fit._get_engine("linear_bias").last_kernel().endswith(
+                {"point": "fast_kernel", "cells": "cells_kernel", "generic": "vk_theory_kernel"}[mapping])
+        finally:
+            del os.environ[env]
+        assert close(res[mapping][:3], g["opt_boss_lb_stream"]), mapping
+    for mapping in ("cells", "generic"):
+        assert np.max(np.abs(res[mapping] - res["point"])) < 1e-10 * np.max(np.abs(res["point"])), mapping

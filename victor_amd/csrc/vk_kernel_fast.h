@@ -137,6 +137,12 @@ __device__ __forceinline__ void rebuild_uni_xi(const TheoryArgs& a, double* recs
     const double* c = ((NLR > 1) ? a.uni_xic : a.uni_xi) + l * stride_l + ((size_t)kb * per_l + iq) * 4;
     recs[(iq >> 2) * stride + 8 + 4 * l + (iq & 3)] = fma(fma(fma(c[3], db, c[2]), db, c[1]), db, c[0]);
   }
+  if (a.vr_beta_dep) {   // linear_bias on a reconstructed real-space ccf: V1 follows xi^r_0(beta) (ccf_model.py:358-370)
+    for (int iq = threadIdx.x; iq < per_l; iq += kBlock) {
+      const double* c = a.uni_vb + ((size_t)kb * per_l + iq) * 4;
+      recs[(iq >> 2) * stride + 4 + (iq & 3)] = fma(fma(fma(c[3], db, c[2]), db, c[1]), db, c[0]);
+    }
+  }
 }
 
 // per-point factors of the index-unit formulation (wave-uniform in the point-major and cells kernels, per lane in

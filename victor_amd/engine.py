@@ -123,7 +123,7 @@ def build_tables(model, fit=None, matter_model=None):
     # r and r_sv grids: the lattice form (index arithmetic).  Anything else: the union-grid form (look-up table).
     t.uni_n = 0
     t.uni_lut_n = 0
-    if t.sv_n_mu == 0 and not vr_beta_dep and r[0] > r_ext[0] and model.r_for_sv[0] >= r_ext[0]:
+    if t.sv_n_mu == 0 and r[0] > r_ext[0] and model.r_for_sv[0] >= r_ext[0]:
         grid = None
         if t.xi.inv_h > 0 and t.sv.inv_h > 0 and t.vr.inv_h > 0:
             cr = T.common_refinement(r, model.r_for_sv)
@@ -152,7 +152,13 @@ def build_tables(model, fit=None, matter_model=None):
         if grid is not None:
             left, width = grid
             sv_ref = T.refine_pp_on(model.r_for_sv, T.notaknot_coefficients(model.r_for_sv, model.sv_rmu[0]), left, width)
-            v_ref = T.refine_pp_on(r_ext, vr_coef[0], left, width)
+            if vr_beta_dep:       # V1 as beta polynomials, rebuilt per point like xi^r (vr_coef[0]: (n_beta-1, n_int, 4, 4))
+                vb = T.refine_pp_on(r_ext, np.moveaxis(vr_coef[0], 0, -1), left, width)    # (n, 4, 4, n_beta-1)
+                uni_vb = arr(np.moveaxis(vb, -1, 0))                                       # (n_beta-1, n, 4, 4)
+                t.uni_vb = N.as_dp(uni_vb)
+                v_ref = np.zeros_like(sv_ref)
+            else:
+                v_ref = T.refine_pp_on(r_ext, vr_coef[0], left, width)
             uni_sv_v = arr(np.stack([sv_ref, v_ref], axis=1))                         # (n, 2, 4)
             if model.fixed_real_input:
                 uni_xi = arr(np.stack([T.refine_pp_on(r, coef[l], left, width) for l in range(n_ell_r)]))   # (L, n, 4)
