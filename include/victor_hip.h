@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 9
+#define VK_ABI_VERSION 10
 
 /* error codes */
 #define VK_OK 0
@@ -157,6 +157,8 @@ typedef struct vk_tables {
                            B = 3 xi_2/2 - 15 xi_4/4, C = 35 xi_4/8; used when the anisotropic sum is asked for  */
   const double* uni_vb; /* vr_beta_dep only (else NULL): V1 on the unified grid as beta polynomials,
                            [n_beta_r-1][uni_n][4][4]; the V half of uni_sv_v is then rebuilt per point            */
+  const double* uni_v2; /* fixed velocity tables only (else NULL): V2 = r*Delta*delta on the unified grid, [uni_n][4];
+                           with empirical_corr the V half of the records becomes V1 + Av V2 per point            */
   /* Union-grid form of the same tables for knots that are not uniform or not commensurate: uni_n intervals between
    * the sorted distinct knots uni_knots[0..uni_n] of vr (uni_knots[0] = vr.knots[0] = 0.01), xi and sv; the
    * coefficient arrays above are then in units of each interval's own width.  A uniform look-up table of

@@ -393,3 +393,35 @@ def test_boss_linear_bias_runs_on_the_fast_kernels(gold):
         assert close(res[mapping][:3], g["opt_boss_lb_stream"]), mapping
     for mapping in ("cells", "generic"):
         assert np.max(np.abs(res[mapping] - res["point"])) < 1e-10 * np.max(np.abs(res["point"])), mapping
+
+
+def test_empirical_corr_runs_on_the_fast_kernels(gold):
+    """empirical_corr on fixed velocity tables: the kernels that own a point per workgroup rewrite V = V1 + Av V2 for it
+    (vk_tables.uni_v2); golden rows from the reference first, then a batch with a different Av per point."""
+    import os
+    import victor_amd
+    g, meta = gold
+    for name, opts, beta, key in (("synth", cases.synth_options(3), False, "opt_synth_emp_stream"),
+                                  ("boss", cases.boss_options("config"), True, "opt_boss_emp_stream")):
+        fit = victor_amd.CCFFit(*opts)
+        if name == "synth":
+            pts = [dict(q, beta=0.4, bias=1.7, Av=-0.5, M=1.1, Q=0.9) for q in meta["synth_points"][:3]]
+        else:
+            pts = [dict(q, bias=2.1, Av=0.7, M=1.05, Q=0.95) for q in meta["boss_points"][:3]]
+        model = fit._merged({"empirical_corr": True})
+        hp = cases.halton_params(1500, with_beta=beta)
+        hp = dict(hp, Av=np.linspace(-1.0, 1.0, 1500))
+        batch = np.vstack([fit._fit_rows(dict(p), model) for p in pts] + [fit._fit_rows(hp, model)])
+        res = {}
+        for mapping in ("point", "cells", "generic"):
+            env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
+            os.environ[env] = "1" if mapping == "generic" else mapping
+            try:
+                res[mapping] = fit.theory_vector_batch(batch, empirical_corr=True)
+                assert fit._get_engine().last_kernel().endswith(
+                    {"point": "fast_kernel", "cells": "cells_kernel", "generic": "vk_theory_kernel"}[mapping])
+            finally:
+                del os.environ[env]
+            assert close(res[mapping][:3], g[key]), (name, mapping)
+        for mapping in ("cells", "generic"):
+            assert np.max(np.abs(res[mapping] - res["point"])) < 1e-10 * np.max(np.abs(res["point"])), (name, mapping)

@@ -67,7 +67,7 @@ struct vk_ctx {
   const double *d_sv_mu = nullptr, *d_sv2d = nullptr;
   int uni_n = 0;             // unified refined grid (fast kernels need it)
   double uni_u0 = 0, uni_inv_h = 0;
-  const double *d_uni_sv_v = nullptr, *d_uni_xi = nullptr, *d_uni_xic = nullptr, *d_uni_vb = nullptr;
+  const double *d_uni_sv_v = nullptr, *d_uni_xi = nullptr, *d_uni_xic = nullptr, *d_uni_vb = nullptr, *d_uni_v2 = nullptr;
   int uni_lut_n = 0;         // > 0: union-grid form of the unified tables
   double uni_lut_inv_g = 0;
   const unsigned short* d_uni_lut = nullptr;
@@ -257,6 +257,7 @@ int theory_args(vk_ctx* ctx, const vk_eval_opts* o, TheoryArgs* a, int* nlr) {
   a->uni_xi = ctx->d_uni_xi;
   a->uni_xic = ctx->d_uni_xic;
   a->uni_vb = ctx->d_uni_vb;
+  a->uni_v2 = ctx->d_uni_v2;
   a->uni_lut_n = ctx->uni_lut_n;
   a->uni_lut_inv_g = ctx->uni_lut_inv_g;
   a->uni_lut = ctx->d_uni_lut;
@@ -289,7 +290,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   if (a.n <= 0) return VK_OK;
   choose_split(ctx, a.n, a.n_s, &a.sbins_per_item, &a.team);
   // the fast kernel (streaming only) packs LDS byte offsets of the mu and (x, w) records into 16 bits each
-  const bool fast = a.rsd == VK_RSD_STREAMING && ctx->fast_ok && !a.from_data && !a.empirical &&
+  const bool fast = a.rsd == VK_RSD_STREAMING && ctx->fast_ok && !a.from_data && (!a.empirical || a.uni_v2) &&
                     a.n_mu <= 1024 && a.n_x <= 2048 && !getenv("VICTOR_HIP_FORCE_GENERIC");
   size_t lds;
   if (fast) {
@@ -307,7 +308,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   const int grid = (int)(items < cap ? items : cap);
   // lanes-over-batch variant: batch-constant tables and enough points to fill the chip with n_s * n/64 waves
   const char* mapping = getenv("VICTOR_HIP_MAPPING");
-  const bool lanes_ok = fast && a.n_beta_r == 0;
+  const bool lanes_ok = fast && a.n_beta_r == 0 && !a.empirical;   // per-point tables need a workgroup per point
   // One wave per (s bin, 64-point chunk).  LDS and registers hold up to 5 workgroups (20 waves) per CU, so the
   // chip holds `slots` waves at a time; the last round of waves is only partly filled.  The lanes kernel is ~1.2x
   // faster per integrand than the point-major one (56 vs ~68 VALU instructions), so it wins once that fill
@@ -588,7 +589,7 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
     o_svmu = up.add(t->sv_mu, t->sv_n_mu);
     o_sv2d = up.add(t->sv2d, (size_t)t->sv.n_int * (t->sv_n_mu - 1) * 16);
   }
-  size_t o_usv = 0, o_uxi = 0, o_uxc = 0, o_ulut = 0, o_uk = 0, o_uvb = 0;
+  size_t o_usv = 0, o_uxi = 0, o_uxc = 0, o_ulut = 0, o_uk = 0, o_uvb = 0, o_uv2 = 0;
   const bool have_lut = t->uni_n > 0 && t->uni_lut_n > 0 && t->uni_lut && t->uni_knots;
   if (have_lut) {
     std::vector<double> packed(((size_t)t->uni_lut_n + 3) / 4, 0.0);        // u16 cells travel inside the double arena
@@ -603,6 +604,7 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
     o_uxc = up.add(t->uni_xic, t->n_beta_r > 0 ? (size_t)t->n_ell_r * (t->n_beta_r - 1) * t->uni_n * 16
                                                : (size_t)t->n_ell_r * t->uni_n * 4);
     if (t->vr_beta_dep && t->uni_vb) o_uvb = up.add(t->uni_vb, (size_t)(t->n_beta_r - 1) * t->uni_n * 16);
+    if (!t->vr_beta_dep && t->uni_v2) o_uv2 = up.add(t->uni_v2, (size_t)t->uni_n * 4);
   }
   size_t o_bd = 0, o_data = 0, o_bc = 0, o_prec = 0, o_ld = 0, o_eig = 0;
   if (t->data) {
@@ -647,6 +649,7 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
     ctx->d_uni_xi = base + o_uxi;
     ctx->d_uni_xic = base + o_uxc;
     if (t->vr_beta_dep && t->uni_vb) ctx->d_uni_vb = base + o_uvb;
+    if (!t->vr_beta_dep && t->uni_v2) ctx->d_uni_v2 = base + o_uv2;
     if (have_lut) {
       ctx->uni_lut_n = t->uni_lut_n;
       ctx->uni_lut_inv_g = t->uni_lut_inv_g;

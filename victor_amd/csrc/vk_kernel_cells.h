@@ -74,9 +74,10 @@ __global__ __launch_bounds__(kBlock, 5) void vk_theory_cells_kernel(TheoryArgs a
   for (long long point = blockIdx.x; point < a.n; point += gridDim.x) {
     const double* row = a.params + point * VK_NPAR;
     const PointScalars ps = point_scalars(a, row);
-    if (a.n_beta_r > 0) {
+    if (a.n_beta_r > 0 || a.empirical) {
       __syncthreads();  // every wave is done with the previous point's records
-      rebuild_uni_xi<NLR>(a, lds + kRecsOff, lds + pl.betar, row[VK_P_BETA]);
+      if (a.n_beta_r > 0) rebuild_uni_xi<NLR>(a, lds + kRecsOff, lds + pl.betar, row[VK_P_BETA]);
+      if (a.empirical) rebuild_uni_v_emp<NLR>(a, lds + kRecsOff, ps.av);
       __syncthreads();
     }
     for (int e = lane; e < kMaxEll * slots; e += 64) l_acc[e * kWaves + wave] = 0.0;

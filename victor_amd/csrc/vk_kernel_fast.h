@@ -145,6 +145,15 @@ __device__ __forceinline__ void rebuild_uni_xi(const TheoryArgs& a, double* recs
   }
 }
 
+// empirical_corr (ccf_model.py:451-455): v_r carries the factor (1 + Av delta), i.e. V = V1 + av V2 with the per-point
+// av; the kernels that own a point per workgroup rewrite the V half of the records for it
+template <int NLR>
+__device__ __forceinline__ void rebuild_uni_v_emp(const TheoryArgs& a, double* recs, double av) {
+  constexpr int stride = uni_stride(NLR);
+  for (int iq = threadIdx.x; iq < a.uni_n * 4; iq += kBlock)
+    recs[(iq >> 2) * stride + 4 + (iq & 3)] = fma(av, a.uni_v2[iq], a.uni_sv_v[(iq >> 2) * 8 + 4 + (iq & 3)]);
+}
+
 // per-point factors of the index-unit formulation (wave-uniform in the point-major and cells kernels, per lane in
 // the lanes kernel)
 struct FastPoint {
@@ -287,9 +296,10 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
     const int g = (int)(item - point * groups);
     const double* row = a.params + point * VK_NPAR;
     const PointScalars ps = point_scalars(a, row);
-    if (a.n_beta_r > 0) {
+    if (a.n_beta_r > 0 || a.empirical) {
       __syncthreads();  // previous item's readers are done with the per-point records
-      rebuild_uni_xi<NLR>(a, lds + kRecsOff, lds + pl.betar, row[VK_P_BETA]);
+      if (a.n_beta_r > 0) rebuild_uni_xi<NLR>(a, lds + kRecsOff, lds + pl.betar, row[VK_P_BETA]);
+      if (a.empirical) rebuild_uni_v_emp<NLR>(a, lds + kRecsOff, ps.av);
       __syncthreads();
     }
     const FastPoint fp = make_fast_point(ps, fc);
