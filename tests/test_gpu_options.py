@@ -96,6 +96,25 @@ def test_realspace_ccf_from_data_with_md_covariance(gold):
                                               fit.poles_s, matter_model="linear_bias", rsd_model="kaiser")
                   for q in pts[:3]])
     assert close(t, g["opt_fromdata_lb_kaiser"])
+    # the streaming branch runs on the fast kernels with a second interval look-up at the fiducial coordinates
+    import os
+    hp = cases.halton_params(1500, with_beta=True)
+    rows = np.vstack([batch_rows, fit._fit_rows(hp, fit.model)])
+    res = {}
+    for aniso in (False, True):
+        for mapping in ("point", "cells", "generic"):
+            env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
+            os.environ[env] = "1" if mapping == "generic" else mapping
+            try:
+                res[mapping] = fit.theory_vector_batch(rows, assume_isotropic=not aniso)
+                assert fit._get_engine().last_kernel().endswith(
+                    {"point": "fast_kernel", "cells": "cells_kernel", "generic": "vk_theory_kernel"}[mapping])
+            finally:
+                del os.environ[env]
+            want = g["opt_fromdata_aniso_theory"] if aniso else g["opt_fromdata_theory"][:3]
+            assert close(res[mapping][:3], want), (aniso, mapping)
+        for mapping in ("cells", "generic"):
+            assert np.max(np.abs(res[mapping] - res["point"])) < 1e-10 * np.max(np.abs(res["point"])), (aniso, mapping)
 
 
 @pytest.mark.parametrize("with_beta", [False, True])

@@ -26,6 +26,15 @@ def run(fit, label, batch, beta, **kw):
     print(f"{label}: {dt*1e3:.2f} ms/batch {batch/dt:.0f} evals/s ({eng.last_kernel()})", flush=True)
     for b in bufs: eng.free(b)
 
+m, d = cases.boss_options("config")
+m["input_model_data_file"] = "boss/measured_model.npy"
+m["realspace_ccf"]["from_data"] = True
+d["covariance_matrix"]["data_file"] = "boss/cov_md_iso.npy"
+fd = victor_amd.CCFFit(m, d)
+run(fd, "boss from_data (measured model + MD covariance)", 16384, True)
+os.environ["VICTOR_HIP_FORCE_GENERIC"] = "1"
+run(fd, "boss from_data, generic kernel", 16384, True)
+del os.environ["VICTOR_HIP_FORCE_GENERIC"]
 for name, opts, beta in (("config3", cases.synth_options(3), False), ("boss", cases.boss_options("config"), True)):
     fit = victor_amd.CCFFit(*opts)
     for kw in ({}, {"rsd_model": "dispersion"}, {"rsd_model": "kaiser"}, {"rsd_model": "euclid_special"},

@@ -178,14 +178,19 @@ int launch_generic(vk_ctx* ctx, const TheoryArgs& a, int nlr, int grid, size_t l
   return fail(ctx, VK_E_ARG, "bad number of real-space multipoles %d", nlr);
 }
 
-template <int NLR, int GRID>
-int launch_fast_ng(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
+template <int NLR, int GRID, int FD>
+int launch_fast_ngf(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 1, GRID>, grid, lds, a);
-    case 2: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 2, GRID>, grid, lds, a);
-    case 3: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 3, GRID>, grid, lds, a);
+    case 1: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 1, GRID, FD>, grid, lds, a);
+    case 2: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 2, GRID, FD>, grid, lds, a);
+    case 3: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 3, GRID, FD>, grid, lds, a);
   }
   return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
+}
+
+template <int NLR, int GRID>
+int launch_fast_ng(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
+  return a.from_data ? launch_fast_ngf<NLR, GRID, 1>(ctx, a, grid, lds) : launch_fast_ngf<NLR, GRID, 0>(ctx, a, grid, lds);
 }
 
 template <int NLR>
@@ -208,14 +213,19 @@ int launch_lanes_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   return a.uni_lut_n > 0 ? launch_lanes_ng<NLR, 1>(ctx, a, grid, lds) : launch_lanes_ng<NLR, 0>(ctx, a, grid, lds);
 }
 
-template <int NLR, int GRID>
-int launch_cells_ng(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
+template <int NLR, int GRID, int FD>
+int launch_cells_ngf(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 1, GRID>, grid, lds, a);
-    case 2: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 2, GRID>, grid, lds, a);
-    case 3: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 3, GRID>, grid, lds, a);
+    case 1: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 1, GRID, FD>, grid, lds, a);
+    case 2: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 2, GRID, FD>, grid, lds, a);
+    case 3: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 3, GRID, FD>, grid, lds, a);
   }
   return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
+}
+
+template <int NLR, int GRID>
+int launch_cells_ng(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
+  return a.from_data ? launch_cells_ngf<NLR, GRID, 1>(ctx, a, grid, lds) : launch_cells_ngf<NLR, GRID, 0>(ctx, a, grid, lds);
 }
 
 template <int NLR>
@@ -290,7 +300,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   if (a.n <= 0) return VK_OK;
   choose_split(ctx, a.n, a.n_s, &a.sbins_per_item, &a.team);
   // the fast kernel (streaming only) packs LDS byte offsets of the mu and (x, w) records into 16 bits each
-  const bool fast = a.rsd == VK_RSD_STREAMING && ctx->fast_ok && !a.from_data && (!a.empirical || a.uni_v2) &&
+  const bool fast = a.rsd == VK_RSD_STREAMING && ctx->fast_ok && (!a.empirical || a.uni_v2) &&
                     a.n_mu <= 1024 && a.n_x <= 2048 && !getenv("VICTOR_HIP_FORCE_GENERIC");
   size_t lds;
   if (fast) {
@@ -308,7 +318,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   const int grid = (int)(items < cap ? items : cap);
   // lanes-over-batch variant: batch-constant tables and enough points to fill the chip with n_s * n/64 waves
   const char* mapping = getenv("VICTOR_HIP_MAPPING");
-  const bool lanes_ok = fast && a.n_beta_r == 0 && !a.empirical;   // per-point tables need a workgroup per point
+  const bool lanes_ok = fast && a.n_beta_r == 0 && !a.empirical && !a.from_data;   // per-point tables need a workgroup per point
   // One wave per (s bin, 64-point chunk).  LDS and registers hold up to 5 workgroups (20 waves) per CU, so the
   // chip holds `slots` waves at a time; the last round of waves is only partly filled.  The lanes kernel is ~1.2x
   // faster per integrand than the point-major one (56 vs ~68 VALU instructions), so it wins once that fill

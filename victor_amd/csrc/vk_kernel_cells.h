@@ -32,7 +32,7 @@ __host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s,
 }
 
 // (130 VGPRs -> 3 waves per SIMD; forcing 4 with __launch_bounds__(256, 4) spills and measured 1.5 % slower)
-template <int NLR, int NL, int GRID>
+template <int NLR, int NL, int GRID, int FD>
 __global__ __launch_bounds__(kBlock, 5) void vk_theory_cells_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
   const CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n);
@@ -92,12 +92,13 @@ __global__ __launch_bounds__(kBlock, 5) void vk_theory_cells_kernel(TheoryArgs a
       const vk_d2 mm = *reinterpret_cast<const vk_d2*>(l_mu + 2 * i);
       const double s_perp = sj * fp.k_perp * mm.y;
       const double sperp2 = s_perp * s_perp;
+      const double sperp2x = sperp2 * fp.fp2;      // from_data only
       const double s_par = sj * fp.k_par * mm.x;
       double g = 0.0;
       for (int k = 0; k < a.n_x; ++k) {
         const vk_d2 xw = cxw[k];             // scalar-cache read (wave-uniform), see vk_kernel_lanes.h
         const double xk = xw.x;
-        g = fma(xw.y, uni_value<NLR, GRID>(lds, fc, fp.AVk, fma(-xk, fp.Bk, s_par), sperp2, xk), g);
+        g = fma(xw.y, uni_value<NLR, GRID, FD>(lds, fc, fp.AVk, fma(-xk, fp.Bk, s_par), sperp2, xk, fp.fa, sperp2x), g);
       }
       if (!live) g = 0.0;
       // projection: this trip's cells belong to s bin jj0 or jj0 + 1

@@ -157,6 +157,7 @@ __device__ __forceinline__ void rebuild_uni_v_emp(const TheoryArgs& a, double* r
 // per-point factors of the index-unit formulation (wave-uniform in the point-major and cells kernels, per lane in
 // the lanes kernel)
 struct FastPoint {
+  double fa, fp2;         // from_data: c/apar and (c/aperp)^2 (fiducial coordinates of xi^r, see uni_value)
   double k_perp, k_par;   // aperp k, apar k: s_perp' = s sqrt(1-mu^2) k_perp, s_par' = s mu k_par
   double Bk;              // sigma_v iaH_true k / kExpScale: r_par' = s_par' - x_k' Bk with x_k' = kExpScale x_k
   double AVk;             // kExpScale g / (3 iaH_true sigma_v): y = (x_k' + AVk V mu_r) / SV
@@ -169,41 +170,63 @@ __device__ __forceinline__ FastPoint make_fast_point(const PointScalars& ps, con
   fp.k_par = ps.apar * k;
   fp.Bk = ps.B * k * (1.0 / vkm::kExpScale);
   fp.AVk = ps.A * vkm::kExpScale;
+  const double c = 1.0 / ps.inv_c;
+  fp.fa = c * ps.inv_apar;
+  fp.fp2 = (c * ps.inv_aperp) * (c * ps.inv_aperp);
   return fp;
+}
+
+// Record and local coordinate of a radius: `x` is the interval coordinate t = r' + off (GRID 0) or the radius u = r'
+// itself (GRID 1, union grid), not yet clamped.
+template <int NLR, int GRID>
+__device__ __forceinline__ const double* locate(const double* __restrict__ lds, const FastConsts& fc, double x,
+                                                double& tq) {
+  constexpr int stride = uni_stride(NLR);
+  if (GRID == 0) {
+    const double t = vmin_f64(vmax_f64(x, fc.t_lo), fc.n_eps);
+    tq = __builtin_amdgcn_fract(t);
+    return lds_at(lds + kRecsOff, __mul24((int)t, stride * 8));
+  }
+  const double u = vmin_f64(vmax_f64(x, fc.t_lo), fc.n_eps);
+  const int cell = (int)(u * fc.inv_g);
+  const int q0 = *reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(lds) + fc.lut_off + 2 * cell);
+  const double* rec0 = lds_at(lds + kRecsOff, __mul24(q0, stride * 8));
+  const double k1 = rec0[2 * stride - 2], k2 = rec0[3 * stride - 2];      // left knots of the next two records
+  const int q = q0 + (u >= k1) + (u >= k2);
+  const double* rec = lds_at(lds + kRecsOff, __mul24(q, stride * 8));
+  const vk_d2 kw = *reinterpret_cast<const vk_d2*>(rec + stride - 2);
+  tq = (u - kw.x) * kw.y;
+  return rec;
 }
 
 // (1 + xi^r) * exp(-z^2/2) / SV at one integrand point, given r_par' and s_perp'^2 in index units and the scaled
 // velocity node xk' (ccf_model.py:648-657, 681-690).  For NLR > 1 the records hold the Legendre sum regrouped in
 // powers of m = mu_r^2 (A, B, C of vk_tables.uni_xic), so xi^r = A + m (B + m C).
-template <int NLR, int GRID>
+// FD = 1: realspace_ccf_from_data (ccf_model.py:618-619, 675-679) - xi^r is read at the fiducial coordinates
+// (r_par / apar, s_perp / aperp) on an abscissa that is not rescaled by c, i.e. at r_par' * fa and sperp2' * fp^2 with
+// fa = c/apar, fp = c/aperp (`sperp2x` carries the second product), through a second interval look-up.
+template <int NLR, int GRID, int FD>
 __device__ __forceinline__ double uni_value(const double* __restrict__ lds, const FastConsts& fc, double AVk,
-                                            double r_par, double sperp2, double xk) {
-  constexpr int stride = uni_stride(NLR);
+                                            double r_par, double sperp2, double xk, double fa, double sperp2x) {
   const double r2 = fma(r_par, r_par, sperp2);
   const double inv_r = vkm::rsqrt3(r2);
   const double mu_r = r_par * inv_r;
-  const double* rec;
+  double mu_x = mu_r;                           // the mu at which xi^r is read
   double tq;
-  if (GRID == 0) {
-    const double t = vmin_f64(vmax_f64(fma(r2, inv_r, fc.off), fc.t_lo), fc.n_eps);
-    tq = __builtin_amdgcn_fract(t);
-    rec = lds_at(lds + kRecsOff, __mul24((int)t, stride * 8));
-  } else {
-    const double u = vmin_f64(vmax_f64(r2 * inv_r, fc.t_lo), fc.n_eps);
-    const int cell = (int)(u * fc.inv_g);
-    const int q0 = *reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(lds) + fc.lut_off + 2 * cell);
-    const double* rec0 = lds_at(lds + kRecsOff, __mul24(q0, stride * 8));
-    const double k1 = rec0[2 * stride - 2], k2 = rec0[3 * stride - 2];      // left knots of the next two records
-    const int q = q0 + (u >= k1) + (u >= k2);
-    rec = lds_at(lds + kRecsOff, __mul24(q, stride * 8));
-    const vk_d2 kw = *reinterpret_cast<const vk_d2*>(rec + stride - 2);
-    tq = (u - kw.x) * kw.y;
-  }
+  const double* rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(r2, inv_r, fc.off) : r2 * inv_r, tq);
   const double SV = cubic_b128(rec, tq);
   const double V = cubic_b128(rec + 4, tq);
+  const double ynum = fma(AVk * V, mu_r, xk);
+  if (FD) {
+    const double rp = r_par * fa;
+    const double r2x = fma(rp, rp, sperp2x);
+    const double inv_rx = vkm::rsqrt3(r2x);
+    mu_x = rp * inv_rx;
+    rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(r2x, inv_rx, fc.off) : r2x * inv_rx, tq);
+  }
   double xir = cubic_b128(rec + 8, tq);
   if (NLR > 1) {
-    const double m2 = mu_r * mu_r;
+    const double m2 = mu_x * mu_x;
     if (NLR == 2) {
       xir = fma(cubic_b128(rec + 12, tq), m2, xir);
     } else {
@@ -211,7 +234,7 @@ __device__ __forceinline__ double uni_value(const double* __restrict__ lds, cons
     }
   }
   const double inv_sv = vkm::recip(SV);
-  const double y = fma(AVk * V, mu_r, xk) * inv_sv;
+  const double y = ynum * inv_sv;
   const double e = vkm::exp_scaled(-y * y, lds + kEtabOff);
   return inv_sv * fma(e, xir, e);
 }
@@ -236,7 +259,7 @@ __host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int uni_n,
   return p;
 }
 
-template <int NLR, int NL, int GRID>
+template <int NLR, int NL, int GRID, int FD>
 __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
   const FastPlan pl = make_fast_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n);
@@ -322,7 +345,9 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
           const vk_d2 m01 = *reinterpret_cast<const vk_d2*>(mr);
           const vk_d2 xw = *reinterpret_cast<const vk_d2*>(x_bytes + (pk >> 16));
           const double s_perp = s_aperp * m01.y;
-          const double f = xw.y * uni_value<NLR, GRID>(lds, fc, fp.AVk, fma(-xw.x, fp.Bk, s_apar * m01.x), s_perp * s_perp, xw.x);
+          const double sperp2 = s_perp * s_perp;
+          const double f = xw.y * uni_value<NLR, GRID, FD>(lds, fc, fp.AVk, fma(-xw.x, fp.Bk, s_apar * m01.x), sperp2, xw.x,
+                                                          fp.fa, sperp2 * fp.fp2);
           const vk_d2 w01 = *reinterpret_cast<const vk_d2*>(mr + 2);
           acc[0] = fma(w01.x, f, acc[0]);
           if (NL > 1) acc[1] = fma(w01.y, f, acc[1]);

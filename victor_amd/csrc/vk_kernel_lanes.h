@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kBlock, 5) void vk_theory_lanes_kernel(TheoryArgs a
       for (int k = 0; k < a.n_x; ++k) {
         const vk_d2 xw = cxw[k];
         const double xk = xw.x;
-        g = fma(xw.y, uni_value<NLR, GRID>(lds, fc, fp.AVk, fma(-xk, fp.Bk, s_par), sperp2, xk), g);
+        g = fma(xw.y, uni_value<NLR, GRID, 0>(lds, fc, fp.AVk, fma(-xk, fp.Bk, s_par), sperp2, xk, 0.0, 0.0), g);
       }
 #pragma unroll
       for (int l = 0; l < NL; ++l) acc[l] = fma(a.w_ell[l * a.n_mu + i], g, acc[l]);
