@@ -107,3 +107,26 @@ def test_walker_example_under_torchrun_single_rank():
     assert 0.02 < res["acceptance"] < 0.95
     assert 0.2 <= res["mean"]["beta"] <= 0.6 and 100 <= res["mean"]["sigma_v"] <= 500
     assert res["best_lnl_over_all_ranks"] > 250          # the reference point alone gives lnL = 284.8
+
+
+def test_integration_stub_runs_as_written():
+    """The ctypes stub printed in INTEGRATION.md (route B) is executed verbatim against a CCFFit and must reproduce
+    the package's own batch API."""
+    import os
+    import re
+    import numpy as np
+    import victor_amd
+    from tests import cases
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = [b for b in blocks if "class HipLikelihood" in b]
+    assert len(stub) == 1
+    ns = {}
+    exec(compile(stub[0], "INTEGRATION.md", "exec"), ns)
+    fit = victor_amd.CCFFit(*cases.boss_options("config"))
+    like = ns["HipLikelihood"](fit)
+    rows = fit._fit_rows(cases.halton_params(257, with_beta=True), fit.model)
+    lnl, chi2 = like(rows)
+    want_l, want_c = fit.log_likelihood_batch(rows)
+    assert np.array_equal(lnl, want_l) and np.array_equal(chi2, want_c)
