@@ -215,6 +215,29 @@ def test_large_batch_properties(synth_fit):
     assert np.max(np.abs(chi_s / chi2[idx] - 1)) < 1e-12
 
 
+def test_full_size_linearity_in_the_real_space_ccf(tmp_path):
+    """xi^s + 1 = int (1 + xi^r) pdf dv is affine in the real-space multipoles: with the tables scaled by 0, 1 and 2 the
+    theory vectors of the full 65536-point batch must satisfy T(2 xi) - 2 T(xi) + T(0) = 0 (size-independent check of
+    the whole theory kernel; the velocity tables come from the matter template and do not change)."""
+    import victor_amd
+    src = np.load(os.path.join(cases.GOLDEN, "synth", "model.npy"), allow_pickle=True).item()
+    n = 65536
+    hp = cases.halton_params(n)
+    th = {}
+    for scale in (0.0, 1.0, 2.0):
+        tab = dict(src)
+        for key in ("monopole", "quadrupole", "hexadecapole"):
+            tab[key] = scale * np.asarray(src[key])
+        np.save(tmp_path / f"model_x{int(scale)}.npy", tab, allow_pickle=True)
+        model, data = cases.synth_options(3)
+        model = dict(model, dir=str(tmp_path), input_model_data_file=f"model_x{int(scale)}.npy")
+        th[scale] = victor_amd.CCFFit(model, data).theory_vector_batch(hp)
+        assert th[scale].shape == (n, 120)
+    resid = th[2.0] - 2.0 * th[1.0] + th[0.0]
+    assert np.max(np.abs(resid)) < 1e-12 * np.max(np.abs(th[1.0]))
+    assert np.max(np.abs(th[1.0] - th[0.0])) > 1e-3          # the tables do matter
+
+
 def test_failure_guards(boss_fit):
     fit = boss_fit["config"]
     lnl, chi2 = fit.log_likelihood({"fsigma8": np.nan, "beta": 0.37, "sigma_v": 380, "epsilon": 1.0})
