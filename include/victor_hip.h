@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 10
+#define VK_ABI_VERSION 11
 
 /* error codes */
 #define VK_OK 0
@@ -159,6 +159,8 @@ typedef struct vk_tables {
                            [n_beta_r-1][uni_n][4][4]; the V half of uni_sv_v is then rebuilt per point            */
   const double* uni_v2; /* fixed velocity tables only (else NULL): V2 = r*Delta*delta on the unified grid, [uni_n][4];
                            with empirical_corr the V half of the records becomes V1 + Av V2 per point            */
+  const double* uni_da; /* fixed velocity tables only (else NULL): Da = delta - 2 Delta/3 on the unified grid,
+                           [uni_n][4]; lets the dispersion model run on the fast kernels                        */
   /* Union-grid form of the same tables for knots that are not uniform or not commensurate: uni_n intervals between
    * the sorted distinct knots uni_knots[0..uni_n] of vr (uni_knots[0] = vr.knots[0] = 0.01), xi and sv; the
    * coefficient arrays above are then in units of each interval's own width.  A uniform look-up table of

@@ -444,3 +444,32 @@ def test_empirical_corr_runs_on_the_fast_kernels(gold):
             assert close(res[mapping][:3], g[key]), (name, mapping)
         for mapping in ("cells", "generic"):
             assert np.max(np.abs(res[mapping] - res["point"])) < 1e-10 * np.max(np.abs(res["point"])), (name, mapping)
+
+
+def test_dispersion_model_runs_on_the_fast_kernels(gold):
+    """rsd_model='dispersion' on fixed velocity tables: the fixed-point coordinate, Jacobian and zero-mean pdf evaluated on
+    the unified records (vk_tables.uni_da); reference goldens first, then a batch through every mapping."""
+    import os
+    import victor_amd
+    g, meta = gold
+    for name, opts, beta, key, npts in (("synth", cases.synth_options(3), False, None, 0),
+                                        ("boss", cases.boss_options("config"), True, "boss_dispersion_theory", 3)):
+        fit = victor_amd.CCFFit(*opts)
+        model = fit._merged({"rsd_model": "dispersion"})
+        hp = cases.halton_params(1200, with_beta=beta)
+        parts = [fit._fit_rows(dict(p), model) for p in meta["boss_points"][:npts]] + [fit._fit_rows(hp, model)]
+        rows = np.vstack(parts)
+        res = {}
+        for mapping in ("point", "cells", "generic"):
+            env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
+            os.environ[env] = "1" if mapping == "generic" else mapping
+            try:
+                res[mapping] = fit.theory_vector_batch(rows, rsd_model="dispersion")
+                assert fit._get_engine().last_kernel().endswith(
+                    {"point": "fast_kernel", "cells": "cells_kernel", "generic": "vk_theory_kernel"}[mapping])
+            finally:
+                del os.environ[env]
+            if key:
+                assert close(res[mapping][:npts], g[key]), (name, mapping)
+        for mapping in ("cells", "generic"):
+            assert np.max(np.abs(res[mapping] - res["point"])) < 1e-10 * np.max(np.abs(res["point"])), (name, mapping)

@@ -67,7 +67,7 @@ struct vk_ctx {
   const double *d_sv_mu = nullptr, *d_sv2d = nullptr;
   int uni_n = 0;             // unified refined grid (fast kernels need it)
   double uni_u0 = 0, uni_inv_h = 0;
-  const double *d_uni_sv_v = nullptr, *d_uni_xi = nullptr, *d_uni_xic = nullptr, *d_uni_vb = nullptr, *d_uni_v2 = nullptr;
+  const double *d_uni_sv_v = nullptr, *d_uni_xi = nullptr, *d_uni_xic = nullptr, *d_uni_vb = nullptr, *d_uni_v2 = nullptr, *d_uni_da = nullptr;
   int uni_lut_n = 0;         // > 0: union-grid form of the unified tables
   double uni_lut_inv_g = 0;
   const unsigned short* d_uni_lut = nullptr;
@@ -178,19 +178,21 @@ int launch_generic(vk_ctx* ctx, const TheoryArgs& a, int nlr, int grid, size_t l
   return fail(ctx, VK_E_ARG, "bad number of real-space multipoles %d", nlr);
 }
 
-template <int NLR, int GRID, int FD>
+template <int NLR, int GRID, int MODE>
 int launch_fast_ngf(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 1, GRID, FD>, grid, lds, a);
-    case 2: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 2, GRID, FD>, grid, lds, a);
-    case 3: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 3, GRID, FD>, grid, lds, a);
+    case 1: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 1, GRID, MODE>, grid, lds, a);
+    case 2: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 2, GRID, MODE>, grid, lds, a);
+    case 3: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 3, GRID, MODE>, grid, lds, a);
   }
   return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
 }
 
 template <int NLR, int GRID>
 int launch_fast_ng(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
-  return a.from_data ? launch_fast_ngf<NLR, GRID, 1>(ctx, a, grid, lds) : launch_fast_ngf<NLR, GRID, 0>(ctx, a, grid, lds);
+  if (a.rsd == VK_RSD_DISPERSION) return launch_fast_ngf<NLR, GRID, kModeDispersion>(ctx, a, grid, lds);
+  return a.from_data ? launch_fast_ngf<NLR, GRID, kModeFromData>(ctx, a, grid, lds)
+                     : launch_fast_ngf<NLR, GRID, kModeStreaming>(ctx, a, grid, lds);
 }
 
 template <int NLR>
@@ -213,19 +215,21 @@ int launch_lanes_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   return a.uni_lut_n > 0 ? launch_lanes_ng<NLR, 1>(ctx, a, grid, lds) : launch_lanes_ng<NLR, 0>(ctx, a, grid, lds);
 }
 
-template <int NLR, int GRID, int FD>
+template <int NLR, int GRID, int MODE>
 int launch_cells_ngf(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 1, GRID, FD>, grid, lds, a);
-    case 2: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 2, GRID, FD>, grid, lds, a);
-    case 3: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 3, GRID, FD>, grid, lds, a);
+    case 1: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 1, GRID, MODE>, grid, lds, a);
+    case 2: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 2, GRID, MODE>, grid, lds, a);
+    case 3: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 3, GRID, MODE>, grid, lds, a);
   }
   return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
 }
 
 template <int NLR, int GRID>
 int launch_cells_ng(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
-  return a.from_data ? launch_cells_ngf<NLR, GRID, 1>(ctx, a, grid, lds) : launch_cells_ngf<NLR, GRID, 0>(ctx, a, grid, lds);
+  if (a.rsd == VK_RSD_DISPERSION) return launch_cells_ngf<NLR, GRID, kModeDispersion>(ctx, a, grid, lds);
+  return a.from_data ? launch_cells_ngf<NLR, GRID, kModeFromData>(ctx, a, grid, lds)
+                     : launch_cells_ngf<NLR, GRID, kModeStreaming>(ctx, a, grid, lds);
 }
 
 template <int NLR>
@@ -268,6 +272,7 @@ int theory_args(vk_ctx* ctx, const vk_eval_opts* o, TheoryArgs* a, int* nlr) {
   a->uni_xic = ctx->d_uni_xic;
   a->uni_vb = ctx->d_uni_vb;
   a->uni_v2 = ctx->d_uni_v2;
+  a->uni_da = ctx->d_uni_da;
   a->uni_lut_n = ctx->uni_lut_n;
   a->uni_lut_inv_g = ctx->uni_lut_inv_g;
   a->uni_lut = ctx->d_uni_lut;
@@ -300,11 +305,13 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   if (a.n <= 0) return VK_OK;
   choose_split(ctx, a.n, a.n_s, &a.sbins_per_item, &a.team);
   // the fast kernel (streaming only) packs LDS byte offsets of the mu and (x, w) records into 16 bits each
-  const bool fast = a.rsd == VK_RSD_STREAMING && ctx->fast_ok && (!a.empirical || a.uni_v2) &&
+  // fast kernels: the streaming model, and the dispersion model on fixed velocity tables (cells / point-major only)
+  const bool disp = a.rsd == VK_RSD_DISPERSION && a.uni_da && !a.from_data && !a.empirical && !a.vr_beta_dep;
+  const bool fast = (a.rsd == VK_RSD_STREAMING || disp) && ctx->fast_ok && (!a.empirical || a.uni_v2) &&
                     a.n_mu <= 1024 && a.n_x <= 2048 && !getenv("VICTOR_HIP_FORCE_GENERIC");
   size_t lds;
   if (fast) {
-    lds = (size_t)make_fast_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n).total * sizeof(double);
+    lds = (size_t)make_fast_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, disp).total * sizeof(double);
   } else {
     lds = (size_t)make_plan(a.n_mu, a.n_x, a.n_ell, a.sv.n_int, a.vr.n_int, a.xi.n_int, nlr, a.n_beta_r).total *
           sizeof(double);
@@ -318,7 +325,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   const int grid = (int)(items < cap ? items : cap);
   // lanes-over-batch variant: batch-constant tables and enough points to fill the chip with n_s * n/64 waves
   const char* mapping = getenv("VICTOR_HIP_MAPPING");
-  const bool lanes_ok = fast && a.n_beta_r == 0 && !a.empirical && !a.from_data;   // per-point tables need a workgroup per point
+  const bool lanes_ok = fast && a.n_beta_r == 0 && !a.empirical && !a.from_data && !disp;   // per-point tables need a workgroup per point
   // One wave per (s bin, 64-point chunk).  LDS and registers hold up to 5 workgroups (20 waves) per CU, so the
   // chip holds `slots` waves at a time; the last round of waves is only partly filled.  The lanes kernel is ~1.2x
   // faster per integrand than the point-major one (56 vs ~68 VALU instructions), so it wins once that fill
@@ -351,7 +358,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   if (cells) {
     ctx->last_kernel = "vk_theory_cells_kernel";
     const size_t lds_c =
-        (size_t)make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n).total * sizeof(double);
+        (size_t)make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, disp).total * sizeof(double);
     if (lds_c > 160 * 1024) return fail(ctx, VK_E_ARG, "tables need %zu bytes of LDS (> 160 KiB)", lds_c);
     const long long capc = (pcap_env ? atoll(pcap_env) : 64LL) * ctx->n_cu;
     const int grid_c = (int)(a.n < capc ? a.n : capc);
@@ -599,7 +606,7 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
     o_svmu = up.add(t->sv_mu, t->sv_n_mu);
     o_sv2d = up.add(t->sv2d, (size_t)t->sv.n_int * (t->sv_n_mu - 1) * 16);
   }
-  size_t o_usv = 0, o_uxi = 0, o_uxc = 0, o_ulut = 0, o_uk = 0, o_uvb = 0, o_uv2 = 0;
+  size_t o_usv = 0, o_uxi = 0, o_uxc = 0, o_ulut = 0, o_uk = 0, o_uvb = 0, o_uv2 = 0, o_uda = 0;
   const bool have_lut = t->uni_n > 0 && t->uni_lut_n > 0 && t->uni_lut && t->uni_knots;
   if (have_lut) {
     std::vector<double> packed(((size_t)t->uni_lut_n + 3) / 4, 0.0);        // u16 cells travel inside the double arena
@@ -615,6 +622,7 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
                                                : (size_t)t->n_ell_r * t->uni_n * 4);
     if (t->vr_beta_dep && t->uni_vb) o_uvb = up.add(t->uni_vb, (size_t)(t->n_beta_r - 1) * t->uni_n * 16);
     if (!t->vr_beta_dep && t->uni_v2) o_uv2 = up.add(t->uni_v2, (size_t)t->uni_n * 4);
+    if (!t->vr_beta_dep && t->uni_da) o_uda = up.add(t->uni_da, (size_t)t->uni_n * 4);
   }
   size_t o_bd = 0, o_data = 0, o_bc = 0, o_prec = 0, o_ld = 0, o_eig = 0;
   if (t->data) {
@@ -660,6 +668,7 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
     ctx->d_uni_xic = base + o_uxc;
     if (t->vr_beta_dep && t->uni_vb) ctx->d_uni_vb = base + o_uvb;
     if (!t->vr_beta_dep && t->uni_v2) ctx->d_uni_v2 = base + o_uv2;
+    if (!t->vr_beta_dep && t->uni_da) ctx->d_uni_da = base + o_uda;
     if (have_lut) {
       ctx->uni_lut_n = t->uni_lut_n;
       ctx->uni_lut_inv_g = t->uni_lut_inv_g;

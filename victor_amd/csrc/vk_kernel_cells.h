@@ -14,11 +14,11 @@ namespace vk {
 // (a wave's 64 cells straddle at most two s bins when n_mu >= 64), accumulated by lane 0 in wave-private LDS.
 // --------------------------------------------------------------------------------------------------
 struct CellsPlan {
-  int mu, w, s, betar, acc, total;
+  int mu, w, s, betar, acc, da, total;
 };
 
 __host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s, int uni_n, int nlr, int n_beta_r,
-                                                     int lut_n) {
+                                                     int lut_n, int with_da) {
   CellsPlan p;
   int o = fast_fixed_doubles(uni_n, nlr, lut_n);          // exp table + records first (fixed offsets)
   o = (o + 1) & ~1;
@@ -27,15 +27,17 @@ __host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s,
   p.s = o;     o += (n_s + 1) & ~1;
   p.betar = o; o += (n_beta_r + 1) & ~1;
   p.acc = o;   o += kMaxEll * ((n_s + kWaves - 1) / kWaves) * kWaves;   // [l][slot][wave]
+  o = (o + 1) & ~1;
+  p.da = o;    o += with_da ? uni_n * 4 : 0;      // Da table of the dispersion model
   p.total = o;
   return p;
 }
 
 // (130 VGPRs -> 3 waves per SIMD; forcing 4 with __launch_bounds__(256, 4) spills and measured 1.5 % slower)
-template <int NLR, int NL, int GRID, int FD>
+template <int NLR, int NL, int GRID, int MODE>
 __global__ __launch_bounds__(kBlock, 5) void vk_theory_cells_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
-  const CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n);
+  const CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, MODE == kModeDispersion);
   const int tid = threadIdx.x;
   for (int i = tid; i < a.n_mu; i += kBlock) {
     const double m = a.mu[i];
@@ -46,6 +48,7 @@ __global__ __launch_bounds__(kBlock, 5) void vk_theory_cells_kernel(TheoryArgs a
   }
   for (int j = tid; j < a.n_s; j += kBlock) lds[pl.s + j] = a.s[j];
   stage_uni_records<NLR>(a, lds);
+  if (MODE == kModeDispersion) stage_da<NLR>(a, lds + pl.da);
   if (a.n_beta_r > 0)
     for (int i = tid; i < a.n_beta_r; i += kBlock) lds[pl.betar + i] = a.beta_r[i];
   const FastConsts fc = make_fast_consts<NLR>(a);
@@ -98,7 +101,12 @@ __global__ __launch_bounds__(kBlock, 5) void vk_theory_cells_kernel(TheoryArgs a
       for (int k = 0; k < a.n_x; ++k) {
         const vk_d2 xw = cxw[k];             // scalar-cache read (wave-uniform), see vk_kernel_lanes.h
         const double xk = xw.x;
-        g = fma(xw.y, uni_value<NLR, GRID, FD>(lds, fc, fp.AVk, fma(-xk, fp.Bk, s_par), sperp2, xk, fp.fa, sperp2x), g);
+        const double num = fma(-xk, fp.Bk, s_par);
+        g = fma(xw.y,
+                MODE == kModeDispersion
+                    ? disp_value<NLR, GRID>(lds, lds + pl.da, fc, fp, a.niter, num, s_par, sperp2, xk)
+                    : uni_value<NLR, GRID, MODE == kModeFromData>(lds, fc, fp.AVk, num, sperp2, xk, fp.fa, sperp2x),
+                g);
       }
       if (!live) g = 0.0;
       // projection: this trip's cells belong to s bin jj0 or jj0 + 1

@@ -158,6 +158,7 @@ __device__ __forceinline__ void rebuild_uni_v_emp(const TheoryArgs& a, double* r
 // the lanes kernel)
 struct FastPoint {
   double fa, fp2;         // from_data: c/apar and (c/aperp)^2 (fiducial coordinates of xi^r, see uni_value)
+  double Gk, gD;          // dispersion model: aH^-1 v_r/r = -Gk V(u) / r' and aH^-1 v_r' = -gD Da(u) (see disp_value)
   double k_perp, k_par;   // aperp k, apar k: s_perp' = s sqrt(1-mu^2) k_perp, s_par' = s mu k_par
   double Bk;              // sigma_v iaH_true k / kExpScale: r_par' = s_par' - x_k' Bk with x_k' = kExpScale x_k
   double AVk;             // kExpScale g / (3 iaH_true sigma_v): y = (x_k' + AVk V mu_r) / SV
@@ -173,6 +174,8 @@ __device__ __forceinline__ FastPoint make_fast_point(const PointScalars& ps, con
   const double c = 1.0 / ps.inv_c;
   fp.fa = c * ps.inv_apar;
   fp.fp2 = (c * ps.inv_aperp) * (c * ps.inv_aperp);
+  fp.Gk = ps.G * k;
+  fp.gD = ps.gD;
   return fp;
 }
 
@@ -180,12 +183,13 @@ __device__ __forceinline__ FastPoint make_fast_point(const PointScalars& ps, con
 // itself (GRID 1, union grid), not yet clamped.
 template <int NLR, int GRID>
 __device__ __forceinline__ const double* locate(const double* __restrict__ lds, const FastConsts& fc, double x,
-                                                double& tq) {
+                                                double& tq, int& qi) {
   constexpr int stride = uni_stride(NLR);
   if (GRID == 0) {
     const double t = vmin_f64(vmax_f64(x, fc.t_lo), fc.n_eps);
     tq = __builtin_amdgcn_fract(t);
-    return lds_at(lds + kRecsOff, __mul24((int)t, stride * 8));
+    qi = (int)t;
+    return lds_at(lds + kRecsOff, __mul24(qi, stride * 8));
   }
   const double u = vmin_f64(vmax_f64(x, fc.t_lo), fc.n_eps);
   const int cell = (int)(u * fc.inv_g);
@@ -193,6 +197,7 @@ __device__ __forceinline__ const double* locate(const double* __restrict__ lds, 
   const double* rec0 = lds_at(lds + kRecsOff, __mul24(q0, stride * 8));
   const double k1 = rec0[2 * stride - 2], k2 = rec0[3 * stride - 2];      // left knots of the next two records
   const int q = q0 + (u >= k1) + (u >= k2);
+  qi = q;
   const double* rec = lds_at(lds + kRecsOff, __mul24(q, stride * 8));
   const vk_d2 kw = *reinterpret_cast<const vk_d2*>(rec + stride - 2);
   tq = (u - kw.x) * kw.y;
@@ -213,7 +218,8 @@ __device__ __forceinline__ double uni_value(const double* __restrict__ lds, cons
   const double mu_r = r_par * inv_r;
   double mu_x = mu_r;                           // the mu at which xi^r is read
   double tq;
-  const double* rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(r2, inv_r, fc.off) : r2 * inv_r, tq);
+  int qi;
+  const double* rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(r2, inv_r, fc.off) : r2 * inv_r, tq, qi);
   const double SV = cubic_b128(rec, tq);
   const double V = cubic_b128(rec + 4, tq);
   const double ynum = fma(AVk * V, mu_r, xk);
@@ -222,7 +228,7 @@ __device__ __forceinline__ double uni_value(const double* __restrict__ lds, cons
     const double r2x = fma(rp, rp, sperp2x);
     const double inv_rx = vkm::rsqrt3(r2x);
     mu_x = rp * inv_rx;
-    rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(r2x, inv_rx, fc.off) : r2x * inv_rx, tq);
+    rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(r2x, inv_rx, fc.off) : r2x * inv_rx, tq, qi);
   }
   double xir = cubic_b128(rec + 8, tq);
   if (NLR > 1) {
@@ -239,14 +245,59 @@ __device__ __forceinline__ double uni_value(const double* __restrict__ lds, cons
   return inv_sv * fma(e, xir, e);
 }
 
+// The dispersion model (ccf_model.py:658-671) on the same records: zero-mean Gaussian pdf of width sigma_v SV(r), the
+// real-space coordinate from the reference's fixed-point iteration r_par <- (s_par - v/aH) / (1 + q(r)),
+// q(r) = aH^-1 v_r(r)/r, started at the redshift-space separation and repeated `niter` more times, and the Jacobian
+// 1 / (1 + q + mu_r^2 (dq - q)) with dq = aH^-1 v_r'(r).  `da` = LDS table of Da = delta - 2 Delta/3 on the unified
+// grid, [uni_n][4].  All lengths in index units; `num` = s_par' - x_k' Bk.
+template <int NLR, int GRID>
+__device__ __forceinline__ double disp_value(const double* __restrict__ lds, const double* __restrict__ da,
+                                             const FastConsts& fc, const FastPoint& fp, int niter, double num,
+                                             double s_par, double sperp2, double xk) {
+  double tq;
+  int qi;
+  auto q_at = [&](double r2) {
+    const double inv_r = vkm::rsqrt3(r2);
+    const double* rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(r2, inv_r, fc.off) : r2 * inv_r, tq, qi);
+    return -fp.Gk * cubic_b128(rec + 4, tq) * inv_r;
+  };
+  double r_par = num * vkm::recip(1.0 + q_at(fma(s_par, s_par, sperp2)));
+  for (int it = 0; it < niter; ++it) r_par = num * vkm::recip(1.0 + q_at(fma(r_par, r_par, sperp2)));
+  const double r2 = fma(r_par, r_par, sperp2);
+  const double inv_r = vkm::rsqrt3(r2);
+  const double mu_r = r_par * inv_r;
+  const double* rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(r2, inv_r, fc.off) : r2 * inv_r, tq, qi);
+  const double SV = cubic_b128(rec, tq);
+  const double q = -fp.Gk * cubic_b128(rec + 4, tq) * inv_r;
+  const double dq = -fp.gD * cubic_b128(da + 4 * qi, tq);
+  const double m2 = mu_r * mu_r;
+  double xir = cubic_b128(rec + 8, tq);
+  if (NLR == 2) xir = fma(cubic_b128(rec + 12, tq), m2, xir);
+  if (NLR == 3) xir = fma(fma(cubic_b128(rec + 16, tq), m2, cubic_b128(rec + 12, tq)), m2, xir);
+  const double inv_sv = vkm::recip(SV);
+  const double jac = vkm::recip(1.0 + q + m2 * (dq - q));
+  const double y = xk * inv_sv;
+  const double e = vkm::exp_scaled(-y * y, lds + kEtabOff);
+  return inv_sv * jac * fma(e, xir, e);
+}
+
+// MODE of the kernels that own a point per workgroup: streaming, streaming on a measured real-space ccf, dispersion
+constexpr int kModeStreaming = 0, kModeFromData = 1, kModeDispersion = 2;
+
+template <int NLR>
+__device__ __forceinline__ void stage_da(const TheoryArgs& a, double* da) {
+  for (int e = threadIdx.x; e < a.uni_n * 4; e += kBlock) da[e] = a.uni_da[e];
+}
+
 // --------------------------------------------------------------------------------------------------
 // K1 point-major fast kernel: one wave owns one (point, s bin); lanes sweep the flattened (mu, v) plane.
 // --------------------------------------------------------------------------------------------------
 struct FastPlan {
-  int murec, xrec, betar, red, node, total;
+  int murec, xrec, betar, red, node, da, total;
 };
 
-__host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int uni_n, int nlr, int n_beta_r, int lut_n) {
+__host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int uni_n, int nlr, int n_beta_r, int lut_n,
+                                                   int with_da) {
   FastPlan p;
   int o = fast_fixed_doubles(uni_n, nlr, lut_n);   // exp table + records first (fixed offsets)
   o = (o + 1) & ~1;
@@ -255,14 +306,16 @@ __host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int uni_n,
   p.betar = o; o += (n_beta_r + 1) & ~1;
   p.red = o;   o += kWaves * kMaxEll;
   p.node = o;  o += (n_mu * n_x + 1) / 2;   // one packed u32 per (mu, v) node
+  o = (o + 1) & ~1;
+  p.da = o;    o += with_da ? uni_n * 4 : 0;  // Da table of the dispersion model
   p.total = o;
   return p;
 }
 
-template <int NLR, int NL, int GRID, int FD>
+template <int NLR, int NL, int GRID, int MODE>
 __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
-  const FastPlan pl = make_fast_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n);
+  const FastPlan pl = make_fast_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, MODE == kModeDispersion);
   const int tid = threadIdx.x;
   // ---- stage batch-constant tables -------------------------------------------------------------
   for (int i = tid; i < a.n_mu; i += kBlock) {
@@ -279,6 +332,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
     lds[pl.xrec + 2 * i + 1] = a.w_x[i];
   }
   stage_uni_records<NLR>(a, lds);
+  if (MODE == kModeDispersion) stage_da<NLR>(a, lds + pl.da);
   if (a.n_beta_r > 0)
     for (int i = tid; i < a.n_beta_r; i += kBlock) lds[pl.betar + i] = a.beta_r[i];
   // byte offsets of the mu record (low 16 bits) and the (x, w) record (high 16 bits) of every plane node, so the
@@ -346,8 +400,12 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
           const vk_d2 xw = *reinterpret_cast<const vk_d2*>(x_bytes + (pk >> 16));
           const double s_perp = s_aperp * m01.y;
           const double sperp2 = s_perp * s_perp;
-          const double f = xw.y * uni_value<NLR, GRID, FD>(lds, fc, fp.AVk, fma(-xw.x, fp.Bk, s_apar * m01.x), sperp2, xw.x,
-                                                          fp.fa, sperp2 * fp.fp2);
+          const double s_par = s_apar * m01.x;
+          const double num = fma(-xw.x, fp.Bk, s_par);
+          const double f = xw.y * (MODE == kModeDispersion
+                                       ? disp_value<NLR, GRID>(lds, lds + pl.da, fc, fp, a.niter, num, s_par, sperp2, xw.x)
+                                       : uni_value<NLR, GRID, MODE == kModeFromData>(lds, fc, fp.AVk, num, sperp2, xw.x, fp.fa,
+                                                                                    sperp2 * fp.fp2));
           const vk_d2 w01 = *reinterpret_cast<const vk_d2*>(mr + 2);
           acc[0] = fma(w01.x, f, acc[0]);
           if (NL > 1) acc[1] = fma(w01.y, f, acc[1]);

@@ -161,6 +161,8 @@ def build_tables(model, fit=None, matter_model=None):
                 v_ref = T.refine_pp_on(r_ext, vr_coef[0], left, width)
                 uni_v2 = arr(T.refine_pp_on(r_ext, vr_coef[2], left, width))              # empirical_corr: V = V1 + Av V2
                 t.uni_v2 = N.as_dp(uni_v2)
+                uni_da = arr(T.refine_pp_on(r_ext, vr_coef[1], left, width))              # dispersion model: v_r'(r)
+                t.uni_da = N.as_dp(uni_da)
             uni_sv_v = arr(np.stack([sv_ref, v_ref], axis=1))                         # (n, 2, 4)
             if model.fixed_real_input:
                 uni_xi = arr(np.stack([T.refine_pp_on(r, coef[l], left, width) for l in range(n_ell_r)]))   # (L, n, 4)
