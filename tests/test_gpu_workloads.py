@@ -130,3 +130,35 @@ def test_integration_stub_runs_as_written():
     lnl, chi2 = like(rows)
     want_l, want_c = fit.log_likelihood_batch(rows)
     assert np.array_equal(lnl, want_l) and np.array_equal(chi2, want_c)
+
+
+def test_two_dimensional_model_grids():
+    """theory_xi_2D / xi_2D_from_multipoles (ccf_model.py:862-934): grid nodes against scalar oracle evaluations, and
+    the call convention of the returned interpolant."""
+    import os
+    import sys
+    import numpy as np
+    import victor_amd
+    from tests import cases
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import victor_oracle as vo
+    fit = victor_amd.CCFFit(*cases.boss_options("config"))
+    ora = vo.OracleFit(*cases.boss_options("config"))
+    p = {"fsigma8": 0.47, "beta": 0.37, "sigma_v": 380, "epsilon": 1.02}
+    f2d = fit.theory_xi_2D(dict(p), rmax=85)
+    sperp, spar = np.linspace(0.01, 85), np.linspace(-85, 85)
+    assert f2d.z.shape == (50, 50) and np.array_equal(f2d.x, sperp) and np.array_equal(f2d.y, spar)
+    for i, j in ((0, 0), (7, 3), (24, 25), (49, 49), (30, 12)):
+        s = np.hypot(sperp[i], spar[j])
+        want = ora.theory_xi(np.array([s]), np.array([spar[j] / s]), dict(p))[0, 0]
+        assert abs(f2d.z[j, i] - want) < 1e-9 * max(abs(want), 1e-3), (i, j)
+        assert abs(f2d(sperp[i], spar[j])[0] - f2d.z[j, i]) < 1e-15
+    assert f2d(np.array([1.0, 2.0, 3.0]), np.array([-5.0, 5.0])).shape == (2, 3)
+    m2d = fit.xi_2D_from_multipoles(dict(p), rmax=85)
+    s1 = np.linspace(0.01, 85)
+    poles, _ = ora.theory_multipoles(s1, dict(p), poles=[0, 2, 4])
+    from victor_amd import tables as T
+    i, j = 11, 40
+    s = np.hypot(sperp[i], spar[j])
+    want = sum(T.notaknot(s1, poles[f"{l}"])(min(s, 85.0)) * T.legendre_values(l, spar[j] / s) for l in (0, 2, 4))
+    assert abs(m2d.z[j, i] - want) < 1e-9 * abs(want)

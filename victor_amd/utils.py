@@ -56,6 +56,43 @@ def bilinear_on_grid(x, y, z):
     return f
 
 
+class GridInterpolant:
+    """Bilinear interpolant of ``z`` tabulated on ``(y, x)`` with the call convention of
+    ``scipy.interpolate.interp2d(x, y, z)`` (default ``kind='linear'``; removed from SciPy 1.14): ``f(xq, yq)`` with
+    scalars or sorted 1-D arrays returns shape ``(len(yq), len(xq))`` (squeezed for scalars); queries outside the
+    grid take the nearest edge value.  Used for the 2-D model grids of ccf_model.py:862-934."""
+
+    def __init__(self, x, y, z):
+        self.x = np.asarray(x, dtype=float)
+        self.y = np.asarray(y, dtype=float)
+        self.z = np.asarray(z, dtype=float)
+        if self.z.shape != (len(self.y), len(self.x)):
+            raise InputError("GridInterpolant: z must have shape (len(y), len(x))")
+
+    @staticmethod
+    def _weights(grid, q):
+        q = np.clip(q, grid[0], grid[-1])
+        i = np.clip(np.searchsorted(grid, q, side="right") - 1, 0, len(grid) - 2)
+        t = (q - grid[i]) / (grid[i + 1] - grid[i])
+        return i, t
+
+    def __call__(self, xq, yq):
+        xs, ys = np.atleast_1d(np.asarray(xq, dtype=float)), np.atleast_1d(np.asarray(yq, dtype=float))
+        i, tx = self._weights(self.x, xs)
+        j, ty = self._weights(self.y, ys)
+        z = self.z
+        lo = z[j][:, i] * (1 - tx) + z[j][:, i + 1] * tx
+        hi = z[j + 1][:, i] * (1 - tx) + z[j + 1][:, i + 1] * tx
+        out = lo * (1 - ty)[:, None] + hi * ty[:, None]
+        if np.ndim(xq) == 0 and np.ndim(yq) == 0:
+            return out[0]                       # interp2d returns a length-1 array for scalar queries
+        if np.ndim(xq) == 0:
+            return out[:, 0]
+        if np.ndim(yq) == 0:
+            return out[0]
+        return out
+
+
 def read_input_file(path, extensions):
     """ccf_model.py:57-68: choose the reader from the file extension (npy dict or HDF5)."""
     fmt = None
