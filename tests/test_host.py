@@ -397,3 +397,19 @@ def test_anisotropic_dispersion_and_velocity_template_setup(tmp_path):
     a = np.array(mm.velocity_terms(mm.r, p))
     b = np.array(om.velocity_terms(om.r, p, om.model))
     assert np.max(np.abs(a / b - 1)) < 1e-12
+
+
+def test_background_cosmology_and_multipole_helpers(boss_fit):
+    """victor.BackgroundCosmology (E(z) of the path, cosmology.py:27-45) and utils.fn_from_multipoles (utils.py:60-94)."""
+    import victor
+    g, _ = cases.golden_outputs()
+    c = victor.BackgroundCosmology({"Omega_m": 0.31})
+    assert (1 + 0.57) / (100 * c.Ez(0.57)) == float(g["boss_iaH"]) == boss_fit.iaH
+    assert c.H(0.0) == 67.5 and abs(c.Om(0.0) - 0.31) < 1e-15 and c.OmegaL == 1 - 0.31
+    ck = victor.BackgroundCosmology({"Omega_m": 0.3, "Omega_K": 0.05, "H0": 70.0})
+    assert abs(ck.Ez(1.0) - np.sqrt(0.3 * 8 + 0.05 * 4 + 0.65)) < 1e-15 and ck.H(0) == 70.0
+    r = np.linspace(1, 10, 10)
+    f = victor.utils.fn_from_multipoles(r, [0, 2], np.vstack([r, np.ones_like(r)]))
+    assert abs(f(5.0, 1.0)[0] - 6.0) < 1e-12 and f(r, np.linspace(-1, 1, 7)).shape == (7, 10)
+    with pytest.raises(ValueError):
+        victor.utils.fn_from_multipoles(r, [0, 2], np.ones((3, 10)))

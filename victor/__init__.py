@@ -4,4 +4,4 @@ Existing scripts, notebooks and cobaya YAML files written for seshnadathur/victo
 (``from victor import CCFFit``; ``python_path: ./victor/likelihoods/``) keep working unchanged.
 """
 
-from victor_amd import CCFFit, CCFModel, InputError, __version__, utils  # noqa: F401
+from victor_amd import BackgroundCosmology, CCFFit, CCFModel, InputError, __version__, utils  # noqa: F401

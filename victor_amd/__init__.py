@@ -7,7 +7,8 @@ likelihood path; evaluation runs in hand-written HIP kernels behind ``libvictor_
 from . import utils
 from .ccf_fit import CCFFit
 from .ccf_model import CCFModel
+from .cosmology import BackgroundCosmology
 from .utils import InputError
 
 __version__ = "0.1.0"
-__all__ = ["CCFModel", "CCFFit", "InputError", "utils", "__version__"]
+__all__ = ["CCFModel", "CCFFit", "BackgroundCosmology", "InputError", "utils", "__version__"]

@@ -16,6 +16,7 @@ from . import _native as N
 from . import tables as T
 from . import utils
 from . import velocity_tables
+from .cosmology import BackgroundCosmology
 from .utils import InputError
 
 EXTENSIONS = {"npy": [".npy"],
@@ -23,13 +24,8 @@ EXTENSIONS = {"npy": [".npy"],
 
 
 def _ez(z, cosmology):
-    """E(z) of a LambdaCDM background without radiation (reference: cosmology.py:27-45; astropy's
-    ``LambdaCDM`` defaults to ``Tcmb0 = 0``)."""
-    cosmology = cosmology or {}
-    om = cosmology.get("Omega_m", 0.31)
-    ok = cosmology.get("Omega_K", 0)
-    ol = 1 - om - ok
-    return np.sqrt(om * (1 + z) ** 3 + ok * (1 + z) ** 2 + ol)
+    """E(z) of a LambdaCDM background without radiation (reference: cosmology.py:27-45)."""
+    return BackgroundCosmology(cosmology).Ez(z)
 
 
 class CCFModel:

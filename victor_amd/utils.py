@@ -93,6 +93,22 @@ class GridInterpolant:
         return out
 
 
+def fn_from_multipoles(r, poles, multipoles, npts=200):
+    """f(r, mu) = sum_l multipoles[l](r) P_l(mu) tabulated on ``npts`` values of mu in [-1, 1], as a bilinear
+    interpolant with the ``interp2d`` call convention (reference: utils.py:60-94)."""
+    from .tables import legendre_values
+    poles = [poles] if isinstance(poles, int) else poles
+    multipoles = np.asarray(multipoles, dtype=float)
+    if multipoles.shape != (len(poles), len(r)):
+        raise ValueError(f"Wrong shape of multipoles: expected ({len(poles)}, {len(r)}), "
+                         f"but received {multipoles.shape}")
+    mu = np.linspace(-1, 1, npts)
+    grid = np.zeros((len(mu), len(r)))
+    for i, ell in enumerate(poles):
+        grid += legendre_values(int(ell), mu)[:, None] * multipoles[i]
+    return GridInterpolant(r, mu, grid)
+
+
 def read_input_file(path, extensions):
     """ccf_model.py:57-68: choose the reader from the file extension (npy dict or HDF5)."""
     fmt = None
