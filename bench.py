@@ -235,7 +235,7 @@ def main():
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cores = host_cores()
-        ns = min(args.cpu_sample or max(16, 25 * cores), B)      # ~25 oracle evaluations per core: 10-30 s of CPU work
+        ns = min(args.cpu_sample or max(16, 40 * cores), B)      # ~40 oracle evaluations per core (~50 ms each): ~30 core-seconds of CPU work
         sel = np.linspace(0, B - 1, ns).astype(int)
         base, vals, theory_o = cpu_baseline([cases.point(mine, int(i)) for i in sel])
 
@@ -367,7 +367,7 @@ def main():
             chi_o = np.array([v[1] for v in vals])
             lnl_o = np.array([v[0] for v in vals])
             out["cpu_baseline"] = {"value": base["evals_per_s"], "unit": "evals/s", "cores": base["cores"],
-                                   "kind": "port",
+                                   "value_per_core": base["evals_per_s"] / base["cores"], "kind": "port",
                                    "sample": f"{ns} of the {B} batch points through oracle/victor_oracle.py "
                                              f"(NumPy/SciPy restatement, bit-identical to the reference here), "
                                              f"{base['cores']} processes x 1 thread, {base['busy_s']:.1f} s busy"}
