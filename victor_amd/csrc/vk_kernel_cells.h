@@ -35,7 +35,7 @@ __host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s,
 
 // (130 VGPRs -> 3 waves per SIMD; forcing 4 with __launch_bounds__(256, 4) spills and measured 1.5 % slower)
 template <int NLR, int NL, int GRID, int MODE>
-__global__ __launch_bounds__(kBlock, 5) void vk_theory_cells_kernel(TheoryArgs a) {
+__global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_theory_cells_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
   const CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, MODE == kModeDispersion);
   const int tid = threadIdx.x;
