@@ -162,3 +162,33 @@ def test_two_dimensional_model_grids():
     s = np.hypot(sperp[i], spar[j])
     want = sum(T.notaknot(s1, poles[f"{l}"])(min(s, 85.0)) * T.legendre_values(l, spar[j] / s) for l in (0, 2, 4))
     assert abs(m2d.z[j, i] - want) < 1e-9 * abs(want)
+
+
+def test_plain_c_client_of_the_abi(tmp_path):
+    """examples/c_abi_client.c (no Python, no C++): load a dumped vk_tables, vk_create, vk_eval_batch - must reproduce
+    the Python path bit for bit."""
+    import os
+    import subprocess
+    import numpy as np
+    import victor_amd
+    from tests import cases
+    from victor_amd.engine import build_tables, dump_tables
+    from victor_amd import _native as N
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_client")
+    subprocess.run(["gcc", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "c_abi_client.c"),
+                    "-ldl", "-o", exe], check=True)
+    fit = victor_amd.CCFFit(*cases.boss_options("config"))
+    tables, keep = build_tables(fit, fit)
+    dump_tables(tables, str(tmp_path / "tables.bin"))
+    rows = fit._fit_rows(cases.halton_params(300, with_beta=True), fit.model)
+    rows.tofile(str(tmp_path / "params.bin"))
+    like = fit.fit_options["likelihood"]
+    args = [exe, N.library_path(), str(tmp_path / "tables.bin"), str(tmp_path / "params.bin"), str(tmp_path / "out.bin"),
+            str(int(not fit.model["velocity_independent_of_AP"])), str(int(fit.model["assume_isotropic"])),
+            str(N.LIKE[like["form"].lower()]), str(like.get("nmocks", 1)), str(like.get("nparams", 0))]
+    done = subprocess.run(args, capture_output=True, text=True, timeout=120)
+    assert done.returncode == 0, done.stderr
+    out = np.fromfile(str(tmp_path / "out.bin"))
+    want_l, want_c = fit.log_likelihood_batch(rows)
+    assert np.array_equal(out[:300], want_l) and np.array_equal(out[300:], want_c)

@@ -413,3 +413,37 @@ def test_background_cosmology_and_multipole_helpers(boss_fit):
     assert abs(f(5.0, 1.0)[0] - 6.0) < 1e-12 and f(r, np.linspace(-1, 1, 7)).shape == (7, 10)
     with pytest.raises(ValueError):
         victor.utils.fn_from_multipoles(r, [0, 2], np.ones((3, 10)))
+
+
+def test_table_dump_covers_every_field_and_c_client_compiles(boss_fit, tmp_path):
+    """victor_amd.engine.dump_tables writes one record per scalar / array of vk_tables (names = C field paths), and the
+    plain-C client that reads it compiles against the header."""
+    import struct
+    from victor_amd.engine import build_tables, dump_tables, table_array_lengths
+    t, keep = build_tables(boss_fit, boss_fit)
+    path = tmp_path / "tables.bin"
+    dump_tables(t, str(path))
+    raw = path.read_bytes()
+    assert raw[:8] == b"VKTB1\0\0\0"
+    pos, names, sizes = 8, [], {}
+    while True:
+        name = raw[pos:pos + 24].rstrip(b"\0").decode()
+        kind, count = struct.unpack_from("<iq", raw, pos + 24)
+        pos += 36
+        if name == "END":
+            break
+        nbytes = 8 if kind < 2 else ((count * (8 if kind == 2 else 2) + 7) // 8) * 8
+        names.append(name)
+        sizes[name] = count
+        pos += nbytes
+    assert pos == len(raw)
+    src = open(os.path.join(ROOT, "examples", "c_abi_client.c")).read()
+    declared = re.findall(r'\{"([a-z0-9_.A-Z]+)", [0-3], &t\.', src)
+    assert sorted(declared) == sorted(names), set(declared) ^ set(names)
+    lengths = table_array_lengths(t)
+    assert sizes["prec"] == 31 * 60 * 60 and sizes["uni_xi"] == lengths["uni_xi"] > 0 and sizes["vr_emp"] == 0
+    exe = str(tmp_path / "c_abi_client")
+    subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "c_abi_client.c"), "-ldl", "-o", exe], check=True)
+    done = subprocess.run([exe], capture_output=True, text=True)
+    assert done.returncode == 2 and "usage" in done.stderr

@@ -226,6 +226,72 @@ def build_tables(model, fit=None, matter_model=None):
     return t, keep
 
 
+def table_array_lengths(t):
+    """Element counts of every array of a ``vk_tables`` (the shapes documented in include/victor_hip.h)."""
+    N_ = t.n_ell * t.n_s
+    nb = t.n_beta_r
+    per_beta = lambda fixed, dep: dep if nb > 0 else fixed   # noqa: E731
+    out = {
+        "s": t.n_s, "mu": t.n_mu, "w_ell": t.n_ell * t.n_mu, "x": t.n_x, "w_x": t.n_x, "beta_r": nb,
+        "xi.knots": t.xi.n_int + 1,
+        "xi.coef": per_beta(t.n_ell_r * t.xi.n_int * 4, t.n_ell_r * (nb - 1) * t.xi.n_int * 16),
+        "vr.knots": t.vr.n_int + 1,
+        "vr.coef": 2 * (nb - 1) * t.vr.n_int * 16 if t.vr_beta_dep else 5 * t.vr.n_int * 4,
+        "vr_emp": 3 * (nb - 1) * t.vr.n_int * 28 if (t.vr_beta_dep and t.vr_emp) else 0,
+        "sv.knots": t.sv.n_int + 1, "sv.coef": 4 if t.sv_n_mu else t.sv.n_int * 4,
+        "sv_mu": t.sv_n_mu, "sv2d": t.sv.n_int * (t.sv_n_mu - 1) * 16 if t.sv_n_mu else 0,
+        "uni_sv_v": t.uni_n * 8,
+        "uni_xi": per_beta(t.n_ell_r * t.uni_n * 4, t.n_ell_r * (nb - 1) * t.uni_n * 16) if t.uni_n else 0,
+        "uni_xic": per_beta(t.n_ell_r * t.uni_n * 4, t.n_ell_r * (nb - 1) * t.uni_n * 16) if t.uni_n else 0,
+        "uni_vb": (nb - 1) * t.uni_n * 16 if (t.uni_n and t.vr_beta_dep and t.uni_vb) else 0,
+        "uni_v2": t.uni_n * 4 if (t.uni_n and t.uni_v2) else 0,
+        "uni_da": t.uni_n * 4 if (t.uni_n and t.uni_da) else 0,
+        "uni_lut": t.uni_lut_n, "uni_knots": t.uni_n + 1 if t.uni_lut_n else 0,
+        "beta_d": t.n_beta_d, "data": (t.n_beta_d - 1) * N_ * 4 if t.n_beta_d else (N_ if t.data else 0),
+        "beta_c": t.n_beta_c, "prec": (max(t.n_beta_c, 1) * N_ * N_) if t.prec else 0,
+        "logdet": t.n_beta_c, "eig": t.n_beta_c * N_,
+    }
+    return out
+
+
+def dump_tables(t, path):
+    """Write a ``vk_tables`` as a flat record stream (name[24], kind, count, payload) that a client in any language can
+    load into the C struct - see examples/c_abi_client.c."""
+    import struct
+    lengths = table_array_lengths(t)
+
+    def walk(obj, prefix=""):
+        for name, ctype in obj._fields_:
+            val = getattr(obj, name)
+            full = prefix + name
+            if isinstance(val, C.Structure):
+                yield from walk(val, full + ".")
+            elif ctype is C.c_int32:
+                yield full, 0, int(val)
+            elif ctype is C.c_double:
+                yield full, 1, float(val)
+            else:
+                n = lengths[full] if val else 0
+                kind = 3 if ctype._type_ is C.c_uint16 else 2
+                dtype = np.uint16 if kind == 3 else np.float64
+                arr = np.ctypeslib.as_array(val, shape=(n,)).astype(dtype, copy=True) if n else np.empty(0, dtype)
+                yield full, kind, arr
+
+    with open(path, "wb") as f:
+        f.write(b"VKTB1\0\0\0")
+        for name, kind, val in walk(t):
+            head = name.encode().ljust(24, b"\0")
+            if kind == 0:
+                f.write(head + struct.pack("<iq", 0, 1) + struct.pack("<q", val))
+            elif kind == 1:
+                f.write(head + struct.pack("<iq", 1, 1) + struct.pack("<d", val))
+            else:
+                raw = val.tobytes()
+                raw += b"\0" * (-len(raw) % 8)
+                f.write(head + struct.pack("<iq", kind, len(val)) + raw)
+        f.write(b"END".ljust(24, b"\0") + struct.pack("<iq", 0, 0))
+
+
 class Engine:
     def __init__(self, model, fit=None, device=0, matter_model=None):
         self._lib = N.load()
