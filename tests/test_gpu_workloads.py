@@ -192,3 +192,38 @@ def test_plain_c_client_of_the_abi(tmp_path):
     out = np.fromfile(str(tmp_path / "out.bin"))
     want_l, want_c = fit.log_likelihood_batch(rows)
     assert np.array_equal(out[:300], want_l) and np.array_equal(out[300:], want_c)
+
+
+def test_small_batches_replay_a_captured_graph():
+    """Host-buffer batches of up to 4096 points are launch-bound: from their second use on, (H2D, theory kernel,
+    likelihood kernel, D2H) is one hipGraph launch.  Results must be bit-identical to the eager path, follow the
+    parameters of every call, and survive a change of batch size and options."""
+    import os
+    import numpy as np
+    import victor_amd
+    from tests import cases
+    fit = victor_amd.CCFFit(*cases.boss_options("config"))
+    hp = cases.halton_params(64, with_beta=True)
+    rows = fit._fit_rows(hp, fit.model)
+    os.environ["VICTOR_HIP_NO_GRAPH"] = "1"
+    try:
+        want = {n: fit.log_likelihood_batch(rows[:n]) for n in (1, 8, 64)}
+        want_shift = fit.log_likelihood_batch(rows[8:16])
+        want_kaiser = fit.log_likelihood_batch(rows[:8], rsd_model="kaiser")
+    finally:
+        del os.environ["VICTOR_HIP_NO_GRAPH"]
+    for rep in range(4):                       # call 1 eager, call 2 captures, calls 3-4 replay
+        for n in (1, 8, 64):
+            got = fit.log_likelihood_batch(rows[:n])
+            assert np.array_equal(got[0], want[n][0]) and np.array_equal(got[1], want[n][1]), (rep, n)
+        got = fit.log_likelihood_batch(rows[8:16])                  # same shape, other parameters
+        assert np.array_equal(got[0], want_shift[0]) and np.array_equal(got[1], want_shift[1]), rep
+        got = fit.log_likelihood_batch(rows[:8], rsd_model="kaiser")  # same shape, other options -> another graph
+        assert np.array_equal(got[0], want_kaiser[0]), rep
+    big = fit.log_likelihood_batch(fit._fit_rows(cases.halton_params(5000, with_beta=True), fit.model))   # regrows scratch
+    assert np.all(np.isfinite(big[0]))
+    got = fit.log_likelihood_batch(rows[:8])
+    assert np.array_equal(got[0], want[8][0])
+    p = cases.point(hp, 3)
+    single = [fit.log_likelihood(dict(p)) for _ in range(5)]
+    assert all(s == single[0] for s in single)

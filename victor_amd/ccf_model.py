@@ -357,8 +357,14 @@ class CCFModel:
         n = lengths.pop() if lengths else 1           # an empty batch (length 0) is legal
         rows = np.empty((n, N.VK_NPAR))
 
-        def col(v):
-            return np.broadcast_to(np.asarray(v, dtype=float), (n,))
+        if lengths:
+            def col(v):
+                return np.broadcast_to(np.asarray(v, dtype=float), (n,))
+        else:
+            # one point given as scalars (the reference's calling convention, one call per MCMC step): same array
+            # arithmetic as a batch, without the broadcasting machinery
+            def col(v):
+                return np.array([v], dtype=float)
 
         if need_fsigma8:
             rows[:, N.P_FSIGMA8] = col(params["fsigma8"])        # KeyError if absent, as ccf_model.py:432-435

@@ -28,6 +28,7 @@
 #include <limits>
 #include <new>
 #include <algorithm>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -85,7 +86,16 @@ struct vk_ctx {
   // RCCL (loaded lazily)
   void* rccl_lib = nullptr;
   void* comm = nullptr;
+  // small host-buffer batches are launch-bound: (H2D, theory kernel, likelihood kernel, D2H) is captured once per
+  // (n, options) into a hipGraph over pinned staging buffers and replayed with a single launch
+  double* h_pin = nullptr;                      // pinned: params[kGraphMaxN][VK_NPAR] | lnl, chi2 [2 kGraphMaxN]
+  std::map<std::string, hipGraphExec_t> graphs;  // key: n + option bytes + requested outputs
+  std::map<std::string, int> graph_seen;         // a key is captured on its second use (the first one runs eagerly)
+  std::map<std::string, const char*> graph_kernel;
+  bool graphs_off = false;
 };
+
+constexpr int64_t kGraphMaxN = 4096;
 
 namespace {
 
@@ -118,8 +128,16 @@ struct Uploader {
   }
 };
 
+void drop_graphs(vk_ctx* ctx) {
+  for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
+  ctx->graphs.clear();
+  ctx->graph_seen.clear();
+  ctx->graph_kernel.clear();
+}
+
 int ensure_scratch(vk_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->scratch_bytes) return VK_OK;
+  drop_graphs(ctx);   // captured graphs hold pointers into the old scratch allocation
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   ctx->d_scratch = nullptr;
   ctx->scratch_bytes = 0;
@@ -698,6 +716,8 @@ void vk_destroy(vk_ctx* ctx) {
   if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
   if (ctx->comm) vk_comm_destroy(ctx);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  drop_graphs(ctx);
+  if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
   if (ctx->d_tables) (void)hipFree(ctx->d_tables);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   for (auto& evt : ctx->ev)
@@ -804,6 +824,61 @@ int vk_eval_batch_device_async(vk_ctx* ctx, const vk_eval_opts* opts, const doub
   return VK_OK;
 }
 
+// The launch-bound small-batch case of vk_eval_batch: one hipGraph launch per call (see vk_ctx::graphs).
+// Returns 1 when it handled the call, 0 when the caller should take the eager path, < 0 on error.
+static int eval_batch_graph(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, int64_t n, double* lnl,
+                            double* chi2, double* d_par, double* d_th, double* d_lnl, double* d_chi) {
+  if (ctx->graphs_off || n > kGraphMaxN || ctx->timing || !(lnl || chi2) || getenv("VICTOR_HIP_NO_GRAPH") ||
+      getenv("VICTOR_HIP_MAPPING") || getenv("VICTOR_HIP_FORCE_GENERIC"))
+    return 0;
+  std::string key(reinterpret_cast<const char*>(opts), sizeof *opts);
+  key.append(reinterpret_cast<const char*>(&n), sizeof n);
+  key.push_back(lnl ? 1 : 0);
+  key.push_back(chi2 ? 1 : 0);
+  auto hit = ctx->graphs.find(key);
+  if (hit == ctx->graphs.end()) {
+    if (ctx->graph_seen[key]++ == 0) return 0;         // first use of this shape: eager (also warms attributes)
+    if (ctx->graphs.size() >= 32) drop_graphs(ctx);
+    if (!ctx->h_pin) {
+      if (hipHostMalloc((void**)&ctx->h_pin, (size_t)kGraphMaxN * (VK_NPAR + 2) * sizeof(double), hipHostMallocDefault) !=
+          hipSuccess) {
+        ctx->graphs_off = true;
+        return 0;
+      }
+    }
+    double* h_in = ctx->h_pin;
+    double* h_out = ctx->h_pin + (size_t)kGraphMaxN * VK_NPAR;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    bool ok = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) == hipSuccess;
+    if (ok) {
+      ok = hipMemcpyAsync(d_par, h_in, (size_t)n * VK_NPAR * sizeof(double), hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+      ok = ok && vk_eval_batch_device_async(ctx, opts, d_par, n, d_lnl, d_chi, d_th) == VK_OK;
+      // d_lnl and d_chi are adjacent in the scratch layout: one copy brings both back
+      ok = ok && hipMemcpyAsync(h_out, d_lnl, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+      ok = (hipStreamEndCapture(ctx->stream, &graph) == hipSuccess) && ok && graph;
+    }
+    if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+    if (graph) (void)hipGraphDestroy(graph);
+    if (!ok) {
+      (void)hipGetLastError();
+      ctx->graphs_off = true;                          // never try again on this context; the eager path is complete
+      return 0;
+    }
+    ctx->graph_kernel[key] = ctx->last_kernel;
+    hit = ctx->graphs.emplace(key, exec).first;
+  }
+  double* h_in = ctx->h_pin;
+  double* h_out = ctx->h_pin + (size_t)kGraphMaxN * VK_NPAR;
+  memcpy(h_in, params, (size_t)n * VK_NPAR * sizeof(double));
+  VK_HIP(ctx, hipGraphLaunch(hit->second, ctx->stream));
+  VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->last_kernel = ctx->graph_kernel[key];
+  if (lnl) memcpy(lnl, h_out, (size_t)n * sizeof(double));
+  if (chi2) memcpy(chi2, h_out + n, (size_t)n * sizeof(double));
+  return 1;
+}
+
 int vk_eval_batch(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, int64_t n, double* lnl, double* chi2,
                   double* theory) {
   if (!ctx) return VK_E_ARG;
@@ -816,12 +891,19 @@ int vk_eval_batch(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, i
   const size_t nb_par = (size_t)n * VK_NPAR * sizeof(double);
   const size_t nb_th = (size_t)n * ctx->N * sizeof(double);
   const size_t nb_out = (size_t)n * sizeof(double);
-  rc = ensure_scratch(ctx, nb_par + nb_th + 2 * nb_out);
+  // small batches share one scratch layout sized for kGraphMaxN so that captured graphs stay valid across sizes
+  const int64_t n_lay = n <= kGraphMaxN ? kGraphMaxN : n;
+  rc = ensure_scratch(ctx, (size_t)n_lay * (VK_NPAR + ctx->N + 2) * sizeof(double));
   if (rc) return rc;
   double* d_par = ctx->d_scratch;
-  double* d_th = d_par + (size_t)n * VK_NPAR;
-  double* d_lnl = d_th + (size_t)n * ctx->N;
+  double* d_th = d_par + (size_t)n_lay * VK_NPAR;
+  double* d_lnl = d_th + (size_t)n_lay * ctx->N;
   double* d_chi = d_lnl + n;
+  if (!theory) {
+    rc = eval_batch_graph(ctx, opts, params, n, lnl, chi2, d_par, d_th, d_lnl, d_chi);
+    if (rc < 0) return rc;
+    if (rc == 1) return VK_OK;
+  }
   VK_HIP(ctx, hipMemcpyAsync(d_par, params, nb_par, hipMemcpyHostToDevice, ctx->stream));
   rc = vk_eval_batch_device_async(ctx, opts, d_par, n, lnl ? d_lnl : nullptr, chi2 ? d_chi : nullptr, d_th);
   if (rc) return rc;
