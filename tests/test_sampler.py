@@ -76,3 +76,33 @@ def test_out_of_prior_proposals_are_never_evaluated():
     allv = np.concatenate(seen)
     assert np.all((allv >= 0) & (allv <= 1))
     assert ens.n_evals == len(allv) < 32 * 11
+
+
+def test_stretch_move_recovers_a_correlated_gaussian():
+    """EnsembleStretch on a strongly correlated 3-d Gaussian inside a wide prior box: mean and covariance come back
+    without any proposal tuning (the affine-invariant move does not care about the correlation)."""
+    from victor_amd.sampler import EnsembleStretch, ParamSpec
+    from victor_amd.utils import InputError
+    mean = np.array([0.5, -1.0, 2.0])
+    A = np.array([[1.0, 0.0, 0.0], [0.95, 0.3, 0.0], [-0.5, 0.2, 0.1]])
+    cov = A @ A.T
+    icov = np.linalg.inv(cov)
+    calls = []
+
+    def evaluate(batch):
+        x = np.stack([batch["a"], batch["b"], batch["c"]], axis=1) - mean
+        calls.append(len(x))
+        return -0.5 * np.einsum("ni,ij,nj->n", x, icov, x)
+
+    specs = [ParamSpec(n, -20, 20, m, 0.5, 0.1) for n, m in zip("abc", mean)]
+    ens = EnsembleStretch(evaluate, specs, 64, seed=3)
+    chain, lnl = ens.run(1500)
+    assert chain.shape == (1500, 64, 3) and 0.2 < ens.acceptance < 0.8
+    assert set(calls[1:]) == {32}                                   # two half-ensemble batches per step
+    flat = chain[300:].reshape(-1, 3)
+    assert np.max(np.abs(flat.mean(axis=0) - mean)) < 0.08
+    assert np.max(np.abs(np.cov(flat.T) - cov)) < 0.12 * np.max(cov)
+    with pytest.raises(InputError):
+        EnsembleStretch(evaluate, specs, 7)
+    with pytest.raises(InputError):
+        EnsembleStretch(evaluate, specs, 6)

@@ -147,6 +147,43 @@ class EnsembleMetropolis:
         return self.n_accept / max(1, self.n_steps * self.n_walkers)
 
 
+class EnsembleStretch(EnsembleMetropolis):
+    """Affine-invariant ensemble sampler (Goodman & Weare 2010 stretch move, parallel form of Foreman-Mackey et al.
+    2013): the ensemble is split in two halves, each half moves along lines through walkers drawn from the other half
+    and is evaluated as ONE likelihood batch - two batches of W/2 per step, no proposal widths to tune.  Same
+    ``evaluate`` / ``specs`` / prior-box conventions as :class:`EnsembleMetropolis`; W must be even and >= 2 (P + 1).
+    """
+
+    def __init__(self, evaluate, specs, n_walkers, seed=0, fixed=None, a=2.0):
+        super().__init__(evaluate, specs, n_walkers, seed=seed, fixed=fixed)
+        if self.n_walkers % 2 or self.n_walkers < 2 * (len(self.specs) + 1):
+            raise InputError("the stretch move needs an even number of walkers, at least 2 (n_params + 1)")
+        self.a = float(a)
+
+    def step(self):
+        if self.x is None:
+            self.initialise()
+        half = self.n_walkers // 2
+        ndim = len(self.specs)
+        accepted = np.zeros(self.n_walkers, dtype=bool)
+        for first in (True, False):
+            move = slice(0, half) if first else slice(half, None)
+            other = self.x[half:] if first else self.x[:half]
+            # z ~ g(z) proportional to 1/sqrt(z) on [1/a, a]
+            z = ((self.a - 1.0) * self.rng.random(half) + 1.0) ** 2 / self.a
+            partner = other[self.rng.integers(0, half, size=half)]
+            prop = partner + z[:, None] * (self.x[move] - partner)
+            logu = np.log(self.rng.random(half))
+            lnl_prop = self._lnl(prop)
+            accept = logu < (ndim - 1) * np.log(z) + lnl_prop - self.lnl[move]
+            self.x[move] = np.where(accept[:, None], prop, self.x[move])
+            self.lnl[move] = np.where(accept, lnl_prop, self.lnl[move])
+            accepted[move] = accept
+        self.n_accept += int(accepted.sum())
+        self.n_steps += 1
+        return accepted
+
+
 def gelman_rubin(chain):
     """R-1 per parameter from ``chain[steps, walkers, params]`` (between- over within-walker variance)."""
     n = chain.shape[0]
