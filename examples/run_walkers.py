@@ -27,12 +27,15 @@ def main():
     ap.add_argument("--walkers", type=int, default=8, help="walkers per GPU")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--sampler", choices=["metropolis", "stretch"], default="metropolis",
+                    help="random-walk Metropolis walkers, or the affine-invariant stretch-move ensemble")
     args = ap.parse_args()
 
     import numpy as np
     import yaml
     import victor_amd
-    from victor_amd.sampler import DistributedEnsemble, gelman_rubin, parse_cobaya_params
+    from victor_amd.sampler import (DistributedEnsemble, EnsembleMetropolis, EnsembleStretch, gelman_rubin,
+                                    parse_cobaya_params)
     from victor_amd.sharding import Dist, RcclGather
 
     os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")      # keep RCCL's log lines off stdout
@@ -48,7 +51,8 @@ def main():
     gather = RcclGather(fit._get_engine(), dist, args.walkers)
 
     ens = DistributedEnsemble(lambda batch: fit.log_likelihood_batch(batch)[0], specs, args.walkers, dist,
-                              seed=args.seed, fixed=fixed, gather=gather)
+                              seed=args.seed, fixed=fixed, gather=gather,
+                              sampler=EnsembleStretch if args.sampler == "stretch" else EnsembleMetropolis)
     t0 = time.perf_counter()
     chain, lnl, all_lnl = ens.run(args.steps)
     wall = time.perf_counter() - t0

@@ -201,9 +201,11 @@ class DistributedEnsemble:
     the walkers themselves never interact, so the collective is monitoring traffic only (W doubles per rank).
     """
 
-    def __init__(self, evaluate, specs, walkers_per_rank, dist, seed=0, fixed=None, gather=None):
+    def __init__(self, evaluate, specs, walkers_per_rank, dist, seed=0, fixed=None, gather=None,
+                 sampler=None):
         self.dist = dist
-        self.local = EnsembleMetropolis(evaluate, specs, walkers_per_rank, seed=seed + 7919 * dist.rank, fixed=fixed)
+        self.local = (sampler or EnsembleMetropolis)(evaluate, specs, walkers_per_rank, seed=seed + 7919 * dist.rank,
+                                                     fixed=fixed)
         self.gather = gather or (lambda v: dist.allgather_host(v, len(v)))
         self.all_lnl = []
 
