@@ -9,7 +9,7 @@ namespace vk {
 // One workgroup owns one parameter point (its xi^r records are rebuilt in LDS as in the point-major kernel); each
 // of its four waves owns the s bins j = wave, wave+4, ... and spreads the (s bin, mu) cells of those bins over its
 // lanes, with the 50 velocity nodes as the inner, wave-uniform loop.  Like the lanes kernel this forms s_perp and
-// s_par once per cell, reads x_k, w_k as LDS broadcasts and closes the v sum before the projection, so the
+// s_par once per cell, reads x_k, w_k through the scalar cache and closes the v sum before the projection, so the
 // integrand costs the same ~56 instructions; the projection sum over mu is a two-segment wave reduction per trip
 // (a wave's 64 cells straddle at most two s bins when n_mu >= 64), accumulated by lane 0 in wave-private LDS.
 // --------------------------------------------------------------------------------------------------
@@ -33,7 +33,8 @@ __host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s,
   return p;
 }
 
-// (130 VGPRs -> 3 waves per SIMD; forcing 4 with __launch_bounds__(256, 4) spills and measured 1.5 % slower)
+// 5 workgroups per CU for the streaming mode (<= 96 VGPRs, a few dwords of scratch outside the hot loop); the from_data
+// and dispersion modes need more registers and run 4 per CU without spills
 template <int NLR, int NL, int GRID, int MODE>
 __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_theory_cells_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
@@ -123,15 +124,18 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
         }
       }
     }
-    __builtin_amdgcn_wave_barrier();
-    for (int e = lane; e < NL * my_bins; e += 64) {
-      const int l = e / my_bins, jj = e - l * my_bins;
+    // the point's theory vector is complete in LDS once every wave has finished its s bins: write it as one
+    // contiguous run (coalesced; 8-byte stores strided by the s-bin ownership of the waves cost 1.5x the bytes in HBM)
+    __syncthreads();
+    for (int e = tid; e < NL * a.n_s; e += kBlock) {
+      const int l = e / a.n_s, j = e - l * a.n_s;
       double ws = wsum[0];
 #pragma unroll
       for (int q = 1; q < NL; ++q) ws = (l == q) ? wsum[q] : ws;
-      a.out[point * (long long)(a.n_ell * a.n_s) + (long long)l * a.n_s + wave + kWaves * jj] =
-          l_acc[(l * slots + jj) * kWaves + wave] - ws + ps.poison;
+      a.out[point * (long long)(a.n_ell * a.n_s) + e] =
+          l_acc[(l * slots + j / kWaves) * kWaves + (j & (kWaves - 1))] - ws + ps.poison;
     }
+    __syncthreads();      // l_acc is zeroed (and the records may be rebuilt) at the top of the next point
   }
 }
 
