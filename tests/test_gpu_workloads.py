@@ -227,3 +227,23 @@ def test_small_batches_replay_a_captured_graph():
     p = cases.point(hp, 3)
     single = [fit.log_likelihood(dict(p)) for _ in range(5)]
     assert all(s == single[0] for s in single)
+
+
+def test_one_process_driving_several_contexts():
+    """victor_amd.sharding.MultiGPUFit: contiguous shards of a batch evaluated concurrently from host threads, one
+    context per listed device (the one-GPU box lists device 0 three times); identical to the single-context result."""
+    import numpy as np
+    import victor_amd
+    from victor_amd.sharding import MultiGPUFit
+    from tests import cases
+    opts = cases.boss_options("config")
+    multi = MultiGPUFit(*opts, devices=[0, 0, 0])
+    single = victor_amd.CCFFit(*opts)
+    for n in (1, 2, 1000, 20001):
+        hp = cases.halton_params(n, with_beta=True)
+        got = multi.log_likelihood_batch(hp)
+        want = single.log_likelihood_batch(hp)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), n
+    th = multi.theory_vector_batch(cases.halton_params(77, with_beta=True), rsd_model="dispersion")
+    assert th.shape == (77, 60) and np.all(np.isfinite(th))
+    multi.close()

@@ -179,3 +179,60 @@ class RcclGather:
         self.engine.free(self.d_send)
         self.engine.free(self.d_recv)
         self.engine.comm_destroy()
+
+
+class MultiGPUFit:
+    """One process driving several GPUs ("one host process per GPU, or one process driving G
+    contexts"): a ``CCFFit`` per device, contiguous shards of every batch evaluated concurrently from host threads
+    (ctypes releases the GIL for the duration of each library call; every context has its own stream).
+
+    ``devices`` defaults to all visible GPUs.  The same device may be listed more than once (rehearsal on a one-GPU box).
+    """
+
+    def __init__(self, model, data, devices=None):
+        from . import _native
+        from .ccf_fit import CCFFit
+        if devices is None:
+            devices = list(range(max(_native.load().vk_device_count(), 1)))
+        if not devices:
+            raise ValueError("no devices given")
+        self.devices = list(devices)
+        self.fits = [CCFFit(model, data, device=d) for d in self.devices]
+        self._pool = None
+
+    def _executor(self):
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=len(self.fits))
+        return self._pool
+
+    def _rows(self, params, kwargs):
+        fit = self.fits[0]
+        model = fit._merged(kwargs)
+        return fit._fit_rows(params, model)
+
+    def log_likelihood_batch(self, params, **kwargs):
+        """(lnL[n], chi2[n]); same arguments as ``CCFFit.log_likelihood_batch``."""
+        rows = self._rows(params, kwargs)
+        n, g = len(rows), len(self.fits)
+        bounds = [shard_bounds(n, g, r) for r in range(g)]
+        jobs = [self._executor().submit(f.log_likelihood_batch, rows[lo:hi], **kwargs)
+                for f, (lo, hi) in zip(self.fits, bounds) if hi > lo]
+        parts = [j.result() for j in jobs]
+        if not parts:
+            return np.empty(0), np.empty(0)
+        return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+
+    def theory_vector_batch(self, params, **kwargs):
+        rows = self._rows(params, kwargs)
+        n, g = len(rows), len(self.fits)
+        bounds = [shard_bounds(n, g, r) for r in range(g)]
+        jobs = [self._executor().submit(f.theory_vector_batch, rows[lo:hi], **kwargs)
+                for f, (lo, hi) in zip(self.fits, bounds) if hi > lo]
+        parts = [j.result() for j in jobs]
+        return np.concatenate(parts) if parts else np.empty((0, 0))
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.shutdown()
+            self._pool = None
