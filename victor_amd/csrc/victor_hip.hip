@@ -837,7 +837,9 @@ static int eval_batch_graph(vk_ctx* ctx, const vk_eval_opts* opts, const double*
   key.push_back(chi2 ? 1 : 0);
   auto hit = ctx->graphs.find(key);
   if (hit == ctx->graphs.end()) {
-    if (ctx->graph_seen[key]++ == 0) return 0;         // first use of this shape: eager (also warms attributes)
+    int& seen = ctx->graph_seen[key];
+    if (seen < 0) return 0;                            // capturing this shape failed before: stay eager
+    if (seen++ == 0) return 0;                         // first use of this shape: eager (also warms attributes)
     if (ctx->graphs.size() >= 32) drop_graphs(ctx);
     if (!ctx->h_pin) {
       if (hipHostMalloc((void**)&ctx->h_pin, (size_t)kGraphMaxN * (VK_NPAR + 2) * sizeof(double), hipHostMallocDefault) !=
@@ -862,7 +864,7 @@ static int eval_batch_graph(vk_ctx* ctx, const vk_eval_opts* opts, const double*
     if (graph) (void)hipGraphDestroy(graph);
     if (!ok) {
       (void)hipGetLastError();
-      ctx->graphs_off = true;                          // never try again on this context; the eager path is complete
+      ctx->graph_seen[key] = -1;                       // e.g. an unsupported option combination: the eager path reports it
       return 0;
     }
     ctx->graph_kernel[key] = ctx->last_kernel;
