@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 11
+#define VK_ABI_VERSION 12
 
 /* error codes */
 #define VK_OK 0
@@ -161,6 +161,9 @@ typedef struct vk_tables {
                            with empirical_corr the V half of the records becomes V1 + Av V2 per point            */
   const double* uni_da; /* fixed velocity tables only (else NULL): Da = delta - 2 Delta/3 on the unified grid,
                            [uni_n][4]; lets the dispersion model run on the fast kernels                        */
+  const double* uni_ge; /* fixed velocity tables only (else NULL): the numerical-gradient tables Ge1, Ge2 of the
+                           empirical_corr branch on the unified grid, [2][uni_n][4]: the dispersion model then uses
+                           Ge1 + Av Ge2 in place of Da (ccf_model.py:455-459)                                    */
   /* Union-grid form of the same tables for knots that are not uniform or not commensurate: uni_n intervals between
    * the sorted distinct knots uni_knots[0..uni_n] of vr (uni_knots[0] = vr.knots[0] = 0.01), xi and sv; the
    * coefficient arrays above are then in units of each interval's own width.  A uniform look-up table of

@@ -216,7 +216,8 @@ def test_example_void_model_hdf5_non_uniform_grids():
         want, _ = o.theory_multipoles(s, dict(p), poles=[0, 2], **kw)
         for key in ("0", "2"):
             assert np.max(np.abs(got[key] - want[key])) < RTOL * np.max(np.abs(want[key])), (kw, key)
-    assert m._get_engine().last_kernel() == "vk_theory_kernel"
+    # non-uniform grids take the union-grid form of the fast kernels, dispersion + empirical_corr included
+    assert m._get_engine().last_kernel() == "vk_theory_fast_kernel"
 
 
 def test_special_amplitudes_in_every_fast_mapping(tmp_path, gold):
@@ -452,19 +453,27 @@ def test_dispersion_model_runs_on_the_fast_kernels(gold):
     import os
     import victor_amd
     g, meta = gold
-    for name, opts, beta, key, npts in (("synth", cases.synth_options(3), False, None, 0),
-                                        ("boss", cases.boss_options("config"), True, "boss_dispersion_theory", 3)):
+    emp_pts = [dict(q, bias=2.1, Av=0.7, M=1.05, Q=0.95) for q in meta["boss_points"][:3]]
+    for name, opts, beta, key, pts, kw in (
+            ("synth", cases.synth_options(3), False, None, [], {}),
+            ("boss", cases.boss_options("config"), True, "boss_dispersion_theory", meta["boss_points"][:3], {}),
+            ("boss+empirical_corr", cases.boss_options("config"), True, "opt_boss_emp_disp", emp_pts,
+             {"empirical_corr": True})):
+        kw = dict(kw, rsd_model="dispersion")
         fit = victor_amd.CCFFit(*opts)
-        model = fit._merged({"rsd_model": "dispersion"})
+        model = fit._merged(kw)
         hp = cases.halton_params(1200, with_beta=beta)
-        parts = [fit._fit_rows(dict(p), model) for p in meta["boss_points"][:npts]] + [fit._fit_rows(hp, model)]
+        if "empirical_corr" in kw:
+            hp = dict(hp, Av=np.linspace(-1.0, 1.0, 1200))
+        npts = len(pts)
+        parts = [fit._fit_rows(dict(p), model) for p in pts] + [fit._fit_rows(hp, model)]
         rows = np.vstack(parts)
         res = {}
         for mapping in ("point", "cells", "generic"):
             env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
             os.environ[env] = "1" if mapping == "generic" else mapping
             try:
-                res[mapping] = fit.theory_vector_batch(rows, rsd_model="dispersion")
+                res[mapping] = fit.theory_vector_batch(rows, **kw)
                 assert fit._get_engine().last_kernel().endswith(
                     {"point": "fast_kernel", "cells": "cells_kernel", "generic": "vk_theory_kernel"}[mapping])
             finally:

@@ -68,7 +68,7 @@ struct vk_ctx {
   const double *d_sv_mu = nullptr, *d_sv2d = nullptr;
   int uni_n = 0;             // unified refined grid (fast kernels need it)
   double uni_u0 = 0, uni_inv_h = 0;
-  const double *d_uni_sv_v = nullptr, *d_uni_xi = nullptr, *d_uni_xic = nullptr, *d_uni_vb = nullptr, *d_uni_v2 = nullptr, *d_uni_da = nullptr;
+  const double *d_uni_sv_v = nullptr, *d_uni_xi = nullptr, *d_uni_xic = nullptr, *d_uni_vb = nullptr, *d_uni_v2 = nullptr, *d_uni_da = nullptr, *d_uni_ge = nullptr;
   int uni_lut_n = 0;         // > 0: union-grid form of the unified tables
   double uni_lut_inv_g = 0;
   const unsigned short* d_uni_lut = nullptr;
@@ -291,6 +291,7 @@ int theory_args(vk_ctx* ctx, const vk_eval_opts* o, TheoryArgs* a, int* nlr) {
   a->uni_vb = ctx->d_uni_vb;
   a->uni_v2 = ctx->d_uni_v2;
   a->uni_da = ctx->d_uni_da;
+  a->uni_ge = ctx->d_uni_ge;
   a->uni_lut_n = ctx->uni_lut_n;
   a->uni_lut_inv_g = ctx->uni_lut_inv_g;
   a->uni_lut = ctx->d_uni_lut;
@@ -324,7 +325,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   choose_split(ctx, a.n, a.n_s, &a.sbins_per_item, &a.team);
   // the fast kernel (streaming only) packs LDS byte offsets of the mu and (x, w) records into 16 bits each
   // fast kernels: the streaming model, and the dispersion model on fixed velocity tables (cells / point-major only)
-  const bool disp = a.rsd == VK_RSD_DISPERSION && a.uni_da && !a.from_data && !a.empirical && !a.vr_beta_dep;
+  const bool disp = a.rsd == VK_RSD_DISPERSION && a.uni_da && !a.from_data && (!a.empirical || a.uni_ge) && !a.vr_beta_dep;
   const bool fast = (a.rsd == VK_RSD_STREAMING || disp) && ctx->fast_ok && (!a.empirical || a.uni_v2) &&
                     a.n_mu <= 1024 && a.n_x <= 2048 && !getenv("VICTOR_HIP_FORCE_GENERIC");
   size_t lds;
@@ -624,7 +625,7 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
     o_svmu = up.add(t->sv_mu, t->sv_n_mu);
     o_sv2d = up.add(t->sv2d, (size_t)t->sv.n_int * (t->sv_n_mu - 1) * 16);
   }
-  size_t o_usv = 0, o_uxi = 0, o_uxc = 0, o_ulut = 0, o_uk = 0, o_uvb = 0, o_uv2 = 0, o_uda = 0;
+  size_t o_usv = 0, o_uxi = 0, o_uxc = 0, o_ulut = 0, o_uk = 0, o_uvb = 0, o_uv2 = 0, o_uda = 0, o_uge = 0;
   const bool have_lut = t->uni_n > 0 && t->uni_lut_n > 0 && t->uni_lut && t->uni_knots;
   if (have_lut) {
     std::vector<double> packed(((size_t)t->uni_lut_n + 3) / 4, 0.0);        // u16 cells travel inside the double arena
@@ -641,6 +642,7 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
     if (t->vr_beta_dep && t->uni_vb) o_uvb = up.add(t->uni_vb, (size_t)(t->n_beta_r - 1) * t->uni_n * 16);
     if (!t->vr_beta_dep && t->uni_v2) o_uv2 = up.add(t->uni_v2, (size_t)t->uni_n * 4);
     if (!t->vr_beta_dep && t->uni_da) o_uda = up.add(t->uni_da, (size_t)t->uni_n * 4);
+    if (!t->vr_beta_dep && t->uni_ge) o_uge = up.add(t->uni_ge, (size_t)t->uni_n * 8);
   }
   size_t o_bd = 0, o_data = 0, o_bc = 0, o_prec = 0, o_ld = 0, o_eig = 0;
   if (t->data) {
@@ -687,6 +689,7 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
     if (t->vr_beta_dep && t->uni_vb) ctx->d_uni_vb = base + o_uvb;
     if (!t->vr_beta_dep && t->uni_v2) ctx->d_uni_v2 = base + o_uv2;
     if (!t->vr_beta_dep && t->uni_da) ctx->d_uni_da = base + o_uda;
+    if (!t->vr_beta_dep && t->uni_ge) ctx->d_uni_ge = base + o_uge;
     if (have_lut) {
       ctx->uni_lut_n = t->uni_lut_n;
       ctx->uni_lut_inv_g = t->uni_lut_inv_g;

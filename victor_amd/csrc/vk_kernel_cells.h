@@ -82,6 +82,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
       __syncthreads();  // every wave is done with the previous point's records
       if (a.n_beta_r > 0) rebuild_uni_xi<NLR>(a, lds + kRecsOff, lds + pl.betar, row[VK_P_BETA]);
       if (a.empirical) rebuild_uni_v_emp<NLR>(a, lds + kRecsOff, ps.av);
+      if (MODE == kModeDispersion && a.empirical) rebuild_da_emp(a, lds + pl.da, ps.av);
       __syncthreads();
     }
     for (int e = lane; e < kMaxEll * slots; e += 64) l_acc[e * kWaves + wave] = 0.0;

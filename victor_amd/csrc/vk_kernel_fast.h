@@ -289,6 +289,13 @@ __device__ __forceinline__ void stage_da(const TheoryArgs& a, double* da) {
   for (int e = threadIdx.x; e < a.uni_n * 4; e += kBlock) da[e] = a.uni_da[e];
 }
 
+// empirical_corr in the dispersion model: v_r' comes from the numerical-gradient tables, Dq = Ge1 + av Ge2
+// (ccf_model.py:455-459), rebuilt per point like V = V1 + av V2
+__device__ __forceinline__ void rebuild_da_emp(const TheoryArgs& a, double* da, double av) {
+  const int n4 = a.uni_n * 4;
+  for (int e = threadIdx.x; e < n4; e += kBlock) da[e] = fma(av, a.uni_ge[n4 + e], a.uni_ge[e]);
+}
+
 // --------------------------------------------------------------------------------------------------
 // K1 point-major fast kernel: one wave owns one (point, s bin); lanes sweep the flattened (mu, v) plane.
 // --------------------------------------------------------------------------------------------------
@@ -377,6 +384,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
       __syncthreads();  // previous item's readers are done with the per-point records
       if (a.n_beta_r > 0) rebuild_uni_xi<NLR>(a, lds + kRecsOff, lds + pl.betar, row[VK_P_BETA]);
       if (a.empirical) rebuild_uni_v_emp<NLR>(a, lds + kRecsOff, ps.av);
+      if (MODE == kModeDispersion && a.empirical) rebuild_da_emp(a, lds + pl.da, ps.av);
       __syncthreads();
     }
     const FastPoint fp = make_fast_point(ps, fc);

@@ -163,6 +163,9 @@ def build_tables(model, fit=None, matter_model=None):
                 t.uni_v2 = N.as_dp(uni_v2)
                 uni_da = arr(T.refine_pp_on(r_ext, vr_coef[1], left, width))              # dispersion model: v_r'(r)
                 t.uni_da = N.as_dp(uni_da)
+                uni_ge = arr(np.stack([T.refine_pp_on(r_ext, vr_coef[3], left, width),
+                                       T.refine_pp_on(r_ext, vr_coef[4], left, width)]))   # empirical_corr: v_r'(r)
+                t.uni_ge = N.as_dp(uni_ge)
             uni_sv_v = arr(np.stack([sv_ref, v_ref], axis=1))                         # (n, 2, 4)
             if model.fixed_real_input:
                 uni_xi = arr(np.stack([T.refine_pp_on(r, coef[l], left, width) for l in range(n_ell_r)]))   # (L, n, 4)
@@ -246,6 +249,7 @@ def table_array_lengths(t):
         "uni_vb": (nb - 1) * t.uni_n * 16 if (t.uni_n and t.vr_beta_dep and t.uni_vb) else 0,
         "uni_v2": t.uni_n * 4 if (t.uni_n and t.uni_v2) else 0,
         "uni_da": t.uni_n * 4 if (t.uni_n and t.uni_da) else 0,
+        "uni_ge": t.uni_n * 8 if (t.uni_n and t.uni_ge) else 0,
         "uni_lut": t.uni_lut_n, "uni_knots": t.uni_n + 1 if t.uni_lut_n else 0,
         "beta_d": t.n_beta_d, "data": (t.n_beta_d - 1) * N_ * 4 if t.n_beta_d else (N_ if t.data else 0),
         "beta_c": t.n_beta_c, "prec": (max(t.n_beta_c, 1) * N_ * N_) if t.prec else 0,
