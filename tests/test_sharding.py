@@ -134,3 +134,12 @@ def test_two_rank_distributed_ensemble(tmp_path):
         assert f"rank {rank} ok" in out
         sums.append(out.strip().split()[-1])
     assert sums[0] == sums[1]                       # both ranks hold the identical gathered log-likelihood history
+
+
+def test_default_device_follows_the_launcher():
+    from victor_amd.sharding import default_device
+    assert default_device({}, 8) == 0
+    assert default_device({"VICTOR_HIP_DEVICE": "5", "LOCAL_RANK": "2"}, 8) == 5
+    assert default_device({"OMPI_COMM_WORLD_LOCAL_RANK": "3"}, 8) == 3
+    assert default_device({"SLURM_LOCALID": "9"}, 8) == 1
+    assert default_device({"LOCAL_RANK": "2"}, 1) == 0

@@ -39,7 +39,8 @@ class CCFLikelihood(Likelihood):
                 info = yaml.full_load(fh)
             self.model = info["model"]
             self.data = info["data"]
-        self.ccf = CCFFit(self.model, self.data, device=int(os.environ.get("VICTOR_HIP_DEVICE", "0")))
+        from victor_amd.sharding import default_device
+        self.ccf = CCFFit(self.model, self.data, device=default_device())   # one chain per GPU under mpirun / torchrun
 
     def get_can_provide_params(self):
         return ["fsigma8"]

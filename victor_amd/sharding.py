@@ -15,6 +15,24 @@ import os
 import numpy as np
 
 
+def default_device(environ=None, n_devices=None):
+    """GPU for this process: ``VICTOR_HIP_DEVICE`` if set, else the launcher's local rank (torchrun, Open MPI,
+    MPICH / Intel MPI, Slurm) modulo the number of visible GPUs, else 0 - so that ``mpirun -n 8 cobaya-run ...``
+    (the reference's way of running several chains, README.md:30) lands one chain on each GPU."""
+    env = os.environ if environ is None else environ
+    if env.get("VICTOR_HIP_DEVICE", "") != "":
+        return int(env["VICTOR_HIP_DEVICE"])
+    for key in ("LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "MV2_COMM_WORLD_LOCAL_RANK",
+                "SLURM_LOCALID"):
+        if env.get(key, "") != "":
+            rank = int(env[key])
+            if n_devices is None:
+                from . import _native
+                n_devices = _native.load().vk_device_count()
+            return rank % max(int(n_devices), 1)
+    return 0
+
+
 def shard_bounds(n, world, rank):
     """Contiguous, balanced split of ``n`` rows: the first ``n % world`` ranks get one extra row."""
     if world < 1 or not (0 <= rank < world):
