@@ -17,7 +17,10 @@ def params(n, beta, seed, fmax=2.0):
 def run(fit, label, beta, fmax=2.0, **kw):
     n = 131072
     model = fit._merged(kw)
-    rows = fit._fit_rows(params(n, beta, 7, fmax), model)
+    p = params(n, beta, 7, fmax)
+    if kw.get("empirical_corr"):
+        p["Av"] = np.random.default_rng(8).uniform(-1.5, 1.5, n)
+    rows = fit._fit_rows(p, model)
     os.environ["VICTOR_HIP_FORCE_GENERIC"] = "1"
     ref = fit.theory_vector_batch(rows, **kw)
     del os.environ["VICTOR_HIP_FORCE_GENERIC"]
@@ -47,6 +50,15 @@ def main():
     boss = victor_amd.CCFFit(*cases.boss_options("config"))
     run(boss, "boss", True)
     run(boss, "boss linear_bias", True, matter_model="linear_bias")
+    run(boss, "boss empirical_corr", True, empirical_corr=True)
+    run(boss, "boss dispersion + empirical_corr, fsigma8 < 1.0", True, 1.0, rsd_model="dispersion", empirical_corr=True)
+    m, d = cases.boss_options("config")
+    m["input_model_data_file"] = "boss/measured_model.npy"
+    m["realspace_ccf"]["from_data"] = True
+    d["covariance_matrix"]["data_file"] = "boss/cov_md_iso.npy"
+    fd = victor_amd.CCFFit(m, d)
+    run(fd, "boss from_data", True)
+    run(fd, "boss from_data, anisotropic sum", True, assume_isotropic=False)
     src = np.load(os.path.join(cases.GOLDEN, "synth", "model.npy"), allow_pickle=True).item()
     rng = np.random.default_rng(5)
     d = dict(src)
