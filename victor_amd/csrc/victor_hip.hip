@@ -208,7 +208,9 @@ int launch_fast_ngf(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
 
 template <int NLR, int GRID>
 int launch_fast_ng(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
-  if (a.rsd == VK_RSD_DISPERSION) return launch_fast_ngf<NLR, GRID, kModeDispersion>(ctx, a, grid, lds);
+  if (a.rsd == VK_RSD_DISPERSION)
+    return a.from_data ? launch_fast_ngf<NLR, GRID, kModeDispersionFromData>(ctx, a, grid, lds)
+                       : launch_fast_ngf<NLR, GRID, kModeDispersion>(ctx, a, grid, lds);
   return a.from_data ? launch_fast_ngf<NLR, GRID, kModeFromData>(ctx, a, grid, lds)
                      : launch_fast_ngf<NLR, GRID, kModeStreaming>(ctx, a, grid, lds);
 }
@@ -245,7 +247,9 @@ int launch_cells_ngf(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
 
 template <int NLR, int GRID>
 int launch_cells_ng(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
-  if (a.rsd == VK_RSD_DISPERSION) return launch_cells_ngf<NLR, GRID, kModeDispersion>(ctx, a, grid, lds);
+  if (a.rsd == VK_RSD_DISPERSION)
+    return a.from_data ? launch_cells_ngf<NLR, GRID, kModeDispersionFromData>(ctx, a, grid, lds)
+                       : launch_cells_ngf<NLR, GRID, kModeDispersion>(ctx, a, grid, lds);
   return a.from_data ? launch_cells_ngf<NLR, GRID, kModeFromData>(ctx, a, grid, lds)
                      : launch_cells_ngf<NLR, GRID, kModeStreaming>(ctx, a, grid, lds);
 }
@@ -325,7 +329,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   choose_split(ctx, a.n, a.n_s, &a.sbins_per_item, &a.team);
   // the fast kernel (streaming only) packs LDS byte offsets of the mu and (x, w) records into 16 bits each
   // fast kernels: the streaming model, and the dispersion model on fixed velocity tables (cells / point-major only)
-  const bool disp = a.rsd == VK_RSD_DISPERSION && a.uni_da && !a.from_data && (!a.empirical || a.uni_ge) && !a.vr_beta_dep;
+  const bool disp = a.rsd == VK_RSD_DISPERSION && a.uni_da && (!a.empirical || a.uni_ge) && !a.vr_beta_dep;
   const bool fast = (a.rsd == VK_RSD_STREAMING || disp) && ctx->fast_ok && (!a.empirical || a.uni_v2) &&
                     a.n_mu <= 1024 && a.n_x <= 2048 && !getenv("VICTOR_HIP_FORCE_GENERIC");
   size_t lds;

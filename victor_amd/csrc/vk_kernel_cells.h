@@ -38,7 +38,7 @@ __host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s,
 template <int NLR, int NL, int GRID, int MODE>
 __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_theory_cells_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
-  const CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, MODE == kModeDispersion);
+  const CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, mode_is_dispersion(MODE));
   const int tid = threadIdx.x;
   for (int i = tid; i < a.n_mu; i += kBlock) {
     const double m = a.mu[i];
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
   }
   for (int j = tid; j < a.n_s; j += kBlock) lds[pl.s + j] = a.s[j];
   stage_uni_records<NLR>(a, lds);
-  if (MODE == kModeDispersion) stage_da<NLR>(a, lds + pl.da);
+  if (mode_is_dispersion(MODE)) stage_da<NLR>(a, lds + pl.da);
   if (a.n_beta_r > 0)
     for (int i = tid; i < a.n_beta_r; i += kBlock) lds[pl.betar + i] = a.beta_r[i];
   const FastConsts fc = make_fast_consts<NLR>(a);
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
       __syncthreads();  // every wave is done with the previous point's records
       if (a.n_beta_r > 0) rebuild_uni_xi<NLR>(a, lds + kRecsOff, lds + pl.betar, row[VK_P_BETA]);
       if (a.empirical) rebuild_uni_v_emp<NLR>(a, lds + kRecsOff, ps.av);
-      if (MODE == kModeDispersion && a.empirical) rebuild_da_emp(a, lds + pl.da, ps.av);
+      if (mode_is_dispersion(MODE) && a.empirical) rebuild_da_emp(a, lds + pl.da, ps.av);
       __syncthreads();
     }
     for (int e = lane; e < kMaxEll * slots; e += 64) l_acc[e * kWaves + wave] = 0.0;
@@ -105,8 +105,9 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
         const double xk = xw.x;
         const double num = fma(-xk, fp.Bk, s_par);
         g = fma(xw.y,
-                MODE == kModeDispersion
-                    ? disp_value<NLR, GRID>(lds, lds + pl.da, fc, fp, a.niter, num, s_par, sperp2, xk)
+                mode_is_dispersion(MODE)
+                    ? disp_value<NLR, GRID, MODE == kModeDispersionFromData>(lds, lds + pl.da, fc, fp, a.niter, num, s_par, sperp2,
+                                                                           xk)
                     : uni_value<NLR, GRID, MODE == kModeFromData>(lds, fc, fp.AVk, num, sperp2, xk, fp.fa, sperp2x),
                 g);
       }

@@ -250,7 +250,7 @@ __device__ __forceinline__ double uni_value(const double* __restrict__ lds, cons
 // q(r) = aH^-1 v_r(r)/r, started at the redshift-space separation and repeated `niter` more times, and the Jacobian
 // 1 / (1 + q + mu_r^2 (dq - q)) with dq = aH^-1 v_r'(r).  `da` = LDS table of Da = delta - 2 Delta/3 on the unified
 // grid, [uni_n][4].  All lengths in index units; `num` = s_par' - x_k' Bk.
-template <int NLR, int GRID>
+template <int NLR, int GRID, int FD>
 __device__ __forceinline__ double disp_value(const double* __restrict__ lds, const double* __restrict__ da,
                                              const FastConsts& fc, const FastPoint& fp, int niter, double num,
                                              double s_par, double sperp2, double xk) {
@@ -271,9 +271,18 @@ __device__ __forceinline__ double disp_value(const double* __restrict__ lds, con
   const double q = -fp.Gk * cubic_b128(rec + 4, tq) * inv_r;
   const double dq = -fp.gD * cubic_b128(da + 4 * qi, tq);
   const double m2 = mu_r * mu_r;
+  double mx2 = m2;
+  if (FD) {   // xi^r at the fiducial coordinates, as in uni_value
+    const double rp = r_par * fp.fa;
+    const double r2x = fma(rp, rp, sperp2 * fp.fp2);
+    const double inv_rx = vkm::rsqrt3(r2x);
+    const double mu_x = rp * inv_rx;
+    mx2 = mu_x * mu_x;
+    rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(r2x, inv_rx, fc.off) : r2x * inv_rx, tq, qi);
+  }
   double xir = cubic_b128(rec + 8, tq);
-  if (NLR == 2) xir = fma(cubic_b128(rec + 12, tq), m2, xir);
-  if (NLR == 3) xir = fma(fma(cubic_b128(rec + 16, tq), m2, cubic_b128(rec + 12, tq)), m2, xir);
+  if (NLR == 2) xir = fma(cubic_b128(rec + 12, tq), mx2, xir);
+  if (NLR == 3) xir = fma(fma(cubic_b128(rec + 16, tq), mx2, cubic_b128(rec + 12, tq)), mx2, xir);
   const double inv_sv = vkm::recip(SV);
   const double jac = vkm::recip(1.0 + q + m2 * (dq - q));
   const double y = xk * inv_sv;
@@ -282,7 +291,8 @@ __device__ __forceinline__ double disp_value(const double* __restrict__ lds, con
 }
 
 // MODE of the kernels that own a point per workgroup: streaming, streaming on a measured real-space ccf, dispersion
-constexpr int kModeStreaming = 0, kModeFromData = 1, kModeDispersion = 2;
+constexpr int kModeStreaming = 0, kModeFromData = 1, kModeDispersion = 2, kModeDispersionFromData = 3;
+__host__ __device__ constexpr bool mode_is_dispersion(int mode) { return mode >= kModeDispersion; }
 
 template <int NLR>
 __device__ __forceinline__ void stage_da(const TheoryArgs& a, double* da) {
@@ -322,7 +332,7 @@ __host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int uni_n,
 template <int NLR, int NL, int GRID, int MODE>
 __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
-  const FastPlan pl = make_fast_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, MODE == kModeDispersion);
+  const FastPlan pl = make_fast_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, mode_is_dispersion(MODE));
   const int tid = threadIdx.x;
   // ---- stage batch-constant tables -------------------------------------------------------------
   for (int i = tid; i < a.n_mu; i += kBlock) {
@@ -339,7 +349,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
     lds[pl.xrec + 2 * i + 1] = a.w_x[i];
   }
   stage_uni_records<NLR>(a, lds);
-  if (MODE == kModeDispersion) stage_da<NLR>(a, lds + pl.da);
+  if (mode_is_dispersion(MODE)) stage_da<NLR>(a, lds + pl.da);
   if (a.n_beta_r > 0)
     for (int i = tid; i < a.n_beta_r; i += kBlock) lds[pl.betar + i] = a.beta_r[i];
   // byte offsets of the mu record (low 16 bits) and the (x, w) record (high 16 bits) of every plane node, so the
@@ -384,7 +394,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
       __syncthreads();  // previous item's readers are done with the per-point records
       if (a.n_beta_r > 0) rebuild_uni_xi<NLR>(a, lds + kRecsOff, lds + pl.betar, row[VK_P_BETA]);
       if (a.empirical) rebuild_uni_v_emp<NLR>(a, lds + kRecsOff, ps.av);
-      if (MODE == kModeDispersion && a.empirical) rebuild_da_emp(a, lds + pl.da, ps.av);
+      if (mode_is_dispersion(MODE) && a.empirical) rebuild_da_emp(a, lds + pl.da, ps.av);
       __syncthreads();
     }
     const FastPoint fp = make_fast_point(ps, fc);
@@ -410,8 +420,9 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
           const double sperp2 = s_perp * s_perp;
           const double s_par = s_apar * m01.x;
           const double num = fma(-xw.x, fp.Bk, s_par);
-          const double f = xw.y * (MODE == kModeDispersion
-                                       ? disp_value<NLR, GRID>(lds, lds + pl.da, fc, fp, a.niter, num, s_par, sperp2, xw.x)
+          const double f = xw.y * (mode_is_dispersion(MODE)
+                                       ? disp_value<NLR, GRID, MODE == kModeDispersionFromData>(lds, lds + pl.da, fc, fp, a.niter, num,
+                                                                                              s_par, sperp2, xw.x)
                                        : uni_value<NLR, GRID, MODE == kModeFromData>(lds, fc, fp.AVk, num, sperp2, xw.x, fp.fa,
                                                                                     sperp2 * fp.fp2));
           const vk_d2 w01 = *reinterpret_cast<const vk_d2*>(mr + 2);
