@@ -1,0 +1,23 @@
+"""Cells kernel (BOSS): resident evals/s vs VICTOR_HIP_POINT_CAP (workgroups per CU in the launch) at several batch sizes."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import victor_amd
+from tests import cases
+fit = victor_amd.CCFFit(*cases.boss_options("config"))
+eng = fit._get_engine()
+o = eng.make_opts(fit.model, fit.fit_options)
+for batch in (16384, 65536, 100000, 262144):
+    rows = fit._fit_rows(cases.halton_params(batch, with_beta=True), fit.model)
+    bufs = [eng.alloc(rows.size), eng.alloc(batch), eng.alloc(batch), eng.alloc(batch * eng.n_data)]
+    eng.upload(bufs[0], rows)
+    for cap in ("16", "32", "64", "128", "256", "100000"):
+        os.environ["VICTOR_HIP_POINT_CAP"] = cap
+        for _ in range(2):
+            eng.eval_device_async(o, bufs[0], batch, bufs[1], bufs[2], bufs[3]); eng.sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            eng.eval_device_async(o, bufs[0], batch, bufs[1], bufs[2], bufs[3])
+        eng.sync()
+        dt = (time.perf_counter() - t0) / 3
+        print(f"batch {batch} cap {cap}: {dt*1e3:.2f} ms -> {batch/dt:.0f} evals/s ({eng.last_kernel()})", flush=True)
+    for b in bufs: eng.free(b)

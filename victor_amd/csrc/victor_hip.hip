@@ -342,9 +342,11 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   if (lds > 160 * 1024) return fail(ctx, VK_E_ARG, "tables need %zu bytes of LDS (> 160 KiB)", lds);
   const long long groups = (a.n_s + a.sbins_per_item - 1) / a.sbins_per_item;
   const long long items = a.n * groups;
-  // over-subscribe: 27.9 / 25.9 / 24.8 / 24.0 ms at 4 / 8 / 16 / 64 workgroups per CU on BOSS x 65536 (4 are resident)
+  // over-subscribe: 27.9 / 25.9 / 24.8 / 24.0 ms at 4 / 8 / 16 / 64 workgroups per CU on BOSS x 65536 (4-5 are resident);
+  // 64 -> 256 gains another 0.5-2 % at 65536-262144 points (tools/gpu_cells_cap_sweep.py), staging per workgroup is cheap
   const char* pcap_env = getenv("VICTOR_HIP_POINT_CAP");            // tuning knob: workgroups per CU in the launch
-  const long long cap = (pcap_env ? atoll(pcap_env) : 64LL) * ctx->n_cu;
+  const long long kDefaultCap = 256;
+  const long long cap = (pcap_env ? atoll(pcap_env) : kDefaultCap) * ctx->n_cu;
   const int grid = (int)(items < cap ? items : cap);
   // lanes-over-batch variant: batch-constant tables and enough points to fill the chip with n_s * n/64 waves
   const char* mapping = getenv("VICTOR_HIP_MAPPING");
@@ -363,10 +365,12 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   if (lanes) {
     ctx->last_kernel = "vk_theory_lanes_kernel";
     const long long blocks = (waves + kWaves - 1) / kWaves;
-    // Many more workgroups than fit at once: letting the dispatcher refill CUs as workgroups retire measured
-    // 38.1 / 36.0 / 34.6 / 33.8 ms at 4 / 8 / 16 / 64 workgroups per CU on the bench workload (4 are resident)
-    const char* cap_env = getenv("VICTOR_HIP_LANES_CAP");          // tuning knob: workgroups per CU in the launch
-    const long long capl = (cap_env ? atoll(cap_env) : 64LL) * ctx->n_cu;
+    // One workgroup per four items, never a grid-stride loop by default: letting the dispatcher refill CUs as
+    // workgroups retire measured 38.1 / 36.0 / 34.6 / 33.8 ms at 4 / 8 / 16 / 64 workgroups per CU on the bench workload
+    // (5 are resident), and a cap that makes workgroups loop leaves a ragged tail of 0.6 ms items - 131072 points ran at
+    // 1.61 M evals/s under a 64-per-CU cap against 2.35 M without (tools/gpu_lanes_big.py)
+    const char* cap_env = getenv("VICTOR_HIP_LANES_CAP");          // A/B knob: workgroups per CU in the launch
+    const long long capl = cap_env ? atoll(cap_env) * ctx->n_cu : (long long)INT32_MAX;
     const int grid_l = (int)(blocks < capl ? blocks : capl);
     switch (nlr) {
       case 1: return launch_lanes_nl<1>(ctx, a, grid_l, lds_l);
@@ -383,7 +387,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
     const size_t lds_c =
         (size_t)make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, disp).total * sizeof(double);
     if (lds_c > 160 * 1024) return fail(ctx, VK_E_ARG, "tables need %zu bytes of LDS (> 160 KiB)", lds_c);
-    const long long capc = (pcap_env ? atoll(pcap_env) : 64LL) * ctx->n_cu;
+    const long long capc = (pcap_env ? atoll(pcap_env) : kDefaultCap) * ctx->n_cu;
     const int grid_c = (int)(a.n < capc ? a.n : capc);
     switch (nlr) {
       case 1: return launch_cells_nl<1>(ctx, a, grid_c, lds_c);
