@@ -247,3 +247,44 @@ def test_one_process_driving_several_contexts():
     th = multi.theory_vector_batch(cases.halton_params(77, with_beta=True), rsd_model="dispersion")
     assert th.shape == (77, 60) and np.all(np.isfinite(th))
     multi.close()
+
+
+def test_c_abi_rejects_bad_calls_without_crashing():
+    """Error conventions of the boundary: NULL handles and buffers, negative sizes, unknown option values and grids the
+    kernels cannot take all come back as VK_E_ARG with a message - nothing is launched."""
+    import ctypes as C
+    import numpy as np
+    import victor_amd
+    from victor_amd import _native as N
+    from tests import cases
+    lib = N.load()
+    fit = victor_amd.CCFFit(*cases.synth_options(2))
+    eng = fit._get_engine()
+    ctx = eng._ctx
+    opts = eng.make_opts(fit.model, fit.fit_options)
+    rows = fit._fit_rows(cases.halton_params(4), fit.model)
+    out = np.empty(4)
+    dp = N.as_dp
+    assert lib.vk_eval_batch(None, C.byref(opts), dp(rows), 4, dp(out), dp(out), None) == -1
+    assert lib.vk_eval_batch(ctx, None, dp(rows), 4, dp(out), dp(out), None) == -1
+    assert lib.vk_eval_batch(ctx, C.byref(opts), None, 4, dp(out), dp(out), None) == -1
+    assert lib.vk_eval_batch(ctx, C.byref(opts), dp(rows), -1, dp(out), dp(out), None) == -1
+    assert b"NULL" in lib.vk_last_error(ctx) or lib.vk_last_error(ctx)
+    assert lib.vk_eval_batch(ctx, C.byref(opts), dp(rows), 0, None, None, None) == 0          # empty batch is legal
+    bad = N.vk_eval_opts.from_buffer_copy(bytes(opts))
+    bad.rsd_model = 9
+    assert lib.vk_eval_batch(ctx, C.byref(bad), dp(rows), 4, dp(out), dp(out), None) == -1
+    bad = N.vk_eval_opts.from_buffer_copy(bytes(opts))
+    bad.like_form = -3
+    assert lib.vk_eval_batch(ctx, C.byref(bad), dp(rows), 4, dp(out), dp(out), None) == -1
+    s = np.linspace(5.0, 100.0, 6)
+    mu = np.linspace(0.0, 1.0, 100)
+    w = np.ones((2, 100))
+    th = np.empty((4, 2, 6))
+    assert lib.vk_theory_batch(ctx, C.byref(opts), dp(rows), 4, dp(s), 6, dp(mu), 1, dp(w), 2, dp(th)) == -1
+    assert lib.vk_theory_batch(ctx, C.byref(opts), dp(rows), 4, dp(s), 6, dp(mu), 100, dp(w), 7, dp(th)) == -1
+    assert lib.vk_theory_batch(ctx, C.byref(opts), dp(rows), 4, dp(s), 6, dp(mu), 100, dp(w), 2, dp(th)) == 0
+    assert np.all(np.isfinite(th))
+    # the context is still healthy
+    lnl, chi2 = fit.log_likelihood_batch(rows)
+    assert np.all(np.isfinite(lnl))
