@@ -351,20 +351,20 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   // lanes-over-batch variant: batch-constant tables and enough points to fill the chip with n_s * n/64 waves
   const char* mapping = getenv("VICTOR_HIP_MAPPING");
   const bool lanes_ok = fast && a.n_beta_r == 0 && !a.empirical && !a.from_data && !disp;   // per-point tables need a workgroup per point
-  // One wave per (s bin, 64-point chunk).  LDS and registers hold up to 5 workgroups (20 waves) per CU, so the
-  // chip holds `slots` waves at a time; the last round of waves is only partly filled.  The lanes kernel is ~1.2x
-  // faster per integrand than the point-major one (56 vs ~68 VALU instructions), so it wins once that fill
-  // efficiency exceeds ~0.85.
+  // One wave per (s bin, 64-point chunk), one workgroup per four of them; 5 workgroups are resident per CU.  Every item
+  // runs for ~0.6 ms, so the launch ends with a ragged tail about one residency round long, while the cells kernel
+  // (one workgroup per point, 2.20-2.25 M evals/s on config 3 from 2000 points on) has none: measured, the lanes kernel
+  // (2.44 M evals/s asymptotically) only pulls ahead once the launch is ~4 rounds deep - 1.85 / 2.14 / 2.03 / 2.23 / 2.33 /
+  // 2.40 M evals/s at 7000 / 8192 / 14000 / 30000 / 50000 / 100000 points (tools/gpu_batch_curve.py).
   const long long waves = ((a.n + 63) >> 6) * (long long)a.n_s;
+  const long long blocks_l = (waves + kWaves - 1) / kWaves;
   const size_t lds_l = (size_t)make_lanes_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.uni_lut_n).total * sizeof(double);
   const long long wg_per_cu = std::max<long long>(1, std::min<long long>(5, (160 * 1024) / (lds_l ? lds_l : 1)));
-  const long long slots = kWaves * wg_per_cu * ctx->n_cu;
-  const long long rounds = (waves + slots - 1) / slots;
-  const double fill = (double)waves / (double)(rounds * slots);
-  const bool lanes = lanes_ok && lds_l <= 160 * 1024 && (mapping ? !strcmp(mapping, "lanes") : fill >= 0.85);
+  const bool lanes = lanes_ok && lds_l <= 160 * 1024 &&
+                     (mapping ? !strcmp(mapping, "lanes") : blocks_l >= 4 * wg_per_cu * ctx->n_cu);
   if (lanes) {
     ctx->last_kernel = "vk_theory_lanes_kernel";
-    const long long blocks = (waves + kWaves - 1) / kWaves;
+    const long long blocks = blocks_l;
     // One workgroup per four items, never a grid-stride loop by default: letting the dispatcher refill CUs as
     // workgroups retire measured 38.1 / 36.0 / 34.6 / 33.8 ms at 4 / 8 / 16 / 64 workgroups per CU on the bench workload
     // (5 are resident), and a cap that makes workgroups loop leaves a ragged tail of 0.6 ms items - 131072 points ran at
