@@ -231,7 +231,7 @@ def test_small_batches_replay_a_captured_graph():
 
 def test_one_process_driving_several_contexts():
     """victor_amd.sharding.MultiGPUFit: contiguous shards of a batch evaluated concurrently from host threads, one
-    context per listed device (the one-GPU box lists device 0 three times); identical to the single-context result."""
+    context per listed device (the one-GPU box lists device 0 three times); same as the single-context result."""
     import numpy as np
     import victor_amd
     from victor_amd.sharding import MultiGPUFit
@@ -243,7 +243,8 @@ def test_one_process_driving_several_contexts():
         hp = cases.halton_params(n, with_beta=True)
         got = multi.log_likelihood_batch(hp)
         want = single.log_likelihood_batch(hp)
-        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), n
+        # shards of a different size may take another kernel mapping: agreement to rounding, not bit for bit
+        assert np.max(np.abs(got[1] / want[1] - 1)) < 1e-12 and np.max(np.abs(got[0] / want[0] - 1)) < 1e-12, n
     th = multi.theory_vector_batch(cases.halton_params(77, with_beta=True), rsd_model="dispersion")
     assert th.shape == (77, 60) and np.all(np.isfinite(th))
     multi.close()

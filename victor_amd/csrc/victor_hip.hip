@@ -381,7 +381,9 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   // cells variant: one workgroup per point with the velocity loop innermost; needs enough points to fill the chip
   // and n_mu >= 64 (a wave's 64 cells must not straddle more than two s bins)
   const bool cells_ok = fast && a.n_mu >= 64 && a.n_mu <= 4096 && a.n_x <= 2048;
-  const bool cells = cells_ok && (mapping ? !strcmp(mapping, "cells") : a.n >= 4LL * ctx->n_cu);
+  // crossover against the point-major kernel measured between 512 and 768 points (config 3) and near 500 (BOSS),
+  // tools/gpu_small_batch_ab.py: one workgroup per point needs ~2.5 workgroups per CU to keep the SIMDs fed
+  const bool cells = cells_ok && (mapping ? !strcmp(mapping, "cells") : a.n >= (5LL * ctx->n_cu) / 2);
   if (cells) {
     ctx->last_kernel = "vk_theory_cells_kernel";
     const size_t lds_c =
