@@ -168,11 +168,21 @@ int launch_on_stream(vk_ctx* ctx, Kern kern, int grid, size_t lds, const Args& a
 }
 
 void choose_split(const vk_ctx* ctx, long long n, int n_s, int* spi, int* team) {
-  // enough workgroups to fill 256 CUs several times over, otherwise split finer
+  // A/B knob "spi,team": s bins per workgroup visit and waves cooperating on one s bin (1, 2 or 4)
+  if (const char* env = getenv("VICTOR_HIP_SPLIT")) {
+    int s = 0, t = 0;
+    if (sscanf(env, "%d,%d", &s, &t) == 2 && s >= 1 && (t == 1 || t == 2 || t == 4) && (t == 1 || s == 1)) {
+      *spi = s < n_s ? s : n_s;
+      *team = t;
+      return;
+    }
+  }
+  // Measured (tools/gpu_split_sweep.py, resident, config 3 / BOSS): four s bins per workgroup (one per wave) is the
+  // fastest split from ~50 points on (64 points: 76 / 51 us against 102 / 77 us for two waves per s bin), four
+  // cooperating waves per s bin below that (1-16 points: 40 / 29 us); two waves per s bin never wins.
   const long long want = 4LL * ctx->n_cu;
   if (n >= want) { *spi = n_s; *team = 1; return; }
-  if (n * ((n_s + 3) / 4) >= want) { *spi = 4; *team = 1; return; }
-  if (n * n_s >= want) { *spi = 1; *team = 2; return; }
+  if (n * ((n_s + 3) / 4) >= want / 2) { *spi = 4; *team = 1; return; }
   *spi = 1; *team = 4;
 }
 
