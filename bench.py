@@ -41,14 +41,16 @@ def flops_per_eval(n_s, n_mu, n_x, n_ell, aniso):
 
 def cpu_worker(args):
     """Time the oracle on a slice of the sample (runs in a child process, one per host core)."""
-    idx, pts = args
+    idx, pts, rule = args
     os.environ["OMP_NUM_THREADS"] = os.environ["OPENBLAS_NUM_THREADS"] = "1"
     import warnings
     warnings.filterwarnings("ignore")
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import victor_oracle as vo
     from tests import cases
-    fit = vo.OracleFit(*cases.synth_options(CONFIG))
+    model, data = cases.synth_options(CONFIG)
+    model["numerics"] = {"simpson_even": rule}
+    fit = vo.OracleFit(model, data)
     out = []
     t0 = time.perf_counter()
     for p in pts:
@@ -98,11 +100,11 @@ def host_cores():
     return max(1, min(cores, int(os.environ.get("VICTOR_BENCH_CORES", "16"))))
 
 
-def cpu_baseline(sample_pts):
+def cpu_baseline(sample_pts, rule):
     """Oracle ('port' of the reference algorithm) on the host cores, bounded sample."""
     import multiprocessing as mp
     cores = max(1, min(host_cores(), len(sample_pts)))
-    chunks = [(i, sample_pts[i::cores]) for i in range(cores)]
+    chunks = [(i, sample_pts[i::cores], rule) for i in range(cores)]
     t0 = time.perf_counter()
     with mp.get_context("spawn").Pool(cores) as pool:
         res = pool.map(cpu_worker, chunks)
@@ -199,6 +201,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-boss", action="store_true", help="skip the secondary BOSS CMASS measurement")
     ap.add_argument("--cpu-sample", type=int, default=0, help="oracle evaluations (default: about 10 per core)")
+    ap.add_argument("--simpson-even", default="simpson",
+                    help="even-N Simpson convention of the velocity integral: 'simpson' (SciPy >= 1.11, default) or "
+                         "'avg' (SciPy < 1.11); same cost, recorded in config.simpson_even")
     args = ap.parse_args()
 
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
@@ -227,6 +232,7 @@ def main():
     dist.barrier()
 
     model, data = cases.synth_options(CONFIG)
+    model["numerics"] = {"simpson_even": args.simpson_even}
     B = args.batch
     hp_all = cases.halton_params(B * world)
     mine = {k: v[rank * B:(rank + 1) * B] for k, v in hp_all.items()}
@@ -237,7 +243,7 @@ def main():
         cores = host_cores()
         ns = min(args.cpu_sample or max(16, 40 * cores), B)      # ~40 oracle evaluations per core (~50 ms each): ~30 core-seconds of CPU work
         sel = np.linspace(0, B - 1, ns).astype(int)
-        base, vals, theory_o = cpu_baseline([cases.point(mine, int(i)) for i in sel])
+        base, vals, theory_o = cpu_baseline([cases.point(mine, int(i)) for i in sel], args.simpson_even)
 
     # one rank per GPU; on a box with fewer GPUs than ranks (rehearsals) ranks share devices and the RCCL communicator
     # cannot be built, which exercises the host-gather fallback below
@@ -342,6 +348,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE config 3: synthetic 40 s x 100 mu x 50 v grid, xi_r l=0,2,4, data l=0,2,4 "
                                    "(N=120), AP-dependent rescale, sigma_v(r) template, gaussian likelihood",
+                       "simpson_even": eng.simpson_even + (" (SciPy >= 1.11 simps rule; 'avg' = SciPy < 1.11)"
+                                                           if eng.simpson_even == "simpson" else " (SciPy < 1.11 simps rule)"),
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"batch-sharded x{world}",
                        "gather": "rccl allgather of lnL" if use_comm else
                        ("host allgather of lnL (RCCL unavailable)" if host_gather else "none (single process)")},

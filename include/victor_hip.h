@@ -105,7 +105,10 @@ typedef struct vk_tables {
   const double* w_ell;  /* [n_ell][n_mu] projection weights (utils.py:45-56 composed with
                            the cubic interp2d of ccf_model.py:824)             */
   const double* x;      /* [n_x] v/sigma_v nodes, linspace(-6,6,n_x)           */
-  const double* w_x;    /* [n_x] Simpson weights * dx / sqrt(2 pi) (ccf_model.py:690) */
+  const double* w_x;    /* [n_x] Simpson weights * dx / sqrt(2 pi) (ccf_model.py:690).  For the reference's 50 (even) nodes
+                           the caller chooses which SciPy's default `simps` rule the weights restate: SciPy >= 1.11
+                           (1/3,4/3,2/3,...,4/3 - 1/12, 1/3 + 2/3, 5/12) or SciPy < 1.11, even='avg'
+                           (5/12, 13/12, 1, ..., 1, 13/12, 5/12); victor_amd.tables.simpson_weights builds both */
 
   /* ---- real-space CCF multipoles xi^r_l(r) (ccf_model.py:615-621) ---------- */
   int32_t n_ell_r;      /* real-space multipoles available: 1..3 (l = 0,2,4)   */

@@ -15,7 +15,15 @@ Writes
                                              (SURVEY.md App. E); data vectors come from the
                                              reference's own theory at the fiducial point.
   tests/golden/ref_outputs.npz               reference outputs (theory vectors, chi2, lnL,
-                                             xi(s,mu)) for every golden case.
+                                             xi(s,mu)) for every golden case, with ``simps`` standing
+                                             for SciPy >= 1.11 (this image's ``simpson``).
+  tests/golden/ref_outputs_avg.npz           (``--set avg``) the streaming / dispersion cases again with
+                                             ``simps`` standing for SciPy < 1.11 (``even='avg'``), the
+                                             convention of the reference's published notebook numbers;
+                                             same input files as above.
+
+    python oracle/make_golden.py             # both sets
+    python oracle/make_golden.py --set avg   # only the second one (inputs and ref_outputs.npz untouched)
 """
 
 import json
@@ -151,7 +159,58 @@ def synth_options(config):
 
 
 # --------------------------------------------------------------------------- #
+def main_avg():
+    """Reference outputs under the SciPy < 1.11 ``simps`` (even='avg'), on the inputs ``main`` wrote."""
+    ref_shim.set_simpson_rule("avg")
+    v = ref_shim.load()
+    meta = json.loads(str(np.load(os.path.join(GOLD, "ref_outputs.npz"))["meta_json"]))
+    boss_points, hp = meta["boss_points"], meta["synth_points"]
+    out = {}
+    model, data = boss_options("config")
+    model["dir"] = data["dir"] = GOLD
+    fit = v.CCFFit(model, data)
+    # the converted inputs reproduce the reference's own config + HDF5 files under this rule too
+    info = ref_shim.boss_config()
+    fit0 = v.CCFFit(info["model"], info["data"])
+    assert fit0.log_likelihood(dict(boss_points[0])) == fit.log_likelihood(dict(boss_points[0]))
+    ll = [fit.log_likelihood(dict(p)) for p in boss_points]
+    out["boss_config_theory"] = np.array([fit.theory_multipole_vector(fit.s, dict(p), fit.poles_s) for p in boss_points])
+    out["boss_config_lnl"] = np.array([a for a, b in ll])
+    out["boss_config_chi2"] = np.array([b for a, b in ll])
+    p = boss_points[0]
+    nb = {"streaming": {}, "dispersion": dict(rsd_model="dispersion"), "kaiser": dict(rsd_model="kaiser"),
+          "anisotropic": dict(assume_isotropic=False), "beta_likelihood": dict(beta_interpolation="likelihood")}
+    for k, kw in nb.items():
+        l, c = fit.log_likelihood(dict(p), **kw)
+        out[f"boss_nb_{k}"] = np.array([c, l])
+    out["boss_dispersion_theory"] = np.array(
+        [fit.theory_multipole_vector(fit.s, dict(q), fit.poles_s, rsd_model="dispersion") for q in boss_points[:3]])
+    out["boss_aniso_theory"] = np.array(
+        [fit.theory_multipole_vector(fit.s, dict(q), fit.poles_s, assume_isotropic=False) for q in boss_points[:3]])
+    out["boss_config_xi_smu_p0"] = fit.theory_xi(*np.meshgrid(fit.s, np.linspace(0, 1, 100)), dict(p))
+    for config in (2, 3):
+        model, data = synth_options(config)
+        model["dir"] = data["dir"] = GOLD
+        fit = v.CCFFit(model, data)
+        pts = list(hp)
+        if config == 3:
+            pts = [{"fsigma8": 0.47, "sigma_v": 380, "aperp": 1.02, "apar": 0.97}] + pts
+        pts = pts[:9]
+        ll = [fit.log_likelihood(dict(q)) for q in pts]
+        out[f"synth{config}_theory"] = np.array([fit.theory_multipole_vector(fit.s, dict(q), fit.poles_s) for q in pts])
+        out[f"synth{config}_lnl"] = np.array([a for a, b in ll])
+        out[f"synth{config}_chi2"] = np.array([b for a, b in ll])
+    out["meta_json"] = np.array(json.dumps({"simps": "scipy<1.11 even='avg'", "boss_points": boss_points,
+                                            "synth_points": hp[:9]}))
+    np.savez_compressed(os.path.join(GOLD, "ref_outputs_avg.npz"), **out)
+    ref_shim.set_simpson_rule("simpson")
+    for k in sorted(out):
+        if k.startswith("boss_nb"):
+            print("avg", k, np.array2string(out[k], precision=12))
+
+
 def main():
+    ref_shim.set_simpson_rule("simpson")
     v = ref_shim.load()
     out = {}
     meta = {}
@@ -354,4 +413,11 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--set", choices=["all", "default", "avg"], default="all")
+    which = ap.parse_args().set
+    if which in ("all", "default"):
+        main()
+    if which in ("all", "avg"):
+        main_avg()

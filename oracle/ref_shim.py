@@ -18,8 +18,14 @@ and the reference source itself is left untouched:
    dump; falls back to our h5lite reader when h5dump is absent);
 2. ``astropy.cosmology.LambdaCDM`` -> closed-form flat/curved LCDM ``H(z)``
    with ``Tcmb0 = 0`` (astropy's default), all that ``cosmology.py:41-45`` uses;
-3. ``scipy.integrate.simps = scipy.integrate.simpson`` (the same routine, renamed
-   upstream in SciPy 1.14);
+3. ``scipy.integrate.simps`` (removed in SciPy 1.14).  The reference calls it with the default
+   ``even=`` on 50 nodes (ccf_model.py:690), and that default CHANGED in SciPy 1.11, so there are two
+   legitimate stand-ins under the reference's pin (``scipy>=1.6.3``, setup.py:31) and the result differs
+   between them by up to 2e-4 relative in chi2:
+   ``'simpson'`` = this image's ``scipy.integrate.simpson`` (what ``simps`` does in SciPy 1.11-1.13), and
+   ``'avg'``     = the SciPy < 1.11 default (``victor_oracle.simps_legacy``, a restatement of the documented
+   rule: mean of {Simpson + end trapezoid} taken from either end), the convention behind the numbers printed in
+   the reference's notebook.  :func:`set_simpson_rule` switches the stand-in (also after the import);
 4. ``scipy.interpolate.interp2d`` -> ``RectBivariateSpline(x, y, z.T, kx, ky, s=0)``,
    SciPy's own documented replacement for regular grids (identical FITPACK fit).
 """
@@ -144,6 +150,48 @@ def _make_interp2d():
 
 
 _victor = None
+_simpson_rule = "simpson"
+
+
+def _make_simps(rule):
+    import scipy.integrate
+    if rule == "simpson":
+        return scipy.integrate.simpson
+    if rule != "avg":
+        raise ValueError("simps stand-in: rule must be 'simpson' (SciPy >= 1.11) or 'avg' (SciPy < 1.11)")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    try:
+        from victor_oracle import simps_legacy
+    finally:
+        sys.path.pop(0)
+
+    def simps(y, x=None, dx=1.0, axis=-1, even="avg"):
+        y = np.asarray(y, dtype=float)
+        if x is None:
+            x = dx * np.arange(y.shape[axis])
+        return simps_legacy(y, x, axis=axis, even=even)
+
+    return simps
+
+
+def set_simpson_rule(rule):
+    """Choose which SciPy's ``simps`` the reference sees: 'simpson' (SciPy >= 1.11, default) or 'avg' (SciPy < 1.11).
+    Works before or after :func:`load` (the reference binds the name at import, ccf_model.py:8, so the stand-in is
+    swapped in the imported module's namespace as well; the reference source is not touched)."""
+    global _simpson_rule
+    fn = _make_simps(rule)
+    _simpson_rule = rule
+    import scipy.integrate
+    scipy.integrate.simps = fn
+    if _victor is not None:
+        for name in ("victor.ccf_model", "victor.ccf"):
+            mod = sys.modules.get(name)
+            if mod is not None and hasattr(mod, "simps"):
+                mod.simps = fn
+
+
+def simpson_rule():
+    return _simpson_rule
 
 
 def load():
@@ -171,8 +219,7 @@ def load():
 
     import scipy.integrate
     import scipy.interpolate
-    if not hasattr(scipy.integrate, "simps"):
-        scipy.integrate.simps = scipy.integrate.simpson
+    scipy.integrate.simps = _make_simps(_simpson_rule)
     scipy.interpolate.interp2d = _make_interp2d()
 
     # our own repo also ships a drop-in package called ``victor`` (a thin alias

@@ -18,7 +18,13 @@ The arithmetic of the reference lives in SciPy/NumPy (``setup.py:31`` pins only
 SciPy primitives the reference calls (FITPACK ``InterpolatedUnivariateSpline``
 / ``RectBivariateSpline``, ``PchipInterpolator``, ``simpson``, ``norm.pdf``,
 ``legendre``, ``quad``, ``savgol_filter``) from this image's numpy 2.2 / scipy
-1.15, so version-dependent behaviour (the Simpson even-N rule) is inherited.
+1.15.  One primitive is SciPy-version dependent in a way that matters (2e-4 relative on the
+BOSS anisotropic chi2): the reference calls ``simps`` with its default ``even=`` on 50 nodes
+(ccf_model.py:690), which is the 'avg' rule in SciPy < 1.11 and the corrected Simpson rule
+from 1.11 on.  Both are "the reference" under its pin, so the oracle carries both:
+``simpson_even='simpson'`` (default, SciPy's own ``simpson`` of this image) and ``'avg'``
+(:func:`simps_legacy`, a restatement of the documented SciPy < 1.11 rule, under which all five
+published notebook pairs reproduce at printed precision).
 
 Every function cites the reference lines (paths relative to the reference
 root) it restates.  The code is written independently of the reference
@@ -37,6 +43,55 @@ _trapz = getattr(np, "trapezoid", None) or np.trapz
 
 class OracleInputError(Exception):
     """Bad input (the reference raises ``victor.utils.InputError``, utils.py:5)."""
+
+
+def simps_legacy(y, x, axis=-1, even="avg"):
+    """``scipy.integrate.simps`` as documented for SciPy < 1.11 (the SciPy behind the reference's published numbers).
+
+    Composite Simpson for samples at (possibly unequal) abscissae ``x`` - same shape as ``y`` or 1-D along ``axis``.
+    For an even number of samples the composite rule covers N-2 of the N-1 intervals and ``even`` says what happens
+    to the remaining one: 'first' = Simpson on the first N-2 intervals + trapezoid on the last interval, 'last' =
+    trapezoid on the first interval + Simpson on the last N-2, 'avg' (the default the reference gets,
+    ccf_model.py:690) = the mean of the two.
+    """
+    y = np.moveaxis(np.asarray(y, dtype=float), axis, -1)
+    x = np.asarray(x, dtype=float)
+    x = np.moveaxis(x, axis, -1) if x.ndim == y.ndim else x
+    x = np.broadcast_to(x, y.shape)
+
+    def composite(yy, xx):          # odd number of samples: one parabola per pair of intervals
+        h = np.diff(xx, axis=-1)
+        ha, hb = h[..., 0::2], h[..., 1::2]
+        both = ha + hb
+        left = yy[..., 0:-2:2] * (2 - hb / ha)
+        mid = yy[..., 1:-1:2] * (both * both / (ha * hb))
+        right = yy[..., 2::2] * (2 - ha / hb)
+        return np.sum(both / 6.0 * (left + mid + right), axis=-1)
+
+    n = y.shape[-1]
+    if n % 2 == 1:
+        return composite(y, x)
+    if even not in ("avg", "first", "last"):
+        raise ValueError("even must be 'avg', 'first' or 'last'")
+    total, parts = 0.0, 0
+    if even in ("avg", "first"):
+        total = total + composite(y[..., :-1], x[..., :-1]) + 0.5 * (x[..., -1] - x[..., -2]) * (y[..., -1] + y[..., -2])
+        parts += 1
+    if even in ("avg", "last"):
+        total = total + composite(y[..., 1:], x[..., 1:]) + 0.5 * (x[..., 1] - x[..., 0]) * (y[..., 0] + y[..., 1])
+        parts += 1
+    return total / parts
+
+
+def velocity_integral(y, x, axis, rule):
+    """The ``simps(..., x=v_par, axis=2)`` of ccf_model.py:690 under the named SciPy convention."""
+    if rule in ("simpson", "scipy>=1.11"):
+        return simpson(y, x=x, axis=axis)
+    if rule in ("avg", "scipy<1.11"):
+        return simps_legacy(y, x, axis=axis, even="avg")
+    if rule in ("first", "last"):
+        return simps_legacy(y, x, axis=axis, even=rule)
+    raise OracleInputError(f"unknown simpson_even rule '{rule}'")
 
 
 def _ius(x, y):
@@ -115,6 +170,8 @@ class OracleModel:
             "mean_model": model["velocity_pdf"]["mean"].get("model", "linear"),
             "empirical_corr": model["velocity_pdf"]["mean"].get("empirical_corr", False),
             "velocity_independent_of_AP": model["velocity_pdf"].get("rescale_templates_independent_of_AP", True),
+            # which SciPy's even-N Simpson rule ccf_model.py:690 runs under (not a reference key)
+            "simpson_even": (model.get("numerics") or {}).get("simpson_even", "simpson"),
         }
 
     # ----- init tables ------------------------------------------------------ #
@@ -360,7 +417,7 @@ class OracleModel:
                 sv = sigma_v * sv_spl.ev(r, mu_r)
                 pdf = norm.pdf(v_par, loc=0, scale=sv)
                 jac = 1 / (1 + vr_i(r) * iaH_true / r + iaH_true * mu_r ** 2 * (dvr_i(r) - vr_i(r) / r))
-            return simpson((1 + xi_real(r, mu_r)) * jac * pdf, x=v_par, axis=2) - 1
+            return velocity_integral((1 + xi_real(r, mu_r)) * jac * pdf, v_par, 2, model["simpson_even"]) - 1
 
         if rsd in ("kaiser", "euclid_special"):
             M = params.get("M", 1.0)

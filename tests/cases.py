@@ -72,10 +72,24 @@ def synth_options(config):
     return model, data
 
 
-def golden_outputs():
-    g = np.load(os.path.join(GOLDEN, "ref_outputs.npz"))
+def golden_outputs(simpson_even="simpson"):
+    """Reference outputs: ``'simpson'`` = the reference with SciPy >= 1.11's ``simps`` (the default rule of this repo),
+    ``'avg'`` = with SciPy < 1.11's (oracle/make_golden.py --set avg); same inputs."""
+    name = {"simpson": "ref_outputs.npz", "avg": "ref_outputs_avg.npz"}[simpson_even]
+    g = np.load(os.path.join(GOLDEN, name))
     meta = json.loads(str(g["meta_json"]))
     return g, meta
+
+
+# (chi2, lnL) printed by the reference's notebook, notebooks/victor_usage_demo.ipynb:491-499, and the call options
+NOTEBOOK_POINT = {"fsigma8": 0.47, "beta": 0.37, "sigma_v": 380, "epsilon": 1.0}
+NOTEBOOK_PRINTED = {
+    "streaming": ((65.01, 284.76), {}),
+    "dispersion": ((65.03, 284.76), {"rsd_model": "dispersion"}),
+    "kaiser": ((103.90, 266.81), {"rsd_model": "kaiser"}),
+    "anisotropic": ((64.39, 285.06), {"assume_isotropic": False}),
+    "beta_likelihood": ((64.80, 285.30), {"beta_interpolation": "likelihood"}),
+}
 
 
 def halton(n, bases=(2, 3, 5, 7), skip=1):

@@ -77,6 +77,64 @@ def test_boss_known_answer_from_reference_notebook(boss_fit):
     assert cov.shape == (60, 60)
 
 
+def test_all_five_published_pairs_under_the_legacy_simpson_rule(boss_fit, oracle):
+    """notebooks/victor_usage_demo.ipynb:491-499 on the GPU.  The notebook was produced with SciPy < 1.11, whose ``simps``
+    (ccf_model.py:690, default even='avg') differs from SciPy >= 1.11's on the 50 velocity nodes; with
+    ``simpson_even='avg'`` all five printed (chi2, lnL) pairs reproduce at two decimals - given per call and at
+    construction (model['numerics']) - and match the reference run with that ``simps`` (ref_outputs_avg.npz)."""
+    import victor_amd
+    ga, meta = cases.golden_outputs("avg")
+    model, data = cases.boss_options("config")
+    model["numerics"] = {"simpson_even": "avg"}
+    fit_avg = victor_amd.CCFFit(model, data)
+    assert fit_avg.model["simpson_even"] == "avg" and boss_fit["config"].model["simpson_even"] == "simpson"
+    for name, ((chi_nb, lnl_nb), kw) in cases.NOTEBOOK_PRINTED.items():
+        for fit, extra in ((fit_avg, {}), (boss_fit["config"], {"simpson_even": "scipy<1.11"})):
+            lnl, chi2 = fit.log_likelihood(dict(cases.NOTEBOOK_POINT), **kw, **extra)
+            assert round(chi2, 2) == chi_nb and round(lnl, 2) == lnl_nb, name
+            assert abs(chi2 - ga[f"boss_nb_{name}"][0]) <= RTOL * chi2, name
+            assert abs(lnl - ga[f"boss_nb_{name}"][1]) <= RTOL * abs(lnl), name
+    assert fit_avg._get_engine().simpson_even == "avg"
+    # the default rule is untouched by the per-call override (separate device contexts)
+    lnl, chi2 = boss_fit["config"].log_likelihood(dict(cases.NOTEBOOK_POINT), assume_isotropic=False)
+    assert round(chi2, 2) == 64.40 and round(lnl, 2) == 285.05
+    # batch + goldens under 'avg': BOSS (cells / point-major kernels) ...
+    rows = np.concatenate([fit_avg._fit_rows(dict(p), fit_avg.model) for p in meta["boss_points"]])
+    lnl, chi2 = fit_avg.log_likelihood_batch(rows)
+    assert np.max(np.abs(chi2 / ga["boss_config_chi2"] - 1)) < RTOL and np.max(np.abs(lnl / ga["boss_config_lnl"] - 1)) < RTOL
+    th = fit_avg.theory_vector_batch(rows)
+    assert vec_close(th, ga["boss_config_theory"])
+    for kw, key in ((dict(rsd_model="dispersion"), "boss_dispersion_theory"), (dict(assume_isotropic=False), "boss_aniso_theory")):
+        t = fit_avg.theory_vector_batch(rows[:3], **kw)
+        assert vec_close(t, ga[key]), key
+    xi = fit_avg.theory_xi(*np.meshgrid(fit_avg.s, np.linspace(0, 1, 100)), dict(meta["boss_points"][0]))
+    assert np.max(np.abs(xi - ga["boss_config_xi_smu_p0"])) < RTOL * np.max(np.abs(ga["boss_config_xi_smu_p0"]))
+    # ... and the synthetic configs 2 / 3, every fast mapping (the lanes kernel needs a deep launch: tile the points)
+    for config in (2, 3):
+        model, data = cases.synth_options(config)
+        model["numerics"] = {"simpson_even": "avg"}
+        fit = victor_amd.CCFFit(model, data)
+        pts = list(meta["synth_points"])
+        if config == 3:
+            pts = [{"fsigma8": 0.47, "sigma_v": 380, "aperp": 1.02, "apar": 0.97}] + pts
+        pts = pts[:9]
+        rows = np.concatenate([fit._fit_rows(dict(p), fit.model) for p in pts])
+        lnl, chi2 = fit.log_likelihood_batch(rows)
+        assert np.max(np.abs(chi2 / ga[f"synth{config}_chi2"] - 1)) < RTOL
+        assert np.max(np.abs(lnl / ga[f"synth{config}_lnl"] - 1)) < RTOL
+        assert vec_close(fit.theory_vector_batch(rows), ga[f"synth{config}_theory"])
+        big = np.tile(rows, (4096, 1))
+        lnl_b, chi_b = fit.log_likelihood_batch(big)
+        assert fit._get_engine().last_kernel() == "vk_theory_lanes_kernel"
+        assert np.max(np.abs(chi_b.reshape(4096, 9) / ga[f"synth{config}_chi2"] - 1)) < RTOL
+        # live oracle on a fresh point under the same rule
+        ofit = oracle.OracleFit(model, data)
+        p = cases.point(cases.halton_params(40), 37)
+        o_lnl, o_chi = ofit.log_likelihood(dict(p))
+        g_lnl, g_chi = fit.log_likelihood(dict(p))
+        assert abs(g_chi - o_chi) <= RTOL * o_chi and abs(g_lnl - o_lnl) <= RTOL * abs(o_lnl)
+
+
 def test_boss_batch_equals_single(boss_fit, gold):
     g, meta = gold
     fit = boss_fit["config"]

@@ -176,6 +176,45 @@ def test_param_rows(boss_fit):
     from victor_amd import InputError
     with pytest.raises(InputError):
         boss_fit._fit_rows({"fsigma8": 0.4}, boss_fit.model)        # beta needed for beta-dependent data
+    # a dict of arrays and the same points passed one by one give identical rows (both branches of _param_rows)
+    hp = cases.halton_params(7, with_beta=True)
+    hp["epsilon"] = hp.pop("aperp") / hp.pop("apar")
+    hp["alpha"] = 1.01                                              # scalar next to arrays: broadcast
+    batch = boss_fit._fit_rows(hp, boss_fit.model)
+    single = np.concatenate([boss_fit._fit_rows(cases.point(hp, i), boss_fit.model) for i in range(7)])
+    assert batch.shape == single.shape == (7, N.VK_NPAR)
+    assert np.max(np.abs(batch - single)) < 4e-16 * np.max(np.abs(single[:, [N.P_APERP, N.P_APAR]]))   # array pow vs scalar pow: last ulp at most
+    assert np.allclose(batch, single, rtol=4e-16, atol=0)
+    cols = [N.P_FSIGMA8, N.P_SIGMAV, N.P_EPSILON, N.P_BETA, N.P_ASTAR, N.P_M, N.P_Q, N.P_BIAS, N.P_AV]
+    assert np.array_equal(batch[:, cols], single[:, cols])
+    assert boss_fit._fit_rows({"fsigma8": np.zeros(0), "beta": np.zeros(0)}, boss_fit.model).shape == (0, N.VK_NPAR)
+    with pytest.raises(InputError):
+        boss_fit._fit_rows({"fsigma8": np.zeros((2, 2)), "beta": 0.3}, boss_fit.model)
+    with pytest.raises(InputError):
+        boss_fit._fit_rows({"fsigma8": np.zeros(2), "beta": np.zeros(3)}, boss_fit.model)
+
+
+def test_simpson_even_option(boss_fit):
+    """The even-N Simpson convention of the velocity integral (ccf_model.py:690; SciPy < 1.11 vs >= 1.11) is an
+    explicit option: ``model['numerics']['simpson_even']`` at construction, ``simpson_even=`` per call."""
+    import victor_amd
+    from victor_amd import InputError
+    from victor_amd import tables as T
+    from victor_amd.engine import build_tables
+    assert boss_fit.model["simpson_even"] == "simpson"
+    scale = (12.0 / 49) / np.sqrt(2 * np.pi)
+    for rule, canon in (("avg", "avg"), ("scipy<1.11", "avg"), ("SciPy >= 1.11", "simpson"), (None, "simpson")):
+        t, keep = build_tables(boss_fit, boss_fit, simpson_even=rule)
+        w = np.ctypeslib.as_array(t.w_x, shape=(50,))
+        assert np.allclose(w, T.simpson_weights(50, canon) * scale, rtol=1e-15, atol=0)
+    model, data = cases.boss_options("config")
+    model["numerics"] = {"simpson_even": "scipy<1.11"}
+    assert victor_amd.CCFModel(model).model["simpson_even"] == "avg"
+    model["numerics"] = {"simpson_even": "middle"}
+    with pytest.raises(InputError):
+        victor_amd.CCFModel(model)
+    with pytest.raises(InputError):
+        build_tables(boss_fit, boss_fit, simpson_even="middle")
 
 
 def test_input_errors(tmp_path):

@@ -34,6 +34,35 @@ def test_reference_runs_its_own_config_and_files(ref):
     assert round(chi2, 2) == 65.01 and round(lnl, 2) == 284.76           # notebook line 491
 
 
+def test_reference_reproduces_all_five_published_pairs_with_the_legacy_simps(ref):
+    """notebooks/victor_usage_demo.ipynb:491-499: all five (chi2, lnL) pairs at printed precision when ``simps`` stands
+    for SciPy < 1.11 (even='avg'); with the SciPy >= 1.11 rule the anisotropic pair is 64.40 / 285.05.  Unmodified
+    reference, its own config and HDF5 files."""
+    import ref_shim
+    import victor_oracle as vo
+    info = ref_shim.boss_config()
+    fit = ref.CCFFit(info["model"], info["data"])
+    ofit = vo.OracleFit(*cases.boss_options("config"))
+    try:
+        ref_shim.set_simpson_rule("avg")
+        for name, ((chi_nb, lnl_nb), kw) in cases.NOTEBOOK_PRINTED.items():
+            lnl, chi2 = fit.log_likelihood(dict(cases.NOTEBOOK_POINT), **kw)
+            assert round(chi2, 2) == chi_nb and round(lnl, 2) == lnl_nb, name
+            o_lnl, o_chi2 = ofit.log_likelihood(dict(cases.NOTEBOOK_POINT), simpson_even="avg", **kw)
+            assert abs(o_chi2 - chi2) <= 1e-12 * chi2 and abs(o_lnl - lnl) <= 1e-12 * abs(lnl), name
+        hp = cases.halton_params(64, with_beta=True)
+        for i in (7, 41):
+            p = cases.point(hp, i)
+            for kw in ({}, {"assume_isotropic": False}, {"rsd_model": "dispersion"}):
+                ta = fit.theory_multipole_vector(fit.s, dict(p), fit.poles_s, **kw)
+                tb = ofit.theory_multipole_vector(ofit.s, dict(p), ofit.poles_s, simpson_even="avg", **kw)
+                assert np.max(np.abs(ta - tb)) < 1e-13
+    finally:
+        ref_shim.set_simpson_rule("simpson")
+    lnl, chi2 = fit.log_likelihood(dict(cases.NOTEBOOK_POINT), assume_isotropic=False)
+    assert round(chi2, 2) == 64.40 and round(lnl, 2) == 285.05
+
+
 def test_oracle_equals_reference_on_fresh_points(ref):
     import victor_oracle as vo
     for opts in (cases.boss_options("config"), cases.boss_options("cobaya"), cases.synth_options(2),

@@ -73,6 +73,31 @@ def test_simpson_weights_match_scipy(n):
     assert abs(T.simpson_weights(n) @ y * h - simpson(y, x=x)) < 1e-10 * h
 
 
+@pytest.mark.parametrize("n", [4, 8, 50, 51])
+def test_simpson_weights_legacy_even_rules(n):
+    """SciPy < 1.11 ``simps(even=...)``: 'first' / 'last' integrate quadratics exactly on n-2 intervals and use a
+    trapezoid on the remaining end interval; 'avg' is their mean (the rule the reference's notebook numbers come from)."""
+    x = np.linspace(-6, 6, n)
+    h = x[1] - x[0]
+    first, last, avg = (T.simpson_weights(n, r) for r in ("first", "last", "avg"))
+    assert np.array_equal(T.simpson_weights(n, "scipy<1.11"), avg)
+    assert np.array_equal(T.simpson_weights(n, "scipy>=1.11"), T.simpson_weights(n))
+    if n % 2:
+        assert np.array_equal(first, T.simpson_weights(n)) and np.array_equal(avg, first)
+        return
+    assert np.allclose(avg, 0.5 * (first + last), rtol=0, atol=1e-16) and np.allclose(last, first[::-1])
+    for w in (first, last, avg):
+        assert abs(w.sum() - (n - 1)) < 1e-13                      # constants exactly
+        assert abs(w @ x * h) < 1e-12                              # straight lines exactly
+    q = 3 * x ** 2 - x + 1
+    exact = lambda a, b: (b ** 3 - b ** 2 / 2 + b) - (a ** 3 - a ** 2 / 2 + a)   # noqa: E731
+    trap = lambda i: 0.5 * h * (q[i] + q[i + 1])                                  # noqa: E731
+    assert abs(first @ q * h - (exact(x[0], x[-2]) + trap(n - 2))) < 1e-10
+    assert abs(last @ q * h - (trap(0) + exact(x[1], x[-1]))) < 1e-10
+    with pytest.raises(ValueError):
+        T.simpson_weights(n, "middle")
+
+
 @pytest.mark.parametrize("poles", [[0, 2], [0, 2, 4], [0], [1, 3], [0, 1, 2]])
 def test_projection_weights_match_reference_construction(poles):
     """Same construction as ccf_model.py:822-825 with FITPACK bicubic + utils.py:45-56."""

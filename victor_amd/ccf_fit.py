@@ -180,7 +180,7 @@ class CCFFit(CCFModel):
         model = self._merged(kwargs)
         self._check_supported(model)
         fit_options = self._merged_fit(kwargs)
-        eng = self._get_engine(self._engine_key(model))
+        eng = self._get_engine(self._engine_key(model), model["simpson_even"])
         opts = eng.make_opts(model, fit_options)
         rows = self._fit_rows(params, model)
         if fit_options["beta_interpolation"] == "likelihood" and not self.fixed_data:
@@ -235,5 +235,5 @@ class CCFFit(CCFModel):
         """Theory vectors (n, N) on the data's own s grid and multipoles."""
         model = self._merged(kwargs)
         self._check_supported(model)
-        eng = self._get_engine(self._engine_key(model))
+        eng = self._get_engine(self._engine_key(model), model["simpson_even"])
         return eng.theory_vector_batch(eng.make_opts(model), self._fit_rows(params, model))

@@ -36,11 +36,12 @@ def _pp(knots, coef, lead=0):
     return pp, (knots, coef)
 
 
-def build_tables(model, fit=None, matter_model=None):
+def build_tables(model, fit=None, matter_model=None, simpson_even=None):
     """Compile a ``CCFModel`` (and optionally the data side of a ``CCFFit``) into vk_tables.
 
     Only plain attributes are read (see :mod:`victor_amd.velocity_tables`), so ``model`` / ``fit`` may equally be
-    objects of the reference package.  Returns ``(tables, keepalive)``.
+    objects of the reference package.  ``simpson_even`` names the even-N Simpson convention of the velocity integral
+    (:func:`victor_amd.tables.simpson_weights`; ``None`` = the default, SciPy >= 1.11).  Returns ``(tables, keepalive)``.
     """
     keep = []
 
@@ -60,7 +61,11 @@ def build_tables(model, fit=None, matter_model=None):
     w = arr(T.projection_weights(mu, poles))
     n_x = 50                                   # ccf_model.py:570 (np.linspace default num)
     x = arr(np.linspace(-6, 6, n_x))
-    w_x = arr(T.simpson_weights(n_x) * (12.0 / (n_x - 1)) / np.sqrt(2 * np.pi))
+    try:
+        w_unit = T.simpson_weights(n_x, simpson_even)          # ccf_model.py:690 (simps, default even=)
+    except ValueError as exc:
+        raise InputError(str(exc))
+    w_x = arr(w_unit * (12.0 / (n_x - 1)) / np.sqrt(2 * np.pi))
     t.n_s, t.n_mu, t.n_x, t.n_ell = len(s), len(mu), n_x, len(poles)
     t.s, t.mu, t.w_ell, t.x, t.w_x = map(N.as_dp, (s, mu, w, x, w_x))
 
@@ -297,11 +302,12 @@ def dump_tables(t, path):
 
 
 class Engine:
-    def __init__(self, model, fit=None, device=0, matter_model=None):
+    def __init__(self, model, fit=None, device=0, matter_model=None, simpson_even=None):
         self._lib = N.load()
         if self._lib.vk_device_count() <= 0:
             raise N.NativeError("no HIP device visible; victor_amd has no CPU fallback")
-        tables, keep = build_tables(model, fit, matter_model)
+        tables, keep = build_tables(model, fit, matter_model, simpson_even)
+        self.simpson_even = T.simpson_even_rule(simpson_even)
         err = C.create_string_buffer(512)
         self._ctx = self._lib.vk_create(C.byref(tables), int(device), err, len(err))
         del keep

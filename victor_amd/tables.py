@@ -184,26 +184,65 @@ def legendre_values(ell, mu):
     raise ValueError("multipoles above ell=4 are not supported")
 
 
-def simpson_weights(n):
-    """Unit-spacing weights w with ``simpson(y, dx=1) == w @ y`` (SciPy >= 1.11 rule).
+#: accepted spellings of the even-N Simpson convention -> canonical name (see :func:`simpson_weights`)
+SIMPSON_EVEN = {"simpson": "simpson", "scipy>=1.11": "simpson", "avg": "avg", "scipy<1.11": "avg",
+                "first": "first", "last": "last"}
+SIMPSON_EVEN_DEFAULT = "simpson"
 
-    Odd n: composite Simpson.  Even n: composite Simpson on the first n-1 points plus the
-    three-point correction for the last interval (5/12, 2/3, -1/12), which is what
-    ``scipy.integrate.simpson`` does on the 50 velocity nodes of ``ccf_model.py:570,690``.
+
+def simpson_even_rule(name=None):
+    """Canonical name of an even-N Simpson convention (``None`` -> the default); ``ValueError`` if unknown."""
+    key = SIMPSON_EVEN_DEFAULT if name is None else str(name).strip().lower().replace(" ", "")
+    if key not in SIMPSON_EVEN:
+        raise ValueError(f"unknown simpson_even rule '{name}': choose from {sorted(SIMPSON_EVEN)}")
+    return SIMPSON_EVEN[key]
+
+
+def _composite_simpson(m):
+    """Unit-spacing composite Simpson weights on an odd number ``m`` of points: (1, 4, 2, ..., 4, 1) / 3."""
+    w = np.full(m, 2.0 / 3.0)
+    w[1::2] = 4.0 / 3.0
+    w[0] = w[-1] = 1.0 / 3.0
+    return w
+
+
+def simpson_weights(n, even=None):
+    """Unit-spacing weights w with ``simps(y, dx=1) == w @ y`` on the velocity nodes of ``ccf_model.py:570,690``.
+
+    Odd n: composite Simpson.  Even n (the reference has n = 50): the reference calls ``scipy.integrate.simps`` with its
+    default ``even=`` argument and pins only ``scipy>=1.6.3`` (``setup.py:31``), so the rule depends on the SciPy it runs on:
+
+    ``'simpson'`` (alias ``'scipy>=1.11'``; the default here)
+        composite Simpson on the first n-1 points plus the three-point correction of the last interval
+        (5/12, 2/3, -1/12) - SciPy >= 1.11;
+    ``'avg'`` (alias ``'scipy<1.11'``)
+        the mean of ``'first'`` and ``'last'`` - SciPy < 1.11, the rule behind the numbers printed in the reference's
+        notebook (``notebooks/victor_usage_demo.ipynb:491-499``);
+    ``'first'`` / ``'last'``
+        composite Simpson on the first / last n-1 points and a trapezoid on the remaining end interval (the other two
+        values of ``even=`` in SciPy < 1.11; not reachable from the reference, which never passes ``even=``).
     """
     if n < 3:
         raise ValueError("need at least 3 points")
+    rule = simpson_even_rule(even)
+    if n % 2 == 1:
+        return _composite_simpson(n)
     w = np.zeros(n)
-    last = n if n % 2 == 1 else n - 1
-    w[0:last:2] += 2.0 / 3.0
-    w[1:last:2] += 4.0 / 3.0
-    w[0] -= 1.0 / 3.0
-    w[last - 1] -= 1.0 / 3.0
-    if n % 2 == 0:
+    if rule == "simpson":
+        w[: n - 1] = _composite_simpson(n - 1)
         w[n - 1] += 5.0 / 12.0
         w[n - 2] += 2.0 / 3.0
         w[n - 3] -= 1.0 / 12.0
-    return w
+        return w
+    first = np.zeros(n)
+    first[: n - 1] = _composite_simpson(n - 1)
+    first[n - 2:] += 0.5
+    if rule == "first":
+        return first
+    last = first[::-1].copy()
+    if rule == "last":
+        return last
+    return 0.5 * (first + last)
 
 
 def projection_weights(mu_nodes, poles, npts=200):
