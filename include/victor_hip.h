@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 12
+#define VK_ABI_VERSION 13
 
 /* error codes */
 #define VK_OK 0
@@ -215,6 +215,9 @@ typedef struct vk_ctx vk_ctx;
 
 int vk_abi_version(void);
 int vk_device_count(void);
+/* The VICTOR_HIP_* tuning / A-B environment knobs are read when a context is created, not per launch; call this after
+ * changing one in a running process and every context re-reads them at its next entry point. */
+void vk_knobs_refresh(void);
 
 /* Copies every table to `device`.  On failure returns NULL and writes a message to err. */
 vk_ctx* vk_create(const vk_tables* tables, int device, char* err, size_t errlen);
@@ -263,6 +266,12 @@ int vk_comm_init(vk_ctx* ctx, const char* id, int rank, int nranks);
 /* all ranks contribute count doubles at d_send, every rank receives nranks*count at d_recv */
 int vk_comm_allgather_async(vk_ctx* ctx, const double* d_send, double* d_recv, int64_t count);
 int vk_comm_destroy(vk_ctx* ctx);
+/* Writes a JSON object naming the HIP runtime this process mapped (path, runtime/driver version, the HIP version the
+ * library was built with) and the RCCL that vk_comm_* uses (path, ncclGetVersion).  RCCL is looked up next to the mapped
+ * HIP runtime first, so both come from one ROCm install (PyTorch's bundled pair when torch was imported before this
+ * library, /opt/rocm's otherwise); VICTOR_HIP_RCCL_LIB overrides.  Returns VK_E_RCCL (buffer still filled) if no RCCL
+ * could be loaded. */
+int vk_comm_info(char* buf, size_t len);
 
 #ifdef __cplusplus
 }

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from tests import cases
+from victor_amd import _native
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-9
@@ -104,13 +105,13 @@ def test_realspace_ccf_from_data_with_md_covariance(gold):
     for aniso in (False, True):
         for mapping in ("point", "cells", "generic"):
             env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
-            os.environ[env] = "1" if mapping == "generic" else mapping
+            _native.set_knob(env, "1" if mapping == "generic" else mapping)
             try:
                 res[mapping] = fit.theory_vector_batch(rows, assume_isotropic=not aniso)
                 assert fit._get_engine().last_kernel().endswith(
                     {"point": "fast_kernel", "cells": "cells_kernel", "generic": "vk_theory_kernel"}[mapping])
             finally:
-                del os.environ[env]
+                _native.set_knob(env, None)
             want = g["opt_fromdata_aniso_theory"] if aniso else g["opt_fromdata_theory"][:3]
             assert close(res[mapping][:3], want), (aniso, mapping)
         for mapping in ("cells", "generic"):
@@ -237,11 +238,11 @@ def test_special_amplitudes_in_every_fast_mapping(tmp_path, gold):
     batch = dict({k: np.concatenate([[p[k] for p in pts], v]) for k, v in hp.items()}, beta=0.4, bias=1.7)
     res = {}
     for mapping in ("point", "cells", "lanes"):
-        os.environ["VICTOR_HIP_MAPPING"] = mapping
+        _native.set_knob("VICTOR_HIP_MAPPING", mapping)
         try:
             th = fit.theory_vector_batch(batch, matter_model="linear_bias")
         finally:
-            del os.environ["VICTOR_HIP_MAPPING"]
+            _native.set_knob("VICTOR_HIP_MAPPING", None)
         assert close(th[:3], g["opt_synth_lb_stream"]), mapping
         res[mapping] = th
     assert close(res["cells"], res["point"]) and close(res["lanes"], res["point"])
@@ -253,13 +254,13 @@ def test_special_amplitudes_in_every_fast_mapping(tmp_path, gold):
     ora = vo.OracleFit(model, data)
     res = {}
     for mapping in ("point", "cells", "lanes"):
-        os.environ["VICTOR_HIP_MAPPING"] = mapping
+        _native.set_knob("VICTOR_HIP_MAPPING", mapping)
         try:
             res[mapping] = fit.log_likelihood_batch(hp)
             assert fit._get_engine("velocity_template").last_kernel().endswith(
                 {"point": "fast_kernel", "cells": "cells_kernel", "lanes": "lanes_kernel"}[mapping])
         finally:
-            del os.environ["VICTOR_HIP_MAPPING"]
+            _native.set_knob("VICTOR_HIP_MAPPING", None)
     for i in (0, 4000, 8202):
         want = ora.log_likelihood(cases.point(hp, i))
         for mapping in res:
@@ -292,13 +293,13 @@ def test_offset_commensurate_grids_in_every_fast_mapping(tmp_path):
     hp = cases.halton_params(4096 + 5)
     res = {}
     for mapping in ("point", "cells", "lanes"):
-        os.environ["VICTOR_HIP_MAPPING"] = mapping
+        _native.set_knob("VICTOR_HIP_MAPPING", mapping)
         try:
             res[mapping] = fit.log_likelihood_batch(hp)
             assert fit._get_engine().last_kernel().endswith(
                 {"point": "fast_kernel", "cells": "cells_kernel", "lanes": "lanes_kernel"}[mapping])
         finally:
-            del os.environ["VICTOR_HIP_MAPPING"]
+            _native.set_knob("VICTOR_HIP_MAPPING", None)
     for i in (0, 1, 2047, 4100):
         want = ora.log_likelihood(cases.point(hp, i))
         for mapping in res:
@@ -334,14 +335,14 @@ def test_non_uniform_grids_in_every_fast_mapping(tmp_path):
     res = {}
     for mapping in ("point", "cells", "lanes", "generic"):
         env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
-        os.environ[env] = "1" if mapping == "generic" else mapping
+        _native.set_knob(env, "1" if mapping == "generic" else mapping)
         try:
             res[mapping] = fit.log_likelihood_batch(hp)
             assert fit._get_engine().last_kernel().endswith(
                 {"point": "fast_kernel", "cells": "cells_kernel", "lanes": "lanes_kernel",
                  "generic": "vk_theory_kernel"}[mapping])
         finally:
-            del os.environ[env]
+            _native.set_knob(env, None)
     for i in (0, 1, 2047, 4100):
         want = ora.log_likelihood(cases.point(hp, i))
         for mapping in res:
@@ -376,11 +377,11 @@ def test_fine_grids_need_more_than_64k_of_lds(tmp_path):
     res = {}
     for mapping in ("point", "cells", "lanes", "generic"):
         env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
-        os.environ[env] = "1" if mapping == "generic" else mapping
+        _native.set_knob(env, "1" if mapping == "generic" else mapping)
         try:
             res[mapping] = fit.log_likelihood_batch(hp)
         finally:
-            del os.environ[env]
+            _native.set_knob(env, None)
     for i in (0, 1026):
         want = ora.log_likelihood(cases.point(hp, i))
         for mapping in res:
@@ -403,13 +404,13 @@ def test_boss_linear_bias_runs_on_the_fast_kernels(gold):
     res = {}
     for mapping in ("point", "cells", "generic"):
         env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
-        os.environ[env] = "1" if mapping == "generic" else mapping
+        _native.set_knob(env, "1" if mapping == "generic" else mapping)
         try:
             res[mapping] = fit.theory_vector_batch(batch, matter_model="linear_bias")
             assert fit._get_engine("linear_bias").last_kernel().endswith(
                 {"point": "fast_kernel", "cells": "cells_kernel", "generic": "vk_theory_kernel"}[mapping])
         finally:
-            del os.environ[env]
+            _native.set_knob(env, None)
         assert close(res[mapping][:3], g["opt_boss_lb_stream"]), mapping
     for mapping in ("cells", "generic"):
         assert np.max(np.abs(res[mapping] - res["point"])) < 1e-10 * np.max(np.abs(res["point"])), mapping
@@ -435,13 +436,13 @@ def test_empirical_corr_runs_on_the_fast_kernels(gold):
         res = {}
         for mapping in ("point", "cells", "generic"):
             env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
-            os.environ[env] = "1" if mapping == "generic" else mapping
+            _native.set_knob(env, "1" if mapping == "generic" else mapping)
             try:
                 res[mapping] = fit.theory_vector_batch(batch, empirical_corr=True)
                 assert fit._get_engine().last_kernel().endswith(
                     {"point": "fast_kernel", "cells": "cells_kernel", "generic": "vk_theory_kernel"}[mapping])
             finally:
-                del os.environ[env]
+                _native.set_knob(env, None)
             assert close(res[mapping][:3], g[key]), (name, mapping)
         for mapping in ("cells", "generic"):
             assert np.max(np.abs(res[mapping] - res["point"])) < 1e-10 * np.max(np.abs(res["point"])), (name, mapping)
@@ -471,13 +472,13 @@ def test_dispersion_model_runs_on_the_fast_kernels(gold):
         res = {}
         for mapping in ("point", "cells", "generic"):
             env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
-            os.environ[env] = "1" if mapping == "generic" else mapping
+            _native.set_knob(env, "1" if mapping == "generic" else mapping)
             try:
                 res[mapping] = fit.theory_vector_batch(rows, **kw)
                 assert fit._get_engine().last_kernel().endswith(
                     {"point": "fast_kernel", "cells": "cells_kernel", "generic": "vk_theory_kernel"}[mapping])
             finally:
-                del os.environ[env]
+                _native.set_knob(env, None)
             if key:
                 assert close(res[mapping][:npts], g[key]), (name, mapping)
         for mapping in ("cells", "generic"):

@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 from tests import cases
+from victor_amd import _native
 
 pytestmark = pytest.mark.gpu
 
@@ -359,12 +360,12 @@ def test_generic_kernel_matches_fast_kernel(synth_fit, boss_fit):
     hb = cases.halton_params(64, with_beta=True)
     a3 = synth_fit[3].log_likelihood_batch(hp)
     ab = boss_fit["config"].log_likelihood_batch(hb)
-    os.environ["VICTOR_HIP_FORCE_GENERIC"] = "1"
+    _native.set_knob("VICTOR_HIP_FORCE_GENERIC", "1")
     try:
         b3 = synth_fit[3].log_likelihood_batch(hp)
         bb = boss_fit["config"].log_likelihood_batch(hb)
     finally:
-        del os.environ["VICTOR_HIP_FORCE_GENERIC"]
+        _native.set_knob("VICTOR_HIP_FORCE_GENERIC", None)
     assert np.max(np.abs(a3[1] / b3[1] - 1)) < 1e-11 and np.max(np.abs(ab[1] / bb[1] - 1)) < 1e-11
     assert not np.array_equal(a3[1], b3[1])          # different arithmetic, so not bit-identical: both paths really ran
 
@@ -377,23 +378,23 @@ def test_lanes_over_batch_mapping_matches_point_major(synth_fit, gold):
     for config in (2, 3):
         fit = synth_fit[config]
         for mapping in ("point", "lanes", "cells"):
-            os.environ["VICTOR_HIP_MAPPING"] = mapping
+            _native.set_knob("VICTOR_HIP_MAPPING", mapping)
             try:
                 out[mapping] = fit.log_likelihood_batch(hp)
                 assert fit._get_engine().last_kernel() == {"point": "vk_theory_fast_kernel", "lanes": "vk_theory_lanes_kernel",
                                                            "cells": "vk_theory_cells_kernel"}[mapping]
             finally:
-                del os.environ["VICTOR_HIP_MAPPING"]
+                _native.set_knob("VICTOR_HIP_MAPPING", None)
             # golden points through each mapping as well
             pts = list(meta["synth_points"])
             if config == 3:
                 pts = [{"fsigma8": 0.47, "sigma_v": 380, "aperp": 1.02, "apar": 0.97}] + pts
             batch = {k: np.array([p[k] for p in pts]) for k in pts[0]}
-            os.environ["VICTOR_HIP_MAPPING"] = mapping
+            _native.set_knob("VICTOR_HIP_MAPPING", mapping)
             try:
                 lnl, chi2 = fit.log_likelihood_batch(batch)
             finally:
-                del os.environ["VICTOR_HIP_MAPPING"]
+                _native.set_knob("VICTOR_HIP_MAPPING", None)
             assert np.max(np.abs(chi2 / g[f"synth{config}_chi2"] - 1)) < RTOL, (config, mapping)
         assert np.max(np.abs(out["point"][1] / out["lanes"][1] - 1)) < 1e-11
         assert np.max(np.abs(out["point"][1] / out["cells"][1] - 1)) < 1e-11
@@ -410,11 +411,11 @@ def test_empty_and_ragged_batches(synth_fit):
     full = fit.log_likelihood_batch(hp)
     for n in (1, 2, 63, 64, 65, 127, 129):
         for mapping in ("point", "lanes", "cells"):
-            os.environ["VICTOR_HIP_MAPPING"] = mapping
+            _native.set_knob("VICTOR_HIP_MAPPING", mapping)
             try:
                 lnl, chi2 = fit.log_likelihood_batch({k: v[:n] for k, v in hp.items()})
             finally:
-                del os.environ["VICTOR_HIP_MAPPING"]
+                _native.set_knob("VICTOR_HIP_MAPPING", None)
             assert lnl.shape == (n,)
             assert np.max(np.abs(chi2 / full[1][:n] - 1)) < 1e-11, (n, mapping)
 
@@ -429,11 +430,11 @@ def test_bad_rows_do_not_contaminate_neighbours(synth_fit, boss_fit):
     bad["sigma_v"][77] = np.inf
     bad["aperp"][8999] = np.nan
     for mapping in ("point", "lanes", "cells"):
-        os.environ["VICTOR_HIP_MAPPING"] = mapping
+        _native.set_knob("VICTOR_HIP_MAPPING", mapping)
         try:
             lnl, chi2 = fit.log_likelihood_batch(bad)
         finally:
-            del os.environ["VICTOR_HIP_MAPPING"]
+            _native.set_knob("VICTOR_HIP_MAPPING", None)
         for i in (5, 77, 8999):
             assert lnl[i] == -np.inf and chi2[i] == np.inf, (mapping, i)
         keep = np.ones(9000, bool)
@@ -472,12 +473,12 @@ def test_cells_mapping_on_beta_dependent_tables(boss_fit, gold):
         rows = np.concatenate([fit._fit_rows(dict(p), fit.model) for p in meta["boss_points"]])
         res = {}
         for mapping in ("point", "cells"):
-            os.environ["VICTOR_HIP_MAPPING"] = mapping
+            _native.set_knob("VICTOR_HIP_MAPPING", mapping)
             try:
                 res[mapping] = fit.log_likelihood_batch(rows)
                 th = fit.theory_vector_batch(rows, assume_isotropic=False)
             finally:
-                del os.environ["VICTOR_HIP_MAPPING"]
+                _native.set_knob("VICTOR_HIP_MAPPING", None)
             assert np.max(np.abs(res[mapping][1] / g[f"boss_{variant}_chi2"] - 1)) < RTOL, (variant, mapping)
             if variant == "config":
                 assert vec_close(th[:3], g["boss_aniso_theory"]), mapping
@@ -486,11 +487,11 @@ def test_cells_mapping_on_beta_dependent_tables(boss_fit, gold):
     fit = boss_fit["config"]
     a = fit.log_likelihood_batch(hb)                      # default choice at this size: cells
     assert fit._get_engine().last_kernel() == "vk_theory_cells_kernel"
-    os.environ["VICTOR_HIP_MAPPING"] = "point"
+    _native.set_knob("VICTOR_HIP_MAPPING", "point")
     try:
         b = fit.log_likelihood_batch(hb)
     finally:
-        del os.environ["VICTOR_HIP_MAPPING"]
+        _native.set_knob("VICTOR_HIP_MAPPING", None)
     assert np.max(np.abs(a[0] / b[0] - 1)) < 1e-11
 
 
@@ -520,18 +521,18 @@ def test_tiled_likelihood_kernel_matches_per_point_kernel(synth_fit):
         fit = synth_fit[config]
         hp = cases.halton_params(1003)                       # not a multiple of the tile
         a = fit.log_likelihood_batch(hp)
-        os.environ["VICTOR_HIP_LIKE_UNTILED"] = "1"
+        _native.set_knob("VICTOR_HIP_LIKE_UNTILED", "1")
         try:
             b = fit.log_likelihood_batch(hp)
         finally:
-            del os.environ["VICTOR_HIP_LIKE_UNTILED"]
+            _native.set_knob("VICTOR_HIP_LIKE_UNTILED", None)
         assert np.max(np.abs(a[1] / b[1] - 1)) < 1e-12 and np.max(np.abs(a[0] / b[0] - 1)) < 1e-12
         for form in ("sellentin", "hartlap", "percival"):
             kw = {"likelihood": {"form": form, "nmocks": 800, "nparams": 4}}
             a = fit.log_likelihood_batch({k: v[:200] for k, v in hp.items()}, **kw)
-            os.environ["VICTOR_HIP_LIKE_UNTILED"] = "1"
+            _native.set_knob("VICTOR_HIP_LIKE_UNTILED", "1")
             try:
                 b = fit.log_likelihood_batch({k: v[:200] for k, v in hp.items()}, **kw)
             finally:
-                del os.environ["VICTOR_HIP_LIKE_UNTILED"]
+                _native.set_knob("VICTOR_HIP_LIKE_UNTILED", None)
             assert np.max(np.abs(a[0] / b[0] - 1)) < 1e-12, form

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from tests import cases
+from victor_amd import _native
 
 pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
@@ -205,13 +206,13 @@ def test_small_batches_replay_a_captured_graph():
     fit = victor_amd.CCFFit(*cases.boss_options("config"))
     hp = cases.halton_params(64, with_beta=True)
     rows = fit._fit_rows(hp, fit.model)
-    os.environ["VICTOR_HIP_NO_GRAPH"] = "1"
+    _native.set_knob("VICTOR_HIP_NO_GRAPH", "1")
     try:
         want = {n: fit.log_likelihood_batch(rows[:n]) for n in (1, 8, 64)}
         want_shift = fit.log_likelihood_batch(rows[8:16])
         want_kaiser = fit.log_likelihood_batch(rows[:8], rsd_model="kaiser")
     finally:
-        del os.environ["VICTOR_HIP_NO_GRAPH"]
+        _native.set_knob("VICTOR_HIP_NO_GRAPH", None)
     for rep in range(4):                       # call 1 eager, call 2 captures, calls 3-4 replay
         for n in (1, 8, 64):
             got = fit.log_likelihood_batch(rows[:n])

@@ -2,6 +2,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import victor_amd
 from tests import cases
+from victor_amd import _native
 for name, opts, beta in (("boss", cases.boss_options("config"), True), ("synth3", cases.synth_options(3), False), ("synth2", cases.synth_options(2), False)):
     fit = victor_amd.CCFFit(*opts)
     eng = fit._get_engine()
@@ -12,7 +13,7 @@ for name, opts, beta in (("boss", cases.boss_options("config"), True), ("synth3"
     eng.upload(bufs[0], rows)
     for mapping in ("point", "cells", "lanes", "point", "cells", "lanes"):
         if mapping == "lanes" and beta: continue
-        os.environ["VICTOR_HIP_MAPPING"] = mapping
+        _native.set_knob("VICTOR_HIP_MAPPING", mapping)
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < 0.25:
             eng.eval_device_async(o, bufs[0], batch, bufs[1], bufs[2], bufs[3]); eng.sync()

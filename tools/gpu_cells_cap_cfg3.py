@@ -3,17 +3,18 @@ import os, sys, time
 sys.path.insert(0, '/root/repo')
 import victor_amd
 from tests import cases
+from victor_amd import _native
 fit = victor_amd.CCFFit(*cases.synth_options(3))
 eng = fit._get_engine()
 o = eng.make_opts(fit.model, fit.fit_options)
-os.environ["VICTOR_HIP_MAPPING"] = "cells"
+_native.set_knob("VICTOR_HIP_MAPPING", "cells")
 for batch in (2000, 10000, 20000, 30000):
     rows = fit._fit_rows(cases.halton_params(batch), fit.model)
     bufs = [eng.alloc(rows.size), eng.alloc(batch), eng.alloc(batch), eng.alloc(batch * eng.n_data)]
     eng.upload(bufs[0], rows)
     line = f"config3 cells batch {batch}:"
     for cap in ("4", "8", "16", "32", "64", "256"):
-        os.environ["VICTOR_HIP_POINT_CAP"] = cap
+        _native.set_knob("VICTOR_HIP_POINT_CAP", cap)
         for _ in range(3):
             eng.eval_device_async(o, bufs[0], batch, bufs[1], bufs[2], bufs[3]); eng.sync()
         t0 = time.perf_counter()

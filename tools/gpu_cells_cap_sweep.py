@@ -3,6 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import victor_amd
 from tests import cases
+from victor_amd import _native
 fit = victor_amd.CCFFit(*cases.boss_options("config"))
 eng = fit._get_engine()
 o = eng.make_opts(fit.model, fit.fit_options)
@@ -11,7 +12,7 @@ for batch in (16384, 65536, 100000, 262144):
     bufs = [eng.alloc(rows.size), eng.alloc(batch), eng.alloc(batch), eng.alloc(batch * eng.n_data)]
     eng.upload(bufs[0], rows)
     for cap in ("16", "32", "64", "128", "256", "100000"):
-        os.environ["VICTOR_HIP_POINT_CAP"] = cap
+        _native.set_knob("VICTOR_HIP_POINT_CAP", cap)
         for _ in range(2):
             eng.eval_device_async(o, bufs[0], batch, bufs[1], bufs[2], bufs[3]); eng.sync()
         t0 = time.perf_counter()

@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import victor_amd
 from tests import cases
+from victor_amd import _native
 
 def params(n, beta, seed, fmax=2.0):
     rng = np.random.default_rng(seed)
@@ -21,15 +22,15 @@ def run(fit, label, beta, fmax=2.0, **kw):
     if kw.get("empirical_corr"):
         p["Av"] = np.random.default_rng(8).uniform(-1.5, 1.5, n)
     rows = fit._fit_rows(p, model)
-    os.environ["VICTOR_HIP_FORCE_GENERIC"] = "1"
+    _native.set_knob("VICTOR_HIP_FORCE_GENERIC", "1")
     ref = fit.theory_vector_batch(rows, **kw)
-    del os.environ["VICTOR_HIP_FORCE_GENERIC"]
+    _native.set_knob("VICTOR_HIP_FORCE_GENERIC", None)
     scale = np.max(np.abs(ref), axis=1, keepdims=True)
     for mapping in ("lanes", "cells", "point"):
-        os.environ["VICTOR_HIP_MAPPING"] = mapping
+        _native.set_knob("VICTOR_HIP_MAPPING", mapping)
         got = fit.theory_vector_batch(rows, **kw)
         kern = fit._get_engine(fit._engine_key(model)).last_kernel()
-        del os.environ["VICTOR_HIP_MAPPING"]
+        _native.set_knob("VICTOR_HIP_MAPPING", None)
         ok = np.all(np.isfinite(got), axis=1) & np.all(np.isfinite(ref), axis=1)
         dev = np.max(np.abs(got[ok] - ref[ok]) / scale[ok])
         only_one = int(np.sum(np.all(np.isfinite(got), axis=1) != np.all(np.isfinite(ref), axis=1)))

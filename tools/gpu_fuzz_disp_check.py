@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import numpy as np
 import victor_amd, victor_oracle as vo
 from tests import cases
+from victor_amd import _native
 from tools.gpu_fuzz import params  # noqa
 
 fit = victor_amd.CCFFit(*cases.synth_options(3))
@@ -13,9 +14,9 @@ kw = {"rsd_model": "dispersion"}
 model = fit._merged(kw)
 p = params(131072, False, 7, 1.0)
 rows = fit._fit_rows(p, model)
-os.environ["VICTOR_HIP_FORCE_GENERIC"] = "1"
+_native.set_knob("VICTOR_HIP_FORCE_GENERIC", "1")
 ref = fit.theory_vector_batch(rows, **kw)
-del os.environ["VICTOR_HIP_FORCE_GENERIC"]
+_native.set_knob("VICTOR_HIP_FORCE_GENERIC", None)
 got = fit.theory_vector_batch(rows, **kw)
 scale = np.max(np.abs(ref), axis=1, keepdims=True)
 dev = np.max(np.abs(got - ref) / scale, axis=1)

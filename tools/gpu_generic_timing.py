@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import victor_amd
 from tests import cases
+from victor_amd import _native
 
 def run(fit, label, batch=32768):
     eng = fit._get_engine()
@@ -24,9 +25,9 @@ def run(fit, label, batch=32768):
 
 fit = victor_amd.CCFFit(*cases.synth_options(3))
 a = run(fit, "config 3, uniform grids, default")
-os.environ["VICTOR_HIP_FORCE_GENERIC"] = "1"
+_native.set_knob("VICTOR_HIP_FORCE_GENERIC", "1")
 b = run(fit, "config 3, uniform grids, generic kernel")
-del os.environ["VICTOR_HIP_FORCE_GENERIC"]
+_native.set_knob("VICTOR_HIP_FORCE_GENERIC", None)
 print("max rel diff", np.max(np.abs(a / b - 1)))
 # jitter the r grid (bin centres as mean separations): nearly uniform -> generic kernel with estimate + correction
 import tempfile
@@ -43,7 +44,7 @@ dd["dir"] = ""
 m["dir"] = tmp; m["input_model_data_file"] = "jitter.npy"
 fitj = victor_amd.CCFFit(m, dd)
 a = run(fitj, "config 3, jittered r grid: union-grid fast path")
-os.environ["VICTOR_HIP_FORCE_GENERIC"] = "1"
+_native.set_knob("VICTOR_HIP_FORCE_GENERIC", "1")
 b = run(fitj, "config 3, jittered r grid: generic kernel")
-del os.environ["VICTOR_HIP_FORCE_GENERIC"]
+_native.set_knob("VICTOR_HIP_FORCE_GENERIC", None)
 print("max rel diff", np.max(np.abs(a / b - 1)))

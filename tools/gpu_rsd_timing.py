@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import victor_amd
 from tests import cases
+from victor_amd import _native
 
 def run(fit, label, batch, beta, **kw):
     model = fit._merged(kw)
@@ -32,9 +33,9 @@ m["realspace_ccf"]["from_data"] = True
 d["covariance_matrix"]["data_file"] = "boss/cov_md_iso.npy"
 fd = victor_amd.CCFFit(m, d)
 run(fd, "boss from_data (measured model + MD covariance)", 16384, True)
-os.environ["VICTOR_HIP_FORCE_GENERIC"] = "1"
+_native.set_knob("VICTOR_HIP_FORCE_GENERIC", "1")
 run(fd, "boss from_data, generic kernel", 16384, True)
-del os.environ["VICTOR_HIP_FORCE_GENERIC"]
+_native.set_knob("VICTOR_HIP_FORCE_GENERIC", None)
 for name, opts, beta in (("config3", cases.synth_options(3), False), ("boss", cases.boss_options("config"), True)):
     fit = victor_amd.CCFFit(*opts)
     for kw in ({}, {"rsd_model": "dispersion"}, {"rsd_model": "kaiser"}, {"rsd_model": "euclid_special"},

@@ -3,6 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import victor_amd
 from tests import cases
+from victor_amd import _native
 for name, opts, beta in (("config3", cases.synth_options(3), False), ("boss", cases.boss_options("config"), True)):
     fit = victor_amd.CCFFit(*opts)
     eng = fit._get_engine()
@@ -13,7 +14,7 @@ for name, opts, beta in (("config3", cases.synth_options(3), False), ("boss", ca
         eng.upload(bufs[0], rows)
         line = f"{name} batch {batch:5d}:"
         for mapping in ("point", "cells"):
-            os.environ["VICTOR_HIP_MAPPING"] = mapping
+            _native.set_knob("VICTOR_HIP_MAPPING", mapping)
             for _ in range(20):
                 eng.eval_device_async(o, bufs[0], batch, bufs[1], bufs[2], bufs[3])
             eng.sync()
@@ -23,5 +24,5 @@ for name, opts, beta in (("config3", cases.synth_options(3), False), ("boss", ca
             eng.sync()
             dt = (time.perf_counter() - t0) / 200
             line += f"  {mapping} {dt*1e3:7.3f} ms {batch/dt:9.0f} evals/s"
-        del os.environ["VICTOR_HIP_MAPPING"]
+        _native.set_knob("VICTOR_HIP_MAPPING", None)
         print(line, flush=True)

@@ -3,7 +3,8 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import victor_amd
 from tests import cases
-os.environ["VICTOR_HIP_MAPPING"] = "point"
+from victor_amd import _native
+_native.set_knob("VICTOR_HIP_MAPPING", "point")
 for name, opts, beta in (("config3", cases.synth_options(3), False), ("boss", cases.boss_options("config"), True)):
     fit = victor_amd.CCFFit(*opts)
     eng = fit._get_engine()
@@ -17,7 +18,7 @@ for name, opts, beta in (("config3", cases.synth_options(3), False), ("boss", ca
             if split == "default":
                 os.environ.pop("VICTOR_HIP_SPLIT", None)
             else:
-                os.environ["VICTOR_HIP_SPLIT"] = split
+                _native.set_knob("VICTOR_HIP_SPLIT", split)
             for _ in range(30):
                 eng.eval_device_async(o, bufs[0], batch, bufs[1], bufs[2], bufs[3])
             eng.sync()

@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-VK_ABI_VERSION = 12
+VK_ABI_VERSION = 13
 VK_NPAR = 12
 (P_FSIGMA8, P_SIGMAV, P_APERP, P_APAR, P_EPSILON, P_BETA, P_ASTAR, P_M, P_Q, P_BIAS, P_AV, P_SPARE) = range(12)
 MATTER = {"template": 0, "linear_bias": 1, "velocity_template": 2}
@@ -69,6 +69,7 @@ _optp = C.POINTER(vk_eval_opts)
 SYMBOLS = {
     "vk_abi_version": (C.c_int, []),
     "vk_device_count": (C.c_int, []),
+    "vk_knobs_refresh": (None, []),
     "vk_create": (_vp, [C.POINTER(vk_tables), C.c_int, C.c_char_p, C.c_size_t]),
     "vk_destroy": (None, [_vp]),
     "vk_last_error": (C.c_char_p, [_vp]),
@@ -89,6 +90,7 @@ SYMBOLS = {
     "vk_comm_init": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int]),
     "vk_comm_allgather_async": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
     "vk_comm_destroy": (C.c_int, [_vp]),
+    "vk_comm_info": (C.c_int, [C.c_char_p, C.c_size_t]),
 }
 
 _lib = None
@@ -116,6 +118,27 @@ def load():
         raise NativeError("libvictor_hip.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib
+
+
+def set_knob(name, value):
+    """Set (``value`` a string) or clear (``None``) a ``VICTOR_HIP_*`` tuning / A-B knob in this process and make every
+    context re-read the knobs at its next call (they are cached per context, not read per launch)."""
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = str(value)
+    if _lib is not None:
+        _lib.vk_knobs_refresh()
+
+
+def comm_info():
+    """Which HIP runtime / RCCL the process is using (dict; see vk_comm_info in include/victor_hip.h)."""
+    import json
+    buf = C.create_string_buffer(2048)
+    rc = load().vk_comm_info(buf, len(buf))
+    info = json.loads(buf.value.decode() or "{}")
+    info["rccl_loaded"] = rc == 0
+    return info
 
 
 def as_dp(a):

@@ -28,6 +28,7 @@
 #include <limits>
 #include <new>
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <string>
 #include <vector>
@@ -45,8 +46,23 @@ using namespace vk;
 // ==================================================================================================
 // host side
 // ==================================================================================================
+// Tuning / A-B knobs from the environment (VICTOR_HIP_*), read once per context - not once per launch - and again
+// after vk_knobs_refresh() (tests and tools/ change them between calls).
+struct Knobs {
+  int split_s = 0, split_t = 0;        // VICTOR_HIP_SPLIT "spi,team"
+  bool force_generic = false;          // VICTOR_HIP_FORCE_GENERIC
+  long long point_cap = 0;             // VICTOR_HIP_POINT_CAP   (workgroups per CU; 0 = default)
+  long long lanes_cap = 0;             // VICTOR_HIP_LANES_CAP   (0 = uncapped)
+  int mapping = 0;                     // VICTOR_HIP_MAPPING: 0 auto, 1 point, 2 cells, 3 lanes, -1 unknown name
+  bool like_untiled = false;           // VICTOR_HIP_LIKE_UNTILED
+  bool no_graph = false;               // VICTOR_HIP_NO_GRAPH
+  bool no_fuse = false;                // VICTOR_HIP_NO_FUSE: keep chi2 in its own launch (A/B of the fused small-batch path)
+};
+
 struct vk_ctx {
   int device = -1;
+  Knobs knobs;
+  unsigned knob_gen = 0;
   hipStream_t stream = nullptr;
   std::string err;
   int n_cu = 256;
@@ -100,6 +116,32 @@ constexpr int64_t kGraphMaxN = 4096;
 namespace {
 
 thread_local std::string g_create_err;
+std::atomic<unsigned> g_knob_gen{1};
+
+void load_knobs(vk_ctx* ctx) {
+  Knobs k;
+  if (const char* env = getenv("VICTOR_HIP_SPLIT")) {
+    int sp = 0, t = 0;
+    if (sscanf(env, "%d,%d", &sp, &t) == 2 && sp >= 1 && (t == 1 || t == 2 || t == 4) && (t == 1 || sp == 1)) {
+      k.split_s = sp;
+      k.split_t = t;
+    }
+  }
+  k.force_generic = getenv("VICTOR_HIP_FORCE_GENERIC") != nullptr;
+  if (const char* env = getenv("VICTOR_HIP_POINT_CAP")) k.point_cap = atoll(env);
+  if (const char* env = getenv("VICTOR_HIP_LANES_CAP")) k.lanes_cap = atoll(env);
+  if (const char* env = getenv("VICTOR_HIP_MAPPING"))
+    k.mapping = !strcmp(env, "point") ? 1 : !strcmp(env, "cells") ? 2 : !strcmp(env, "lanes") ? 3 : -1;
+  k.like_untiled = getenv("VICTOR_HIP_LIKE_UNTILED") != nullptr;
+  k.no_graph = getenv("VICTOR_HIP_NO_GRAPH") != nullptr;
+  k.no_fuse = getenv("VICTOR_HIP_NO_FUSE") != nullptr;
+  ctx->knobs = k;
+  ctx->knob_gen = g_knob_gen.load(std::memory_order_relaxed);
+}
+
+inline void sync_knobs(vk_ctx* ctx) {
+  if (ctx->knob_gen != g_knob_gen.load(std::memory_order_relaxed)) load_knobs(ctx);
+}
 
 int fail(vk_ctx* ctx, int code, const char* fmt, ...) {
   char buf[512];
@@ -169,13 +211,10 @@ int launch_on_stream(vk_ctx* ctx, Kern kern, int grid, size_t lds, const Args& a
 
 void choose_split(const vk_ctx* ctx, long long n, int n_s, int* spi, int* team) {
   // A/B knob "spi,team": s bins per workgroup visit and waves cooperating on one s bin (1, 2 or 4)
-  if (const char* env = getenv("VICTOR_HIP_SPLIT")) {
-    int s = 0, t = 0;
-    if (sscanf(env, "%d,%d", &s, &t) == 2 && s >= 1 && (t == 1 || t == 2 || t == 4) && (t == 1 || s == 1)) {
-      *spi = s < n_s ? s : n_s;
-      *team = t;
-      return;
-    }
+  if (ctx->knobs.split_s > 0) {
+    *spi = ctx->knobs.split_s < n_s ? ctx->knobs.split_s : n_s;
+    *team = ctx->knobs.split_t;
+    return;
   }
   // Measured (tools/gpu_split_sweep.py, resident, config 3 / BOSS): four s bins per workgroup (one per wave) is the
   // fastest split from ~50 points on (64 points: 76 / 51 us against 102 / 77 us for two waves per s bin), four
@@ -341,7 +380,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   // fast kernels: the streaming model, and the dispersion model on fixed velocity tables (cells / point-major only)
   const bool disp = a.rsd == VK_RSD_DISPERSION && a.uni_da && (!a.empirical || a.uni_ge) && !a.vr_beta_dep;
   const bool fast = (a.rsd == VK_RSD_STREAMING || disp) && ctx->fast_ok && (!a.empirical || a.uni_v2) &&
-                    a.n_mu <= 1024 && a.n_x <= 2048 && !getenv("VICTOR_HIP_FORCE_GENERIC");
+                    a.n_mu <= 1024 && a.n_x <= 2048 && !ctx->knobs.force_generic;
   size_t lds;
   if (fast) {
     lds = (size_t)make_fast_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, disp).total * sizeof(double);
@@ -354,12 +393,11 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   const long long items = a.n * groups;
   // over-subscribe: 27.9 / 25.9 / 24.8 / 24.0 ms at 4 / 8 / 16 / 64 workgroups per CU on BOSS x 65536 (4-5 are resident);
   // 64 -> 256 gains another 0.5-2 % at 65536-262144 points (tools/gpu_cells_cap_sweep.py), staging per workgroup is cheap
-  const char* pcap_env = getenv("VICTOR_HIP_POINT_CAP");            // tuning knob: workgroups per CU in the launch
-  const long long kDefaultCap = 256;
-  const long long cap = (pcap_env ? atoll(pcap_env) : kDefaultCap) * ctx->n_cu;
+  const long long kDefaultCap = 256;                                // VICTOR_HIP_POINT_CAP: workgroups per CU in the launch
+  const long long cap = (ctx->knobs.point_cap > 0 ? ctx->knobs.point_cap : kDefaultCap) * ctx->n_cu;
   const int grid = (int)(items < cap ? items : cap);
   // lanes-over-batch variant: batch-constant tables and enough points to fill the chip with n_s * n/64 waves
-  const char* mapping = getenv("VICTOR_HIP_MAPPING");
+  const int mapping = ctx->knobs.mapping;                           // VICTOR_HIP_MAPPING: 0 = choose by batch size
   const bool lanes_ok = fast && a.n_beta_r == 0 && !a.empirical && !a.from_data && !disp;   // per-point tables need a workgroup per point
   // One wave per (s bin, 64-point chunk), one workgroup per four of them; 5 workgroups are resident per CU.  Every item
   // runs for ~0.6 ms, so the launch ends with a ragged tail about one residency round long, while the cells kernel
@@ -371,7 +409,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   const size_t lds_l = (size_t)make_lanes_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.uni_lut_n).total * sizeof(double);
   const long long wg_per_cu = std::max<long long>(1, std::min<long long>(5, (160 * 1024) / (lds_l ? lds_l : 1)));
   const bool lanes = lanes_ok && lds_l <= 160 * 1024 &&
-                     (mapping ? !strcmp(mapping, "lanes") : blocks_l >= 4 * wg_per_cu * ctx->n_cu);
+                     (mapping ? mapping == 3 : blocks_l >= 4 * wg_per_cu * ctx->n_cu);
   if (lanes) {
     ctx->last_kernel = "vk_theory_lanes_kernel";
     const long long blocks = blocks_l;
@@ -379,8 +417,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
     // workgroups retire measured 38.1 / 36.0 / 34.6 / 33.8 ms at 4 / 8 / 16 / 64 workgroups per CU on the bench workload
     // (5 are resident), and a cap that makes workgroups loop leaves a ragged tail of 0.6 ms items - 131072 points ran at
     // 1.61 M evals/s under a 64-per-CU cap against 2.35 M without (tools/gpu_lanes_big.py)
-    const char* cap_env = getenv("VICTOR_HIP_LANES_CAP");          // A/B knob: workgroups per CU in the launch
-    const long long capl = cap_env ? atoll(cap_env) * ctx->n_cu : (long long)INT32_MAX;
+    const long long capl = ctx->knobs.lanes_cap > 0 ? ctx->knobs.lanes_cap * ctx->n_cu : (long long)INT32_MAX;   // A/B knob
     const int grid_l = (int)(blocks < capl ? blocks : capl);
     switch (nlr) {
       case 1: return launch_lanes_nl<1>(ctx, a, grid_l, lds_l);
@@ -393,13 +430,13 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   const bool cells_ok = fast && a.n_mu >= 64 && a.n_mu <= 4096 && a.n_x <= 2048;
   // crossover against the point-major kernel measured between 512 and 768 points (config 3) and near 500 (BOSS),
   // tools/gpu_small_batch_ab.py: one workgroup per point needs ~2.5 workgroups per CU to keep the SIMDs fed
-  const bool cells = cells_ok && (mapping ? !strcmp(mapping, "cells") : a.n >= (5LL * ctx->n_cu) / 2);
+  const bool cells = cells_ok && (mapping ? mapping == 2 : a.n >= (5LL * ctx->n_cu) / 2);
   if (cells) {
     ctx->last_kernel = "vk_theory_cells_kernel";
     const size_t lds_c =
         (size_t)make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, disp).total * sizeof(double);
     if (lds_c > 160 * 1024) return fail(ctx, VK_E_ARG, "tables need %zu bytes of LDS (> 160 KiB)", lds_c);
-    const long long capc = (pcap_env ? atoll(pcap_env) : kDefaultCap) * ctx->n_cu;
+    const long long capc = cap;
     const int grid_c = (int)(a.n < capc ? a.n : capc);
     switch (nlr) {
       case 1: return launch_cells_nl<1>(ctx, a, grid_c, lds_c);
@@ -450,7 +487,7 @@ int launch_like(vk_ctx* ctx, const vk_eval_opts* o, const double* d_params, cons
   // fixed covariance: 8 points per wave share the loads of the precision matrix (LDS: 4 waves x 8 x N doubles)
   constexpr int kTile = 8;
   const size_t lds_tiled = (size_t)kWaves * kTile * ctx->N * sizeof(double);
-  if (ctx->n_beta_c == 0 && n >= 4 * kTile * kWaves && lds_tiled <= 64 * 1024 && !getenv("VICTOR_HIP_LIKE_UNTILED")) {
+  if (ctx->n_beta_c == 0 && n >= 4 * kTile * kWaves && lds_tiled <= 64 * 1024 && !ctx->knobs.like_untiled) {
     const long long tiles = (n + kTile - 1) / kTile;
     const long long blocks = (tiles + kWaves - 1) / kWaves;
     const int grid = (int)(blocks < cap ? blocks : cap);
@@ -483,14 +520,48 @@ typedef int (*fn_allgather)(const void*, void*, size_t, int, void*, hipStream_t)
 typedef int (*fn_destroy)(void*);
 typedef const char* (*fn_errstr)(int);
 
-void* open_rccl() {
+// Path of the shared object that defines `addr` (empty if unknown)
+std::string object_of(const void* addr) {
+  Dl_info info;
+  if (addr && dladdr(addr, &info) && info.dli_fname) return info.dli_fname;
+  return std::string();
+}
+
+std::string dir_of(const std::string& path) {
+  const size_t cut = path.find_last_of('/');
+  return cut == std::string::npos ? std::string() : path.substr(0, cut);
+}
+
+// The HIP runtime this library is actually running on.  libamdhip64 has one soname (libamdhip64.so.7) in every ROCm 7
+// install, so whichever copy the process mapped first serves everybody: /opt/rocm's when this library is loaded into a
+// fresh interpreter, PyTorch's bundled copy when torch was imported before (torch.distributed launchers).
+std::string hip_runtime_path() { return object_of(reinterpret_cast<const void*>(&hipGetDeviceCount)); }
+
+// RCCL must come from the same ROCm install as that runtime (its kernels and its HIP calls are built against it), so
+// look next to the mapped libamdhip64 first and only then fall back to the loader's search order.
+void* open_rccl(std::string* how = nullptr) {
   static void* lib = nullptr;
-  if (lib) return lib;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* nm : names) {
-    lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-    if (lib) break;
+  static std::string chosen;
+  if (!lib) {
+    std::vector<std::string> names;
+    if (const char* env = getenv("VICTOR_HIP_RCCL_LIB")) names.push_back(env);           // explicit override
+    const std::string dir = dir_of(hip_runtime_path());
+    if (!dir.empty()) {
+      names.push_back(dir + "/librccl.so.1");
+      names.push_back(dir + "/librccl.so");
+    }
+    names.push_back("librccl.so.1");
+    names.push_back("librccl.so");
+    names.push_back("/opt/rocm/lib/librccl.so.1");
+    for (const std::string& nm : names) {
+      lib = dlopen(nm.c_str(), RTLD_NOW | RTLD_GLOBAL);
+      if (lib) {
+        chosen = nm;
+        break;
+      }
+    }
   }
+  if (how) *how = chosen;
   return lib;
 }
 
@@ -499,6 +570,8 @@ void* open_rccl() {
 extern "C" {
 
 int vk_abi_version(void) { return VK_ABI_VERSION; }
+
+void vk_knobs_refresh(void) { g_knob_gen.fetch_add(1, std::memory_order_relaxed); }
 
 int vk_device_count(void) {
   int n = 0;
@@ -592,6 +665,7 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
   for (auto& evt : ctx->ev)
     if ((rc = hipEventCreate(&evt)) != hipSuccess) return hip_bail(rc, "hipEventCreate");
 
+  load_knobs(ctx);
   ctx->n_s = t->n_s; ctx->n_mu = t->n_mu; ctx->n_x = t->n_x; ctx->n_ell = t->n_ell; ctx->n_ell_r = t->n_ell_r;
   ctx->n_beta_r = t->n_beta_r; ctx->N = N; ctx->iaH = t->iaH; ctx->template_sigma8 = t->template_sigma8;
   ctx->n_beta_d = t->data ? t->n_beta_d : 0;
@@ -812,6 +886,7 @@ int vk_timing_read(vk_ctx* ctx, double* theory_ms, double* like_ms, int64_t* lau
 int vk_eval_batch_device_async(vk_ctx* ctx, const vk_eval_opts* opts, const double* d_params, int64_t n,
                                double* d_lnl, double* d_chi2, double* d_theory_ws) {
   if (!ctx) return VK_E_ARG;
+  sync_knobs(ctx);
   int rc = check_opts(ctx, opts);
   if (rc) return rc;
   if (n < 0 || (n > 0 && (!d_params || !d_theory_ws))) return fail(ctx, VK_E_ARG, "bad device buffers");
@@ -851,8 +926,8 @@ int vk_eval_batch_device_async(vk_ctx* ctx, const vk_eval_opts* opts, const doub
 // Returns 1 when it handled the call, 0 when the caller should take the eager path, < 0 on error.
 static int eval_batch_graph(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, int64_t n, double* lnl,
                             double* chi2, double* d_par, double* d_th, double* d_lnl, double* d_chi) {
-  if (ctx->graphs_off || n > kGraphMaxN || ctx->timing || !(lnl || chi2) || getenv("VICTOR_HIP_NO_GRAPH") ||
-      getenv("VICTOR_HIP_MAPPING") || getenv("VICTOR_HIP_FORCE_GENERIC"))
+  if (ctx->graphs_off || n > kGraphMaxN || ctx->timing || !(lnl || chi2) || ctx->knobs.no_graph || ctx->knobs.mapping ||
+      ctx->knobs.force_generic || ctx->knobs.no_fuse)
     return 0;
   std::string key(reinterpret_cast<const char*>(opts), sizeof *opts);
   key.append(reinterpret_cast<const char*>(&n), sizeof n);
@@ -907,6 +982,7 @@ static int eval_batch_graph(vk_ctx* ctx, const vk_eval_opts* opts, const double*
 int vk_eval_batch(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, int64_t n, double* lnl, double* chi2,
                   double* theory) {
   if (!ctx) return VK_E_ARG;
+  sync_knobs(ctx);
   int rc = check_opts(ctx, opts);
   if (rc) return rc;
   if (n < 0 || (n > 0 && !params)) return fail(ctx, VK_E_ARG, "params is NULL");
@@ -942,6 +1018,7 @@ static int general_grid(vk_ctx* ctx, const vk_eval_opts* opts, const double* par
                         int32_t n_s, const double* mu, int32_t n_mu, const double* w_ell, int32_t n_ell, double* out,
                         bool project) {
   if (!ctx) return VK_E_ARG;
+  sync_knobs(ctx);
   int rc = check_opts(ctx, opts);
   if (rc) return rc;
   if (n < 0 || n_s < 1 || n_mu < 2 || !params || !s || !mu || !out) return fail(ctx, VK_E_ARG, "bad arguments");
@@ -1025,7 +1102,7 @@ int vk_comm_unique_id(char* id_out) {
 int vk_comm_init(vk_ctx* ctx, const char* id, int rank, int nranks) {
   if (!ctx || !id) return VK_E_ARG;
   void* lib = open_rccl();
-  if (!lib) return fail(ctx, VK_E_RCCL, "cannot load librccl: %s", dlerror());
+  if (!lib) return fail(ctx, VK_E_RCCL, "cannot load librccl (looked next to %s first): %s", hip_runtime_path().c_str(), dlerror());
   auto init = (fn_init_rank)dlsym(lib, "ncclCommInitRank");
   if (!init) return fail(ctx, VK_E_RCCL, "ncclCommInitRank not found");
   VK_HIP(ctx, hipSetDevice(ctx->device));
@@ -1049,6 +1126,29 @@ int vk_comm_allgather_async(vk_ctx* ctx, const double* d_send, double* d_recv, i
   int rc = ag(d_send, d_recv, (size_t)count, kNcclDouble, ctx->comm, ctx->stream);
   if (rc != 0) return fail(ctx, VK_E_RCCL, "ncclAllGather failed (%d)", rc);
   return VK_OK;
+}
+
+// Which HIP runtime and which RCCL this process ended up with (a multi-GPU record must be diagnosable from its JSON line)
+int vk_comm_info(char* buf, size_t len) {
+  if (!buf || len == 0) return VK_E_ARG;
+  int hip_rt = 0, hip_drv = 0, rccl_ver = 0;
+  (void)hipRuntimeGetVersion(&hip_rt);
+  (void)hipDriverGetVersion(&hip_drv);
+  std::string asked, rccl_path;
+  void* lib = open_rccl(&asked);
+  if (lib) {
+    typedef int (*fn_ver)(int*);
+    if (auto ver = (fn_ver)dlsym(lib, "ncclGetVersion")) (void)ver(&rccl_ver);
+    rccl_path = object_of(dlsym(lib, "ncclAllGather"));
+  }
+  const std::string hip_path = hip_runtime_path();
+  const bool same_dir = lib && !rccl_path.empty() && dir_of(rccl_path) == dir_of(hip_path);
+  snprintf(buf, len,
+           "{\"hip_runtime\": \"%s\", \"hip_runtime_version\": %d, \"hip_driver_version\": %d, \"built_with_hip\": \"%d.%d.%d\", "
+           "\"rccl\": \"%s\", \"rccl_opened_as\": \"%s\", \"rccl_version\": %d, \"rccl_next_to_hip_runtime\": %s}",
+           hip_path.c_str(), hip_rt, hip_drv, HIP_VERSION_MAJOR, HIP_VERSION_MINOR, HIP_VERSION_PATCH,
+           lib ? rccl_path.c_str() : "", asked.c_str(), rccl_ver, same_dir ? "true" : "false");
+  return lib ? VK_OK : VK_E_RCCL;
 }
 
 int vk_comm_destroy(vk_ctx* ctx) {
