@@ -22,6 +22,8 @@ def test_device_math_within_two_ulp(tmp_path):
                                src, "-o", exe], stderr=subprocess.DEVNULL)
     out = subprocess.check_output([exe]).decode().strip().splitlines()[-1]
     res = json.loads(out)
+    # the DPP wave reduction: identical in every lane, 6 rounding steps deep
+    assert res["wave_sum_uniform"] == 1 and res["wave_sum_rel"] <= 8 * 2.3e-16
     # 4M samples each: sqrt/rsqrt over x in [2e-9, 5e8], recip likewise, exp over [-760, 0]
     assert res["sqrt_ulp"] <= 2.0 and res["rsqrt_ulp"] <= 2.0 and res["recip_ulp"] <= 1.0
     assert res["exp_ulp_normal"] <= 2.5

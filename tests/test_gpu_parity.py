@@ -515,24 +515,102 @@ def test_odd_multipoles_use_the_full_mu_range(synth_fit, oracle):
     assert xi.shape == (3, 2) and np.max(np.abs(xi - xo)) < RTOL * np.max(np.abs(xo))
 
 
+class knobs:
+    """Set VICTOR_HIP_* knobs for the duration of a ``with`` block."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            _native.set_knob("VICTOR_HIP_" + k, v)
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            _native.set_knob("VICTOR_HIP_" + k, None)
+        return False
+
+
 def test_tiled_likelihood_kernel_matches_per_point_kernel(synth_fit):
-    """Fixed covariance: the 8-points-per-wave chi-square kernel vs the one-point-per-wave kernel."""
+    """Fixed covariance: the 8-points-per-wave chi-square kernel vs the one-point-per-wave kernel vs one workgroup per
+    point (all three as separate launches: NO_FUSE)."""
     for config in (2, 3):
         fit = synth_fit[config]
         hp = cases.halton_params(1003)                       # not a multiple of the tile
-        a = fit.log_likelihood_batch(hp)
-        _native.set_knob("VICTOR_HIP_LIKE_UNTILED", "1")
-        try:
-            b = fit.log_likelihood_batch(hp)
-        finally:
-            _native.set_knob("VICTOR_HIP_LIKE_UNTILED", None)
-        assert np.max(np.abs(a[1] / b[1] - 1)) < 1e-12 and np.max(np.abs(a[0] / b[0] - 1)) < 1e-12
+        with knobs(NO_FUSE="1", LIKE_WIDE="0"):
+            a = fit.log_likelihood_batch(hp)
+            with knobs(LIKE_UNTILED="1"):
+                b = fit.log_likelihood_batch(hp)
+        with knobs(NO_FUSE="1", LIKE_WIDE="1"):
+            c = fit.log_likelihood_batch(hp)
+        for other in (b, c):
+            assert np.max(np.abs(a[1] / other[1] - 1)) < 1e-12 and np.max(np.abs(a[0] / other[0] - 1)) < 1e-12
         for form in ("sellentin", "hartlap", "percival"):
             kw = {"likelihood": {"form": form, "nmocks": 800, "nparams": 4}}
-            a = fit.log_likelihood_batch({k: v[:200] for k, v in hp.items()}, **kw)
-            _native.set_knob("VICTOR_HIP_LIKE_UNTILED", "1")
-            try:
-                b = fit.log_likelihood_batch({k: v[:200] for k, v in hp.items()}, **kw)
-            finally:
-                _native.set_knob("VICTOR_HIP_LIKE_UNTILED", None)
-            assert np.max(np.abs(a[0] / b[0] - 1)) < 1e-12, form
+            sub = {k: v[:200] for k, v in hp.items()}
+            with knobs(NO_FUSE="1", LIKE_WIDE="0"):
+                a = fit.log_likelihood_batch(sub, **kw)
+                with knobs(LIKE_UNTILED="1"):
+                    b = fit.log_likelihood_batch(sub, **kw)
+            c = fit.log_likelihood_batch(sub, **kw)                     # default: fused into the theory kernel
+            assert np.max(np.abs(a[0] / b[0] - 1)) < 1e-12 and np.max(np.abs(a[0] / c[0] - 1)) < 1e-12, form
+
+
+@pytest.mark.parametrize("which", ["boss", "config3", "config2"])
+def test_fused_and_split_launches_agree_with_separate_kernels(boss_fit, synth_fit, which):
+    """Small and medium batches take the chi-square inside the theory kernel (the workgroup that completes a point's
+    theory vector - found through a per-point completion counter when several workgroups share the point - computes it),
+    and a handful of points is split over more workgroups (s bins x parts of the (mu, v) plane).  Every split and both
+    kernels must agree with the plain two-launch path, launch after launch (the counters reset themselves)."""
+    fit = boss_fit["config"] if which == "boss" else synth_fit[int(which[-1])]
+    hp = cases.halton_params(700, with_beta=(which == "boss"))
+    rows = fit._fit_rows(hp, fit.model)
+    eng = fit._get_engine()
+    with knobs(NO_FUSE="1", NO_GRAPH="1"):
+        ref_l, ref_c = fit.log_likelihood_batch(rows)
+        ref_t = fit.theory_vector_batch(rows)
+
+    def check(n, tag, want_kernel=None):
+        for rep in range(2):                                               # second launch: counters must be back at zero
+            lnl, chi = fit.log_likelihood_batch(rows[:n])
+            assert np.max(np.abs(chi / ref_c[:n] - 1)) < 1e-12, (tag, n, rep)
+            assert np.max(np.abs(lnl / ref_l[:n] - 1)) < 1e-12, (tag, n, rep)
+        if want_kernel:
+            assert eng.last_kernel() == want_kernel, (tag, eng.last_kernel())
+        lnl, chi, th = eng.eval_batch(eng.make_opts(fit.model, fit.fit_options), rows[:n], want_theory=True)
+        assert np.max(np.abs(th - ref_t[:n])) <= 1e-12 * np.max(np.abs(ref_t)), tag   # the workspace holds the theory vector too
+        assert np.max(np.abs(chi / ref_c[:n] - 1)) < 1e-12, tag
+
+    with knobs(NO_GRAPH="1"):
+        for n in (1, 2, 3, 17, 64, 200):                                   # default choices
+            check(n, "default", "vk_theory_fast_kernel")
+        check(700, "default", "vk_theory_cells_kernel")
+        for split in ("1,4,1", "1,4,2", "1,4,4", "1,4,8", "1,2,3", "1,1,2", "4,1,1", "4,1,2", "40,1,1", "40,1,4"):
+            with knobs(SPLIT=split, MAPPING="point"):
+                for n in (1, 5, 64):
+                    check(n, "split " + split, "vk_theory_fast_kernel")
+        for parts in ("1", "2", "3", "4", "7"):
+            with knobs(CELLS_PARTS=parts, MAPPING="cells"):
+                for n in (1, 6, 130, 700):
+                    check(n, "cells parts " + parts, "vk_theory_cells_kernel")
+        with knobs(POINT_CAP="1"):                                          # 256 workgroups loop over many items each
+            check(700, "capped cells")
+            with knobs(MAPPING="point"):
+                check(300, "capped point-major")
+    # the hipGraph replay of host-buffer batches contains the fused launch
+    for rep in range(4):
+        lnl, chi = fit.log_likelihood_batch(rows[:9])
+        assert np.max(np.abs(chi / ref_c[:9] - 1)) < 1e-12
+
+
+def test_fused_path_keeps_the_failure_guards(boss_fit):
+    """NaN parameters and the singular-covariance guard return (-inf, inf) from the fused tail as from the K2 kernels."""
+    fit = boss_fit["config"]
+    rows = fit._fit_rows(cases.halton_params(6, with_beta=True), fit.model)
+    rows[2, _native.P_SIGMAV] = np.nan
+    rows[4, _native.P_FSIGMA8] = np.inf
+    for kn in ({}, {"NO_FUSE": "1"}, {"MAPPING": "cells"}, {"SPLIT": "1,4,4", "MAPPING": "point"}):
+        with knobs(NO_GRAPH="1", **kn):
+            lnl, chi = fit.log_likelihood_batch(rows)
+        assert np.all(np.isneginf(lnl[[2, 4]])) and np.all(np.isposinf(chi[[2, 4]])), kn
+        assert np.all(np.isfinite(lnl[[0, 1, 3, 5]])) and np.all(chi[[0, 1, 3, 5]] > 0), kn

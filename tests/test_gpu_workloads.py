@@ -245,7 +245,9 @@ def test_one_process_driving_several_contexts():
         got = multi.log_likelihood_batch(hp)
         want = single.log_likelihood_batch(hp)
         # shards of a different size may take another kernel mapping: agreement to rounding, not bit for bit
-        assert np.max(np.abs(got[1] / want[1] - 1)) < 1e-12 and np.max(np.abs(got[0] / want[0] - 1)) < 1e-12, n
+        # (lnL = -1/2 log det - n/2 log(1 + chi2/(n-1)) crosses zero: compare it on the scale of its two terms)
+        assert np.max(np.abs(got[1] / want[1] - 1)) < 1e-12, n
+        assert np.max(np.abs(got[0] - want[0]) / (np.abs(want[0]) + want[1] + 300.0)) < 1e-12, n
     th = multi.theory_vector_batch(cases.halton_params(77, with_beta=True), rsd_model="dispersion")
     assert th.shape == (77, 60) and np.all(np.isfinite(th))
     multi.close()

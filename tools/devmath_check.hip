@@ -20,6 +20,12 @@ __global__ void run(const double* x, const double* a, double* g, double* ir, dou
   raw_rcp[i] = __builtin_amdgcn_rcp(x[i]);
 }
 
+// vkm::wave_sum (DPP reduction): every lane of a wavefront must receive the same total of the wave's 64 inputs
+__global__ void run_wave_sum(const double* x, double* out, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = vkm::wave_sum(x[i]);
+}
+
 static double ulp_err(double got, long double want) {
   if (want == 0.0L) return got == 0.0 ? 0.0 : 1e300;
   int e;
@@ -62,7 +68,25 @@ int main() {
     raw1 = fmax(raw1, fabs((double)((long double)r1[i] * sqrtl(xl) - 1.0L)));
     raw2 = fmax(raw2, fabs((double)((long double)r2[i] * xl - 1.0L)));
   }
-  printf("{\"sqrt_ulp\": %.3f, \"rsqrt_ulp\": %.3f, \"recip_ulp\": %.3f, \"exp_ulp_normal\": %.3f, \"exp_ulp_denormal_tail\": %.3f, "
-         "\"raw_v_rsq_f64_rel\": %.3e, \"raw_v_rcp_f64_rel\": %.3e}\n", m_g, m_ir, m_rc, m_exn, m_ex, raw1, raw2);
+  // wave_sum on the first 2^16 samples of x and of a (signed), 64 consecutive values per wavefront
+  const int nw = 1 << 16;
+  double *dws;
+  hipMalloc(&dws, nw * sizeof(double));
+  double ws_rel = 0;
+  int ws_uniform = 1;
+  for (int pass = 0; pass < 2; ++pass) {
+    hipLaunchKernelGGL(run_wave_sum, dim3(nw / 256), dim3(256), 0, 0, pass ? da : dx, dws, nw);
+    std::vector<double> w(nw);
+    hipMemcpy(w.data(), dws, nw * sizeof(double), hipMemcpyDeviceToHost);
+    const std::vector<double>& src = pass ? a : x;
+    for (int g = 0; g < nw; g += 64) {
+      long double want = 0, mag = 0;
+      for (int l = 0; l < 64; ++l) { want += src[g + l]; mag += fabsl((long double)src[g + l]); }
+      for (int l = 1; l < 64; ++l) ws_uniform &= (w[g + l] == w[g]);
+      ws_rel = fmax(ws_rel, (double)(fabsl((long double)w[g] - want) / mag));
+    }
+  }
+  printf("{\"wave_sum_rel\": %.3e, \"wave_sum_uniform\": %d, \"sqrt_ulp\": %.3f, \"rsqrt_ulp\": %.3f, \"recip_ulp\": %.3f, \"exp_ulp_normal\": %.3f, \"exp_ulp_denormal_tail\": %.3f, "
+         "\"raw_v_rsq_f64_rel\": %.3e, \"raw_v_rcp_f64_rel\": %.3e}\n", ws_rel, ws_uniform, m_g, m_ir, m_rc, m_exn, m_ex, raw1, raw2);
   return 0;
 }

@@ -42,6 +42,21 @@
 
 using namespace vk;
 
+// vk_create: the tables every launch copies into LDS unchanged - the scaled exp table of vk_devmath.h and the mu records
+// {mu, sqrt(1 - mu^2), W_0, W_1, W_2, 0} of the context's own grid - computed once, on the device (same bits as the
+// in-kernel staging of the general-grid entry points)
+__global__ void vk_init_stage_kernel(const double* mu, const double* w_ell, int n_mu, int n_ell, double* exp_tab, double* stage_mu) {
+  for (int j = threadIdx.x; j < vkm::kExpTab; j += blockDim.x) exp_tab[j] = vkm::exp2_frac_c4(j);
+  for (int i = threadIdx.x; i < n_mu; i += blockDim.x) {
+    const double m = mu[i];
+    double* rec = stage_mu + i * kMuRec;
+    rec[0] = m;
+    rec[1] = sqrt(1.0 - m * m);
+    for (int l = 0; l < kMaxEll; ++l) rec[2 + l] = (l < n_ell) ? w_ell[l * n_mu + i] : 0.0;
+    rec[5] = 0.0;
+  }
+}
+
 
 // ==================================================================================================
 // host side
@@ -56,7 +71,11 @@ struct Knobs {
   int mapping = 0;                     // VICTOR_HIP_MAPPING: 0 auto, 1 point, 2 cells, 3 lanes, -1 unknown name
   bool like_untiled = false;           // VICTOR_HIP_LIKE_UNTILED
   bool no_graph = false;               // VICTOR_HIP_NO_GRAPH
-  bool no_fuse = false;                // VICTOR_HIP_NO_FUSE: keep chi2 in its own launch (A/B of the fused small-batch path)
+  bool no_fuse = false;                // VICTOR_HIP_NO_FUSE: keep chi2 in its own launch (A/B of the fused path)
+  long long fuse_max = -1;             // VICTOR_HIP_FUSE_MAX: largest batch whose chi2 is taken inside the theory kernel (-1 = default)
+  int split_q = 0;                     // third field of VICTOR_HIP_SPLIT "spi,team,parts": workgroups per (mu, v) plane
+  int cells_parts = 0;                 // VICTOR_HIP_CELLS_PARTS: workgroups per point in the cells kernel (0 = choose)
+  int like_wide = -1;                  // VICTOR_HIP_LIKE_WIDE: 1 / 0 force the workgroup-per-point chi2 kernel on / off
 };
 
 struct vk_ctx {
@@ -89,7 +108,16 @@ struct vk_ctx {
   double uni_lut_inv_g = 0;
   const unsigned short* d_uni_lut = nullptr;
   const double* d_uni_knots = nullptr;
+  // batch-independent staging tables and the bookkeeping of the fused / split launches (one device allocation)
+  double* d_aux = nullptr;
+  const double* d_exp_tab = nullptr;   // [vkm::kExpTab]
+  const double* d_stage_mu = nullptr;  // [n_mu][kMuRec]
+  unsigned* d_counters = nullptr;      // [kCounterCap], zero between launches
+  double* d_partial = nullptr;         // [partial_doubles]
+  size_t partial_doubles = 0;
+  double wsum[3] = {0, 0, 0};
   const char* last_kernel = "none";  // theory kernel variant of the most recent launch
+  bool last_fused = false;           // ... and whether it took the chi-square as well
   // scratch for the host-buffer entry points
   double* d_scratch = nullptr;
   size_t scratch_bytes = 0;
@@ -112,6 +140,9 @@ struct vk_ctx {
 };
 
 constexpr int64_t kGraphMaxN = 4096;
+constexpr long long kCounterCap = 16384;   // points per launch that may share work between workgroups (completion counters)
+constexpr int kMaxParts = 8;               // workgroups per (mu, v) plane in the point-major kernel
+constexpr long long kPartialPoints = 64;   // ... for batches up to this many points
 
 namespace {
 
@@ -121,12 +152,17 @@ std::atomic<unsigned> g_knob_gen{1};
 void load_knobs(vk_ctx* ctx) {
   Knobs k;
   if (const char* env = getenv("VICTOR_HIP_SPLIT")) {
-    int sp = 0, t = 0;
-    if (sscanf(env, "%d,%d", &sp, &t) == 2 && sp >= 1 && (t == 1 || t == 2 || t == 4) && (t == 1 || sp == 1)) {
+    int sp = 0, t = 0, q = 1;
+    const int got = sscanf(env, "%d,%d,%d", &sp, &t, &q);
+    if (got >= 2 && sp >= 1 && (t == 1 || t == 2 || t == 4) && (t == 1 || sp == 1) && q >= 1 && q <= 16) {
       k.split_s = sp;
       k.split_t = t;
+      k.split_q = got == 3 ? q : 0;
     }
   }
+  if (const char* env = getenv("VICTOR_HIP_FUSE_MAX")) k.fuse_max = atoll(env);
+  if (const char* env = getenv("VICTOR_HIP_CELLS_PARTS")) k.cells_parts = atoi(env);
+  if (const char* env = getenv("VICTOR_HIP_LIKE_WIDE")) k.like_wide = atoi(env) ? 1 : 0;
   k.force_generic = getenv("VICTOR_HIP_FORCE_GENERIC") != nullptr;
   if (const char* env = getenv("VICTOR_HIP_POINT_CAP")) k.point_cap = atoll(env);
   if (const char* env = getenv("VICTOR_HIP_LANES_CAP")) k.lanes_cap = atoll(env);
@@ -209,20 +245,25 @@ int launch_on_stream(vk_ctx* ctx, Kern kern, int grid, size_t lds, const Args& a
   return VK_OK;
 }
 
-void choose_split(const vk_ctx* ctx, long long n, int n_s, int* spi, int* team) {
-  // A/B knob "spi,team": s bins per workgroup visit and waves cooperating on one s bin (1, 2 or 4)
+void choose_split(const vk_ctx* ctx, long long n, int n_s, int* spi, int* team, int* parts) {
+  *parts = 1;
+  // A/B knob "spi,team[,parts]": s bins per workgroup visit, waves cooperating on one s bin (1, 2 or 4), workgroups per plane
   if (ctx->knobs.split_s > 0) {
     *spi = ctx->knobs.split_s < n_s ? ctx->knobs.split_s : n_s;
     *team = ctx->knobs.split_t;
+    if (ctx->knobs.split_q > 0) *parts = ctx->knobs.split_q;
     return;
   }
-  // Measured (tools/gpu_split_sweep.py, resident, config 3 / BOSS): four s bins per workgroup (one per wave) is the
-  // fastest split from ~50 points on (64 points: 76 / 51 us against 102 / 77 us for two waves per s bin), four
-  // cooperating waves per s bin below that (1-16 points: 40 / 29 us); two waves per s bin never wins.
+  // Measured (tools/gpu_split_sweep.py, resident, config 3 / BOSS): four s bins per workgroup (one per wave) from ~50 points
+  // on, one s bin per workgroup (four cooperating waves) below that, and for a handful of points the (mu, v) plane of every
+  // s bin is shared by several workgroups so that a single point still spreads over >= 160 of them.
   const long long want = 4LL * ctx->n_cu;
   if (n >= want) { *spi = n_s; *team = 1; return; }
   if (n * ((n_s + 3) / 4) >= want / 2) { *spi = 4; *team = 1; return; }
   *spi = 1; *team = 4;
+  const long long wgs = n * n_s;
+  long long q = (160 + wgs - 1) / wgs;
+  *parts = (int)(q < 1 ? 1 : (q > 4 ? 4 : q));
 }
 
 template <int RSD, int NLR>
@@ -373,29 +414,34 @@ int theory_args(vk_ctx* ctx, const vk_eval_opts* o, TheoryArgs* a, int* nlr) {
   return VK_OK;
 }
 
-int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
+// idx / d as one mul_hi: exact for every idx < 2^32 / d when magic = ceil(2^32 / d) (the planes here are < 2^22)
+unsigned div_magic(int d) { return (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
+
+// `like`: the likelihood stage of this call, or NULL (theory only).  *fused is set when the theory kernel took the
+// chi-square as well (the caller then skips the K2 launch).
+int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool* fused) {
+  if (fused) *fused = false;
   if (a.n <= 0) return VK_OK;
-  choose_split(ctx, a.n, a.n_s, &a.sbins_per_item, &a.team);
+  const int N = a.n_ell * a.n_s;
+  choose_split(ctx, a.n, a.n_s, &a.sbins_per_item, &a.team, &a.parts);
+  a.exp_tab = ctx->d_exp_tab;
+  a.nx_magic = div_magic(a.n_x);
+  a.nmu_magic = div_magic(a.n_mu);
+  a.counters = ctx->d_counters;
+  a.partial = ctx->d_partial;
+  a.fuse = 0;
   // the fast kernel (streaming only) packs LDS byte offsets of the mu and (x, w) records into 16 bits each
   // fast kernels: the streaming model, and the dispersion model on fixed velocity tables (cells / point-major only)
   const bool disp = a.rsd == VK_RSD_DISPERSION && a.uni_da && (!a.empirical || a.uni_ge) && !a.vr_beta_dep;
   const bool fast = (a.rsd == VK_RSD_STREAMING || disp) && ctx->fast_ok && (!a.empirical || a.uni_v2) &&
                     a.n_mu <= 1024 && a.n_x <= 2048 && !ctx->knobs.force_generic;
-  size_t lds;
-  if (fast) {
-    lds = (size_t)make_fast_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, disp).total * sizeof(double);
-  } else {
-    lds = (size_t)make_plan(a.n_mu, a.n_x, a.n_ell, a.sv.n_int, a.vr.n_int, a.xi.n_int, nlr, a.n_beta_r).total *
-          sizeof(double);
-  }
-  if (lds > 160 * 1024) return fail(ctx, VK_E_ARG, "tables need %zu bytes of LDS (> 160 KiB)", lds);
-  const long long groups = (a.n_s + a.sbins_per_item - 1) / a.sbins_per_item;
-  const long long items = a.n * groups;
-  // over-subscribe: 27.9 / 25.9 / 24.8 / 24.0 ms at 4 / 8 / 16 / 64 workgroups per CU on BOSS x 65536 (4-5 are resident);
-  // 64 -> 256 gains another 0.5-2 % at 65536-262144 points (tools/gpu_cells_cap_sweep.py), staging per workgroup is cheap
+  // chi-square inside the theory kernel: point-major and cells kernels only, up to fuse_max points (A/B: DESIGN.md section 5)
+  const long long kFuseMaxDefault = 8192;
+  const long long fuse_max = ctx->knobs.fuse_max >= 0 ? ctx->knobs.fuse_max : kFuseMaxDefault;
+  const bool want_fuse = like && !ctx->knobs.no_fuse && a.n <= fuse_max && like_lds_doubles(N) * sizeof(double) <= 32 * 1024;
+  if (like) a.like = *like;
   const long long kDefaultCap = 256;                                // VICTOR_HIP_POINT_CAP: workgroups per CU in the launch
   const long long cap = (ctx->knobs.point_cap > 0 ? ctx->knobs.point_cap : kDefaultCap) * ctx->n_cu;
-  const int grid = (int)(items < cap ? items : cap);
   // lanes-over-batch variant: batch-constant tables and enough points to fill the chip with n_s * n/64 waves
   const int mapping = ctx->knobs.mapping;                           // VICTOR_HIP_MAPPING: 0 = choose by batch size
   const bool lanes_ok = fast && a.n_beta_r == 0 && !a.empirical && !a.from_data && !disp;   // per-point tables need a workgroup per point
@@ -412,6 +458,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
                      (mapping ? mapping == 3 : blocks_l >= 4 * wg_per_cu * ctx->n_cu);
   if (lanes) {
     ctx->last_kernel = "vk_theory_lanes_kernel";
+    a.parts = 1;
     const long long blocks = blocks_l;
     // One workgroup per four items, never a grid-stride loop by default: letting the dispatcher refill CUs as
     // workgroups retire measured 38.1 / 36.0 / 34.6 / 33.8 ms at 4 / 8 / 16 / 64 workgroups per CU on the bench workload
@@ -433,11 +480,20 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   const bool cells = cells_ok && (mapping ? mapping == 2 : a.n >= (5LL * ctx->n_cu) / 2);
   if (cells) {
     ctx->last_kernel = "vk_theory_cells_kernel";
-    const size_t lds_c =
-        (size_t)make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, disp).total * sizeof(double);
+    // a point may be shared by `parts` workgroups (contiguous slices of its s bins): finer items balance a launch that is
+    // only one or two residency rounds deep
+    int S = ctx->knobs.cells_parts > 0 ? ctx->knobs.cells_parts : 1;
+    if (S > a.n_s) S = a.n_s;
+    if (S > 1 && a.n > kCounterCap) S = 1;
+    a.parts = S;
+    a.fuse = want_fuse && (S == 1 || a.n <= kCounterCap) ? 1 : 0;
+    const bool tail = a.fuse || S > 1;
+    const size_t lds_c = (size_t)make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, disp, S,
+                                                 tail ? N : 0).total * sizeof(double);
     if (lds_c > 160 * 1024) return fail(ctx, VK_E_ARG, "tables need %zu bytes of LDS (> 160 KiB)", lds_c);
-    const long long capc = cap;
-    const int grid_c = (int)(a.n < capc ? a.n : capc);
+    const long long items_c = a.n * S;
+    const int grid_c = (int)(items_c < cap ? items_c : cap);
+    if (fused) *fused = a.fuse != 0;
     switch (nlr) {
       case 1: return launch_cells_nl<1>(ctx, a, grid_c, lds_c);
       case 2: return launch_cells_nl<2>(ctx, a, grid_c, lds_c);
@@ -446,6 +502,18 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   }
   ctx->last_kernel = fast ? "vk_theory_fast_kernel" : "vk_theory_kernel";
   if (fast) {
+    const long long groups = (a.n_s + a.sbins_per_item - 1) / a.sbins_per_item;
+    if (a.parts > kMaxParts) a.parts = kMaxParts;
+    if (a.parts > 1 && ((size_t)a.n * a.n_s * a.parts * kMaxEll > ctx->partial_doubles || a.n > kCounterCap)) a.parts = 1;
+    const bool need_counters = groups * a.parts > 1;
+    a.fuse = want_fuse && (!need_counters || a.n <= kCounterCap) ? 1 : 0;
+    const bool tail = a.fuse || a.parts > 1;
+    const size_t lds = (size_t)make_fast_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, disp, tail ? N : 0).total *
+                       sizeof(double);
+    if (lds > 160 * 1024) return fail(ctx, VK_E_ARG, "tables need %zu bytes of LDS (> 160 KiB)", lds);
+    const long long items = a.n * groups * a.parts;
+    const int grid = (int)(items < cap ? items : cap);
+    if (fused) *fused = a.fuse != 0;
     switch (nlr) {
       case 1: return launch_fast_nl<1>(ctx, a, grid, lds);
       case 2: return launch_fast_nl<2>(ctx, a, grid, lds);
@@ -453,6 +521,13 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
     }
     return fail(ctx, VK_E_ARG, "bad number of real-space multipoles %d", nlr);
   }
+  a.parts = 1;
+  const size_t lds = (size_t)make_plan(a.n_mu, a.n_x, a.n_ell, a.sv.n_int, a.vr.n_int, a.xi.n_int, nlr, a.n_beta_r).total *
+                     sizeof(double);
+  if (lds > 160 * 1024) return fail(ctx, VK_E_ARG, "tables need %zu bytes of LDS (> 160 KiB)", lds);
+  const long long groups = (a.n_s + a.sbins_per_item - 1) / a.sbins_per_item;
+  const long long items = a.n * groups;
+  const int grid = (int)(items < cap ? items : cap);
   switch (a.rsd) {
     case VK_RSD_STREAMING: return launch_generic<VK_RSD_STREAMING>(ctx, a, nlr, grid, lds);
     case VK_RSD_DISPERSION: return launch_generic<VK_RSD_DISPERSION>(ctx, a, nlr, grid, lds);
@@ -462,28 +537,40 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr) {
   return fail(ctx, VK_E_ARG, "unknown rsd_model %d", a.rsd);
 }
 
-int launch_like(vk_ctx* ctx, const vk_eval_opts* o, const double* d_params, const double* d_theory, long long n,
-                double* d_lnl, double* d_chi2) {
+void fill_like_args(const vk_ctx* ctx, const vk_eval_opts* o, const double* d_params, const double* d_theory, long long n,
+                    double* d_lnl, double* d_chi2, LikeArgs* a) {
+  *a = LikeArgs{};
+  a->params = d_params;
+  a->theory = d_theory;
+  a->n = n;
+  a->N = ctx->N;
+  a->n_beta_d = ctx->n_beta_d;
+  a->beta_d = ctx->d_beta_d;
+  a->data = ctx->d_data;
+  a->n_beta_c = ctx->n_beta_c;
+  a->beta_c = ctx->d_beta_c;
+  a->prec = ctx->d_prec;
+  a->logdet = ctx->d_logdet;
+  a->eig = ctx->d_eig;
+  a->like_form = o->like_form;
+  a->nmocks = o->nmocks;
+  a->nparams = o->nparams;
+  a->lnl = d_lnl;
+  a->chi2 = d_chi2;
+}
+
+int launch_like(vk_ctx* ctx, const LikeArgs& a) {
+  const long long n = a.n;
   if (n <= 0) return VK_OK;
-  LikeArgs a{};
-  a.params = d_params;
-  a.theory = d_theory;
-  a.n = n;
-  a.N = ctx->N;
-  a.n_beta_d = ctx->n_beta_d;
-  a.beta_d = ctx->d_beta_d;
-  a.data = ctx->d_data;
-  a.n_beta_c = ctx->n_beta_c;
-  a.beta_c = ctx->d_beta_c;
-  a.prec = ctx->d_prec;
-  a.logdet = ctx->d_logdet;
-  a.eig = ctx->d_eig;
-  a.like_form = o->like_form;
-  a.nmocks = o->nmocks;
-  a.nparams = o->nparams;
-  a.lnl = d_lnl;
-  a.chi2 = d_chi2;
   const long long cap = 16LL * ctx->n_cu;
+  // small batches: one workgroup per point (the wave-per-point kernels below need >= 1024 points to fill the chip; a
+  // single point took 27 us in one wave against the ~3 us of 256 threads)
+  const size_t lds_wide = (size_t)like_lds_doubles(ctx->N) * sizeof(double);
+  const bool wide = ctx->knobs.like_wide >= 0 ? ctx->knobs.like_wide == 1 : n <= 2048;
+  if (wide && lds_wide <= 160 * 1024) {
+    const long long capw = 64LL * ctx->n_cu;
+    return launch_on_stream(ctx, vk_like_wide_kernel, (int)(n < capw ? n : capw), lds_wide, a);
+  }
   // fixed covariance: 8 points per wave share the loads of the precision matrix (LDS: 4 waves x 8 x N doubles)
   constexpr int kTile = 8;
   const size_t lds_tiled = (size_t)kWaves * kTile * ctx->N * sizeof(double);
@@ -797,6 +884,30 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
     ctx->d_sv_mu = base + o_svmu;
     ctx->d_sv2d = base + o_sv2d;
   }
+  {
+    // batch-independent staging tables + bookkeeping of the split / fused launches
+    const size_t n_stage = (size_t)t->n_mu * kMuRec;
+    ctx->partial_doubles = (size_t)kPartialPoints * t->n_s * kMaxParts * kMaxEll;
+    const size_t aux_doubles = vkm::kExpTab + n_stage + ctx->partial_doubles + (kCounterCap * sizeof(unsigned) + 7) / 8;
+    if ((rc = hipMalloc((void**)&ctx->d_aux, aux_doubles * sizeof(double))) != hipSuccess) return hip_bail(rc, "hipMalloc(aux)");
+    if ((rc = hipMemsetAsync(ctx->d_aux, 0, aux_doubles * sizeof(double), ctx->stream)) != hipSuccess)
+      return hip_bail(rc, "hipMemset(aux)");
+    double* exp_tab = ctx->d_aux;
+    double* stage_mu = exp_tab + vkm::kExpTab;
+    ctx->d_partial = stage_mu + n_stage;
+    ctx->d_counters = reinterpret_cast<unsigned*>(ctx->d_partial + ctx->partial_doubles);
+    hipLaunchKernelGGL(vk_init_stage_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->d_mu, ctx->d_w, t->n_mu, t->n_ell, exp_tab,
+                       stage_mu);
+    if ((rc = hipGetLastError()) != hipSuccess) return hip_bail(rc, "vk_init_stage_kernel");
+    if ((rc = hipStreamSynchronize(ctx->stream)) != hipSuccess) return hip_bail(rc, "vk_init_stage_kernel");
+    ctx->d_exp_tab = exp_tab;
+    ctx->d_stage_mu = stage_mu;
+    for (int l = 0; l < t->n_ell; ++l) {
+      double ws = 0.0;
+      for (int i = 0; i < t->n_mu; ++i) ws += t->w_ell[(size_t)l * t->n_mu + i];
+      ctx->wsum[l] = ws;
+    }
+  }
   if (t->data) {
     ctx->d_beta_d = t->n_beta_d > 0 ? base + o_bd : nullptr;
     ctx->d_data = base + o_data;
@@ -816,6 +927,7 @@ void vk_destroy(vk_ctx* ctx) {
   drop_graphs(ctx);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
   if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+  if (ctx->d_aux) (void)hipFree(ctx->d_aux);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   for (auto& evt : ctx->ev)
     if (evt) (void)hipEventDestroy(evt);
@@ -902,17 +1014,23 @@ int vk_eval_batch_device_async(vk_ctx* ctx, const vk_eval_opts* opts, const doub
   a.n = n;
   a.n_s = ctx->n_s; a.n_mu = ctx->n_mu; a.n_ell = ctx->n_ell;
   a.s = ctx->d_s; a.mu = ctx->d_mu; a.w_ell = ctx->d_w;
+  a.stage_mu = ctx->d_stage_mu;
+  for (int l = 0; l < 3; ++l) a.wsum[l] = ctx->wsum[l];
   a.out = d_theory_ws;
+  LikeArgs la;
+  if (want_like) fill_like_args(ctx, opts, d_params, d_theory_ws, n, d_lnl, d_chi2, &la);
   const bool timed = ctx->timing && want_like;
   if (timed) {
     harvest_timing(ctx);
     VK_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   }
-  rc = launch_theory(ctx, a, nlr);
+  bool fused = false;
+  rc = launch_theory(ctx, a, nlr, want_like ? &la : nullptr, &fused);
   if (rc) return rc;
+  ctx->last_fused = fused;
   if (timed) VK_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-  if (want_like) {
-    rc = launch_like(ctx, opts, d_params, d_theory_ws, n, d_lnl, d_chi2);
+  if (want_like && !fused) {
+    rc = launch_like(ctx, la);
     if (rc) return rc;
   }
   if (timed) {
@@ -1053,8 +1171,14 @@ static int general_grid(vk_ctx* ctx, const vk_eval_opts* opts, const double* par
   a.n_s = n_s; a.n_mu = n_mu; a.n_ell = ne;
   a.s = d_s; a.mu = d_mu; a.w_ell = d_w;
   a.out = d_out;
+  a.stage_mu = nullptr;                          // the caller's own (mu, W) grid: staged inside the kernel
+  for (int l = 0; l < 3; ++l) {
+    a.wsum[l] = 0.0;
+    if (project && l < n_ell)
+      for (int i = 0; i < n_mu; ++i) a.wsum[l] += w_ell[(size_t)l * n_mu + i];
+  }
   if (project) {
-    rc = launch_theory(ctx, a, nlr);
+    rc = launch_theory(ctx, a, nlr, nullptr, nullptr);
     if (rc) return rc;
   } else {
     const LdsPlan pl = make_plan(a.n_mu, a.n_x, a.n_ell, a.sv.n_int, a.vr.n_int, a.xi.n_int, nlr, a.n_beta_r);
@@ -1064,6 +1188,8 @@ static int general_grid(vk_ctx* ctx, const vk_eval_opts* opts, const double* par
     const int grid = (int)(n < cap ? n : cap);
     a.sbins_per_item = 1;
     a.team = 1;
+    a.parts = 1;
+    a.exp_tab = ctx->d_exp_tab;
     switch (a.rsd) {
       case VK_RSD_STREAMING: rc = launch_xi_smu<VK_RSD_STREAMING>(ctx, a, nlr, grid, lds); break;
       case VK_RSD_DISPERSION: rc = launch_xi_smu<VK_RSD_DISPERSION>(ctx, a, nlr, grid, lds); break;

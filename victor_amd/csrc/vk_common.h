@@ -23,6 +23,25 @@ struct PPView {           // a vk_pp living in global memory (device pointers)
   const double* coef;
 };
 
+struct LikeArgs {
+  const double* params;
+  const double* theory;   // [n][N]
+  long long n;
+  int N;
+  int n_beta_d;
+  const double* beta_d;
+  const double* data;
+  int n_beta_c;
+  const double* beta_c;
+  const double* prec;
+  const double* logdet;
+  const double* eig;
+  int like_form;
+  double nmocks, nparams;
+  double* lnl;
+  double* chi2;
+};
+
 struct TheoryArgs {
   const double* params;   // [n][VK_NPAR]
   long long n;
@@ -70,25 +89,18 @@ struct TheoryArgs {
   int sbins_per_item;     // s bins handled by one workgroup visit
   int team;               // waves cooperating on one s bin (1, 2 or 4)
   double* out;            // theory: [n][n_ell*n_s];  xi_smu: [n][n_mu][n_s]
-};
-
-struct LikeArgs {
-  const double* params;
-  const double* theory;   // [n][N]
-  long long n;
-  int N;
-  int n_beta_d;
-  const double* beta_d;
-  const double* data;
-  int n_beta_c;
-  const double* beta_c;
-  const double* prec;
-  const double* logdet;
-  const double* eig;
-  int like_form;
-  double nmocks, nparams;
-  double* lnl;
-  double* chi2;
+  // ---- staging tables that do not depend on the batch (built once in vk_create) --------------------------------
+  const double* exp_tab;  // [vkm::kExpTab] c4 2^(j/256) (vk_devmath.h), computed on the device so every launch copies the same bits
+  const double* stage_mu; // [n_mu][kMuRec] {mu, sqrt(1-mu^2), W_0, W_1, W_2, 0} of the context's own (mu, W) grid, or NULL
+  double wsum[3];         // sum_i W_l[i]: the "-1" of ccf_model.py:690 projects to -sum_i W_l[i] (not 0 for l > 0)
+  unsigned nx_magic;      // ceil(2^32 / n_x):  idx / n_x  == __umulhi(idx, nx_magic)  for every idx of the (mu, v) plane
+  unsigned nmu_magic;     // ceil(2^32 / n_mu): cell / n_mu likewise (cells kernel)
+  // ---- small and medium batches: finer work split and the chi-square in the same launch ----------------------------
+  int parts;              // point-major: workgroups sharing one (point, s-bin group) plane; cells: workgroups per point
+  int fuse;               // 1: the workgroup that completes a point's theory vector also computes its chi2 / lnL (`like`)
+  unsigned* counters;     // [n] workgroups finished per point; zero on entry, reset to zero by the finishing workgroup
+  double* partial;        // [n][n_s][parts][kMaxEll] partial projections (point-major, parts > 1)
+  LikeArgs like;
 };
 
 // piecewise-cubic table resident in LDS
@@ -140,10 +152,35 @@ __device__ __forceinline__ double pp_eval_at(const PPLds& t, int var, int i, dou
 
 __device__ __forceinline__ double clampd(double u, double lo, double hi) { return fmin(fmax(u, lo), hi); }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+__device__ __forceinline__ double wave_sum(double v) { return vkm::wave_sum(v); }
+
+// Data handed from one workgroup to another INSIDE a launch (partial projections, theory vectors awaiting their
+// chi-square) is written and read with device-scope relaxed atomics: on gfx950 those are write-through stores / L2-coherent
+// loads (sc1), which is all the coherence the eight per-XCD L2s need.  The alternative - ordinary stores plus
+// __threadfence() - costs a write-back and an invalidation of the whole L2 per workgroup (buffer_wbl2 / buffer_inv): every
+// table the next workgroup stages then misses, and a 64-point batch ran 30 % slower than without the fused tail.
+__device__ __forceinline__ void store_shared(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_shared(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// "This workgroup finished one of the `total` work items of `point`": returns true (to every thread) in the workgroup
+// that finished the last one.  Everything the workgroups stored with store_shared() before their call is then readable
+// with load_shared() (stores complete - s_waitcnt at the barrier - before the device-scope counter increment; the reader's
+// loads are issued after its own increment returned).  The finishing workgroup resets counters[point] for the next launch.
+// `flag`: one int of LDS.
+__device__ __forceinline__ bool point_completed(unsigned* counters, long long point, unsigned total, int* flag) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned done = __hip_atomic_fetch_add(counters + point, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    if (done == total) __hip_atomic_store(counters + point, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = done == total ? 1 : 0;
+  }
+  __syncthreads();
+  return *flag != 0;
 }
 
 // Growth term and powers of the bias (ccf_model.py:426-443, 358-370): v_r(r) = -gb [V1 + av V2](r/c) / (3 aH_true).

@@ -11,6 +11,30 @@
 
 namespace vkm {
 
+// Sum over the 64 lanes of a wavefront, returned to every lane (wave-uniform: the compiler may keep it in SGPRs).
+// Cross-lane traffic goes through DPP (quad permutes, row mirrors, row broadcasts), not through ds_bpermute: the LDS pipe
+// is the second-busiest unit of the theory kernels and a reduction there costs 12 LDS instructions per sum.
+// Fixed association order: pairs, quads, half rows, rows of 16, then rows 0+1, 2+3, and the two halves.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_move<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  v += dpp_move<0x141, 0xF>(v);   // row_half_mirror
+  v += dpp_move<0x140, 0xF>(v);   // row_mirror: every lane of a row of 16 holds the row's sum
+  v += dpp_move<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3 (disabled rows receive 0)
+  v += dpp_move<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
 // g ~ sqrt(x), returns also ir ~ 1/sqrt(x).  x must be a positive normal number (r^2 of a separation in
 // Mpc/h); x = 0 gives NaN, which is what the reference's r_par / r produces there too.
 // One third-order (Halley-type) step from the 2^-24 hardware seed: y' = y (1 + e/2 + 3e^2/8), e = 1 - x y^2,

@@ -6,19 +6,24 @@ namespace vk {
 
 // --------------------------------------------------------------------------------------------------
 // K1 "cells" variant: the lanes kernel's inner loop for per-point tables (reconstruction beta, BOSS).
-// One workgroup owns one parameter point (its xi^r records are rebuilt in LDS as in the point-major kernel); each
-// of its four waves owns the s bins j = wave, wave+4, ... and spreads the (s bin, mu) cells of those bins over its
-// lanes, with the 50 velocity nodes as the inner, wave-uniform loop.  Like the lanes kernel this forms s_perp and
-// s_par once per cell, reads x_k, w_k through the scalar cache and closes the v sum before the projection, so the
-// integrand costs the same ~56 instructions; the projection sum over mu is a two-segment wave reduction per trip
-// (a wave's 64 cells straddle at most two s bins when n_mu >= 64), accumulated by lane 0 in wave-private LDS.
+// One workgroup owns one parameter point - or one of `parts` contiguous slices of its s bins - with the xi^r records
+// rebuilt in LDS as in the point-major kernel.  The (s bin, mu) cells of the slice are flattened (s bin major) and dealt to
+// the four waves in trips of 64 (wave w takes trips w, w + 4, ...: every wave gets the same number of trips to within one,
+// whatever n_s is - with whole s bins per wave, 30 bins meant 8 + 8 + 7 + 7), lanes over the cells, the 50 velocity nodes
+// as the inner, wave-uniform loop.  Like the lanes kernel this forms s_perp and s_par once per cell, reads x_k, w_k through
+// the scalar cache and closes the v sum before the projection, so the integrand costs the same instructions; the
+// projection sum over mu is a two-segment wave reduction per trip (a trip's 64 cells straddle at most two s bins when
+// n_mu >= 64), accumulated by lane 0 in wave-private LDS and combined over the waves at the end.
+// With one workgroup per point the finished theory vector sits in LDS and the chi-square is taken there (`fuse`).
 // --------------------------------------------------------------------------------------------------
 struct CellsPlan {
-  int mu, w, s, betar, acc, da, total;
+  int mu, w, s, betar, acc, da, like, total;
 };
 
+__host__ __device__ inline int cells_slice_bins(int n_s, int parts) { return (n_s + parts - 1) / parts; }
+
 __host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s, int uni_n, int nlr, int n_beta_r,
-                                                     int lut_n, int with_da) {
+                                                     int lut_n, int with_da, int parts, int n_like) {
   CellsPlan p;
   int o = fast_fixed_doubles(uni_n, nlr, lut_n);          // exp table + records first (fixed offsets)
   o = (o + 1) & ~1;
@@ -26,19 +31,24 @@ __host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s,
   p.w = o;     o += kMaxEll * n_mu;                // W_l[i]
   p.s = o;     o += (n_s + 1) & ~1;
   p.betar = o; o += (n_beta_r + 1) & ~1;
-  p.acc = o;   o += kMaxEll * ((n_s + kWaves - 1) / kWaves) * kWaves;   // [l][slot][wave]
+  p.acc = o;   o += kMaxEll * (cells_slice_bins(n_s, parts) + 1) * kWaves;   // [l][local bin][wave] (+ one spill bin)
   o = (o + 1) & ~1;
   p.da = o;    o += with_da ? uni_n * 4 : 0;      // Da table of the dispersion model
+  p.like = o;  o += n_like > 0 ? like_lds_doubles(n_like) : 0;
   p.total = o;
   return p;
 }
 
-// 5 workgroups per CU for the streaming mode (<= 96 VGPRs, a few dwords of scratch outside the hot loop); the from_data
-// and dispersion modes need more registers and run 4 per CU without spills
+// 5 workgroups per CU for the streaming mode (<= 96 VGPRs); the from_data and dispersion modes need more registers and
+// run 4 per CU without spills
 template <int NLR, int NL, int GRID, int MODE>
 __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_theory_cells_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
-  const CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, mode_is_dispersion(MODE));
+  const int N = a.n_ell * a.n_s;
+  const int S = a.parts;
+  const bool tail = a.fuse || S > 1;
+  const CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, mode_is_dispersion(MODE), S,
+                                       tail ? N : 0);
   const int tid = threadIdx.x;
   for (int i = tid; i < a.n_mu; i += kBlock) {
     const double m = a.mu[i];
@@ -62,38 +72,33 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
   typedef const vk_d2 __attribute__((address_space(4))) * cvec_ptr;
   const cvec_ptr cxw = (cvec_ptr)(unsigned long long)a.xw_scaled;
   const double* l_s = lds + pl.s;
-  const int slots = (a.n_s + kWaves - 1) / kWaves;        // s bins per wave (upper bound)
-  double* l_acc = lds + pl.acc;                            // [l][slot][wave]: each entry touched by one wave only
-  const int my_bins = (a.n_s - wave + kWaves - 1) / kWaves;  // bins j = wave + 4*jj, jj < my_bins
-  const int cells = my_bins * a.n_mu;
+  const int slots = cells_slice_bins(a.n_s, S) + 1;          // local bins of a slice (+ one that only ever receives zeros)
+  double* l_acc = lds + pl.acc;                              // [l][local bin][wave]: each entry touched by one wave only
+  const long long items = a.n * S;
 
-  double wsum[NL];
-#pragma unroll
-  for (int l = 0; l < NL; ++l) {
-    double t = 0.0;
-    for (int i = lane; i < a.n_mu; i += 64) t += l_w[l * a.n_mu + i];
-    wsum[l] = wave_sum(t);
-  }
-
-  for (long long point = blockIdx.x; point < a.n; point += gridDim.x) {
+  for (long long item = blockIdx.x; item < items; item += gridDim.x) {
+    const long long point = item / S;
+    const int q = (int)(item - point * S);
+    const int j0 = (int)((long long)a.n_s * q / S), j1 = (int)((long long)a.n_s * (q + 1) / S);   // this slice's s bins
+    const int cells = (j1 - j0) * a.n_mu;
     const double* row = a.params + point * VK_NPAR;
     const PointScalars ps = point_scalars(a, row);
+    __syncthreads();      // every wave is done with the previous item's records and accumulators
     if (a.n_beta_r > 0 || a.empirical) {
-      __syncthreads();  // every wave is done with the previous point's records
       if (a.n_beta_r > 0) rebuild_uni_xi<NLR>(a, lds + kRecsOff, lds + pl.betar, row[VK_P_BETA]);
       if (a.empirical) rebuild_uni_v_emp<NLR>(a, lds + kRecsOff, ps.av);
       if (mode_is_dispersion(MODE) && a.empirical) rebuild_da_emp(a, lds + pl.da, ps.av);
-      __syncthreads();
     }
     for (int e = lane; e < kMaxEll * slots; e += 64) l_acc[e * kWaves + wave] = 0.0;
+    __syncthreads();
     const FastPoint fp = make_fast_point(ps, fc);
-    for (int base = 0; base < cells; base += 64) {
+    for (int base = 64 * wave; base < cells; base += 64 * kWaves) {
       const int e = base + lane;
       const bool live = e < cells;
-      const int ec = live ? e : cells - 1;
-      const int jj = ec / a.n_mu;
-      const int i = ec - jj * a.n_mu;
-      const double sj = l_s[wave + kWaves * jj];
+      const unsigned ec = (unsigned)(live ? e : cells - 1);
+      const int jj = (int)__umulhi(ec, a.nmu_magic);           // ec / n_mu
+      const int i = (int)ec - jj * a.n_mu;
+      const double sj = l_s[j0 + jj];
       const vk_d2 mm = *reinterpret_cast<const vk_d2*>(l_mu + 2 * i);
       const double s_perp = sj * fp.k_perp * mm.y;
       const double sperp2 = s_perp * s_perp;
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
                 g);
       }
       if (!live) g = 0.0;
-      // projection: this trip's cells belong to s bin jj0 or jj0 + 1
+      // projection: this trip's cells belong to local bin jj0 or jj0 + 1 (the latter may be the spill bin)
       const int jj0 = __builtin_amdgcn_readfirstlane(jj);
       const bool first = (jj == jj0);
 #pragma unroll
@@ -122,22 +127,34 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
         const double s1 = wave_sum(first ? 0.0 : v);
         if (lane == 0) {
           l_acc[(l * slots + jj0) * kWaves + wave] += s0;
-          if (jj0 + 1 < my_bins) l_acc[(l * slots + jj0 + 1) * kWaves + wave] += s1;
+          l_acc[(l * slots + jj0 + 1) * kWaves + wave] += s1;
         }
       }
     }
-    // the point's theory vector is complete in LDS once every wave has finished its s bins: write it as one
-    // contiguous run (coalesced; 8-byte stores strided by the s-bin ownership of the waves cost 1.5x the bytes in HBM)
+    // the slice's part of the theory vector is complete in LDS once every wave has finished its trips
     __syncthreads();
-    for (int e = tid; e < NL * a.n_s; e += kBlock) {
-      const int l = e / a.n_s, j = e - l * a.n_s;
-      double ws = wsum[0];
-#pragma unroll
-      for (int q = 1; q < NL; ++q) ws = (l == q) ? wsum[q] : ws;
-      a.out[point * (long long)(a.n_ell * a.n_s) + e] =
-          l_acc[(l * slots + j / kWaves) * kWaves + (j & (kWaves - 1))] - ws + ps.poison;
+    const int nb = j1 - j0;
+    double* th = lds + pl.like;
+    for (int e = tid; e < NL * nb; e += kBlock) {
+      const int l = e / nb, jl = e - l * nb;
+      const double* pa = l_acc + (l * slots + jl) * kWaves;
+      const double ws = l == 0 ? a.wsum[0] : (l == 1 ? a.wsum[1] : a.wsum[2]);
+      const double v = ((pa[0] + pa[1]) + (pa[2] + pa[3])) - ws + ps.poison;
+      double* dst = a.out + point * (long long)N + l * a.n_s + j0 + jl;
+      if (S > 1) store_shared(dst, v); else *dst = v;
+      if (tail && S == 1) th[l * a.n_s + jl] = v;
     }
-    __syncthreads();      // l_acc is zeroed (and the records may be rebuilt) at the top of the next point
+    if (tail) {
+      if (S == 1) {
+        __syncthreads();
+        like_point_workgroup(a.like, point, row[VK_P_BETA], th, th + ((N + 1) & ~1));
+      } else {
+        int* flag = reinterpret_cast<int*>(th + ((N + 1) & ~1) + kWaves + 2);
+        if (point_completed(a.counters, point, (unsigned)S, flag)) {
+          finish_point<NL>(a, point, row[VK_P_BETA], ps.poison, th, false);
+        }
+      }
+    }
   }
 }
 

@@ -1,6 +1,7 @@
 // vk_kernel_fast.h: point-major fast theory kernel and the shared fast-path building blocks - part of libvictor_hip.so (see victor_hip.hip for the overview and DESIGN.md section 5).
 #pragma once
 #include "vk_common.h"
+#include "vk_kernel_like.h"
 
 namespace vk {
 
@@ -107,7 +108,7 @@ __device__ __forceinline__ void stage_uni_records(const TheoryArgs& a, double* l
       recs[(iq >> 2) * stride + 8 + 4 * l + (iq & 3)] = src[e];
     }
   }
-  for (int j = tid; j < vkm::kExpTab; j += kBlock) lds[kEtabOff + j] = vkm::exp2_frac_c4(j);
+  for (int j = tid; j < vkm::kExpTab; j += kBlock) lds[kEtabOff + j] = a.exp_tab[j];
   if (a.uni_lut_n > 0) {
     // union-grid mode: pad slots {left knot, 1/width}; two sentinel records whose left knot is the last knot; the table
     for (int q = tid; q <= a.uni_n + 1; q += kBlock) {
@@ -307,14 +308,49 @@ __device__ __forceinline__ void rebuild_da_emp(const TheoryArgs& a, double* da, 
 }
 
 // --------------------------------------------------------------------------------------------------
-// K1 point-major fast kernel: one wave owns one (point, s bin); lanes sweep the flattened (mu, v) plane.
+// Fused tail of the kernels that own whole points or parts of points (point-major, cells): once a point's theory vector
+// is complete - in this workgroup's LDS, or in the global workspace after the last of the workgroups sharing the point
+// has finished (point_completed) - the same workgroup takes the chi-square and the log-likelihood
+// (like_point_workgroup), so a batch needs ONE launch and the theory vector makes no round trip through HBM before it
+// is used.  `th`: LDS, N doubles + kWaves + 4.
+// --------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int like_lds_doubles(int N) { return ((N + 1) & ~1) + kWaves + 4; }
+
+template <int NL>
+__device__ __forceinline__ void finish_point(const TheoryArgs& a, long long point, double beta, double poison, double* th,
+                                             bool gather_partials) {
+  const int N = a.n_ell * a.n_s;
+  double* red = th + ((N + 1) & ~1);
+  for (int e = threadIdx.x; e < N; e += kBlock) {
+    double v;
+    if (gather_partials) {
+      const int l = e / a.n_s, j = e - l * a.n_s;
+      const double* p = a.partial + ((point * a.n_s + j) * a.parts) * kMaxEll + l;
+      v = 0.0;
+      for (int q = 0; q < a.parts; ++q) v += load_shared(p + q * kMaxEll);   // fixed order: independent of which part finished last
+      v = v - (l == 0 ? a.wsum[0] : (l == 1 ? a.wsum[1] : a.wsum[2])) + poison;
+      a.out[point * (long long)N + e] = v;
+    } else {
+      v = load_shared(a.out + point * (long long)N + e);
+    }
+    th[e] = v;
+  }
+  __syncthreads();
+  if (a.fuse) like_point_workgroup(a.like, point, beta, th, red);
+}
+
+// --------------------------------------------------------------------------------------------------
+// K1 point-major fast kernel: one wave owns one (point, s bin) - or a share of it; lanes sweep the flattened (mu, v) plane.
+// Work items are (point, group of s bins, part of the plane): `sbins_per_item` s bins per workgroup visit, `team` waves
+// per s bin, `parts` workgroups per plane - a single point spreads over n_s * parts workgroups (the reference's calling
+// convention is one point per call, CCFLikelihood.py:32-39).
 // --------------------------------------------------------------------------------------------------
 struct FastPlan {
-  int murec, xrec, betar, red, node, da, total;
+  int murec, xrec, betar, red, da, like, total;
 };
 
 __host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int uni_n, int nlr, int n_beta_r, int lut_n,
-                                                   int with_da) {
+                                                   int with_da, int n_like) {
   FastPlan p;
   int o = fast_fixed_doubles(uni_n, nlr, lut_n);   // exp table + records first (fixed offsets)
   o = (o + 1) & ~1;
@@ -322,43 +358,40 @@ __host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int uni_n,
   p.xrec = o;  o += n_x * 2;
   p.betar = o; o += (n_beta_r + 1) & ~1;
   p.red = o;   o += kWaves * kMaxEll;
-  p.node = o;  o += (n_mu * n_x + 1) / 2;   // one packed u32 per (mu, v) node
   o = (o + 1) & ~1;
   p.da = o;    o += with_da ? uni_n * 4 : 0;  // Da table of the dispersion model
+  p.like = o;  o += n_like > 0 ? like_lds_doubles(n_like) : 0;   // theory vector + reduction scratch of the fused tail
   p.total = o;
   return p;
 }
 
 template <int NLR, int NL, int GRID, int MODE>
-__global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
+__global__ __launch_bounds__(kBlock, 4) void vk_theory_fast_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
-  const FastPlan pl = make_fast_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, mode_is_dispersion(MODE));
+  const int N = a.n_ell * a.n_s;
+  const int Q = a.parts;
+  const bool tail = a.fuse || Q > 1;
+  const FastPlan pl = make_fast_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, mode_is_dispersion(MODE), tail ? N : 0);
   const int tid = threadIdx.x;
   // ---- stage batch-constant tables -------------------------------------------------------------
-  for (int i = tid; i < a.n_mu; i += kBlock) {
-    const double m = a.mu[i];
-    double* rec = lds + pl.murec + i * kMuRec;
-    rec[0] = m;
-    rec[1] = sqrt(1.0 - m * m);
+  if (a.stage_mu) {
+    for (int e = tid; e < a.n_mu * kMuRec; e += kBlock) lds[pl.murec + e] = a.stage_mu[e];
+  } else {
+    for (int i = tid; i < a.n_mu; i += kBlock) {
+      const double m = a.mu[i];
+      double* rec = lds + pl.murec + i * kMuRec;
+      rec[0] = m;
+      rec[1] = sqrt(1.0 - m * m);
 #pragma unroll
-    for (int l = 0; l < kMaxEll; ++l) rec[2 + l] = (l < NL) ? a.w_ell[l * a.n_mu + i] : 0.0;
-    rec[5] = 0.0;
+      for (int l = 0; l < kMaxEll; ++l) rec[2 + l] = (l < NL) ? a.w_ell[l * a.n_mu + i] : 0.0;
+      rec[5] = 0.0;
+    }
   }
-  for (int i = tid; i < a.n_x; i += kBlock) {
-    lds[pl.xrec + 2 * i] = a.x[i] * vkm::kExpScale;
-    lds[pl.xrec + 2 * i + 1] = a.w_x[i];
-  }
+  for (int e = tid; e < 2 * a.n_x; e += kBlock) lds[pl.xrec + e] = a.xw_scaled[e];     // {kExpScale x_k, w_k}
   stage_uni_records<NLR>(a, lds);
   if (mode_is_dispersion(MODE)) stage_da<NLR>(a, lds + pl.da);
   if (a.n_beta_r > 0)
     for (int i = tid; i < a.n_beta_r; i += kBlock) lds[pl.betar + i] = a.beta_r[i];
-  // byte offsets of the mu record (low 16 bits) and the (x, w) record (high 16 bits) of every plane node, so the
-  // hot loop needs no index arithmetic: one ds_read_b32 per trip
-  unsigned* node = reinterpret_cast<unsigned*>(lds + pl.node);
-  for (int idx = tid; idx < a.n_mu * a.n_x; idx += kBlock) {
-    const int i = idx / a.n_x, k = idx - i * a.n_x;
-    node[idx] = (unsigned)(i * kMuRec * 8) | ((unsigned)(k * 16) << 16);
-  }
   const FastConsts fc = make_fast_consts<NLR>(a);
   __syncthreads();
 
@@ -369,25 +402,22 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
   const int my_team = wave / team;
   const int my_rank = wave - my_team * team;
   const int groups = (a.n_s + a.sbins_per_item - 1) / a.sbins_per_item;
-  const long long items = a.n * groups;
+  const long long items = a.n * groups * Q;
   const int plane = a.n_mu * a.n_x;
   const int step = 64 * team;
   const int rounds = (a.sbins_per_item + nteams - 1) / nteams;
   const double* murec = lds + pl.murec;
   const double* xrec = lds + pl.xrec;
   double* l_red = lds + pl.red;
-
-  double wsum[NL];
-#pragma unroll
-  for (int l = 0; l < NL; ++l) {
-    double t = 0.0;
-    for (int i = lane; i < a.n_mu; i += 64) t += murec[i * kMuRec + 2 + l];
-    wsum[l] = wave_sum(t);
-  }
+  // byte offsets of a node's mu record and (x, w) record follow idx = i n_x + k incrementally: no node table, no division
+  const unsigned x_wrap = (unsigned)a.n_x * 16u;
+  const unsigned d_mu = (unsigned)(step / a.n_x) * (kMuRec * 8u), d_x = (unsigned)(step % a.n_x) * 16u;
 
   for (long long item = blockIdx.x; item < items; item += gridDim.x) {
-    const long long point = item / groups;
-    const int g = (int)(item - point * groups);
+    const long long pg = item / Q;
+    const int q = (int)(item - pg * Q);
+    const long long point = pg / groups;
+    const int g = (int)(pg - point * groups);
     const double* row = a.params + point * VK_NPAR;
     const PointScalars ps = point_scalars(a, row);
     if (a.n_beta_r > 0 || a.empirical) {
@@ -398,6 +428,9 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
       __syncthreads();
     }
     const FastPoint fp = make_fast_point(ps, fc);
+    const int lo = (int)((long long)plane * q / Q), hi = (int)((long long)plane * (q + 1) / Q);
+    const unsigned idx0 = (unsigned)(lo + lane + 64 * my_rank);
+    const unsigned i0 = __umulhi(idx0, a.nx_magic);
     for (int rd = 0; rd < rounds; ++rd) {
       const int jl = rd * nteams + my_team;
       const int j = g * a.sbins_per_item + jl;
@@ -411,11 +444,11 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
         const double s_apar = sj * fp.k_par;
         const char* mu_bytes = reinterpret_cast<const char*>(murec);
         const char* x_bytes = reinterpret_cast<const char*>(xrec);
-        for (int idx = lane + 64 * my_rank; idx < plane; idx += step) {
-          const unsigned pk = node[idx];
-          const double* mr = reinterpret_cast<const double*>(mu_bytes + (pk & 0xffffu));
+        unsigned moff = i0 * (kMuRec * 8u), xoff = (idx0 - i0 * (unsigned)a.n_x) * 16u;
+        for (int idx = (int)idx0; idx < hi; idx += step) {
+          const double* mr = reinterpret_cast<const double*>(mu_bytes + moff);
           const vk_d2 m01 = *reinterpret_cast<const vk_d2*>(mr);
-          const vk_d2 xw = *reinterpret_cast<const vk_d2*>(x_bytes + (pk >> 16));
+          const vk_d2 xw = *reinterpret_cast<const vk_d2*>(x_bytes + xoff);
           const double s_perp = s_aperp * m01.y;
           const double sperp2 = s_perp * s_perp;
           const double s_par = s_apar * m01.x;
@@ -429,16 +462,28 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
           acc[0] = fma(w01.x, f, acc[0]);
           if (NL > 1) acc[1] = fma(w01.y, f, acc[1]);
           if (NL > 2) acc[2] = fma(mr[4], f, acc[2]);
+          // next node of this lane: k += step mod n_x with at most one wrap, i += step / n_x (+ 1 on a wrap)
+          const unsigned xn = xoff + d_x;
+          xoff = min(xn, xn - x_wrap);                 // xn < x_wrap: the subtraction wraps to a huge value and min keeps xn
+          moff += d_mu + (xoff != xn ? kMuRec * 8u : 0u);
         }
       }
 #pragma unroll
       for (int l = 0; l < NL; ++l) acc[l] = wave_sum(acc[l]);
+      // this (point, s bin)'s share: final when the plane is not split over workgroups, else a partial for finish_point
+      double* dst = Q > 1 ? a.partial + ((point * a.n_s + j) * Q + q) * kMaxEll
+                          : a.out + point * (long long)N + j;
+      const long long dst_stride = Q > 1 ? 1 : a.n_s;
       if (team == 1) {
         if (valid && lane < NL) {
-          double v = acc[0] - wsum[0];
+          double v = acc[0], ws = a.wsum[0];
 #pragma unroll
-          for (int l = 1; l < NL; ++l) v = (lane == l) ? acc[l] - wsum[l] : v;
-          a.out[point * (long long)(a.n_ell * a.n_s) + (long long)lane * a.n_s + j] = v + ps.poison;
+          for (int l = 1; l < NL; ++l) {
+            v = (lane == l) ? acc[l] : v;
+            ws = (lane == l) ? a.wsum[l] : ws;
+          }
+          const double r = Q > 1 ? v : v - ws + ps.poison;
+          if (tail) store_shared(dst + lane * dst_stride, r); else dst[lane * dst_stride] = r;
         }
       } else {
         __syncthreads();
@@ -449,12 +494,20 @@ __global__ __launch_bounds__(kBlock) void vk_theory_fast_kernel(TheoryArgs a) {
         __syncthreads();
         if (valid && my_rank == 0 && lane < NL) {
           double v = 0.0;
-          for (int q = 0; q < team; ++q) v += l_red[(wave + q) * kMaxEll + lane];
-          double ws = wsum[0];
+          for (int r = 0; r < team; ++r) v += l_red[(wave + r) * kMaxEll + lane];
+          double ws = a.wsum[0];
 #pragma unroll
-          for (int l = 1; l < NL; ++l) ws = (lane == l) ? wsum[l] : ws;
-          a.out[point * (long long)(a.n_ell * a.n_s) + (long long)lane * a.n_s + j] = v - ws + ps.poison;
+          for (int l = 1; l < NL; ++l) ws = (lane == l) ? a.wsum[l] : ws;
+          const double r = Q > 1 ? v : v - ws + ps.poison;
+          if (tail) store_shared(dst + lane * dst_stride, r); else dst[lane * dst_stride] = r;
         }
+      }
+    }
+    if (tail) {
+      double* th = lds + pl.like;
+      int* flag = reinterpret_cast<int*>(th + ((N + 1) & ~1) + kWaves + 2);
+      if (point_completed(a.counters, point, (unsigned)(groups * Q), flag)) {
+        finish_point<NL>(a, point, row[VK_P_BETA], ps.poison, th, Q > 1);
       }
     }
   }

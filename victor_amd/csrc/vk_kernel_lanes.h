@@ -124,11 +124,7 @@ __global__ __launch_bounds__(kBlock, 5) void vk_theory_lanes_kernel(TheoryArgs a
     if (valid) {
       double* o = a.out + point * (long long)(a.n_ell * a.n_s) + j;
 #pragma unroll
-      for (int l = 0; l < NL; ++l) {
-        double ws = 0.0;
-        for (int i = 0; i < a.n_mu; ++i) ws += a.w_ell[l * a.n_mu + i];
-        o[(long long)l * a.n_s] = acc[l] - ws + ps.poison;
-      }
+      for (int l = 0; l < NL; ++l) o[(long long)l * a.n_s] = acc[l] - a.wsum[l] + ps.poison;
     }
   }
 }

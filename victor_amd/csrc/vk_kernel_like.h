@@ -5,6 +5,160 @@
 namespace vk {
 
 // --------------------------------------------------------------------------------------------------
+// shared pieces of the likelihood stage
+// --------------------------------------------------------------------------------------------------
+// likelihood form (ccf_fit.py:455-473); `factor` = -1/2 log det of the covariance when it depends on beta, else 0
+__device__ __forceinline__ double like_form(const LikeArgs& a, double chisq, double factor) {
+  const double nm = a.nmocks;
+  if (a.like_form == VK_LIKE_SELLENTIN) return -nm * log(1.0 + chisq / (nm - 1.0)) / 2.0 + factor;
+  if (a.like_form == VK_LIKE_HARTLAP) return -0.5 * chisq * ((nm - a.N - 2.0) / (nm - 1.0)) + factor;
+  if (a.like_form == VK_LIKE_PERCIVAL) {
+    const double nd = (double)a.N;
+    const double B = (nm - nd - 2.0) / ((nm - nd - 1.0) * (nm - nd - 4.0));
+    const double m = a.nparams + 2.0 + (nm - 1.0 + B * (nd - a.nparams)) / (1.0 + B * (nd - a.nparams));
+    return -m * log(1.0 + chisq / (nm - 1.0)) / 2.0 + factor;
+  }
+  return -0.5 * chisq + factor;
+}
+
+// precision / covariance bracket, ccf_fit.py:213-228,245-260: below / above the grid -> first / last slice, exact grid
+// value -> that slice, else blend of slice `lo` and the LAST slice with weight t (upper bracket = last grid entry)
+__device__ __forceinline__ void cov_bracket(const LikeArgs& a, double beta, int* lo_out, double* t_out) {
+  int lo = 0;
+  double t = 0.0;
+  const int last = a.n_beta_c - 1;
+  if (beta < a.beta_c[0]) {
+    lo = 0;
+  } else if (beta > a.beta_c[last]) {
+    lo = last;
+  } else {
+    int exact = -1, below = 0;
+    for (int i = 0; i <= last; ++i) {
+      const double g = a.beta_c[i];
+      if (g == beta && exact < 0) exact = i;
+      if (g < beta) below = i;
+    }
+    if (exact >= 0) {
+      lo = exact;
+    } else {
+      lo = below;
+      t = (beta - a.beta_c[lo]) / (a.beta_c[last] - a.beta_c[lo]);
+    }
+  }
+  *lo_out = lo;
+  *t_out = t;
+}
+
+// One factor 1 - t + t lambda_i of det((1-t) C_lo + t C_last) = det(C_lo) prod_i (1 - t + t lambda_i).  The reference
+// tests the SIGN of the blended determinant (np.linalg.slogdet(...)[0] != 1, ccf_fit.py:447-450): a zero factor or an
+// odd number of negative ones fails, an even number of negative factors passes with log|det|.
+__device__ __forceinline__ double logdet_term(double fct, int* n_neg, int* n_bad) {
+  *n_neg += (fct < 0.0) ? 1 : 0;
+  *n_bad += (fct == 0.0 || fct != fct) ? 1 : 0;
+  return log(fabs(fct));
+}
+
+// sum over the workgroup's kBlock threads, deterministic; `red` = kWaves doubles of LDS; every thread gets the result
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  v = wave_sum(v);
+  __syncthreads();                       // `red` may still be read from a previous call
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = red[0];
+#pragma unroll
+  for (int w = 1; w < kWaves; ++w) s += red[w];
+  return s;
+}
+
+// chi2 / lnL of ONE point by a whole workgroup (kBlock threads).  On entry `th` (LDS, N doubles) holds the point's theory
+// vector and the workgroup is synchronised; `th` is overwritten with the residual.  `red`: kWaves + 2 doubles of LDS.
+// Threads = (row slice, column): the N columns of the precision matrix are spread over `cols` = 64, 128 or 256 consecutive
+// threads (coalesced rows) and the rows over the kBlock / cols slices, so one point's N^2 products run ~60 deep instead
+// of the N^2 / 64 of the wave-per-point kernel - this is what a batch of one (the reference's calling convention,
+// CCFLikelihood.py:32-39) needs.  ccf_fit.py:349-354 (chi2), :166-193 (data vector), :195-260 (bracket), :444-481.
+__device__ __forceinline__ void like_point_workgroup(const LikeArgs& a, long long point, double beta, double* th, double* red) {
+  const int tid = threadIdx.x;
+  const double inf = __longlong_as_double(0x7ff0000000000000LL);
+  if (a.n_beta_d > 0) {
+    int k = 0;
+    for (int i = 1; i < a.n_beta_d - 1; ++i) k = (beta >= a.beta_d[i]) ? i : k;
+    const double db = beta - a.beta_d[k];
+    const double* piece = a.data + (size_t)k * a.N * 4;
+    for (int e = tid; e < a.N; e += kBlock) {
+      const double* c = piece + (size_t)e * 4;
+      th[e] -= fma(fma(fma(c[3], db, c[2]), db, c[1]), db, c[0]);
+    }
+  } else {
+    for (int e = tid; e < a.N; e += kBlock) th[e] -= a.data[e];
+  }
+  int lo = 0;
+  double t = 0.0;
+  const double* P0 = a.prec;
+  const double* P1 = a.prec;
+  if (a.n_beta_c > 0) {
+    cov_bracket(a, beta, &lo, &t);
+    P0 = a.prec + (size_t)lo * a.N * a.N;
+    P1 = a.prec + (size_t)(a.n_beta_c - 1) * a.N * a.N;
+  }
+  __syncthreads();
+  const int cols = a.N <= 64 ? 64 : (a.N <= 128 ? 128 : kBlock);
+  const int slices = kBlock / cols;
+  const int slice = tid / cols;
+  const int rows = (a.N + slices - 1) / slices;
+  const int r0 = slice * rows, r1 = min(a.N, r0 + rows);
+  const double omt = 1.0 - t;
+  double part = 0.0;
+  for (int b = tid - slice * cols; b < a.N; b += cols) {
+    double y = 0.0;
+    if (t != 0.0) {
+      for (int r = r0; r < r1; ++r) y = fma(th[r], omt * P0[(size_t)r * a.N + b] + t * P1[(size_t)r * a.N + b], y);
+    } else {
+      for (int r = r0; r < r1; ++r) y = fma(th[r], P0[(size_t)r * a.N + b], y);
+    }
+    part = fma(y, th[b], part);
+  }
+  const double chisq = block_sum(part, red);
+  double factor = 0.0;
+  bool singular = false;
+  if (a.n_beta_c > 0) {
+    double ld = 0.0;
+    int n_neg = 0, n_bad = 0;
+    if (t != 0.0) {
+      const double* ev = a.eig + (size_t)lo * a.N;
+      for (int e = tid; e < a.N; e += kBlock) ld += logdet_term(fma(t, ev[e], omt), &n_neg, &n_bad);
+    }
+    ld = block_sum(ld, red);
+    const int neg = __syncthreads_count(n_neg & 1);       // parity of the number of negative factors
+    const int bad = __syncthreads_count(n_bad);
+    singular = (neg & 1) || bad || !(fabs(a.logdet[lo]) < inf);
+    factor = -0.5 * (a.logdet[lo] + ld);
+  }
+  if (tid == 0) {
+    double lnl = like_form(a, chisq, factor);
+    double chi_out = chisq;
+    if (singular || lnl != lnl) {  // ccf_fit.py:448-450, 477-481
+      lnl = -inf;
+      chi_out = inf;
+    }
+    if (a.lnl) a.lnl[point] = lnl;
+    if (a.chi2) a.chi2[point] = chi_out;
+  }
+}
+
+// K2 "wide": one workgroup per point (small batches, and the theory kernels that do not carry the fused tail)
+__global__ __launch_bounds__(kBlock) void vk_like_wide_kernel(LikeArgs a) {
+  extern __shared__ double lds[];
+  double* th = lds;
+  double* red = lds + ((a.N + 1) & ~1);
+  for (long long point = blockIdx.x; point < a.n; point += gridDim.x) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < a.N; e += kBlock) th[e] = a.theory[point * a.N + e];
+    __syncthreads();
+    like_point_workgroup(a, point, a.params[point * VK_NPAR + VK_P_BETA], th, red);
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
 // K2: chi-square and log-likelihood, one wave per parameter point
 // --------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void vk_like_kernel(LikeArgs a) {
@@ -36,27 +190,9 @@ __global__ __launch_bounds__(kBlock) void vk_like_kernel(LikeArgs a) {
     const double* P0 = a.prec;
     const double* P1 = a.prec;
     if (a.n_beta_c > 0) {
-      const int last = a.n_beta_c - 1;
-      if (beta < a.beta_c[0]) {
-        lo = 0;
-      } else if (beta > a.beta_c[last]) {
-        lo = last;
-      } else {
-        int exact = -1, below = 0;
-        for (int i = 0; i <= last; ++i) {
-          const double g = a.beta_c[i];
-          if (g == beta && exact < 0) exact = i;
-          if (g < beta) below = i;
-        }
-        if (exact >= 0) {
-          lo = exact;
-        } else {
-          lo = below;
-          t = (beta - a.beta_c[lo]) / (a.beta_c[last] - a.beta_c[lo]);
-        }
-      }
+      cov_bracket(a, beta, &lo, &t);
       P0 = a.prec + (size_t)lo * a.N * a.N;
-      P1 = a.prec + (size_t)last * a.N * a.N;
+      P1 = a.prec + (size_t)(a.n_beta_c - 1) * a.N * a.N;
     }
     __builtin_amdgcn_wave_barrier();
     // chi2 = sum_b (sum_a r_a P_ab) r_b with lanes over b (coalesced rows of P), ccf_fit.py:354
@@ -75,38 +211,22 @@ __global__ __launch_bounds__(kBlock) void vk_like_kernel(LikeArgs a) {
       part = fma(y, res[b], part);
     }
     const double chisq = wave_sum(part);
-    // -1/2 log det of the blended covariance, ccf_fit.py:445-451
+    // -1/2 log det of the blended covariance, ccf_fit.py:445-451 (sign test as np.linalg.slogdet: see logdet_term)
     double factor = 0.0;
     bool singular = false;
     if (a.n_beta_c > 0) {
       double ld = 0.0;
-      int bad = 0;
+      int n_neg = 0, n_bad = 0;
       if (t != 0.0) {
         const double* ev = a.eig + (size_t)lo * a.N;
-        for (int e = lane; e < a.N; e += 64) {
-          const double fct = fma(t, ev[e], omt);
-          bad |= !(fct > 0.0);
-          ld += log(fct);
-        }
+        for (int e = lane; e < a.N; e += 64) ld += logdet_term(fma(t, ev[e], omt), &n_neg, &n_bad);
         ld = wave_sum(ld);
       }
-      singular = __any(bad) || !(fabs(a.logdet[lo]) < inf);
+      const int neg = __popcll(__ballot(n_neg & 1));
+      singular = (neg & 1) || __any(n_bad) || !(fabs(a.logdet[lo]) < inf);
       factor = -0.5 * (a.logdet[lo] + ld);
     }
-    double lnl;
-    const double nm = a.nmocks;
-    if (a.like_form == VK_LIKE_SELLENTIN) {
-      lnl = -nm * log(1.0 + chisq / (nm - 1.0)) / 2.0 + factor;
-    } else if (a.like_form == VK_LIKE_HARTLAP) {
-      lnl = -0.5 * chisq * ((nm - a.N - 2.0) / (nm - 1.0)) + factor;
-    } else if (a.like_form == VK_LIKE_PERCIVAL) {
-      const double nd = (double)a.N;
-      const double B = (nm - nd - 2.0) / ((nm - nd - 1.0) * (nm - nd - 4.0));
-      const double m = a.nparams + 2.0 + (nm - 1.0 + B * (nd - a.nparams)) / (1.0 + B * (nd - a.nparams));
-      lnl = -m * log(1.0 + chisq / (nm - 1.0)) / 2.0 + factor;
-    } else {
-      lnl = -0.5 * chisq + factor;
-    }
+    double lnl = like_form(a, chisq, factor);
     double chi_out = chisq;
     if (singular || lnl != lnl) {  // ccf_fit.py:448-450, 477-481
       lnl = -inf;
@@ -181,20 +301,7 @@ __global__ __launch_bounds__(kBlock) void vk_like_tiled_kernel(LikeArgs a) {
     }
     if (lane < T && p0 + lane < a.n) {
       const double chisq = mine;
-      double lnl;
-      const double nm = a.nmocks;
-      if (a.like_form == VK_LIKE_SELLENTIN) {
-        lnl = -nm * log(1.0 + chisq / (nm - 1.0)) / 2.0;
-      } else if (a.like_form == VK_LIKE_HARTLAP) {
-        lnl = -0.5 * chisq * ((nm - a.N - 2.0) / (nm - 1.0));
-      } else if (a.like_form == VK_LIKE_PERCIVAL) {
-        const double nd = (double)a.N;
-        const double B = (nm - nd - 2.0) / ((nm - nd - 1.0) * (nm - nd - 4.0));
-        const double m = a.nparams + 2.0 + (nm - 1.0 + B * (nd - a.nparams)) / (1.0 + B * (nd - a.nparams));
-        lnl = -m * log(1.0 + chisq / (nm - 1.0)) / 2.0;
-      } else {
-        lnl = -0.5 * chisq;
-      }
+      double lnl = like_form(a, chisq, 0.0);
       double chi_out = chisq;
       if (lnl != lnl) {  // ccf_fit.py:477-481
         lnl = -inf;
