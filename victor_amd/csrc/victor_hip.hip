@@ -42,6 +42,24 @@
 
 using namespace vk;
 
+// LDS image of a kernel variant's batch-constant tables (vk_kernel_fast.h: copy_image): run that variant's own staging
+// code once and keep what it left in LDS.  kind: 0 point-major, 1 cells, 2 lanes.
+template <int NLR>
+__global__ __launch_bounds__(kBlock) void vk_image_kernel(TheoryArgs a, int kind, int with_da, double* image, int n) {
+  extern __shared__ double lds[];
+  for (int e = threadIdx.x; e < n; e += kBlock) lds[e] = 0.0;
+  __syncthreads();
+  if (kind == 0) {
+    stage_fast<NLR>(a, make_fast_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, with_da, 0), lds, with_da != 0);
+  } else if (kind == 1) {
+    stage_cells<NLR>(a, make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, with_da, 1, 0), lds, with_da != 0);
+  } else {
+    stage_lanes<NLR>(a, make_lanes_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.uni_lut_n), lds);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < n; e += kBlock) image[e] = lds[e];
+}
+
 // vk_create: the tables every launch copies into LDS unchanged - the scaled exp table of vk_devmath.h and the mu records
 // {mu, sqrt(1 - mu^2), W_0, W_1, W_2, 0} of the context's own grid - computed once, on the device (same bits as the
 // in-kernel staging of the general-grid entry points)
@@ -116,6 +134,7 @@ struct vk_ctx {
   double* d_partial = nullptr;         // [partial_doubles]
   size_t partial_doubles = 0;
   double wsum[3] = {0, 0, 0};
+  std::map<int, double*> images;     // LDS images per (kernel kind, real-space multipoles, dispersion tables), built on first use
   const char* last_kernel = "none";  // theory kernel variant of the most recent launch
   bool last_fused = false;           // ... and whether it took the chi-square as well
   // scratch for the host-buffer entry points
@@ -141,12 +160,14 @@ struct vk_ctx {
 
 constexpr int64_t kGraphMaxN = 4096;
 constexpr long long kCounterCap = 16384;   // points per launch that may share work between workgroups (completion counters)
-constexpr int kMaxParts = 8;               // workgroups per (mu, v) plane in the point-major kernel
 constexpr long long kPartialPoints = 64;   // ... for batches up to this many points
 
 namespace {
 
 thread_local std::string g_create_err;
+#ifdef VK_PHASES
+long long* g_stamps = nullptr;
+#endif
 std::atomic<unsigned> g_knob_gen{1};
 
 void load_knobs(vk_ctx* ctx) {
@@ -414,6 +435,41 @@ int theory_args(vk_ctx* ctx, const vk_eval_opts* o, TheoryArgs* a, int* nlr) {
   return VK_OK;
 }
 
+// LDS image for launches on the context's own grid (NULL: the kernel stages entry by entry).  Built on first use, never
+// while the stream is being captured into a graph (the first, eager call of a shape has built it by then).
+const double* get_image(vk_ctx* ctx, const TheoryArgs& a, int kind, int nlr, bool with_da, int image_end) {
+  if (!a.stage_mu || image_end <= 0) return nullptr;
+  const int key = kind * 100 + nlr * 10 + (with_da ? 1 : 0);
+  auto hit = ctx->images.find(key);
+  if (hit != ctx->images.end()) return hit->second;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(ctx->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
+  const size_t lds = (size_t)image_end * sizeof(double);
+  double* img = nullptr;
+  if (lds > 160 * 1024 || hipMalloc((void**)&img, lds) != hipSuccess) return nullptr;
+  bool ok = true;
+  switch (nlr) {
+    case 1:
+      if (lds > 64 * 1024) ok = hipFuncSetAttribute(reinterpret_cast<const void*>(vk_image_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+      if (ok) hipLaunchKernelGGL(vk_image_kernel<1>, dim3(1), dim3(kBlock), lds, ctx->stream, a, kind, with_da ? 1 : 0, img, image_end);
+      break;
+    case 2:
+      if (lds > 64 * 1024) ok = hipFuncSetAttribute(reinterpret_cast<const void*>(vk_image_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+      if (ok) hipLaunchKernelGGL(vk_image_kernel<2>, dim3(1), dim3(kBlock), lds, ctx->stream, a, kind, with_da ? 1 : 0, img, image_end);
+      break;
+    default:
+      if (lds > 64 * 1024) ok = hipFuncSetAttribute(reinterpret_cast<const void*>(vk_image_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+      if (ok) hipLaunchKernelGGL(vk_image_kernel<3>, dim3(1), dim3(kBlock), lds, ctx->stream, a, kind, with_da ? 1 : 0, img, image_end);
+      break;
+  }
+  if (!ok || hipGetLastError() != hipSuccess) {
+    (void)hipFree(img);
+    return nullptr;
+  }
+  ctx->images[key] = img;       // same stream as the launches that will read it: ordered without a host sync
+  return img;
+}
+
 // idx / d as one mul_hi: exact for every idx < 2^32 / d when magic = ceil(2^32 / d) (the planes here are < 2^22)
 unsigned div_magic(int d) { return (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
 
@@ -422,6 +478,7 @@ unsigned div_magic(int d) { return (unsigned)((0x100000000ULL + (unsigned)d - 1)
 int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool* fused) {
   if (fused) *fused = false;
   if (a.n <= 0) return VK_OK;
+  if (a.n > (1LL << 31) / ((long long)a.n_s * kMaxParts)) return fail(ctx, VK_E_ARG, "batch of %lld points is too large for one launch", a.n);
   const int N = a.n_ell * a.n_s;
   choose_split(ctx, a.n, a.n_s, &a.sbins_per_item, &a.team, &a.parts);
   a.exp_tab = ctx->d_exp_tab;
@@ -430,6 +487,16 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
   a.counters = ctx->d_counters;
   a.partial = ctx->d_partial;
   a.fuse = 0;
+  a.image = nullptr;
+#ifdef VK_PHASES
+  {
+    static long long* d_stamps = nullptr;
+    if (!d_stamps) (void)hipMalloc((void**)&d_stamps, 4096 * 8 * sizeof(long long));
+    (void)hipMemsetAsync(d_stamps, 0, 4096 * 8 * sizeof(long long), ctx->stream);
+    a.stamps = d_stamps;
+    g_stamps = d_stamps;
+  }
+#endif
   // the fast kernel (streaming only) packs LDS byte offsets of the mu and (x, w) records into 16 bits each
   // fast kernels: the streaming model, and the dispersion model on fixed velocity tables (cells / point-major only)
   const bool disp = a.rsd == VK_RSD_DISPERSION && a.uni_da && (!a.empirical || a.uni_ge) && !a.vr_beta_dep;
@@ -459,6 +526,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
   if (lanes) {
     ctx->last_kernel = "vk_theory_lanes_kernel";
     a.parts = 1;
+    a.image = get_image(ctx, a, 2, nlr, false, make_lanes_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.uni_lut_n).image_end);
     const long long blocks = blocks_l;
     // One workgroup per four items, never a grid-stride loop by default: letting the dispatcher refill CUs as
     // workgroups retire measured 38.1 / 36.0 / 34.6 / 33.8 ms at 4 / 8 / 16 / 64 workgroups per CU on the bench workload
@@ -488,11 +556,12 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
     a.parts = S;
     a.fuse = want_fuse && (S == 1 || a.n <= kCounterCap) ? 1 : 0;
     const bool tail = a.fuse || S > 1;
-    const size_t lds_c = (size_t)make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, disp, S,
-                                                 tail ? N : 0).total * sizeof(double);
+    const CellsPlan plc = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, disp, S, tail ? N : 0);
+    const size_t lds_c = (size_t)plc.total * sizeof(double);
     if (lds_c > 160 * 1024) return fail(ctx, VK_E_ARG, "tables need %zu bytes of LDS (> 160 KiB)", lds_c);
+    a.image = get_image(ctx, a, 1, nlr, disp, plc.image_end);
     const long long items_c = a.n * S;
-    const int grid_c = (int)(items_c < cap ? items_c : cap);
+    const int grid_c = (int)((tail || items_c < cap) ? items_c : cap);     // fused / split launches: one item per workgroup
     if (fused) *fused = a.fuse != 0;
     switch (nlr) {
       case 1: return launch_cells_nl<1>(ctx, a, grid_c, lds_c);
@@ -504,15 +573,16 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
   if (fast) {
     const long long groups = (a.n_s + a.sbins_per_item - 1) / a.sbins_per_item;
     if (a.parts > kMaxParts) a.parts = kMaxParts;
-    if (a.parts > 1 && ((size_t)a.n * a.n_s * a.parts * kMaxEll > ctx->partial_doubles || a.n > kCounterCap)) a.parts = 1;
+    if (a.parts > 1 && ((size_t)a.n * a.n_s * kMaxParts * kMaxEll > ctx->partial_doubles || a.n > kCounterCap)) a.parts = 1;
     const bool need_counters = groups * a.parts > 1;
     a.fuse = want_fuse && (!need_counters || a.n <= kCounterCap) ? 1 : 0;
     const bool tail = a.fuse || a.parts > 1;
-    const size_t lds = (size_t)make_fast_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, disp, tail ? N : 0).total *
-                       sizeof(double);
+    const FastPlan plf = make_fast_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, disp, tail ? N : 0);
+    const size_t lds = (size_t)plf.total * sizeof(double);
     if (lds > 160 * 1024) return fail(ctx, VK_E_ARG, "tables need %zu bytes of LDS (> 160 KiB)", lds);
+    a.image = get_image(ctx, a, 0, nlr, disp, plf.image_end);
     const long long items = a.n * groups * a.parts;
-    const int grid = (int)(items < cap ? items : cap);
+    const int grid = (int)((tail || items < cap) ? items : cap);            // fused / split launches: one item per workgroup
     if (fused) *fused = a.fuse != 0;
     switch (nlr) {
       case 1: return launch_fast_nl<1>(ctx, a, grid, lds);
@@ -657,6 +727,14 @@ void* open_rccl(std::string* how = nullptr) {
 extern "C" {
 
 int vk_abi_version(void) { return VK_ABI_VERSION; }
+
+#ifdef VK_PHASES
+// profiling build only: wall_clock64() marks (100 MHz) of the last point-major launch, [4096][8]
+int vk_debug_read_stamps(long long* out) {
+  if (!g_stamps) return VK_E_ARG;
+  return hipMemcpy(out, g_stamps, 4096 * 8 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? VK_OK : VK_E_HIP;
+}
+#endif
 
 void vk_knobs_refresh(void) { g_knob_gen.fetch_add(1, std::memory_order_relaxed); }
 
@@ -888,7 +966,7 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
     // batch-independent staging tables + bookkeeping of the split / fused launches
     const size_t n_stage = (size_t)t->n_mu * kMuRec;
     ctx->partial_doubles = (size_t)kPartialPoints * t->n_s * kMaxParts * kMaxEll;
-    const size_t aux_doubles = vkm::kExpTab + n_stage + ctx->partial_doubles + (kCounterCap * sizeof(unsigned) + 7) / 8;
+    const size_t aux_doubles = vkm::kExpTab + n_stage + ctx->partial_doubles + (kCounterCap * sizeof(unsigned) + 7) / 8 + 2;
     if ((rc = hipMalloc((void**)&ctx->d_aux, aux_doubles * sizeof(double))) != hipSuccess) return hip_bail(rc, "hipMalloc(aux)");
     if ((rc = hipMemsetAsync(ctx->d_aux, 0, aux_doubles * sizeof(double), ctx->stream)) != hipSuccess)
       return hip_bail(rc, "hipMemset(aux)");
@@ -928,6 +1006,7 @@ void vk_destroy(vk_ctx* ctx) {
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
   if (ctx->d_tables) (void)hipFree(ctx->d_tables);
   if (ctx->d_aux) (void)hipFree(ctx->d_aux);
+  for (auto& kv : ctx->images) (void)hipFree(kv.second);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   for (auto& evt : ctx->ev)
     if (evt) (void)hipEventDestroy(evt);

@@ -11,6 +11,7 @@ constexpr int kBlock = 256;               // 4 wavefronts
 constexpr int kWaves = kBlock / 64;
 constexpr int kMaxEll = 3;
 constexpr int kVrVars = 5;               // V1, Da, V2, Ge1, Ge2 (see vk_tables.vr)
+constexpr int kMaxParts = 8;             // workgroups that may share one (point, s bin) plane of the point-major kernel
 
 // --------------------------------------------------------------------------------------------------
 // device-side views
@@ -92,6 +93,7 @@ struct TheoryArgs {
   // ---- staging tables that do not depend on the batch (built once in vk_create) --------------------------------
   const double* exp_tab;  // [vkm::kExpTab] c4 2^(j/256) (vk_devmath.h), computed on the device so every launch copies the same bits
   const double* stage_mu; // [n_mu][kMuRec] {mu, sqrt(1-mu^2), W_0, W_1, W_2, 0} of the context's own (mu, W) grid, or NULL
+  const double* image;    // LDS image of this kernel variant's batch-constant tables (vk_kernel_fast.h: copy_image), or NULL
   double wsum[3];         // sum_i W_l[i]: the "-1" of ccf_model.py:690 projects to -sum_i W_l[i] (not 0 for l > 0)
   unsigned nx_magic;      // ceil(2^32 / n_x):  idx / n_x  == __umulhi(idx, nx_magic)  for every idx of the (mu, v) plane
   unsigned nmu_magic;     // ceil(2^32 / n_mu): cell / n_mu likewise (cells kernel)
@@ -101,7 +103,16 @@ struct TheoryArgs {
   unsigned* counters;     // [n] workgroups finished per point; zero on entry, reset to zero by the finishing workgroup
   double* partial;        // [n][n_s][parts][kMaxEll] partial projections (point-major, parts > 1)
   LikeArgs like;
+#ifdef VK_PHASES
+  long long* stamps;      // profiling build only (make phases): [workgroup][8] wall_clock64() marks of the point-major kernel
+#endif
 };
+
+#ifdef VK_PHASES
+#define VK_STAMP(a, k) do { if ((a).stamps && threadIdx.x == 0 && blockIdx.x < 4096) (a).stamps[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define VK_STAMP(a, k) do { } while (0)
+#endif
 
 // piecewise-cubic table resident in LDS
 struct PPLds {
@@ -154,6 +165,36 @@ __device__ __forceinline__ double clampd(double u, double lo, double hi) { retur
 
 __device__ __forceinline__ double wave_sum(double v) { return vkm::wave_sum(v); }
 
+// The kernel-argument struct spans ten 64-byte lines and the compiler fetches its fields where it first needs them (they
+// are rematerialised rather than kept in SGPRs), so a workgroup meets the lines one at a time: up to ten dependent
+// round trips from the scalar cache to L2 spread over its serial path.  Touch every line once at kernel entry - all loads in
+// flight together - and the later fetches hit the scalar cache.  Measured on a single-point launch (tools/gpu_phases.py):
+// see DESIGN.md section 5.
+template <int BYTES>
+__device__ __forceinline__ void warm_kernarg_lines() {
+  static_assert(BYTES <= 768, "extend the list of lines");
+  const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+  unsigned d0, d1, d2, d3, d4, d5, d6, d7, d8, d9, d10, d11;
+  asm volatile(
+      "s_load_dword %0, %12, 0x0\n\t"
+      "s_load_dword %1, %12, 0x40\n\t"
+      "s_load_dword %2, %12, 0x80\n\t"
+      "s_load_dword %3, %12, 0xc0\n\t"
+      "s_load_dword %4, %12, 0x100\n\t"
+      "s_load_dword %5, %12, 0x140\n\t"
+      "s_load_dword %6, %12, 0x180\n\t"
+      "s_load_dword %7, %12, 0x1c0\n\t"
+      "s_load_dword %8, %12, 0x200\n\t"
+      "s_load_dword %9, %12, 0x240\n\t"
+      "s_load_dword %10, %12, 0x280\n\t"
+      "s_load_dword %11, %12, 0x2c0\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6), "=&s"(d7), "=&s"(d8), "=&s"(d9),
+        "=&s"(d10), "=&s"(d11)
+      : "s"(kp)
+      : "memory");
+}
+
 // Data handed from one workgroup to another INSIDE a launch (partial projections, theory vectors awaiting their
 // chi-square) is written and read with device-scope relaxed atomics: on gfx950 those are write-through stores / L2-coherent
 // loads (sc1), which is all the coherence the eight per-XCD L2s need.  The alternative - ordinary stores plus
@@ -164,6 +205,24 @@ __device__ __forceinline__ void store_shared(double* p, double v) {
 }
 __device__ __forceinline__ double load_shared(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Eight consecutive doubles written with store_shared(), fetched as four 16-byte L2-coherent loads in flight together
+// (the compiler keeps atomic loads in program order with a wait after each: eight dependent round trips to memory).
+// `p` must be 16-byte aligned; v[0..7] receive p[0..7].
+typedef double vk_shared2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void load_shared_x8(const double* p, double (&v)[8]) {
+  vk_shared2 a, b, c, d;
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off sc1\n\t"
+      "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %2, %4, off offset:32 sc1\n\t"
+      "global_load_dwordx4 %3, %4, off offset:48 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+      : "v"(p)
+      : "memory");
+  v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y; v[6] = d.x; v[7] = d.y;
 }
 
 // "This workgroup finished one of the `total` work items of `point`": returns true (to every thread) in the workgroup
@@ -192,7 +251,7 @@ __device__ __forceinline__ double growth_amplitude(const TheoryArgs& a, const do
   if (a.matter_lb) {
     const double bias = row[VK_P_BIAS];
     if (a.from_data) growth = row[VK_P_BETA] * bias;
-    binv = 1.0 / bias;
+    binv = vkm::recip(bias);
     *extra += bias;
   }
   // velocity template: v_r = growth_t V_t(r/c), growth_t = fsigma8 vt_amp / apar  ==  -gb V_t / (3 aH_true)
@@ -235,25 +294,29 @@ __device__ __forceinline__ PointScalars point_scalars(const TheoryArgs& a, const
     double v = 0.0;
     if (lane < 50) {
       const double m = (lane == 49) ? 1.0 : fma((double)lane, h, 1e-10);
-      v = ps.apar * sqrt(fma(1.0 - m * m, e2, 1.0));
+      double g, ir;
+      vkm::sqrt_rsqrt(fma(1.0 - m * m, e2, 1.0), g, ir);     // <= 2 ulp (vk_devmath.h); the argument is >= min(1, eps^2) > 0
+      v = ps.apar * g;
       if (lane == 0 || lane == 49) v *= 0.5;
     }
     c = wave_sum(v) * h;
   } else {
     c = row[VK_P_ASTAR];
   }
-  ps.inv_c = 1.0 / c;
+  // per-point reciprocals through the refined v_rcp_f64 (<= 1 ulp, vk_devmath.h) instead of IEEE divisions: this set-up is a
+  // serial chain every workgroup runs before it can start, ~3 us of a 15 us single-point launch with the library forms
+  ps.inv_c = vkm::recip(c);
   const double iaH_true = a.iaH * ps.apar;
   double extra = 0.0;
   const double gb = growth_amplitude(a, row, fs8, &ps.av, &extra);
   ps.B = sigv * iaH_true;
-  ps.A = gb / (3.0 * iaH_true * sigv);
-  ps.G = gb / 3.0;
+  ps.A = gb * vkm::recip(3.0 * iaH_true * sigv);
+  ps.G = gb * (1.0 / 3.0);
   ps.gD = gb * ps.inv_c;
   ps.M = row[VK_P_M];
   ps.Q = row[VK_P_Q];
-  ps.inv_aperp = 1.0 / ps.aperp;
-  ps.inv_apar = 1.0 / ps.apar;
+  ps.inv_aperp = vkm::recip(ps.aperp);
+  ps.inv_apar = vkm::recip(ps.apar);
   ps.poison = 0.0 * (gb + sigv + ps.aperp + ps.apar + eps + c + ps.A + extra + (a.n_beta_r > 0 ? row[VK_P_BETA] : 0.0));
   return ps;
 }

@@ -17,7 +17,7 @@ namespace vk {
 // With one workgroup per point the finished theory vector sits in LDS and the chi-square is taken there (`fuse`).
 // --------------------------------------------------------------------------------------------------
 struct CellsPlan {
-  int mu, w, s, betar, acc, da, like, total;
+  int mu, w, s, betar, da, image_end, acc, like, total;
 };
 
 __host__ __device__ inline int cells_slice_bins(int n_s, int parts) { return (n_s + parts - 1) / parts; }
@@ -31,12 +31,31 @@ __host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s,
   p.w = o;     o += kMaxEll * n_mu;                // W_l[i]
   p.s = o;     o += (n_s + 1) & ~1;
   p.betar = o; o += (n_beta_r + 1) & ~1;
+  p.da = o;    o += with_da ? uni_n * 4 : 0;      // Da table of the dispersion model
+  o = (o + 1) & ~1;
+  p.image_end = o;                                 // batch-constant up to here (LDS image, see vk_kernel_fast.h)
   p.acc = o;   o += kMaxEll * (cells_slice_bins(n_s, parts) + 1) * kWaves;   // [l][local bin][wave] (+ one spill bin)
   o = (o + 1) & ~1;
-  p.da = o;    o += with_da ? uni_n * 4 : 0;      // Da table of the dispersion model
   p.like = o;  o += n_like > 0 ? like_lds_doubles(n_like) : 0;
   p.total = o;
   return p;
+}
+
+template <int NLR>
+__device__ __forceinline__ void stage_cells(const TheoryArgs& a, const CellsPlan& pl, double* lds, bool with_da) {
+  const int tid = threadIdx.x;
+  for (int i = tid; i < a.n_mu; i += kBlock) {
+    const double m = a.mu[i];
+    lds[pl.mu + 2 * i] = m;
+    lds[pl.mu + 2 * i + 1] = sqrt(1.0 - m * m);
+#pragma unroll
+    for (int l = 0; l < kMaxEll; ++l) lds[pl.w + l * a.n_mu + i] = (l < a.n_ell) ? a.w_ell[l * a.n_mu + i] : 0.0;
+  }
+  for (int j = tid; j < a.n_s; j += kBlock) lds[pl.s + j] = a.s[j];
+  stage_uni_records<NLR>(a, lds);
+  if (with_da) stage_da<NLR>(a, lds + pl.da);
+  if (a.n_beta_r > 0)
+    for (int i = tid; i < a.n_beta_r; i += kBlock) lds[pl.betar + i] = a.beta_r[i];
 }
 
 // 5 workgroups per CU for the streaming mode (<= 96 VGPRs); the from_data and dispersion modes need more registers and
@@ -44,24 +63,15 @@ __host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s,
 template <int NLR, int NL, int GRID, int MODE>
 __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_theory_cells_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
+  warm_kernarg_lines<sizeof(TheoryArgs)>();
   const int N = a.n_ell * a.n_s;
   const int S = a.parts;
   const bool tail = a.fuse || S > 1;
   const CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, mode_is_dispersion(MODE), S,
                                        tail ? N : 0);
   const int tid = threadIdx.x;
-  for (int i = tid; i < a.n_mu; i += kBlock) {
-    const double m = a.mu[i];
-    lds[pl.mu + 2 * i] = m;
-    lds[pl.mu + 2 * i + 1] = sqrt(1.0 - m * m);
-#pragma unroll
-    for (int l = 0; l < kMaxEll; ++l) lds[pl.w + l * a.n_mu + i] = (l < NL) ? a.w_ell[l * a.n_mu + i] : 0.0;
-  }
-  for (int j = tid; j < a.n_s; j += kBlock) lds[pl.s + j] = a.s[j];
-  stage_uni_records<NLR>(a, lds);
-  if (mode_is_dispersion(MODE)) stage_da<NLR>(a, lds + pl.da);
-  if (a.n_beta_r > 0)
-    for (int i = tid; i < a.n_beta_r; i += kBlock) lds[pl.betar + i] = a.beta_r[i];
+  if (a.image) copy_image(lds, a.image, pl.image_end);
+  else stage_cells<NLR>(a, pl, lds, mode_is_dispersion(MODE));
   const FastConsts fc = make_fast_consts<NLR>(a);
   __syncthreads();
 
@@ -74,11 +84,11 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
   const double* l_s = lds + pl.s;
   const int slots = cells_slice_bins(a.n_s, S) + 1;          // local bins of a slice (+ one that only ever receives zeros)
   double* l_acc = lds + pl.acc;                              // [l][local bin][wave]: each entry touched by one wave only
-  const long long items = a.n * S;
+  const unsigned items = (unsigned)a.n * (unsigned)S;                // the host keeps n * parts below 2^31
 
-  for (long long item = blockIdx.x; item < items; item += gridDim.x) {
-    const long long point = item / S;
-    const int q = (int)(item - point * S);
+  for (unsigned item = blockIdx.x; item < items; item += gridDim.x) {
+    const long long point = item / (unsigned)S;
+    const int q = (int)(item - (unsigned)point * (unsigned)S);
     const int j0 = (int)((long long)a.n_s * q / S), j1 = (int)((long long)a.n_s * (q + 1) / S);   // this slice's s bins
     const int cells = (j1 - j0) * a.n_mu;
     const double* row = a.params + point * VK_NPAR;
@@ -145,6 +155,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
       if (tail && S == 1) th[l * a.n_s + jl] = v;
     }
     if (tail) {
+      // fused / split launches run one item per workgroup and leave from here (see vk_kernel_fast.h)
       if (S == 1) {
         __syncthreads();
         like_point_workgroup(a.like, point, row[VK_P_BETA], th, th + ((N + 1) & ~1));
@@ -154,6 +165,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
           finish_point<NL>(a, point, row[VK_P_BETA], ps.poison, th, false);
         }
       }
+      return;
     }
   }
 }

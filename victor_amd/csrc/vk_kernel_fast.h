@@ -128,15 +128,39 @@ __device__ __forceinline__ void stage_uni_records(const TheoryArgs& a, double* l
 template <int NLR>
 __device__ __forceinline__ void rebuild_uni_xi(const TheoryArgs& a, double* recs, const double* bg, double beta) {
   constexpr int stride = uni_stride(NLR);
+  // PCHIP piece: last i in [1, n-2] with beta >= bg[i], else 0 - a count over the lanes for grids of up to 64 nodes
   int kb = 0;
-  for (int i = 1; i < a.n_beta_r - 1; ++i) kb = (beta >= bg[i]) ? i : kb;
+  if (a.n_beta_r <= 64) {
+    const int lane = threadIdx.x & 63;
+    kb = __popcll(__ballot(lane >= 1 && lane < a.n_beta_r - 1 && beta >= bg[lane < a.n_beta_r ? lane : 0]));
+  } else {
+    for (int i = 1; i < a.n_beta_r - 1; ++i) kb = (beta >= bg[i]) ? i : kb;
+  }
   const double db = beta - bg[kb];
   const int per_l = a.uni_n * 4;
   const size_t stride_l = (size_t)(a.n_beta_r - 1) * per_l * 4;
-  for (int e = threadIdx.x; e < NLR * per_l; e += kBlock) {
-    const int l = e / per_l, iq = e - l * per_l;
-    const double* c = ((NLR > 1) ? a.uni_xic : a.uni_xi) + l * stride_l + ((size_t)kb * per_l + iq) * 4;
-    recs[(iq >> 2) * stride + 8 + 4 * l + (iq & 3)] = fma(fma(fma(c[3], db, c[2]), db, c[1]), db, c[0]);
+  const double* src = ((NLR > 1) ? a.uni_xic : a.uni_xi) + (size_t)kb * per_l * 4;
+  const int total = NLR * per_l;
+  // four entries per thread per pass, their eight 16-byte coefficient loads in flight together
+  for (int base = threadIdx.x; base < total; base += 4 * kBlock) {
+    vk_d2 c01[4], c23[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = min(base + k * kBlock, total - 1);
+      const int l = (NLR > 2 && e >= 2 * per_l) ? 2 : ((NLR > 1 && e >= per_l) ? 1 : 0);
+      const double* c = src + l * stride_l + (size_t)(e - l * per_l) * 4;
+      c01[k] = *reinterpret_cast<const vk_d2*>(c);
+      c23[k] = *reinterpret_cast<const vk_d2*>(c + 2);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = base + k * kBlock;
+      if (e < total) {
+        const int l = (NLR > 2 && e >= 2 * per_l) ? 2 : ((NLR > 1 && e >= per_l) ? 1 : 0);
+        const int iq = e - l * per_l;
+        recs[(iq >> 2) * stride + 8 + 4 * l + (iq & 3)] = fma(fma(fma(c23[k].y, db, c23[k].x), db, c01[k].y), db, c01[k].x);
+      }
+    }
   }
   if (a.vr_beta_dep) {   // linear_bias on a reconstructed real-space ccf: V1 follows xi^r_0(beta) (ccf_model.py:358-370)
     for (int iq = threadIdx.x; iq < per_l; iq += kBlock) {
@@ -316,19 +340,27 @@ __device__ __forceinline__ void rebuild_da_emp(const TheoryArgs& a, double* da, 
 // --------------------------------------------------------------------------------------------------
 __host__ __device__ constexpr int like_lds_doubles(int N) { return ((N + 1) & ~1) + kWaves + 4; }
 
+// partial projections of a split plane: [point][l][s bin][kMaxParts], the parts of one (l, s bin) adjacent (64 bytes)
+__device__ __forceinline__ double* partial_slot(const TheoryArgs& a, long long point, int l, int j) {
+  return a.partial + (((point * kMaxEll + l) * a.n_s + j) * (long long)kMaxParts);
+}
+
 template <int NL>
 __device__ __forceinline__ void finish_point(const TheoryArgs& a, long long point, double beta, double poison, double* th,
                                              bool gather_partials) {
   const int N = a.n_ell * a.n_s;
   double* red = th + ((N + 1) & ~1);
+  const double w0 = a.wsum[0], w1 = a.wsum[1], w2 = a.wsum[2];
   for (int e = threadIdx.x; e < N; e += kBlock) {
     double v;
     if (gather_partials) {
-      const int l = e / a.n_s, j = e - l * a.n_s;
-      const double* p = a.partial + ((point * a.n_s + j) * a.parts) * kMaxEll + l;
+      const int l = (e >= 2 * a.n_s) ? 2 : (e >= a.n_s ? 1 : 0), j = e - l * a.n_s;
+      double part[8];
+      load_shared_x8(partial_slot(a, point, l, j), part);
       v = 0.0;
-      for (int q = 0; q < a.parts; ++q) v += load_shared(p + q * kMaxEll);   // fixed order: independent of which part finished last
-      v = v - (l == 0 ? a.wsum[0] : (l == 1 ? a.wsum[1] : a.wsum[2])) + poison;
+#pragma unroll
+      for (int q = 0; q < kMaxParts; ++q) v += (q < a.parts) ? part[q] : 0.0;   // fixed order: independent of which part finished last
+      v = v - (l == 0 ? w0 : (l == 1 ? w1 : w2)) + poison;
       a.out[point * (long long)N + e] = v;
     } else {
       v = load_shared(a.out + point * (long long)N + e);
@@ -345,8 +377,32 @@ __device__ __forceinline__ void finish_point(const TheoryArgs& a, long long poin
 // per s bin, `parts` workgroups per plane - a single point spreads over n_s * parts workgroups (the reference's calling
 // convention is one point per call, CCFLikelihood.py:32-39).
 // --------------------------------------------------------------------------------------------------
+// Every kernel starts by filling LDS with tables that are the same for the whole batch - and for every launch of a
+// context.  Staging them entry by entry costs a dozen dependent round trips to L2 per workgroup (~10 us, most of a
+// single-point launch), so the host keeps, per kernel variant, an IMAGE of that part of LDS in global memory (made once by
+// vk_image_kernel running the very same staging code) and the kernels copy it with all their loads in flight at once.
+// Plans put the batch-constant regions first: LDS doubles [0, image_end) come from the image.
+__device__ __forceinline__ void copy_image(double* lds, const double* __restrict__ image, int n_doubles) {
+  const vk_d2* src = reinterpret_cast<const vk_d2*>(image);
+  vk_d2* dst = reinterpret_cast<vk_d2*>(lds);
+  const int n2 = n_doubles >> 1;                       // image_end is even
+  for (int base = threadIdx.x; base < n2; base += 8 * kBlock) {
+    vk_d2 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = base + k * kBlock;
+      v[k] = src[i < n2 ? i : base];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = base + k * kBlock;
+      if (i < n2) dst[i] = v[k];
+    }
+  }
+}
+
 struct FastPlan {
-  int murec, xrec, betar, red, da, like, total;
+  int murec, xrec, betar, da, image_end, red, like, total;
 };
 
 __host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int uni_n, int nlr, int n_beta_r, int lut_n,
@@ -357,23 +413,20 @@ __host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int uni_n,
   p.murec = o; o += n_mu * kMuRec;
   p.xrec = o;  o += n_x * 2;
   p.betar = o; o += (n_beta_r + 1) & ~1;
+  p.da = o;    o += with_da ? uni_n * 4 : 0;  // Da table of the dispersion model
+  o = (o + 1) & ~1;
+  p.image_end = o;                            // everything up to here is batch-constant (or rebuilt per point)
   p.red = o;   o += kWaves * kMaxEll;
   o = (o + 1) & ~1;
-  p.da = o;    o += with_da ? uni_n * 4 : 0;  // Da table of the dispersion model
   p.like = o;  o += n_like > 0 ? like_lds_doubles(n_like) : 0;   // theory vector + reduction scratch of the fused tail
   p.total = o;
   return p;
 }
 
-template <int NLR, int NL, int GRID, int MODE>
-__global__ __launch_bounds__(kBlock, 4) void vk_theory_fast_kernel(TheoryArgs a) {
-  extern __shared__ double lds[];
-  const int N = a.n_ell * a.n_s;
-  const int Q = a.parts;
-  const bool tail = a.fuse || Q > 1;
-  const FastPlan pl = make_fast_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, mode_is_dispersion(MODE), tail ? N : 0);
+// batch-constant LDS contents of the point-major kernel (entry by entry: the image builder and the general-grid calls)
+template <int NLR>
+__device__ __forceinline__ void stage_fast(const TheoryArgs& a, const FastPlan& pl, double* lds, bool with_da) {
   const int tid = threadIdx.x;
-  // ---- stage batch-constant tables -------------------------------------------------------------
   if (a.stage_mu) {
     for (int e = tid; e < a.n_mu * kMuRec; e += kBlock) lds[pl.murec + e] = a.stage_mu[e];
   } else {
@@ -383,17 +436,40 @@ __global__ __launch_bounds__(kBlock, 4) void vk_theory_fast_kernel(TheoryArgs a)
       rec[0] = m;
       rec[1] = sqrt(1.0 - m * m);
 #pragma unroll
-      for (int l = 0; l < kMaxEll; ++l) rec[2 + l] = (l < NL) ? a.w_ell[l * a.n_mu + i] : 0.0;
+      for (int l = 0; l < kMaxEll; ++l) rec[2 + l] = (l < a.n_ell) ? a.w_ell[l * a.n_mu + i] : 0.0;
       rec[5] = 0.0;
     }
   }
   for (int e = tid; e < 2 * a.n_x; e += kBlock) lds[pl.xrec + e] = a.xw_scaled[e];     // {kExpScale x_k, w_k}
   stage_uni_records<NLR>(a, lds);
-  if (mode_is_dispersion(MODE)) stage_da<NLR>(a, lds + pl.da);
+  if (with_da) stage_da<NLR>(a, lds + pl.da);
   if (a.n_beta_r > 0)
     for (int i = tid; i < a.n_beta_r; i += kBlock) lds[pl.betar + i] = a.beta_r[i];
+}
+
+template <int NLR, int NL, int GRID, int MODE>
+__global__ __launch_bounds__(kBlock, 3) void vk_theory_fast_kernel(TheoryArgs a) {
+  extern __shared__ double lds[];
+  warm_kernarg_lines<sizeof(TheoryArgs)>();
+  const int N = a.n_ell * a.n_s;
+  const int Q = a.parts;
+  const bool tail = a.fuse || Q > 1;
+  const FastPlan pl = make_fast_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, mode_is_dispersion(MODE), tail ? N : 0);
+  const int tid = threadIdx.x;
+  VK_STAMP(a, 0);
+  // The first work item's per-point scalars (parameter row from global memory, AP integral, reciprocals: a serial chain
+  // of ~1.5 us) are started before the tables are staged so that the two latencies overlap.
+  const int groups = (a.n_s + a.sbins_per_item - 1) / a.sbins_per_item;
+  const unsigned items = (unsigned)a.n * (unsigned)(groups * Q);     // the host keeps n * groups * parts below 2^31
+  unsigned item = blockIdx.x;
+  long long point = item < items ? (item / (unsigned)Q) / (unsigned)groups : 0;
+  PointScalars ps = point_scalars(a, a.params + point * VK_NPAR);
+  // ---- batch-constant tables: from the context's LDS image when there is one ------------------------
+  if (a.image) copy_image(lds, a.image, pl.image_end);
+  else stage_fast<NLR>(a, pl, lds, mode_is_dispersion(MODE));
   const FastConsts fc = make_fast_consts<NLR>(a);
   __syncthreads();
+  VK_STAMP(a, 1);
 
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -401,8 +477,6 @@ __global__ __launch_bounds__(kBlock, 4) void vk_theory_fast_kernel(TheoryArgs a)
   const int nteams = kWaves / team;
   const int my_team = wave / team;
   const int my_rank = wave - my_team * team;
-  const int groups = (a.n_s + a.sbins_per_item - 1) / a.sbins_per_item;
-  const long long items = a.n * groups * Q;
   const int plane = a.n_mu * a.n_x;
   const int step = 64 * team;
   const int rounds = (a.sbins_per_item + nteams - 1) / nteams;
@@ -413,13 +487,11 @@ __global__ __launch_bounds__(kBlock, 4) void vk_theory_fast_kernel(TheoryArgs a)
   const unsigned x_wrap = (unsigned)a.n_x * 16u;
   const unsigned d_mu = (unsigned)(step / a.n_x) * (kMuRec * 8u), d_x = (unsigned)(step % a.n_x) * 16u;
 
-  for (long long item = blockIdx.x; item < items; item += gridDim.x) {
-    const long long pg = item / Q;
-    const int q = (int)(item - pg * Q);
-    const long long point = pg / groups;
-    const int g = (int)(pg - point * groups);
+  while (item < items) {
+    const unsigned pg = item / (unsigned)Q;
+    const int q = (int)(item - pg * (unsigned)Q);
+    const int g = (int)(pg - (unsigned)point * (unsigned)groups);
     const double* row = a.params + point * VK_NPAR;
-    const PointScalars ps = point_scalars(a, row);
     if (a.n_beta_r > 0 || a.empirical) {
       __syncthreads();  // previous item's readers are done with the per-point records
       if (a.n_beta_r > 0) rebuild_uni_xi<NLR>(a, lds + kRecsOff, lds + pl.betar, row[VK_P_BETA]);
@@ -428,6 +500,7 @@ __global__ __launch_bounds__(kBlock, 4) void vk_theory_fast_kernel(TheoryArgs a)
       __syncthreads();
     }
     const FastPoint fp = make_fast_point(ps, fc);
+    VK_STAMP(a, 2);
     const int lo = (int)((long long)plane * q / Q), hi = (int)((long long)plane * (q + 1) / Q);
     const unsigned idx0 = (unsigned)(lo + lane + 64 * my_rank);
     const unsigned i0 = __umulhi(idx0, a.nx_magic);
@@ -471,15 +544,14 @@ __global__ __launch_bounds__(kBlock, 4) void vk_theory_fast_kernel(TheoryArgs a)
 #pragma unroll
       for (int l = 0; l < NL; ++l) acc[l] = wave_sum(acc[l]);
       // this (point, s bin)'s share: final when the plane is not split over workgroups, else a partial for finish_point
-      double* dst = Q > 1 ? a.partial + ((point * a.n_s + j) * Q + q) * kMaxEll
-                          : a.out + point * (long long)N + j;
-      const long long dst_stride = Q > 1 ? 1 : a.n_s;
+      double* dst = Q > 1 ? partial_slot(a, point, 0, j) + q : a.out + point * (long long)N + j;
+      const long long dst_stride = Q > 1 ? (long long)a.n_s * kMaxParts : a.n_s;
       if (team == 1) {
         if (valid && lane < NL) {
           double v = acc[0], ws = a.wsum[0];
 #pragma unroll
           for (int l = 1; l < NL; ++l) {
-            v = (lane == l) ? acc[l] : v;
+            v = (lane == l) ? acc[l < NL ? l : 0] : v;
             ws = (lane == l) ? a.wsum[l] : ws;
           }
           const double r = Q > 1 ? v : v - ws + ps.poison;
@@ -503,11 +575,26 @@ __global__ __launch_bounds__(kBlock, 4) void vk_theory_fast_kernel(TheoryArgs a)
         }
       }
     }
+    VK_STAMP(a, 3);
     if (tail) {
+      // Fused / split launches run ONE item per workgroup (the host sizes the grid so) and leave from here: nothing is
+      // live after the tail, so its registers (the chi-square needs ~100) do not spill the state of the loop above.
       double* th = lds + pl.like;
       int* flag = reinterpret_cast<int*>(th + ((N + 1) & ~1) + kWaves + 2);
-      if (point_completed(a.counters, point, (unsigned)(groups * Q), flag)) {
+      const bool last = point_completed(a.counters, point, (unsigned)(groups * Q), flag);
+      VK_STAMP(a, 4);
+      if (last) {
         finish_point<NL>(a, point, row[VK_P_BETA], ps.poison, th, Q > 1);
+        VK_STAMP(a, 5);
+      }
+      return;
+    }
+    item += gridDim.x;
+    if (item < items) {
+      const long long next = (item / (unsigned)Q) / (unsigned)groups;
+      if (next != point) {
+        point = next;
+        ps = point_scalars(a, a.params + point * VK_NPAR);
       }
     }
   }

@@ -15,7 +15,7 @@ namespace vk {
 // n_s * n/64 wavefronts; the point-major kernel above serves every other case.
 // --------------------------------------------------------------------------------------------------
 struct LanesPlan {
-  int smu, total;
+  int smu, image_end, total;
 };
 
 __host__ __device__ inline LanesPlan make_lanes_plan(int n_mu, int n_x, int uni_n, int nlr, int lut_n) {
@@ -23,8 +23,19 @@ __host__ __device__ inline LanesPlan make_lanes_plan(int n_mu, int n_x, int uni_
   int o = fast_fixed_doubles(uni_n, nlr, lut_n);   // exp table + records first (fixed offsets)
   o = (o + 1) & ~1;
   p.smu = o;   o += 2 * n_mu;           // {mu_i, sqrt(1 - mu_i^2)}
+  p.image_end = o;                      // all of it is batch-constant (LDS image, see vk_kernel_fast.h)
   p.total = o;
   return p;
+}
+
+template <int NLR>
+__device__ __forceinline__ void stage_lanes(const TheoryArgs& a, const LanesPlan& pl, double* lds) {
+  for (int i = threadIdx.x; i < a.n_mu; i += kBlock) {
+    const double m = a.mu[i];
+    lds[pl.smu + 2 * i] = m;
+    lds[pl.smu + 2 * i + 1] = sqrt(1.0 - m * m);
+  }
+  stage_uni_records<NLR>(a, lds);
 }
 
 // per-lane version of point_scalars (each lane integrates its own AP rescaling factor, ccf_model.py:609-611)
@@ -42,25 +53,26 @@ __device__ __forceinline__ PointScalars point_scalars_lane(const TheoryArgs& a, 
     double acc = 0.0;
     for (int m = 0; m < 50; ++m) {
       const double mm = (m == 49) ? 1.0 : fma((double)m, h, 1e-10);
-      const double v = sqrt(fma(1.0 - mm * mm, e2, 1.0));
+      double v, ir;
+      vkm::sqrt_rsqrt(fma(1.0 - mm * mm, e2, 1.0), v, ir);
       acc += (m == 0 || m == 49) ? 0.5 * v : v;
     }
     c = ps.apar * acc * h;
   } else {
     c = row[VK_P_ASTAR];
   }
-  ps.inv_c = 1.0 / c;
+  ps.inv_c = vkm::recip(c);
   const double iaH_true = a.iaH * ps.apar;
   double extra = 0.0;
   const double gb = growth_amplitude(a, row, fs8, &ps.av, &extra);
   ps.B = sigv * iaH_true;
-  ps.A = gb / (3.0 * iaH_true * sigv);
-  ps.G = gb / 3.0;
+  ps.A = gb * vkm::recip(3.0 * iaH_true * sigv);
+  ps.G = gb * (1.0 / 3.0);
   ps.gD = gb * ps.inv_c;
   ps.M = row[VK_P_M];
   ps.Q = row[VK_P_Q];
-  ps.inv_aperp = 1.0 / ps.aperp;
-  ps.inv_apar = 1.0 / ps.apar;
+  ps.inv_aperp = vkm::recip(ps.aperp);
+  ps.inv_apar = vkm::recip(ps.apar);
   ps.poison = 0.0 * (gb + sigv + ps.aperp + ps.apar + eps + c + ps.A + extra);
   return ps;
 }
@@ -70,12 +82,8 @@ __global__ __launch_bounds__(kBlock, 5) void vk_theory_lanes_kernel(TheoryArgs a
   extern __shared__ double lds[];
   const LanesPlan pl = make_lanes_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.uni_lut_n);
   const int tid = threadIdx.x;
-  for (int i = tid; i < a.n_mu; i += kBlock) {
-    const double m = a.mu[i];
-    lds[pl.smu + 2 * i] = m;
-    lds[pl.smu + 2 * i + 1] = sqrt(1.0 - m * m);
-  }
-  stage_uni_records<NLR>(a, lds);
+  if (a.image) copy_image(lds, a.image, pl.image_end);
+  else stage_lanes<NLR>(a, pl, lds);
   const FastConsts fc = make_fast_consts<NLR>(a);
   __syncthreads();
 

@@ -70,18 +70,98 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return s;
 }
 
+// sum_b (sum_{r in [r0, r1)} th[r] P[r][b]) th[b] over this lane's column pairs b = 2 lane, 2 lane + 128, ... (N even), with
+// P = (1-t) P0 + t P1 when BLEND.  The rows of a column pair are streamed through a rolling window of D 16-byte loads:
+// D in flight at any time, so the whole column costs one exposed round trip to L2 plus issue time, in 4 D registers.
+template <bool BLEND>
+__device__ __forceinline__ double like_quadratic(int N, const double* P0, const double* P1, double t, const double* th, int r0,
+                                                 int r1, int lane) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  constexpr int D = BLEND ? 4 : 8;
+  const double omt = 1.0 - t;
+  const int rows = r1 - r0;
+  const unsigned stride = (unsigned)N * 8u;             // bytes; a slice is < 4 GB, so 32-bit byte offsets from its (uniform) base
+  const char* s0 = reinterpret_cast<const char*>(P0);
+  const char* s1 = reinterpret_cast<const char*>(P1);
+  double part = 0.0;
+  for (int b = 2 * lane; b < N; b += 128) {
+    unsigned next = ((unsigned)r0 * (unsigned)N + (unsigned)b) * 8u;   // byte offset of the next row to fetch
+    d2 p[D], q[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      p[j] = d2{0.0, 0.0};
+      q[j] = d2{0.0, 0.0};
+      if (j < rows) {
+        p[j] = *reinterpret_cast<const d2*>(s0 + next);
+        if (BLEND) q[j] = *reinterpret_cast<const d2*>(s1 + next);
+        next += stride;
+      }
+    }
+    double y0 = 0.0, y1 = 0.0;
+    for (int base = 0; base < rows; base += D) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const int i = base + j;
+        const d2 cp = p[j], cq = q[j];
+        if (i + D < rows) {
+          p[j] = *reinterpret_cast<const d2*>(s0 + next);
+          if (BLEND) q[j] = *reinterpret_cast<const d2*>(s1 + next);
+          next += stride;
+        }
+        if (i < rows) {
+          const double w = th[r0 + i];
+          y0 = fma(w, BLEND ? omt * cp.x + t * cq.x : cp.x, y0);
+          y1 = fma(w, BLEND ? omt * cp.y + t * cq.y : cp.y, y1);
+        }
+      }
+    }
+    part = fma(y0, th[b], part);
+    part = fma(y1, th[b + 1], part);
+  }
+  return part;
+}
+
 // chi2 / lnL of ONE point by a whole workgroup (kBlock threads).  On entry `th` (LDS, N doubles) holds the point's theory
 // vector and the workgroup is synchronised; `th` is overwritten with the residual.  `red`: kWaves + 2 doubles of LDS.
-// Threads = (row slice, column): the N columns of the precision matrix are spread over `cols` = 64, 128 or 256 consecutive
-// threads (coalesced rows) and the rows over the kBlock / cols slices, so one point's N^2 products run ~60 deep instead
-// of the N^2 / 64 of the wave-per-point kernel - this is what a batch of one (the reference's calling convention,
-// CCFLikelihood.py:32-39) needs.  ccf_fit.py:349-354 (chi2), :166-193 (data vector), :195-260 (bracket), :444-481.
+// Threads = (row slice, column pair): rows of the precision matrix split over the four waves, lanes over PAIRS of adjacent
+// columns (one 16-byte load serves two), rows streamed through a rolling window of loads (like_quadratic): one point's N^2
+// products cost about one round trip to L2, not the N / 64 * N of the wave-per-point kernel - this is what a batch of one
+// (the reference's calling convention, CCFLikelihood.py:32-39) needs.
+// ccf_fit.py:349-354 (chi2), :166-193 (data vector), :195-260 (bracket), :444-481 (log det, forms, guards).
 __device__ __forceinline__ void like_point_workgroup(const LikeArgs& a, long long point, double beta, double* th, double* red) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
   const int tid = threadIdx.x;
   const double inf = __longlong_as_double(0x7ff0000000000000LL);
-  if (a.n_beta_d > 0) {
-    int k = 0;
+  // Interval searches on the (increasing) beta grids as counts over the threads - one grid value per thread, one
+  // barrier each - instead of loops whose loads the compiler keeps in program order (31 dependent round trips each for
+  // BOSS).  Grids longer than the workgroup fall back to the loops.
+  const bool by_count = a.n_beta_d <= kBlock && a.n_beta_c <= kBlock;
+  int k = 0;                              // PCHIP piece of the data vector: last i in [1, n-2] with beta >= beta_d[i], else 0
+  int lo = 0;
+  double t = 0.0;
+  if (by_count) {
+    if (a.n_beta_d > 0) k = __syncthreads_count(tid >= 1 && tid < a.n_beta_d - 1 && beta >= a.beta_d[tid]);
+    if (a.n_beta_c > 0) {
+      const double g = tid < a.n_beta_c ? a.beta_c[tid] : inf;
+      const int n_lt = __syncthreads_count(tid < a.n_beta_c && g < beta);
+      const int n_eq = __syncthreads_count(tid < a.n_beta_c && g == beta);
+      const int last = a.n_beta_c - 1;
+      if (n_lt == 0 && !n_eq) {
+        lo = 0;                           // below the grid (or NaN): first slice
+      } else if (n_lt == a.n_beta_c) {
+        lo = last;                        // above the grid: last slice
+      } else if (n_eq) {
+        lo = n_lt;                        // exact grid value (ccf_fit.py:221-222)
+      } else {
+        lo = n_lt - 1;
+        t = (beta - a.beta_c[lo]) / (a.beta_c[last] - a.beta_c[lo]);
+      }
+    }
+  } else {
     for (int i = 1; i < a.n_beta_d - 1; ++i) k = (beta >= a.beta_d[i]) ? i : k;
+    if (a.n_beta_c > 0) cov_bracket(a, beta, &lo, &t);
+  }
+  if (a.n_beta_d > 0) {
     const double db = beta - a.beta_d[k];
     const double* piece = a.data + (size_t)k * a.N * 4;
     for (int e = tid; e < a.N; e += kBlock) {
@@ -91,31 +171,29 @@ __device__ __forceinline__ void like_point_workgroup(const LikeArgs& a, long lon
   } else {
     for (int e = tid; e < a.N; e += kBlock) th[e] -= a.data[e];
   }
-  int lo = 0;
-  double t = 0.0;
   const double* P0 = a.prec;
   const double* P1 = a.prec;
   if (a.n_beta_c > 0) {
-    cov_bracket(a, beta, &lo, &t);
     P0 = a.prec + (size_t)lo * a.N * a.N;
     P1 = a.prec + (size_t)(a.n_beta_c - 1) * a.N * a.N;
   }
   __syncthreads();
-  const int cols = a.N <= 64 ? 64 : (a.N <= 128 ? 128 : kBlock);
-  const int slices = kBlock / cols;
-  const int slice = tid / cols;
-  const int rows = (a.N + slices - 1) / slices;
-  const int r0 = slice * rows, r1 = min(a.N, r0 + rows);
+  const int wave = tid >> 6, lane = tid & 63;
+  const int rows = (a.N + kWaves - 1) / kWaves;
+  const int r0 = wave * rows, r1 = min(a.N, r0 + rows);
   const double omt = 1.0 - t;
   double part = 0.0;
-  for (int b = tid - slice * cols; b < a.N; b += cols) {
-    double y = 0.0;
-    if (t != 0.0) {
-      for (int r = r0; r < r1; ++r) y = fma(th[r], omt * P0[(size_t)r * a.N + b] + t * P1[(size_t)r * a.N + b], y);
-    } else {
-      for (int r = r0; r < r1; ++r) y = fma(th[r], P0[(size_t)r * a.N + b], y);
+  if ((a.N & 1) == 0) {
+    part = t != 0.0 ? like_quadratic<true>(a.N, P0, P1, t, th, r0, r1, lane) : like_quadratic<false>(a.N, P0, P1, t, th, r0, r1, lane);
+  } else {
+    for (int b = lane; b < a.N; b += 64) {
+      double y = 0.0;
+      for (int r = r0; r < r1; ++r) {
+        const double p = t != 0.0 ? omt * P0[(size_t)r * a.N + b] + t * P1[(size_t)r * a.N + b] : P0[(size_t)r * a.N + b];
+        y = fma(th[r], p, y);
+      }
+      part = fma(y, th[b], part);
     }
-    part = fma(y, th[b], part);
   }
   const double chisq = block_sum(part, red);
   double factor = 0.0;
@@ -146,7 +224,7 @@ __device__ __forceinline__ void like_point_workgroup(const LikeArgs& a, long lon
 }
 
 // K2 "wide": one workgroup per point (small batches, and the theory kernels that do not carry the fused tail)
-__global__ __launch_bounds__(kBlock) void vk_like_wide_kernel(LikeArgs a) {
+__global__ __launch_bounds__(kBlock, 4) void vk_like_wide_kernel(LikeArgs a) {
   extern __shared__ double lds[];
   double* th = lds;
   double* red = lds + ((a.N + 1) & ~1);
