@@ -582,14 +582,15 @@ def test_fused_and_split_launches_agree_with_separate_kernels(boss_fit, synth_fi
         assert np.max(np.abs(chi / ref_c[:n] - 1)) < 1e-12, tag
 
     with knobs(NO_GRAPH="1"):
-        for n in (1, 2, 3, 17, 64, 200):                                   # default choices
+        for n in (1, 2, 3, 17):                                            # default choices: a handful of points ...
             check(n, "default", "vk_theory_fast_kernel")
-        check(700, "default", "vk_theory_cells_kernel")
+        for n in (24, 64, 200, 700):                                       # ... and cell ranges from two dozen on
+            check(n, "default", "vk_theory_cells_kernel")
         for split in ("1,4,1", "1,4,2", "1,4,4", "1,4,8", "1,2,3", "1,1,2", "4,1,1", "4,1,2", "40,1,1", "40,1,4"):
             with knobs(SPLIT=split, MAPPING="point"):
                 for n in (1, 5, 64):
                     check(n, "split " + split, "vk_theory_fast_kernel")
-        for parts in ("1", "2", "3", "4", "7"):
+        for parts in ("1", "2", "3", "4", "7", "11", "16"):
             with knobs(CELLS_PARTS=parts, MAPPING="cells"):
                 for n in (1, 6, 130, 700):
                     check(n, "cells parts " + parts, "vk_theory_cells_kernel")

@@ -6,6 +6,7 @@ Drop-in for ``victor.CCFFit`` (reference: ``victor/ccf_fit.py:10-483``): same co
 uses for thousands (a batch of one is not special-cased).
 """
 
+import ctypes as C
 import os
 
 import numpy as np
@@ -217,10 +218,36 @@ class CCFFit(CCFModel):
         cov = self.get_interpolated_covariance(params.get("beta", None))
         return float(chi2[0]), cov
 
+    def _single_point_plan(self):
+        """(engine, opts, need_beta, need_fsigma8) of a plain ``log_likelihood(params)`` call, cached until the option
+        dictionaries are changed (they are public attributes in the reference and consulted on every call there)."""
+        plan = getattr(self, "_plan", None)
+        if plan is not None and plan[0] == self.model and plan[1] == self.fit_options:
+            return plan[2]
+        model = self._merged({})
+        self._check_supported(model)
+        fit_options = self._merged_fit({})
+        if fit_options["beta_interpolation"] == "likelihood" and not self.fixed_data:
+            made = None                                         # two evaluations per point: the general path
+        else:
+            eng = self._get_engine(self._engine_key(model), model["simpson_even"])
+            made = (eng, C.byref(eng.make_opts(model, fit_options)), self._needs_beta(model) or not self.fixed_data,
+                    self._needs_fsigma8(model))
+        import copy
+        self._plan = (copy.deepcopy(self.model), copy.deepcopy(self.fit_options), made)
+        return made
+
     def log_likelihood(self, params, **kwargs):
         """(lnL, chi2) at one parameter point (reference: ccf_fit.py:356-483)."""
-        lnl, chi2, _ = self._run(params, kwargs)
-        lnl, chi2 = float(lnl[0]), float(chi2[0])
+        plan = self._single_point_plan() if (not kwargs and type(params) is dict) else None
+        if plan is not None and not any(np.ndim(v) for v in params.values()):
+            eng, opts, need_beta, need_fs8 = plan
+            if not self.fixed_data and params.get("beta", None) is None:
+                raise InputError("Need to supply a valid value of beta for interpolation")   # ccf_fit.py:188-189
+            lnl, chi2 = eng.eval_point(opts, self._scalar_row(params, need_beta, need_fs8))
+        else:
+            lnl, chi2, _ = self._run(params, kwargs)
+            lnl, chi2 = float(lnl[0]), float(chi2[0])
         if lnl == -np.inf and chi2 == np.inf:
             print(f"Likelihood evaluation failed (singular covariance or NaN). Parameters at fail point: {params}")
         return lnl, chi2

@@ -371,17 +371,17 @@ class CCFModel:
         n = next(iter(lengths)) if is_batch else 1    # an empty batch (length 0) is legal
         rows = np.empty((n, N.VK_NPAR))
 
-        if is_batch:
-            def col(v):                               # arrays of length n, scalars broadcast
-                v = np.asarray(v, dtype=float)
-                if v.ndim > 1:
-                    raise InputError("parameter arrays must be one-dimensional")
-                return np.broadcast_to(v, (n,))
-        else:
-            # one point given as scalars (the reference's calling convention, one call per MCMC step): plain floats,
-            # which NumPy broadcasts into the single row without going through np.broadcast_to (47 -> 16 us per call)
-            def col(v):
-                return float(v)
+        if not is_batch:
+            # one point given as scalars (the reference's calling convention, one call per MCMC step): plain Python
+            # floats, one assignment into the row
+            rows[0] = self._scalar_row(params, need_beta, need_fsigma8)
+            return rows
+
+        def col(v):                                   # arrays of length n, scalars broadcast
+            v = np.asarray(v, dtype=float)
+            if v.ndim > 1:
+                raise InputError("parameter arrays must be one-dimensional")
+            return np.broadcast_to(v, (n,))
 
         if need_fsigma8:
             rows[:, N.P_FSIGMA8] = col(params["fsigma8"])        # KeyError if absent, as ccf_model.py:432-435
@@ -411,6 +411,27 @@ class CCFModel:
         rows[:, N.P_AV] = col(get("Av", 0))
         rows[:, N.P_SPARE] = 0.0
         return rows
+
+    def _scalar_row(self, params, need_beta, need_fsigma8=True):
+        """One parameter point given as scalars -> list of VK_NPAR floats in the column order of include/victor_hip.h
+        (reference: ccf_model.py:583-613, 638, 695-696)."""
+        get = params.get
+        fs8 = float(params["fsigma8"]) if need_fsigma8 else float(get("fsigma8", 0.0))   # KeyError as ccf_model.py:432-435
+        if "epsilon" in params:
+            eps = float(params["epsilon"])
+            apar = float(get("alpha", 1)) * eps ** (-2 / 3)
+            aperp = eps * apar
+        else:
+            aperp = float(get("aperp", 1))
+            apar = float(get("apar", 1))
+            eps = aperp / apar
+        if need_beta:
+            beta = float(params["beta"])                           # KeyError if absent, as ccf_model.py:587
+        else:
+            beta = get("beta", None)
+            beta = 0.40 if beta is None else float(beta)
+        return [fs8, float(get("sigma_v", 380)), aperp, apar, eps, beta, float(get("astar", 1)), float(get("M", 1.0)),
+                float(get("Q", 1.0)), float(get("bias", self.model["bias"])), float(get("Av", 0)), 0.0]
 
     def _needs_beta(self, model):
         return not (self.fixed_real_input and model["matter_model"] != "linear_bias")

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kBlock) void vk_image_kernel(TheoryArgs a, int kind
   if (kind == 0) {
     stage_fast<NLR>(a, make_fast_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, with_da, 0), lds, with_da != 0);
   } else if (kind == 1) {
-    stage_cells<NLR>(a, make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, with_da, 1, 0), lds, with_da != 0);
+    stage_cells<NLR>(a, make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, with_da, 64, 0), lds, with_da != 0);
   } else {
     stage_lanes<NLR>(a, make_lanes_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.uni_lut_n), lds);
   }
@@ -94,6 +94,8 @@ struct Knobs {
   int split_q = 0;                     // third field of VICTOR_HIP_SPLIT "spi,team,parts": workgroups per (mu, v) plane
   int cells_parts = 0;                 // VICTOR_HIP_CELLS_PARTS: workgroups per point in the cells kernel (0 = choose)
   int like_wide = -1;                  // VICTOR_HIP_LIKE_WIDE: 1 / 0 force the workgroup-per-point chi2 kernel on / off
+  long long cells_min = -1;            // VICTOR_HIP_CELLS_MIN: smallest batch that takes the cells kernel (-1 = default)
+  bool no_zero_copy = false;           // VICTOR_HIP_NO_ZERO_COPY: small host-buffer batches through the copy / graph path
 };
 
 struct vk_ctx {
@@ -156,11 +158,15 @@ struct vk_ctx {
   std::map<std::string, int> graph_seen;         // a key is captured on its second use (the first one runs eagerly)
   std::map<std::string, const char*> graph_kernel;
   bool graphs_off = false;
+  double* h_zc = nullptr;                       // pinned, device-mapped: params[kZeroCopyMaxN][VK_NPAR] | lnl, chi2 [2 kZeroCopyMaxN]
+  double* d_zc = nullptr;                       // the same memory through the device's eyes
+  bool zero_copy_off = false;
 };
 
 constexpr int64_t kGraphMaxN = 4096;
+constexpr int64_t kZeroCopyMaxN = 32;      // host-buffer batches up to this size: parameters read in place, results written in place
 constexpr long long kCounterCap = 16384;   // points per launch that may share work between workgroups (completion counters)
-constexpr long long kPartialPoints = 64;   // ... for batches up to this many points
+constexpr long long kPartialPoints = 2048;  // batches up to this many points may split a point's work over workgroups (partial sums)
 
 namespace {
 
@@ -184,6 +190,8 @@ void load_knobs(vk_ctx* ctx) {
   if (const char* env = getenv("VICTOR_HIP_FUSE_MAX")) k.fuse_max = atoll(env);
   if (const char* env = getenv("VICTOR_HIP_CELLS_PARTS")) k.cells_parts = atoi(env);
   if (const char* env = getenv("VICTOR_HIP_LIKE_WIDE")) k.like_wide = atoi(env) ? 1 : 0;
+  if (const char* env = getenv("VICTOR_HIP_CELLS_MIN")) k.cells_min = atoll(env);
+  k.no_zero_copy = getenv("VICTOR_HIP_NO_ZERO_COPY") != nullptr;
   k.force_generic = getenv("VICTOR_HIP_FORCE_GENERIC") != nullptr;
   if (const char* env = getenv("VICTOR_HIP_POINT_CAP")) k.point_cap = atoll(env);
   if (const char* env = getenv("VICTOR_HIP_LANES_CAP")) k.lanes_cap = atoll(env);
@@ -503,7 +511,10 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
   const bool fast = (a.rsd == VK_RSD_STREAMING || disp) && ctx->fast_ok && (!a.empirical || a.uni_v2) &&
                     a.n_mu <= 1024 && a.n_x <= 2048 && !ctx->knobs.force_generic;
   // chi-square inside the theory kernel: point-major and cells kernels only, up to fuse_max points (A/B: DESIGN.md section 5)
-  const long long kFuseMaxDefault = 8192;
+  // A/B (tools/gpu_small_batch_ab.py, config 3 / BOSS, resident): the fused launch wins up to ~256 points (64 points: 41.2 vs
+  // 43.7 us, 33.0 vs 34.9), ties at 512 and is 1 % behind the two-launch path from 1024 on (461.5 vs 455.4 us), where the
+  // separate chi-square kernel overlaps the tail of the theory kernel
+  const long long kFuseMaxDefault = 512;
   const long long fuse_max = ctx->knobs.fuse_max >= 0 ? ctx->knobs.fuse_max : kFuseMaxDefault;
   const bool want_fuse = like && !ctx->knobs.no_fuse && a.n <= fuse_max && like_lds_doubles(N) * sizeof(double) <= 32 * 1024;
   if (like) a.like = *like;
@@ -545,22 +556,45 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
   const bool cells_ok = fast && a.n_mu >= 64 && a.n_mu <= 4096 && a.n_x <= 2048;
   // crossover against the point-major kernel measured between 512 and 768 points (config 3) and near 500 (BOSS),
   // tools/gpu_small_batch_ab.py: one workgroup per point needs ~2.5 workgroups per CU to keep the SIMDs fed
-  const bool cells = cells_ok && (mapping ? mapping == 2 : a.n >= (5LL * ctx->n_cu) / 2);
+  // crossover against the point-major kernel (whose finer split wins for a handful of points): config 3 / BOSS 8 points
+  // 21.1 / 20.3 us point-major vs 25.9 / 24.2 cells, 16: 25.7 / 24.5 vs 27.2 / 25.1, 32: 41.3 / 36.7 vs 30.6 / 28.0
+  const long long cells_min = ctx->knobs.cells_min >= 0 ? ctx->knobs.cells_min : 24;
+  const bool cells = cells_ok && (mapping ? mapping == 2 : a.n >= cells_min);
   if (cells) {
     ctx->last_kernel = "vk_theory_cells_kernel";
-    // a point may be shared by `parts` workgroups (contiguous slices of its s bins): finer items balance a launch that is
-    // only one or two residency rounds deep
-    int S = ctx->knobs.cells_parts > 0 ? ctx->knobs.cells_parts : 1;
-    if (S > a.n_s) S = a.n_s;
-    if (S > 1 && a.n > kCounterCap) S = 1;
-    a.parts = S;
-    a.fuse = want_fuse && (S == 1 || a.n <= kCounterCap) ? 1 : 0;
-    const bool tail = a.fuse || S > 1;
-    const CellsPlan plc = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, disp, S, tail ? N : 0);
+    // A point's n_s * n_mu cells may be cut into `parts` ranges, one workgroup each (vk_kernel_cells.h): enough ranges to give
+    // every CU ~6 workgroups when the batch alone would not (a trip per wave - 256 cells - at least, and a range never
+    // so short that an s bin spreads over more than kMaxParts of them); VICTOR_HIP_CELLS_PARTS overrides.
+    const int all_cells = a.n_s * a.n_mu;
+    const int min_cpi = std::max(256, ((a.n_mu + 5) / 7 + 63) / 64 * 64);
+    int R = 1;
+    if (ctx->knobs.cells_parts > 0) {
+      R = ctx->knobs.cells_parts;
+      R = std::max(1, std::min(R, (all_cells + min_cpi - 1) / min_cpi));
+    } else if (a.n <= kPartialPoints) {
+      // measured (tools/gpu_small_batch_ab.py, config 3 / BOSS): ranges of one trip per wave (256 cells) below 128 points, two
+      // below 256, four from there on - 64 points: 56.6 -> 41.7 us against the point-major kernel, 1024 points: 496 -> 462 us
+      // against one workgroup per point; whole trips per wave only (a multiple of 256 cells)
+      const int cpi_want = a.n < 128 ? 256 : (a.n < 256 ? 512 : 1024);
+      R = (all_cells + cpi_want - 1) / cpi_want;
+      R = std::max(1, std::min(R, (all_cells + min_cpi - 1) / min_cpi));
+    }
+    int cpi = ((all_cells + R - 1) / R + 63) / 64 * 64;
+    if (ctx->knobs.cells_parts <= 0 && R > 1) cpi = (cpi + 255) / 256 * 256;
+    R = (all_cells + cpi - 1) / cpi;
+    if (R > 1 && (a.n > kCounterCap || (size_t)a.n * kMaxEll * a.n_s * kMaxParts > ctx->partial_doubles)) {
+      R = 1;
+      cpi = (all_cells + 63) / 64 * 64;
+    }
+    a.parts = R;
+    a.cells_per_item = cpi;
+    a.fuse = want_fuse ? 1 : 0;
+    const bool tail = a.fuse || R > 1;
+    const CellsPlan plc = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, disp, cpi, tail ? N : 0);
     const size_t lds_c = (size_t)plc.total * sizeof(double);
     if (lds_c > 160 * 1024) return fail(ctx, VK_E_ARG, "tables need %zu bytes of LDS (> 160 KiB)", lds_c);
     a.image = get_image(ctx, a, 1, nlr, disp, plc.image_end);
-    const long long items_c = a.n * S;
+    const long long items_c = a.n * R;
     const int grid_c = (int)((tail || items_c < cap) ? items_c : cap);     // fused / split launches: one item per workgroup
     if (fused) *fused = a.fuse != 0;
     switch (nlr) {
@@ -1004,6 +1038,7 @@ void vk_destroy(vk_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   drop_graphs(ctx);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+  if (ctx->h_zc) (void)hipHostFree(ctx->h_zc);
   if (ctx->d_tables) (void)hipFree(ctx->d_tables);
   if (ctx->d_aux) (void)hipFree(ctx->d_aux);
   for (auto& kv : ctx->images) (void)hipFree(kv.second);
@@ -1176,6 +1211,34 @@ static int eval_batch_graph(vk_ctx* ctx, const vk_eval_opts* opts, const double*
   return 1;
 }
 
+// A handful of points (the reference calls the likelihood with ONE, CCFLikelihood.py:32-39): no copies at all.  The parameter
+// rows are placed in pinned host memory that the GPU reads in place (96 bytes per point over the link, overlapped with the
+// staging of the tables) and lnL / chi2 are written straight back into pinned host memory, so the call is one kernel
+// launch and one stream synchronisation instead of a graph of (H2D copy, kernel, D2H copy).
+static int eval_batch_zero_copy(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, int64_t n, double* lnl,
+                                double* chi2, double* d_th) {
+  if (n > kZeroCopyMaxN || ctx->knobs.no_zero_copy || ctx->zero_copy_off || ctx->timing || !(lnl || chi2)) return 0;
+  if (!ctx->h_zc) {
+    void* dev = nullptr;
+    if (hipHostMalloc((void**)&ctx->h_zc, (size_t)kZeroCopyMaxN * (VK_NPAR + 2) * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(&dev, ctx->h_zc, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->zero_copy_off = true;
+      return 0;
+    }
+    ctx->d_zc = static_cast<double*>(dev);
+  }
+  double* h_out = ctx->h_zc + (size_t)kZeroCopyMaxN * VK_NPAR;
+  double* d_out = ctx->d_zc + (size_t)kZeroCopyMaxN * VK_NPAR;
+  memcpy(ctx->h_zc, params, (size_t)n * VK_NPAR * sizeof(double));
+  int rc = vk_eval_batch_device_async(ctx, opts, ctx->d_zc, n, d_out, d_out + n, d_th);
+  if (rc) return rc;
+  VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (lnl) memcpy(lnl, h_out, (size_t)n * sizeof(double));
+  if (chi2) memcpy(chi2, h_out + n, (size_t)n * sizeof(double));
+  return 1;
+}
+
 int vk_eval_batch(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, int64_t n, double* lnl, double* chi2,
                   double* theory) {
   if (!ctx) return VK_E_ARG;
@@ -1198,6 +1261,9 @@ int vk_eval_batch(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, i
   double* d_lnl = d_th + (size_t)n_lay * ctx->N;
   double* d_chi = d_lnl + n;
   if (!theory) {
+    rc = eval_batch_zero_copy(ctx, opts, params, n, lnl, chi2, d_th);
+    if (rc < 0) return rc;
+    if (rc == 1) return VK_OK;
     rc = eval_batch_graph(ctx, opts, params, n, lnl, chi2, d_par, d_th, d_lnl, d_chi);
     if (rc < 0) return rc;
     if (rc == 1) return VK_OK;

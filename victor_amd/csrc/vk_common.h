@@ -99,6 +99,7 @@ struct TheoryArgs {
   unsigned nmu_magic;     // ceil(2^32 / n_mu): cell / n_mu likewise (cells kernel)
   // ---- small and medium batches: finer work split and the chi-square in the same launch ----------------------------
   int parts;              // point-major: workgroups sharing one (point, s-bin group) plane; cells: workgroups per point
+  int cells_per_item;     // cells kernel: (s bin, mu) cells of one work item (multiple of 64); parts = ceil(n_s n_mu / this)
   int fuse;               // 1: the workgroup that completes a point's theory vector also computes its chi2 / lnL (`like`)
   unsigned* counters;     // [n] workgroups finished per point; zero on entry, reset to zero by the finishing workgroup
   double* partial;        // [n][n_s][parts][kMaxEll] partial projections (point-major, parts > 1)

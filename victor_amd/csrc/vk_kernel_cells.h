@@ -5,25 +5,31 @@
 namespace vk {
 
 // --------------------------------------------------------------------------------------------------
-// K1 "cells" variant: the lanes kernel's inner loop for per-point tables (reconstruction beta, BOSS).
-// One workgroup owns one parameter point - or one of `parts` contiguous slices of its s bins - with the xi^r records
-// rebuilt in LDS as in the point-major kernel.  The (s bin, mu) cells of the slice are flattened (s bin major) and dealt to
-// the four waves in trips of 64 (wave w takes trips w, w + 4, ...: every wave gets the same number of trips to within one,
-// whatever n_s is - with whole s bins per wave, 30 bins meant 8 + 8 + 7 + 7), lanes over the cells, the 50 velocity nodes
-// as the inner, wave-uniform loop.  Like the lanes kernel this forms s_perp and s_par once per cell, reads x_k, w_k through
-// the scalar cache and closes the v sum before the projection, so the integrand costs the same instructions; the
-// projection sum over mu is a two-segment wave reduction per trip (a trip's 64 cells straddle at most two s bins when
-// n_mu >= 64), accumulated by lane 0 in wave-private LDS and combined over the waves at the end.
-// With one workgroup per point the finished theory vector sits in LDS and the chi-square is taken there (`fuse`).
+// K1 "cells" variant: the lanes kernel's inner loop for per-point tables (reconstruction beta, BOSS) and for batches too
+// small for the lanes kernel.  A point's n_s * n_mu (s bin, mu) cells are flattened (s bin major) and cut into `parts`
+// ranges of `cells_per_item` cells; one workgroup owns one range of one point, with the xi^r records rebuilt in LDS as in the
+// point-major kernel.  The range is dealt to the four waves in trips of 64 cells (wave w takes trips w, w + 4, ...: every
+// wave gets the same number of trips to within one, whatever n_s is), lanes over the cells, the 50 velocity nodes as the
+// inner, wave-uniform loop.  Like the lanes kernel this forms s_perp and s_par once per cell, reads x_k, w_k through the
+// scalar cache and closes the v sum before the projection, so the integrand costs the same instructions; the projection
+// sum over mu is a two-segment wave reduction per trip (a trip's 64 cells straddle at most two s bins when n_mu >= 64),
+// accumulated by lane 0 in wave-private LDS and combined over the waves at the end.
+//   parts == 1: the finished theory vector sits in LDS and the chi-square is taken there (`fuse`);
+//   parts  > 1: ranges need not respect s-bin boundaries - every (l, s bin) sum is handed over as one partial per
+//               contributing range (partial_slot: at most ceil((n_mu - 1) / cells_per_item) + 1 of them) and the workgroup
+//               that completes the point adds them in range order, so the result does not depend on who finishes last.
+//               64 points x 4000 cells in ranges of 256 are 1024 workgroups of one trip per wave: this is what makes a
+//               64-point batch fill the chip.
 // --------------------------------------------------------------------------------------------------
 struct CellsPlan {
   int mu, w, s, betar, da, image_end, acc, like, total;
 };
 
-__host__ __device__ inline int cells_slice_bins(int n_s, int parts) { return (n_s + parts - 1) / parts; }
+// s bins a range of `cpi` cells can touch
+__host__ __device__ inline int cells_range_bins(int n_mu, int cpi) { return (cpi + n_mu - 2) / n_mu + 1; }
 
 __host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s, int uni_n, int nlr, int n_beta_r,
-                                                     int lut_n, int with_da, int parts, int n_like) {
+                                                     int lut_n, int with_da, int cpi, int n_like) {
   CellsPlan p;
   int o = fast_fixed_doubles(uni_n, nlr, lut_n);          // exp table + records first (fixed offsets)
   o = (o + 1) & ~1;
@@ -34,7 +40,9 @@ __host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s,
   p.da = o;    o += with_da ? uni_n * 4 : 0;      // Da table of the dispersion model
   o = (o + 1) & ~1;
   p.image_end = o;                                 // batch-constant up to here (LDS image, see vk_kernel_fast.h)
-  p.acc = o;   o += kMaxEll * (cells_slice_bins(n_s, parts) + 1) * kWaves;   // [l][local bin][wave] (+ one spill bin)
+  int bins = cells_range_bins(n_mu, cpi);
+  if (bins > n_s) bins = n_s;
+  p.acc = o;   o += kMaxEll * (bins + 1) * kWaves;   // [l][local bin][wave] (+ one spill bin)
   o = (o + 1) & ~1;
   p.like = o;  o += n_like > 0 ? like_lds_doubles(n_like) : 0;
   p.total = o;
@@ -58,6 +66,28 @@ __device__ __forceinline__ void stage_cells(const TheoryArgs& a, const CellsPlan
     for (int i = tid; i < a.n_beta_r; i += kBlock) lds[pl.betar + i] = a.beta_r[i];
 }
 
+// The workgroup that completed a point whose cells were split into ranges: add every (l, s bin)'s partials in range order,
+// publish the theory vector, take the chi-square.  `th`: LDS, see like_lds_doubles.
+template <int NL>
+__device__ __forceinline__ void finish_point_ranges(const TheoryArgs& a, long long point, double beta, double poison, double* th) {
+  const int N = a.n_ell * a.n_s;
+  const double w0 = a.wsum[0], w1 = a.wsum[1], w2 = a.wsum[2];
+  for (int e = threadIdx.x; e < N; e += kBlock) {
+    const int l = (e >= 2 * a.n_s) ? 2 : (e >= a.n_s ? 1 : 0), j = e - l * a.n_s;
+    const int q_first = (j * a.n_mu) / a.cells_per_item, q_last = (j * a.n_mu + a.n_mu - 1) / a.cells_per_item;
+    double part[8];
+    load_shared_x8(partial_slot(a, point, l, j), part);
+    double v = 0.0;
+#pragma unroll
+    for (int c = 0; c < kMaxParts; ++c) v += (c <= q_last - q_first) ? part[c] : 0.0;
+    v = v - (l == 0 ? w0 : (l == 1 ? w1 : w2)) + poison;
+    a.out[point * (long long)N + e] = v;
+    th[e] = v;
+  }
+  __syncthreads();
+  if (a.fuse) like_point_workgroup(a.like, point, beta, th, th + ((N + 1) & ~1));
+}
+
 // 5 workgroups per CU for the streaming mode (<= 96 VGPRs); the from_data and dispersion modes need more registers and
 // run 4 per CU without spills
 template <int NLR, int NL, int GRID, int MODE>
@@ -65,15 +95,18 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
   extern __shared__ double lds[];
   warm_kernarg_lines<sizeof(TheoryArgs)>();
   const int N = a.n_ell * a.n_s;
-  const int S = a.parts;
-  const bool tail = a.fuse || S > 1;
-  const CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, mode_is_dispersion(MODE), S,
+  const int R = a.parts;
+  const int cpi = a.cells_per_item;
+  const bool tail = a.fuse || R > 1;
+  const CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, mode_is_dispersion(MODE), cpi,
                                        tail ? N : 0);
   const int tid = threadIdx.x;
+  VK_STAMP(a, 0);
   if (a.image) copy_image(lds, a.image, pl.image_end);
   else stage_cells<NLR>(a, pl, lds, mode_is_dispersion(MODE));
   const FastConsts fc = make_fast_consts<NLR>(a);
   __syncthreads();
+  VK_STAMP(a, 1);
 
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -82,15 +115,17 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
   typedef const vk_d2 __attribute__((address_space(4))) * cvec_ptr;
   const cvec_ptr cxw = (cvec_ptr)(unsigned long long)a.xw_scaled;
   const double* l_s = lds + pl.s;
-  const int slots = cells_slice_bins(a.n_s, S) + 1;          // local bins of a slice (+ one that only ever receives zeros)
+  const int slots = min(cells_range_bins(a.n_mu, cpi), a.n_s) + 1;   // local bins of a range (+ one that only ever receives zeros)
   double* l_acc = lds + pl.acc;                              // [l][local bin][wave]: each entry touched by one wave only
-  const unsigned items = (unsigned)a.n * (unsigned)S;                // the host keeps n * parts below 2^31
+  const unsigned items = (unsigned)a.n * (unsigned)R;                // the host keeps n * parts below 2^31
+  const int all_cells = a.n_s * a.n_mu;
 
   for (unsigned item = blockIdx.x; item < items; item += gridDim.x) {
-    const long long point = item / (unsigned)S;
-    const int q = (int)(item - (unsigned)point * (unsigned)S);
-    const int j0 = (int)((long long)a.n_s * q / S), j1 = (int)((long long)a.n_s * (q + 1) / S);   // this slice's s bins
-    const int cells = (j1 - j0) * a.n_mu;
+    const long long point = item / (unsigned)R;
+    const int q = (int)(item - (unsigned)point * (unsigned)R);
+    const int c0 = q * cpi, c1 = min(c0 + cpi, all_cells);           // this item's cells
+    const int jf = (int)__umulhi((unsigned)c0, a.nmu_magic);         // first s bin it touches
+    const int nb = (int)__umulhi((unsigned)(c1 - 1), a.nmu_magic) - jf + 1;
     const double* row = a.params + point * VK_NPAR;
     const PointScalars ps = point_scalars(a, row);
     __syncthreads();      // every wave is done with the previous item's records and accumulators
@@ -102,13 +137,15 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
     for (int e = lane; e < kMaxEll * slots; e += 64) l_acc[e * kWaves + wave] = 0.0;
     __syncthreads();
     const FastPoint fp = make_fast_point(ps, fc);
-    for (int base = 64 * wave; base < cells; base += 64 * kWaves) {
+    VK_STAMP(a, 2);
+    for (int base = c0 + 64 * wave; base < c1; base += 64 * kWaves) {
       const int e = base + lane;
-      const bool live = e < cells;
-      const unsigned ec = (unsigned)(live ? e : cells - 1);
-      const int jj = (int)__umulhi(ec, a.nmu_magic);           // ec / n_mu
-      const int i = (int)ec - jj * a.n_mu;
-      const double sj = l_s[j0 + jj];
+      const bool live = e < c1;
+      const unsigned ec = (unsigned)(live ? e : c1 - 1);
+      const int j = (int)__umulhi(ec, a.nmu_magic);            // ec / n_mu
+      const int i = (int)ec - j * a.n_mu;
+      const int jj = j - jf;
+      const double sj = l_s[j];
       const vk_d2 mm = *reinterpret_cast<const vk_d2*>(l_mu + 2 * i);
       const double s_perp = sj * fp.k_perp * mm.y;
       const double sperp2 = s_perp * s_perp;
@@ -141,28 +178,37 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
         }
       }
     }
-    // the slice's part of the theory vector is complete in LDS once every wave has finished its trips
+    // this range's share of the theory vector is complete in LDS once every wave has finished its trips
     __syncthreads();
-    const int nb = j1 - j0;
     double* th = lds + pl.like;
     for (int e = tid; e < NL * nb; e += kBlock) {
       const int l = e / nb, jl = e - l * nb;
+      const int j = jf + jl;
       const double* pa = l_acc + (l * slots + jl) * kWaves;
-      const double ws = l == 0 ? a.wsum[0] : (l == 1 ? a.wsum[1] : a.wsum[2]);
-      const double v = ((pa[0] + pa[1]) + (pa[2] + pa[3])) - ws + ps.poison;
-      double* dst = a.out + point * (long long)N + l * a.n_s + j0 + jl;
-      if (S > 1) store_shared(dst, v); else *dst = v;
-      if (tail && S == 1) th[l * a.n_s + jl] = v;
+      const double sum = (pa[0] + pa[1]) + (pa[2] + pa[3]);
+      if (R > 1) {
+        store_shared(partial_slot(a, point, l, j) + (q - (j * a.n_mu) / cpi), sum);
+      } else {
+        const double v = sum - (l == 0 ? a.wsum[0] : (l == 1 ? a.wsum[1] : a.wsum[2])) + ps.poison;
+        a.out[point * (long long)N + l * a.n_s + j] = v;
+        if (tail) th[l * a.n_s + j] = v;
+      }
     }
+    VK_STAMP(a, 3);
     if (tail) {
       // fused / split launches run one item per workgroup and leave from here (see vk_kernel_fast.h)
-      if (S == 1) {
+      if (R == 1) {
         __syncthreads();
+        VK_STAMP(a, 4);
         like_point_workgroup(a.like, point, row[VK_P_BETA], th, th + ((N + 1) & ~1));
+        VK_STAMP(a, 5);
       } else {
         int* flag = reinterpret_cast<int*>(th + ((N + 1) & ~1) + kWaves + 2);
-        if (point_completed(a.counters, point, (unsigned)S, flag)) {
-          finish_point<NL>(a, point, row[VK_P_BETA], ps.poison, th, false);
+        const bool last = point_completed(a.counters, point, (unsigned)R, flag);
+        VK_STAMP(a, 4);
+        if (last) {
+          finish_point_ranges<NL>(a, point, row[VK_P_BETA], ps.poison, th);
+          VK_STAMP(a, 5);
         }
       }
       return;

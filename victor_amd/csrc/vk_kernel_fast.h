@@ -341,8 +341,11 @@ __device__ __forceinline__ void rebuild_da_emp(const TheoryArgs& a, double* da, 
 __host__ __device__ constexpr int like_lds_doubles(int N) { return ((N + 1) & ~1) + kWaves + 4; }
 
 // partial projections of a split plane: [point][l][s bin][kMaxParts], the parts of one (l, s bin) adjacent (64 bytes)
+__device__ __forceinline__ double* partial_slot(double* partial, int n_s, long long point, int l, int j) {
+  return partial + (((point * kMaxEll + l) * n_s + j) * (long long)kMaxParts);
+}
 __device__ __forceinline__ double* partial_slot(const TheoryArgs& a, long long point, int l, int j) {
-  return a.partial + (((point * kMaxEll + l) * a.n_s + j) * (long long)kMaxParts);
+  return partial_slot(a.partial, a.n_s, point, l, j);
 }
 
 template <int NL>

@@ -374,6 +374,21 @@ class Engine:
                                             N.as_dp(chi2), N.as_dp(theory) if want_theory else None))
         return lnl, chi2, theory
 
+    def eval_point(self, opts, row):
+        """One point (a list of VK_NPAR floats) through ``vk_eval_batch`` with preallocated buffers: the single-point calls
+        of an MCMC driver spend as long in Python as on the GPU, so nothing is allocated or converted per call."""
+        one = getattr(self, "_one", None)
+        if one is None:
+            buf = np.empty((1, N.VK_NPAR))
+            out = np.empty(2)
+            one = self._one = (buf, out, N.as_dp(buf), N.as_dp(out[0:1]), N.as_dp(out[1:2]))
+        buf, out, p_rows, p_lnl, p_chi = one
+        buf[0] = row
+        rc = self._lib.vk_eval_batch(self._ctx, opts, p_rows, 1, p_lnl, p_chi, None)
+        if rc != 0:
+            self._check(rc)
+        return float(out[0]), float(out[1])
+
     def theory_vector_batch(self, opts, rows):
         rows = N.f64(rows).reshape(-1, N.VK_NPAR)
         n = len(rows)
