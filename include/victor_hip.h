@@ -253,6 +253,17 @@ int vk_eval_batch_device_async(vk_ctx* ctx, const vk_eval_opts* opts, const doub
                                int64_t n, double* d_lnl, double* d_chi2, double* d_theory_ws);
 int vk_sync(vk_ctx* ctx);
 
+/* ---- joint fit of several data vectors sharing one parameter batch (block-diagonal covariance) ----------------------
+ * BASELINE config 5 (density-split quantiles: five CCFFit-equivalents, N = 5 x 120): the reference has no joint class
+ * (density-split centres are only mentioned, victor/ccf_model.py:28-30); with a block-diagonal covariance chi2 and lnL of
+ * the blocks add.  One context per block, all on one device; ONE parameter upload, every block's two kernels enqueued on its
+ * own stream behind the lead context's stream (the launches overlap on the GPU), lnL and chi2 summed on the device in block
+ * order; a block that fails its guards (-inf, inf) fails the point.  Enqueued; vk_sync(ctxs[0]) waits for the result.
+ * d_ws: vk_joint_workspace_doubles(...) doubles of device memory. */
+size_t vk_joint_workspace_doubles(vk_ctx* const* ctxs, int32_t n_ctx, int64_t n);
+int vk_joint_eval_device_async(vk_ctx* const* ctxs, int32_t n_ctx, const vk_eval_opts* opts, const double* d_params,
+                               int64_t n, double* d_lnl, double* d_chi2, double* d_ws);
+
 /* ---- timing on the context's stream (HIP events) ------------------------------------ */
 /* Marks: 0 = before theory kernel, 1 = between kernels, 2 = after likelihood kernel, recorded by
  * the next vk_eval_batch_device_async when enabled.  Times accumulate until reset. */

@@ -87,6 +87,20 @@ def test_density_split_joint_fit():
     assert np.max(np.abs(lnl + 0.5 * chi2)) < 1e-9 * np.max(chi2)
     parts = sum(f.log_likelihood_batch({k: v[:64] for k, v in hp.items()})[1] for f in joint.fits)
     assert np.max(np.abs(parts / chi2[:64] - 1)) < 1e-12      # sub-batches use a different work split / summation order
+    # the device-resident joint path (one upload, five table sets on their own streams, sums on the device) against one
+    # host call per block; and per-block options that differ take the per-block route
+    seq_l, seq_c = joint._sequential(hp, {})
+    assert np.max(np.abs(seq_c / chi2 - 1)) < 1e-12 and np.max(np.abs(seq_l / lnl - 1)) < 1e-12
+    assert joint._plan({}) is not None
+    lnl_h, chi_h = joint.log_likelihood_batch({k: v[:300] for k, v in hp.items()}, likelihood={"form": "hartlap", "nmocks": 2000})
+    seq_l, seq_c = joint._sequential({k: v[:300] for k, v in hp.items()}, {"likelihood": {"form": "hartlap", "nmocks": 2000}})
+    assert np.max(np.abs(seq_l / lnl_h - 1)) < 1e-12
+    bad = {k: v[:5].copy() for k, v in hp.items()}
+    bad["sigma_v"][3] = np.nan
+    lnl_b, chi_b = joint.log_likelihood_batch(bad)
+    assert np.isneginf(lnl_b[3]) and np.isposinf(chi_b[3]) and np.all(np.isfinite(lnl_b[[0, 1, 2, 4]]))
+    one = joint.log_likelihood(pts[0])
+    assert abs(one[1] / g["dsplit_chi2"][0] - 1) < 1e-9
 
 
 def test_walker_example_under_torchrun_single_rank():

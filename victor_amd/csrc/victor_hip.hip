@@ -60,6 +60,24 @@ __global__ __launch_bounds__(kBlock) void vk_image_kernel(TheoryArgs a, int kind
   for (int e = threadIdx.x; e < n; e += kBlock) image[e] = lds[e];
 }
 
+// joint fits (block-diagonal covariance): lnL and chi2 of the blocks add, in block order; a failed block fails the point
+__global__ void vk_joint_sum_kernel(const double* ws, long long n, int n_ctx, long long block_stride, double* lnl, double* chi2) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double l = 0.0, c = 0.0;
+  for (int q = 0; q < n_ctx; ++q) {
+    l += ws[q * block_stride + i];
+    c += ws[q * block_stride + n + i];
+  }
+  const double inf = __longlong_as_double(0x7ff0000000000000LL);
+  if (!(fabs(l) < inf)) {          // -inf from a block's guard, or NaN
+    l = -inf;
+    c = inf;
+  }
+  if (lnl) lnl[i] = l;
+  if (chi2) chi2[i] = c;
+}
+
 // vk_create: the tables every launch copies into LDS unchanged - the scaled exp table of vk_devmath.h and the mu records
 // {mu, sqrt(1 - mu^2), W_0, W_1, W_2, 0} of the context's own grid - computed once, on the device (same bits as the
 // in-kernel staging of the general-grid entry points)
@@ -136,6 +154,8 @@ struct vk_ctx {
   double* d_partial = nullptr;         // [partial_doubles]
   size_t partial_doubles = 0;
   double wsum[3] = {0, 0, 0};
+  int depth_mult = 1;                // joint fits: launches of this many contexts share the GPU (vk_joint_eval_device_async)
+  hipEvent_t ev_joint = nullptr;
   std::map<int, double*> images;     // LDS images per (kernel kind, real-space multipoles, dispersion tables), built on first use
   const char* last_kernel = "none";  // theory kernel variant of the most recent launch
   bool last_fused = false;           // ... and whether it took the chi-square as well
@@ -533,7 +553,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
   const size_t lds_l = (size_t)make_lanes_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.uni_lut_n).total * sizeof(double);
   const long long wg_per_cu = std::max<long long>(1, std::min<long long>(5, (160 * 1024) / (lds_l ? lds_l : 1)));
   const bool lanes = lanes_ok && lds_l <= 160 * 1024 &&
-                     (mapping ? mapping == 3 : blocks_l >= 4 * wg_per_cu * ctx->n_cu);
+                     (mapping ? mapping == 3 : blocks_l * ctx->depth_mult >= 4 * wg_per_cu * ctx->n_cu);
   if (lanes) {
     ctx->last_kernel = "vk_theory_lanes_kernel";
     a.parts = 1;
@@ -1045,6 +1065,7 @@ void vk_destroy(vk_ctx* ctx) {
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   for (auto& evt : ctx->ev)
     if (evt) (void)hipEventDestroy(evt);
+  if (ctx->ev_joint) (void)hipEventDestroy(ctx->ev_joint);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1151,6 +1172,55 @@ int vk_eval_batch_device_async(vk_ctx* ctx, const vk_eval_opts* opts, const doub
     VK_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     ctx->pending = true;
   }
+  return VK_OK;
+}
+
+size_t vk_joint_workspace_doubles(vk_ctx* const* ctxs, int32_t n_ctx, int64_t n) {
+  if (!ctxs || n_ctx < 1 || n < 0) return 0;
+  int n_max = 0;
+  for (int q = 0; q < n_ctx; ++q)
+    if (ctxs[q] && ctxs[q]->N > n_max) n_max = ctxs[q]->N;
+  return (size_t)n_ctx * (size_t)n * (n_max + 2);
+}
+
+int vk_joint_eval_device_async(vk_ctx* const* ctxs, int32_t n_ctx, const vk_eval_opts* opts, const double* d_params, int64_t n,
+                               double* d_lnl, double* d_chi2, double* d_ws) {
+  if (!ctxs || n_ctx < 1 || !ctxs[0]) return VK_E_ARG;
+  vk_ctx* lead = ctxs[0];
+  for (int q = 0; q < n_ctx; ++q) {
+    if (!ctxs[q]) return fail(lead, VK_E_ARG, "context %d is NULL", q);
+    if (ctxs[q]->device != lead->device) return fail(lead, VK_E_ARG, "joint fit: every context must live on the same device");
+    if (!ctxs[q]->d_data) return fail(lead, VK_E_ARG, "joint fit: context %d was created without a data vector", q);
+  }
+  if (n < 0 || (n > 0 && (!d_params || !d_ws || !(d_lnl || d_chi2)))) return fail(lead, VK_E_ARG, "bad device buffers");
+  if (n == 0) return VK_OK;
+  VK_HIP(lead, hipSetDevice(lead->device));
+  int n_max = 0;
+  for (int q = 0; q < n_ctx; ++q) n_max = std::max(n_max, ctxs[q]->N);
+  const long long block_stride = (long long)n * (n_max + 2);    // per block: lnl[n] | chi2[n] | theory workspace [n][N]
+  for (int q = 0; q < n_ctx; ++q)
+    if (!ctxs[q]->ev_joint) VK_HIP(lead, hipEventCreateWithFlags(&ctxs[q]->ev_joint, hipEventDisableTiming));
+  // the blocks run on their own streams, all behind what the lead stream has enqueued so far (e.g. the parameter upload)
+  VK_HIP(lead, hipEventRecord(lead->ev_joint, lead->stream));
+  for (int q = 0; q < n_ctx; ++q) {
+    vk_ctx* c = ctxs[q];
+    if (q > 0) VK_HIP(lead, hipStreamWaitEvent(c->stream, lead->ev_joint, 0));
+    double* blk = d_ws + q * block_stride;
+    c->depth_mult = n_ctx;       // the launches overlap on the GPU: the lanes kernel's depth rule sees all of them
+    const int rc = vk_eval_batch_device_async(c, opts, d_params, n, blk, blk + n, blk + 2 * n);
+    c->depth_mult = 1;
+    if (rc) {
+      if (c != lead) lead->err = c->err;
+      return rc;
+    }
+  }
+  for (int q = 1; q < n_ctx; ++q) {
+    VK_HIP(lead, hipEventRecord(ctxs[q]->ev_joint, ctxs[q]->stream));
+    VK_HIP(lead, hipStreamWaitEvent(lead->stream, ctxs[q]->ev_joint, 0));
+  }
+  hipLaunchKernelGGL(vk_joint_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lead->stream, d_ws, (long long)n, n_ctx,
+                     block_stride, d_lnl, d_chi2);
+  VK_HIP(lead, hipGetLastError());
   return VK_OK;
 }
 
