@@ -12,7 +12,9 @@ Inputs are resident in HBM before the timed region; outputs stay in HBM.
 
 For N > 1 the driver launches one process per GPU with torch.distributed.run; torch is used only for the
 host-side rendezvous (gloo: barriers, the RCCL unique id, max-over-ranks of the time).  The data path
-is libvictor_hip.so + RCCL.
+is libvictor_hip.so + RCCL.  After the weak-scaling line's timed loop a multi-rank run also times a fixed global batch
+(65536 points in total, `strong_scaling`) and every rank checks the whole gathered lnL vector against its own
+recomputation of rows from every other rank's shard.
 """
 
 import argparse
@@ -120,6 +122,22 @@ def cpu_baseline(sample_pts, rule):
     return {"evals_per_s": len(sample_pts) / busy, "cores": cores, "wall_s": wall, "busy_s": busy}, vals, theory
 
 
+def cpu_single_thread(sample_pts, rule):
+    """The same oracle in ONE process on ONE thread (SURVEY.md 8(d) leg (i)), timed in a child process so that this
+    process has not touched the GPU yet and the BLAS thread count is pinned before NumPy is imported."""
+    import multiprocessing as mp
+    with mp.get_context("spawn").Pool(1) as pool:
+        _, busy, out, _ = pool.map(cpu_worker, [(0, sample_pts, rule)])[0]
+    return {"evals_per_s": len(sample_pts) / busy, "busy_s": busy, "n": len(sample_pts)}
+
+
+def free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
 def warm_up(eng, launch, seconds=0.3):
     """Run ``launch`` back to back for ``seconds``: the HIP runtime stalls once (~75 ms, kernels unaffected) some tens
     of milliseconds after fresh allocations, which must not land in a short timed window."""
@@ -192,6 +210,66 @@ def batch_sweep():
     return res
 
 
+def api_latency():
+    """Wall-clock of the reference's calling convention - one parameter point per call (CCFLikelihood.py:32-39) - through the
+    Python API, host buffers in and out, and the PCIe-inclusive rate of a full host-buffer batch."""
+    import victor_amd
+    from tests import cases
+    res = {}
+    for name, opts, beta in (("config3", cases.synth_options(CONFIG), False), ("boss_cmass", cases.boss_options("config"), True)):
+        fit = victor_amd.CCFFit(*opts)
+        hp = cases.halton_params(BATCH_PER_GPU, with_beta=beta)
+        p = cases.point(hp, 3)
+        t_end = time.perf_counter() + 0.4      # past the runtime's one-off stall after fresh allocations (see warm_up)
+        while time.perf_counter() < t_end:
+            fit.log_likelihood(p)
+        t0 = time.perf_counter()
+        for _ in range(2000):
+            fit.log_likelihood(p)
+        single = (time.perf_counter() - t0) / 2000
+        rows = fit._fit_rows(hp, fit.model)
+        for _ in range(3):
+            fit.log_likelihood_batch(rows)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            fit.log_likelihood_batch(rows)
+        full = (time.perf_counter() - t0) / 5
+        res[name] = {"log_likelihood_single_point_us": single * 1e6,
+                     "log_likelihood_batch_65536_host_buffers_ms": full * 1e3,
+                     "host_buffer_evals_per_s": BATCH_PER_GPU / full}
+    return res
+
+
+def dsplit_measurement(batch=16384, steps=10):
+    """BASELINE config 5 on one GPU: five table sets sharing one parameter batch (block-diagonal covariance, N = 5 x 120),
+    one upload, the blocks on their own streams, sums on the device (vk_joint_eval_device_async)."""
+    import numpy as np
+    import victor_amd
+    from victor_amd.joint import JointFit
+    from tests import cases
+    joint = JointFit([victor_amd.CCFFit(*cases.dsplit_options(q)) for q in range(5)])
+    engines, opts = joint._plan({})
+    rows = joint.fits[0]._fit_rows(cases.halton_params(batch), joint.fits[0].model)
+    _, (d_rows, d_out, d_ws) = joint._device_buffers(engines, batch)
+    lead = engines[0]
+    lead.upload(d_rows, rows)
+    d_chi = d_out + 8 * batch
+    warm_up(lead, lambda: joint.eval_device_async(engines, opts, d_rows, batch, d_out, d_chi, d_ws))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        joint.eval_device_async(engines, opts, d_rows, batch, d_out, d_chi, d_ws)
+    lead.sync()
+    dt = (time.perf_counter() - t0) / steps
+    out = lead.download(d_out, 2 * batch)
+    kernel = lead.last_kernel()
+    g, meta = cases.golden_outputs()
+    pts = meta["synth_points"][:6]
+    chi6 = joint.log_likelihood_batch({k: np.array([q[k] for q in pts]) for k in pts[0]})[1]
+    return {"joint_evals_per_s": batch / dt, "block_evals_per_s": 5 * batch / dt, "ms_per_batch": dt * 1e3, "batch": batch,
+            "blocks": 5, "n_data": joint.n_data, "kernel": kernel, "all_finite": bool(np.all(np.isfinite(out))),
+            "max_rel_dchi2_vs_reference_golden": float(np.max(np.abs(chi6 / g["dsplit_chi2"] - 1)))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,7 +288,7 @@ def main():
     if args.gpus > 1 and not launched:
         # start one rank per GPU as child processes (never exec: this process may already hold the GPU)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29511"),
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT") or str(free_port()),
                os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
@@ -243,7 +321,9 @@ def main():
         cores = host_cores()
         ns = min(args.cpu_sample or max(16, 40 * cores), B)      # ~40 oracle evaluations per core (~50 ms each): ~30 core-seconds of CPU work
         sel = np.linspace(0, B - 1, ns).astype(int)
-        base, vals, theory_o = cpu_baseline([cases.point(mine, int(i)) for i in sel], args.simpson_even)
+        sample = [cases.point(mine, int(i)) for i in sel]
+        base, vals, theory_o = cpu_baseline(sample, args.simpson_even)
+        base["single_thread"] = cpu_single_thread(sample[:: max(1, len(sample) // 64)][:64], args.simpson_even)
 
     # one rank per GPU; on a box with fewer GPUs than ranks (rehearsals) ranks share devices and the RCCL communicator
     # cannot be built, which exercises the host-gather fallback below
@@ -317,13 +397,61 @@ def main():
     kernel_name = eng.last_kernel()
     lnl = eng.download(d_lnl, B)
     chi2 = eng.download(d_chi, B)
-    gathered_ok = None
-    if use_comm:
-        allv = eng.download(d_all, B * world)
-        gathered_ok = bool(np.array_equal(allv[rank * B:(rank + 1) * B], lnl))
-    elif host_gather:
-        gathered_ok = bool(np.array_equal(step.gathered[rank * B:(rank + 1) * B], lnl))
     ok = bool(np.all(np.isfinite(lnl)) and np.all(chi2 > 0))
+    # Every rank checks the WHOLE gathered vector: its own slot bit for bit, every other rank's slot finite and - for a few
+    # rows spread over that rank's shard - equal to this rank's own evaluation of the same global Halton points (another
+    # batch size, hence possibly another kernel mapping: agreement to rounding).
+    gathered_ok = None
+    gathered = None
+    if use_comm:
+        gathered = eng.download(d_all, B * world)
+    elif host_gather:
+        gathered = step.gathered
+    if gathered is not None:
+        good = bool(np.array_equal(gathered[rank * B:(rank + 1) * B], lnl)) and bool(np.all(np.isfinite(gathered)))
+        probe = np.unique(np.linspace(0, B - 1, 6).astype(int))
+        for other in range(world):
+            if other == rank:
+                continue
+            theirs = {k: v[other * B + probe] for k, v in hp_all.items()}
+            mine_l, _ = fit.log_likelihood_batch(theirs)
+            good = good and bool(np.max(np.abs(gathered[other * B + probe] - mine_l)) <= 1e-9 * np.max(np.abs(mine_l)))
+        gathered_ok = bool(dist.min_float(1.0 if good else 0.0))
+    kernel_ms_ranks = dist.allgather_host(np.array([theory_ms / max(launches, 1)]), 1).tolist() if launched else None
+
+    # fixed global batch next to the weak-scaling line: BATCH_PER_GPU points in total, B / world per rank
+    strong = None
+    if world > 1:
+        Bs = max(1, args.batch // world)
+        mine_s = {k: v[rank * Bs:(rank + 1) * Bs] for k, v in hp_all.items()}
+        eng.upload(d_rows, fit._fit_rows(mine_s, fit.model))
+
+        def step_s():
+            eng.eval_device_async(opts, d_rows, Bs, d_lnl, d_chi, d_ws)
+            if use_comm:
+                eng.comm_allgather_async(d_lnl, d_all, Bs)
+            elif host_gather:
+                eng.sync()
+                step_s.gathered = dist.allgather_host(eng.download(d_lnl, Bs), Bs)
+
+        for _ in range(max(args.warmup, 1)):
+            step_s()
+        eng.sync()
+        dist.barrier()
+        eng.timing(True)
+        eng.read_timing(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_s()
+        eng.sync()
+        dist.barrier()
+        el_s = dist.max_float(time.perf_counter() - t0)
+        th_s, _, n_s = eng.read_timing(reset=True)
+        eng.timing(False)
+        ks = dist.allgather_host(np.array([th_s / max(n_s, 1)]), 1).tolist()
+        strong = {"global_batch": Bs * world, "batch_per_gpu": Bs, "value": Bs * world * args.steps / el_s, "unit": "evals/s",
+                  "ms_per_step": 1e3 * el_s / args.steps, "scaling": "strong", "kernel": eng.last_kernel(),
+                  "theory_kernel_ms_per_rank": ks}
 
     if rank == 0:
         total = B * world * args.steps
@@ -333,13 +461,16 @@ def main():
         aniso = not fit.model["assume_isotropic"]
         F = flops_per_eval(len(fit.s), 100, 50, len(fit.poles_s), aniso)
         achieved_tf = F * B / (k1_ms * 1e-3) / 1e12 if k1_ms > 0 else None
-        traffic = None
+        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (MI355X_MICROARCH.md), which this run
+        # does not make: `traffic` is null here and the last profiled figure is reported beside it with its source
+        traffic_profiled = None
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.isfile(tfile):
             with open(tfile) as fh:
                 tj = json.load(fh)
             if tj.get("batch") == B:
-                traffic = tj.get("theory_kernel_hbm_bytes_per_launch")
+                traffic_profiled = {"bytes_per_launch": tj.get("theory_kernel_hbm_bytes_per_launch"),
+                                    "source": tj.get("source", "profiles/traffic_latest.json"), "kernel": tj.get("kernel")}
         alg_bytes = (8 * 10 + 16) * B     # 80 B of parameters in, lnL + chi2 out, per evaluation
         out = {
             "metric": "likelihood evals/sec (40 s-bins, 100 mu, l=0,2,4)",
@@ -356,7 +487,7 @@ def main():
             "roofline": {"bound": "fp64-valu", "kernel": kernel_name + "<3,3>",
                          "achieved": achieved_tf, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / PEAK_FP64_VALU_TFLOPS if achieved_tf else None,
-                         "traffic": traffic, "flops_per_eval": F, "kernel_ms": k1_ms,
+                         "traffic": None, "traffic_profiled": traffic_profiled, "flops_per_eval": F, "kernel_ms": k1_ms,
                          "note": "path is FP64 vector-ALU bound (no MFMA, ~1e-5 of HBM peak); sqrt/div/exp counted "
                                  "as one flop each per SURVEY.md 8(d)"},
             "roofline_hbm": {"bound": "hbm", "achieved": alg_bytes / ((k1_ms + k2_ms) * 1e-3) / 1e9 if k1_ms else None,
@@ -367,15 +498,25 @@ def main():
             "outputs_finite": ok,
         }
         if gathered_ok is not None:
-            out["gather_matches_local"] = gathered_ok
+            out["gather_matches_local"] = gathered_ok       # every rank, every slot (see above)
+        if launched:
+            out["config"]["rccl"] = _native.comm_info()
+            out["theory_kernel_ms_per_rank"] = kernel_ms_ranks
+        if strong is not None:
+            out["strong_scaling"] = strong
         if world == 1 and not args.no_boss:
             out["boss_cmass"] = boss_measurement(args)
             out["batch_sweep"] = batch_sweep()
+            out["dsplit5"] = dsplit_measurement()
+            out["host_api"] = api_latency()
         if base is not None:
             chi_o = np.array([v[1] for v in vals])
             lnl_o = np.array([v[0] for v in vals])
             out["cpu_baseline"] = {"value": base["evals_per_s"], "unit": "evals/s", "cores": base["cores"],
                                    "value_per_core": base["evals_per_s"] / base["cores"], "kind": "port",
+                                   "single_thread": {"value": base["single_thread"]["evals_per_s"], "unit": "evals/s",
+                                                     "sample": f"{base['single_thread']['n']} of the same points, one process, "
+                                                               f"one thread, {base['single_thread']['busy_s']:.1f} s busy"},
                                    "sample": f"{ns} of the {B} batch points through oracle/victor_oracle.py "
                                              f"(NumPy/SciPy restatement, bit-identical to the reference here), "
                                              f"{base['cores']} processes x 1 thread, {base['busy_s']:.1f} s busy"}
@@ -398,7 +539,7 @@ def main():
     dist.barrier()
     if dist.pg is not None:
         dist.pg.destroy_process_group()
-    if not ok:
+    if not ok or gathered_ok is False:
         sys.exit(1)
 
 

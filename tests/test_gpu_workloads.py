@@ -1,6 +1,7 @@
 """BASELINE.json configs [3] and [4] as parity cases on the GPU (the bench line is config [2])."""
 
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -8,6 +9,8 @@ import pytest
 
 from tests import cases
 from victor_amd import _native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
@@ -122,6 +125,33 @@ def test_walker_example_under_torchrun_single_rank():
     assert 0.02 < res["acceptance"] < 0.95
     assert 0.2 <= res["mean"]["beta"] <= 0.6 and 100 <= res["mean"]["sigma_v"] <= 500
     assert res["best_lnl_over_all_ranks"] > 250          # the reference point alone gives lnL = 284.8
+
+
+def test_bench_two_rank_rehearsal_on_one_gpu():
+    """``bench.py --gpus 2`` on the one-GPU box: the launcher picks a free rendezvous port, both ranks share device 0, the
+    RCCL communicator cannot be built (two ranks on one device) and the gather falls back to the host process group -
+    which exercises everything around the collective: every rank's check of EVERY slot of the gathered vector against its
+    own recomputation of the other rank's rows, the fixed-global-batch leg with per-rank kernel times, and the library
+    diagnostics in the JSON line."""
+    import json
+    env = dict(os.environ)
+    env.pop("MASTER_PORT", None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--batch", "4096", "--no-cpu-baseline", "--no-boss"], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8192 and out["scaling"] == "weak"
+    assert out["gather_matches_local"] is True and out["outputs_finite"] is True
+    assert "host allgather" in out["config"]["gather"] or "rccl" in out["config"]["gather"]
+    rccl = out["config"]["rccl"]
+    assert rccl["hip_runtime"] and rccl["rccl"] and rccl["rccl_version"] > 0 and rccl["rccl_next_to_hip_runtime"] is True
+    assert len(out["theory_kernel_ms_per_rank"]) == 2 and all(t > 0 for t in out["theory_kernel_ms_per_rank"])
+    strong = out["strong_scaling"]
+    assert strong["global_batch"] == 4096 and strong["batch_per_gpu"] == 2048 and strong["value"] > 0
+    assert len(strong["theory_kernel_ms_per_rank"]) == 2
 
 
 def test_integration_stub_runs_as_written():
