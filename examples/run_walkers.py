@@ -48,7 +48,21 @@ def main():
     lk = info["likelihood"]["CCFLikelihood"]
     fit = victor_amd.CCFFit(lk["model"], lk["data"], device=dist.local_rank if dist.launched else 0)
     specs, fixed = parse_cobaya_params(info["params"])
-    gather = RcclGather(fit._get_engine(), dist, args.walkers)
+    # log-likelihoods of all ranks per step: RCCL all-gather on the engine's stream when there are several ranks and a
+    # communicator can be built; the host process group otherwise (one rank, RCCL missing, ranks sharing a device).
+    # Multi-GPU note: the RCCL path has run with one rank per process on the one-GPU development boxes only.
+    gather = None
+    if dist.world > 1:
+        ok = 1.0
+        try:
+            gather = RcclGather(fit._get_engine(), dist, args.walkers)
+        except Exception as exc:                                   # every rank must take the same branch
+            print(f"rank {dist.rank}: RCCL gather unavailable ({exc}); using the host process group", file=sys.stderr)
+            ok = 0.0
+        if dist.min_float(ok) == 0.0:
+            if gather is not None:
+                gather.close()
+            gather = None
 
     ens = DistributedEnsemble(lambda batch: fit.log_likelihood_batch(batch)[0], specs, args.walkers, dist,
                               seed=args.seed, fixed=fixed, gather=gather,
@@ -56,7 +70,8 @@ def main():
     t0 = time.perf_counter()
     chain, lnl, all_lnl = ens.run(args.steps)
     wall = time.perf_counter() - t0
-    gather.close()
+    if gather is not None:
+        gather.close()
     if dist.rank == 0:
         burn = args.steps // 4
         print(json.dumps({
@@ -66,7 +81,8 @@ def main():
             "max_Rminus1": float(np.max(gelman_rubin(chain[burn:]))),
             "mean": dict(zip(ens.local.names, chain[burn:].mean(axis=(0, 1)).round(4).tolist())),
             "best_lnl_over_all_ranks": float(all_lnl.max()),
-            "gathered_shape": list(all_lnl.shape)}))
+            "gathered_shape": list(all_lnl.shape),
+            "gather": "rccl" if gather is not None else "host"}))
     dist.barrier()
 
 

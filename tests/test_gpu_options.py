@@ -330,6 +330,28 @@ def test_non_uniform_grids_in_every_fast_mapping(tmp_path):
     fit = victor_amd.CCFFit(model, data)
     tabs, _keep = build_tables(fit, fit)
     assert tabs.uni_n == len(r) + len(rsv) and tabs.uni_lut_n >= 64
+    # a C-ABI client that hands over a look-up table that does not match its knots (the kernels index LDS with it) is
+    # turned away by vk_create with VK_E_ARG-style diagnostics instead of reading out of bounds
+    import ctypes as C
+    lib = _native.load()
+    err = C.create_string_buffer(256)
+    good_inv_g, good_n = tabs.uni_lut_inv_g, tabs.uni_lut_n
+    lut = np.ctypeslib.as_array(tabs.uni_lut, shape=(good_n,))
+    for what in ("range", "entry", "cells"):
+        saved = lut.copy()
+        if what == "range":
+            tabs.uni_lut_inv_g = good_inv_g * 1.5             # the clamp range now maps beyond the table
+        elif what == "entry":
+            lut[good_n // 2] += 3                            # an entry that is not the interval of its cell's left edge
+        else:
+            tabs.uni_lut_n = good_n // 2                      # a table that stops half way
+        ctx = lib.vk_create(C.byref(tabs), 0, err, len(err))
+        assert not ctx and b"look-up" in err.value, (what, err.value)
+        tabs.uni_lut_inv_g, tabs.uni_lut_n = good_inv_g, good_n
+        lut[:] = saved
+    ctx = lib.vk_create(C.byref(tabs), 0, err, len(err))
+    assert ctx, err.value
+    lib.vk_destroy(ctx)
     ora = vo.OracleFit(model, data)
     hp = cases.halton_params(4096 + 5)
     res = {}

@@ -604,6 +604,46 @@ def test_fused_and_split_launches_agree_with_separate_kernels(boss_fit, synth_fi
         assert np.max(np.abs(chi / ref_c[:9] - 1)) < 1e-12
 
 
+def test_determinant_sign_semantics_of_the_blended_covariance(tmp_path, oracle):
+    """ccf_fit.py:447-450 rejects a point when np.linalg.slogdet of the blended covariance has sign != +1.  With a last
+    slice that has TWO negative eigenvalues the blend passes through zero, one negative factor (sign -1: rejected) and two
+    negative factors (sign +1: accepted with log|det|); the device decides by the parity of the negative factors
+    1 - t + t lambda_i and must agree with the reference's rule (the oracle calls slogdet) in each regime, in the fused tail
+    and in the separate chi-square kernels."""
+    import victor_amd
+    model, data = cases.boss_options("config")
+    cov = np.load(os.path.join(cases.GOLDEN, "boss", "cov.npy"), allow_pickle=True).item()
+    stack = np.array(cov["covmat"], dtype=float)
+    w, v = np.linalg.eigh(stack[-1])
+    # eigenvalues w5 -> -w5 / 4 and w40 -> -4 w40: the factors of the two directions turn negative at t ~ 0.8 and t ~ 0.2
+    flipped = stack[-1] - 1.25 * w[5] * np.outer(v[:, 5], v[:, 5]) - 5.0 * w[40] * np.outer(v[:, 40], v[:, 40])
+    stack[-1] = 0.5 * (flipped + flipped.T)
+    assert np.linalg.slogdet(stack[-1])[0] == 1 and np.sum(np.linalg.eigvalsh(stack[-1]) < 0) == 2
+    path = str(tmp_path / "cov_two_negative.npy")
+    np.save(path, {"beta": cov["beta"], "covmat": stack}, allow_pickle=True)
+    data = cases.clone(data)
+    data["covariance_matrix"]["data_file"] = path
+    fit = victor_amd.CCFFit(model, data)
+    ofit = oracle.OracleFit(model, data)
+    g = np.asarray(cov["beta"], dtype=float)
+    # only the last interval of the grid lets the weight t of the last slice run from 0 to 1 (the lower bracket moves with beta)
+    betas = np.concatenate([g[-2] + (g[-1] - g[-2]) * np.linspace(0.02, 0.98, 49), [g[0] - 0.01, g[-1] + 0.01, g[7], 0.5 * (g[3] + g[4])]])
+    hp = cases.halton_params(len(betas))
+    rows = fit._fit_rows(dict(hp, beta=betas), fit.model)
+    want = [ofit.log_likelihood(dict(cases.point(hp, i), beta=float(b))) for i, b in enumerate(betas)]
+    want_l = np.array([x[0] for x in want])
+    rejected = np.isneginf(want_l)
+    assert 10 <= rejected.sum() <= len(betas) - 15       # the sweep crosses all three regimes
+    assert not rejected[0] and not rejected[48] and rejected[24]
+    for kn in ({}, {"NO_FUSE": "1"}, {"NO_FUSE": "1", "LIKE_WIDE": "0"}, {"MAPPING": "cells"}):
+        with knobs(NO_GRAPH="1", **kn):
+            lnl, chi2 = fit.log_likelihood_batch(rows)
+        assert np.array_equal(np.isneginf(lnl), rejected), kn
+        assert np.all(np.isposinf(chi2[rejected]))
+        ok = ~rejected
+        assert np.max(np.abs(lnl[ok] - want_l[ok]) / (np.abs(want_l[ok]) + 300.0)) < 1e-9, kn
+
+
 def test_fused_path_keeps_the_failure_guards(boss_fit):
     """NaN parameters and the singular-covariance guard return (-inf, inf) from the fused tail as from the K2 kernels."""
     fit = boss_fit["config"]

@@ -900,6 +900,20 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
            t->uni_knots[0] == t->vr.knots[0];
       for (int q = 0; q < t->uni_n && ok; ++q) ok = t->uni_knots[q + 1] > t->uni_knots[q];
       for (int c = 0; c < t->uni_lut_n && ok; ++c) ok = t->uni_lut[c] < t->uni_n;
+      // the kernels index lut[(int)(u * inv_g)] for every u in [knots[0], knots[n]) and look one and two records ahead of
+      // the entry they read: the table must cover the whole clamp range, start at a non-negative radius and each cell's
+      // entry must be the interval of the cell's left edge (a cell may hold at most two further knots)
+      if (ok) {
+        ok = t->uni_knots[0] >= 0.0 && (long long)(t->uni_knots[t->uni_n] * t->uni_lut_inv_g) < (long long)t->uni_lut_n;
+        for (int c = 0; c < t->uni_lut_n && ok; ++c) {
+          const double left = c / t->uni_lut_inv_g, right = (c + 1) / t->uni_lut_inv_g;
+          const int q = t->uni_lut[c];
+          if (left >= t->uni_knots[t->uni_n]) break;                       // cells beyond the last knot are never read
+          ok = q == 0 ? t->uni_knots[1] > left : t->uni_knots[q] <= left * (1.0 + 1e-12);
+          if (ok && q + 3 <= t->uni_n) ok = t->uni_knots[q + 3] >= right * (1.0 - 1e-12);   // at most two knots inside the cell
+        }
+        if (!ok) return bail("union-grid look-up table is inconsistent with its knots (uni_lut / uni_lut_inv_g / uni_knots)");
+      }
     } else if (ok) {
       ok = t->xi.inv_h > 0 && t->xi.lead == 0 && t->sv.inv_h > 0 && t->sv.lead == 0 && t->vr.inv_h > 0 &&
            t->vr.lead == 1 && t->vr.n_int == t->xi.n_int + 1 && t->uni_inv_h > 0 && t->uni_u0 <= t->vr.knots[0];

@@ -224,7 +224,15 @@ def build_tables(model, fit=None, matter_model=None, simpson_even=None):
                 logdet[kk] = ld if sign == 1 else np.nan
                 if kk < nb - 1 and sign == 1:
                     # cov[last] v = lambda cov[k] v  =>  det((1-t) cov[k] + t cov[last]) = det(cov[k]) prod(1-t+t lambda)
-                    eig[kk] = sl.eigh(fit.covmat[-1], fit.covmat[kk], eigvals_only=True)
+                    try:
+                        eig[kk] = sl.eigh(fit.covmat[-1], fit.covmat[kk], eigvals_only=True)
+                    except np.linalg.LinAlgError:
+                        # slice k has a positive determinant but is not positive definite (an even number of negative
+                        # eigenvalues): the identity above does not hold through eigh.  The reference constructs such a
+                        # fit and decides point by point from slogdet of the blend (ccf_fit.py:447-450); here every point
+                        # bracketed by this slice reports a failed evaluation (-inf, inf) - a covariance matrix that is
+                        # not positive definite is an input error in any case.
+                        logdet[kk] = np.nan
             logdet = arr(logdet)
             eig = arr(eig)
             t.n_beta_c = nb
