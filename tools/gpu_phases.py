@@ -37,6 +37,9 @@ for rep in range(60):
     acc.append([live.sum(), np.nanmax(us[:, 0]), np.nanmedian(us[:, 1] - us[:, 0]), np.nanmedian(us[:, 2] - us[:, 1]),
                 np.nanmedian(us[:, 3] - us[:, 2]), np.nanmedian(us[:, 4] - us[:, 3]), np.nanmax(us[:, 4]),
                 np.nanmax(us[:, 5] - us[:, 4]), np.nanmax(us[:, 5])])
+# distribution over the workgroups of the last repetition: start, integrand phase, end of the integrand phase
+pc = lambda v: " / ".join(f"{x:.1f}" for x in np.nanpercentile(v, [0, 10, 50, 90, 100]))   # noqa: E731
+print(f"  workgroup start {pc(us[:, 0])}; integrand phase {pc(us[:, 3] - us[:, 2])}; integrand done at {pc(us[:, 3])}  (min / p10 / median / p90 / max, us)")
 a = np.median(np.array(acc), axis=0)
 print(f"{which} batch {batch}: workgroups {a[0]:.0f}; last workgroup starts at {a[1]:.2f} us; per workgroup (median): staging {a[2]:.2f}, "
       f"point set-up {a[3]:.2f}, integrand + projection {a[4]:.2f}, completion counter {a[5]:.2f}; all counters done at {a[6]:.2f}; "

@@ -534,9 +534,14 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
   // A/B (tools/gpu_small_batch_ab.py, config 3 / BOSS, resident): the fused launch wins up to ~256 points (64 points: 41.2 vs
   // 43.7 us, 33.0 vs 34.9), ties at 512 and is 1 % behind the two-launch path from 1024 on (461.5 vs 455.4 us), where the
   // separate chi-square kernel overlaps the tail of the theory kernel
-  const long long kFuseMaxDefault = 512;
-  const long long fuse_max = ctx->knobs.fuse_max >= 0 ? ctx->knobs.fuse_max : kFuseMaxDefault;
-  const bool want_fuse = like && !ctx->knobs.no_fuse && a.n <= fuse_max && like_lds_doubles(N) * sizeof(double) <= 32 * 1024;
+  // separate chi-square kernel overlaps the tail of the theory kernel.  Large batches (tools/gpu_fuse_ab.py, cells kernel, one
+  // workgroup per point, 8192 / 65536 points): config 3 (fixed covariance, tiled K2 of 0.16 ms) 3.620 -> 3.602 / 28.16 -> 28.33 ms,
+  // i.e. nothing to gain; BOSS (per-point blended precision, K2 0.37 ms) 2.190 -> 2.165 / 17.51 -> 17.08 ms: fused from 8192
+  // points on when the covariance depends on beta.
+  const long long kFuseMaxDefault = 512, kFuseBlendedMin = 8192;
+  const bool fuse_by_size = ctx->knobs.fuse_max >= 0 ? a.n <= ctx->knobs.fuse_max
+                                                     : (a.n <= kFuseMaxDefault || (like && like->n_beta_c > 0 && a.n >= kFuseBlendedMin));
+  const bool want_fuse = like && !ctx->knobs.no_fuse && fuse_by_size && like_lds_doubles(N) * sizeof(double) <= 32 * 1024;
   if (like) a.like = *like;
   const long long kDefaultCap = 256;                                // VICTOR_HIP_POINT_CAP: workgroups per CU in the launch
   const long long cap = (ctx->knobs.point_cap > 0 ? ctx->knobs.point_cap : kDefaultCap) * ctx->n_cu;
