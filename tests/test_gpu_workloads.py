@@ -250,6 +250,17 @@ def test_small_batches_replay_a_captured_graph():
     fit = victor_amd.CCFFit(*cases.boss_options("config"))
     hp = cases.halton_params(64, with_beta=True)
     rows = fit._fit_rows(hp, fit.model)
+    _native.set_knob("VICTOR_HIP_NO_ZERO_COPY", "1")     # the in-place path would serve these sizes first: this test is about the graphs
+    try:
+        _graph_replay_checks(fit, rows, hp)
+    finally:
+        _native.set_knob("VICTOR_HIP_NO_ZERO_COPY", None)
+        _native.set_knob("VICTOR_HIP_NO_GRAPH", None)
+
+
+def _graph_replay_checks(fit, rows, hp):
+    import numpy as np
+    from tests import cases
     _native.set_knob("VICTOR_HIP_NO_GRAPH", "1")
     try:
         want = {n: fit.log_likelihood_batch(rows[:n]) for n in (1, 8, 64)}
@@ -272,6 +283,13 @@ def test_small_batches_replay_a_captured_graph():
     p = cases.point(hp, 3)
     single = [fit.log_likelihood(dict(p)) for _ in range(5)]
     assert all(s == single[0] for s in single)
+    _native.set_knob("VICTOR_HIP_NO_ZERO_COPY", None)
+    # default: host-buffer batches of up to 4096 points are read and written in place (pinned, device-mapped memory): same bits
+    for n in (1, 8, 64):
+        for rep in range(2):
+            got = fit.log_likelihood_batch(rows[:n])
+            assert np.array_equal(got[0], want[n][0]) and np.array_equal(got[1], want[n][1]), (n, rep)
+    assert fit.log_likelihood(dict(p)) == single[0]
 
 
 def test_one_process_driving_several_contexts():

@@ -194,6 +194,25 @@ def test_param_rows(boss_fit):
         boss_fit._fit_rows({"fsigma8": np.zeros(2), "beta": np.zeros(3)}, boss_fit.model)
 
 
+def test_scalar_row_fast_path(boss_fit):
+    """The single-point fast path of ``log_likelihood`` builds its row with ``_scalar_row``: same 12 numbers as the general
+    ``_param_rows`` (bit for bit: Python float arithmetic in both), same KeyError / default behaviour as the reference
+    (ccf_model.py:583-613, 638)."""
+    from victor_amd import _native as N
+    for p in ({"fsigma8": 0.47, "beta": 0.37, "sigma_v": 380, "epsilon": 1.04, "alpha": 1.02},
+              {"fsigma8": 0.3, "beta": 0.251, "aperp": 0.97, "apar": 1.05, "astar": 0.99, "M": 1.1, "Q": 0.9, "bias": 2.2, "Av": -0.3},
+              {"fsigma8": np.float64(0.5), "beta": np.float32(0.25)}):
+        row = boss_fit._scalar_row(p, True, True)
+        assert len(row) == N.VK_NPAR and all(type(x) is float for x in row)
+        assert np.array_equal(np.array(row), boss_fit._param_rows(p, True, True)[0])
+    assert boss_fit._scalar_row({"fsigma8": 0.4}, False, True)[N.P_BETA] == 0.40            # dummy beta (ccf_model.py:583-587)
+    assert boss_fit._scalar_row({"beta": 0.3}, True, False)[N.P_FSIGMA8] == 0.0
+    with pytest.raises(KeyError):
+        boss_fit._scalar_row({"beta": 0.3}, True, True)
+    with pytest.raises(KeyError):
+        boss_fit._scalar_row({"fsigma8": 0.4}, True, True)
+
+
 def test_simpson_even_option(boss_fit):
     """The even-N Simpson convention of the velocity integral (ccf_model.py:690; SciPy < 1.11 vs >= 1.11) is an
     explicit option: ``model['numerics']['simpson_even']`` at construction, ``simpson_even=`` per call."""

@@ -114,6 +114,7 @@ struct Knobs {
   int like_wide = -1;                  // VICTOR_HIP_LIKE_WIDE: 1 / 0 force the workgroup-per-point chi2 kernel on / off
   long long cells_min = -1;            // VICTOR_HIP_CELLS_MIN: smallest batch that takes the cells kernel (-1 = default)
   bool no_zero_copy = false;           // VICTOR_HIP_NO_ZERO_COPY: small host-buffer batches through the copy / graph path
+  long long zero_copy_max = -1;        // VICTOR_HIP_ZERO_COPY_MAX: largest host-buffer batch on the in-place path (-1 = default)
 };
 
 struct vk_ctx {
@@ -178,13 +179,13 @@ struct vk_ctx {
   std::map<std::string, int> graph_seen;         // a key is captured on its second use (the first one runs eagerly)
   std::map<std::string, const char*> graph_kernel;
   bool graphs_off = false;
-  double* h_zc = nullptr;                       // pinned, device-mapped: params[kZeroCopyMaxN][VK_NPAR] | lnl, chi2 [2 kZeroCopyMaxN]
+  double* h_zc = nullptr;                       // pinned, device-mapped: params[kZeroCopyCap][VK_NPAR] | lnl, chi2 [2 kZeroCopyCap]
   double* d_zc = nullptr;                       // the same memory through the device's eyes
   bool zero_copy_off = false;
 };
 
 constexpr int64_t kGraphMaxN = 4096;
-constexpr int64_t kZeroCopyMaxN = 32;      // host-buffer batches up to this size: parameters read in place, results written in place
+constexpr int64_t kZeroCopyCap = 4096;     // capacity of the in-place buffers (points)
 constexpr long long kCounterCap = 16384;   // points per launch that may share work between workgroups (completion counters)
 constexpr long long kPartialPoints = 2048;  // batches up to this many points may split a point's work over workgroups (partial sums)
 
@@ -212,6 +213,7 @@ void load_knobs(vk_ctx* ctx) {
   if (const char* env = getenv("VICTOR_HIP_LIKE_WIDE")) k.like_wide = atoi(env) ? 1 : 0;
   if (const char* env = getenv("VICTOR_HIP_CELLS_MIN")) k.cells_min = atoll(env);
   k.no_zero_copy = getenv("VICTOR_HIP_NO_ZERO_COPY") != nullptr;
+  if (const char* env = getenv("VICTOR_HIP_ZERO_COPY_MAX")) k.zero_copy_max = atoll(env);
   k.force_generic = getenv("VICTOR_HIP_FORCE_GENERIC") != nullptr;
   if (const char* env = getenv("VICTOR_HIP_POINT_CAP")) k.point_cap = atoll(env);
   if (const char* env = getenv("VICTOR_HIP_LANES_CAP")) k.lanes_cap = atoll(env);
@@ -1300,16 +1302,21 @@ static int eval_batch_graph(vk_ctx* ctx, const vk_eval_opts* opts, const double*
   return 1;
 }
 
-// A handful of points (the reference calls the likelihood with ONE, CCFLikelihood.py:32-39): no copies at all.  The parameter
-// rows are placed in pinned host memory that the GPU reads in place (96 bytes per point over the link, overlapped with the
-// staging of the tables) and lnL / chi2 are written straight back into pinned host memory, so the call is one kernel
-// launch and one stream synchronisation instead of a graph of (H2D copy, kernel, D2H copy).
+constexpr int64_t kZeroCopyMaxDefault = 4096;   // host-buffer batches up to this size: parameters read in place, results written in place
+
+// Launch-bound host-buffer batches (the reference calls the likelihood with ONE point, CCFLikelihood.py:32-39): no copies at
+// all.  The parameter rows are placed in pinned host memory that the GPU reads in place (96 bytes per point over the link,
+// overlapped with the staging of the tables) and lnL / chi2 are written straight back into pinned host memory, so the call
+// is one kernel launch and one stream synchronisation instead of a graph of (H2D copy, kernel, D2H copy).  Measured per call,
+// config 3, against the captured graph: 1 point 41 -> 30 us, 33: 66 -> 54, 64: 75 -> 63, 256: 172 -> 154, 1024: 493 -> 483,
+// 4096: 1855 -> 1819 us; the graph path remains for contexts whose in-place buffers cannot be mapped (VICTOR_HIP_NO_ZERO_COPY).
 static int eval_batch_zero_copy(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, int64_t n, double* lnl,
                                 double* chi2, double* d_th) {
-  if (n > kZeroCopyMaxN || ctx->knobs.no_zero_copy || ctx->zero_copy_off || ctx->timing || !(lnl || chi2)) return 0;
+  const int64_t zc_max = ctx->knobs.zero_copy_max >= 0 ? std::min<int64_t>(ctx->knobs.zero_copy_max, kZeroCopyCap) : kZeroCopyMaxDefault;
+  if (n > zc_max || ctx->knobs.no_zero_copy || ctx->zero_copy_off || ctx->timing || !(lnl || chi2)) return 0;
   if (!ctx->h_zc) {
     void* dev = nullptr;
-    if (hipHostMalloc((void**)&ctx->h_zc, (size_t)kZeroCopyMaxN * (VK_NPAR + 2) * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+    if (hipHostMalloc((void**)&ctx->h_zc, (size_t)kZeroCopyCap * (VK_NPAR + 2) * sizeof(double), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(&dev, ctx->h_zc, 0) != hipSuccess) {
       (void)hipGetLastError();
       ctx->zero_copy_off = true;
@@ -1317,8 +1324,8 @@ static int eval_batch_zero_copy(vk_ctx* ctx, const vk_eval_opts* opts, const dou
     }
     ctx->d_zc = static_cast<double*>(dev);
   }
-  double* h_out = ctx->h_zc + (size_t)kZeroCopyMaxN * VK_NPAR;
-  double* d_out = ctx->d_zc + (size_t)kZeroCopyMaxN * VK_NPAR;
+  double* h_out = ctx->h_zc + (size_t)kZeroCopyCap * VK_NPAR;
+  double* d_out = ctx->d_zc + (size_t)kZeroCopyCap * VK_NPAR;
   memcpy(ctx->h_zc, params, (size_t)n * VK_NPAR * sizeof(double));
   int rc = vk_eval_batch_device_async(ctx, opts, ctx->d_zc, n, d_out, d_out + n, d_th);
   if (rc) return rc;
