@@ -22,7 +22,7 @@ namespace vk {
 //               64-point batch fill the chip.
 // --------------------------------------------------------------------------------------------------
 struct CellsPlan {
-  int mu, w, s, betar, da, image_end, acc, like, total;
+  int mu, w, s, betar, da, v1, image_end, acc, like, total;
 };
 
 // s bins a range of `cpi` cells can touch
@@ -38,6 +38,7 @@ __host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s,
   p.s = o;     o += (n_s + 1) & ~1;
   p.betar = o; o += (n_beta_r + 1) & ~1;
   p.da = o;    o += with_da ? uni_n * 4 : 0;      // Da table of the dispersion model
+  p.v1 = o;    o += with_da ? 0 : uni_n * 4;      // unscaled V1 cubics (streaming modes, see scale_uni_v)
   o = (o + 1) & ~1;
   p.image_end = o;                                 // batch-constant up to here (LDS image, see vk_kernel_fast.h)
   int bins = cells_range_bins(n_mu, cpi);
@@ -62,6 +63,7 @@ __device__ __forceinline__ void stage_cells(const TheoryArgs& a, const CellsPlan
   for (int j = tid; j < a.n_s; j += kBlock) lds[pl.s + j] = a.s[j];
   stage_uni_records<NLR>(a, lds);
   if (with_da) stage_da<NLR>(a, lds + pl.da);
+  else for (int e = tid; e < a.uni_n * 4; e += kBlock) lds[pl.v1 + e] = a.uni_sv_v[(e >> 2) * 8 + 4 + (e & 3)];
   if (a.n_beta_r > 0)
     for (int i = tid; i < a.n_beta_r; i += kBlock) lds[pl.betar + i] = a.beta_r[i];
 }
@@ -128,15 +130,13 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
     const int nb = (int)__umulhi((unsigned)(c1 - 1), a.nmu_magic) - jf + 1;
     const double* row = a.params + point * VK_NPAR;
     const PointScalars ps = point_scalars(a, row);
+    const FastPoint fp = make_fast_point(ps, fc);
+    constexpr int PV = mode_is_dispersion(MODE) ? 0 : 1;
     __syncthreads();      // every wave is done with the previous item's records and accumulators
-    if (a.n_beta_r > 0 || a.empirical) {
-      if (a.n_beta_r > 0) rebuild_uni_xi<NLR>(a, lds + kRecsOff, lds + pl.betar, row[VK_P_BETA]);
-      if (a.empirical) rebuild_uni_v_emp<NLR>(a, lds + kRecsOff, ps.av);
-      if (mode_is_dispersion(MODE) && a.empirical) rebuild_da_emp(a, lds + pl.da, ps.av);
-    }
+    rebuild_point_tables<NLR, PV>(a, lds, pl.betar, pl.v1, row[VK_P_BETA], ps.av, fp.AVk);
+    if (mode_is_dispersion(MODE) && a.empirical) rebuild_da_emp(a, lds + pl.da, ps.av);
     for (int e = lane; e < kMaxEll * slots; e += 64) l_acc[e * kWaves + wave] = 0.0;
     __syncthreads();
-    const FastPoint fp = make_fast_point(ps, fc);
     VK_STAMP(a, 2);
     for (int base = c0 + 64 * wave; base < c1; base += 64 * kWaves) {
       const int e = base + lane;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
                 mode_is_dispersion(MODE)
                     ? disp_value<NLR, GRID, MODE == kModeDispersionFromData>(lds, lds + pl.da, fc, fp, a.niter, num, s_par, sperp2,
                                                                            xk)
-                    : uni_value<NLR, GRID, MODE == kModeFromData>(lds, fc, fp.AVk, num, sperp2, xk, fp.fa, sperp2x),
+                    : uni_value<NLR, GRID, MODE == kModeFromData, 1>(lds, fc, fp.AVk, num, sperp2, xk, fp.fa, sperp2x),
                 g);
       }
       if (!live) g = 0.0;

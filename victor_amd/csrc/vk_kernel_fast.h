@@ -126,7 +126,7 @@ __device__ __forceinline__ void stage_uni_records(const TheoryArgs& a, double* l
 // Per-point xi^r records when the real-space input depends on the reconstruction beta (PCHIP piece kb, extrapolating
 // with the end pieces as PchipInterpolator does; ccf_model.py:323-326).  `bg` = beta grid in LDS.
 template <int NLR>
-__device__ __forceinline__ void rebuild_uni_xi(const TheoryArgs& a, double* recs, const double* bg, double beta) {
+__device__ __forceinline__ void rebuild_uni_xi(const TheoryArgs& a, double* recs, const double* bg, double beta, double vs = 1.0) {
   constexpr int stride = uni_stride(NLR);
   // PCHIP piece: last i in [1, n-2] with beta >= bg[i], else 0 - a count over the lanes for grids of up to 64 nodes
   int kb = 0;
@@ -165,7 +165,7 @@ __device__ __forceinline__ void rebuild_uni_xi(const TheoryArgs& a, double* recs
   if (a.vr_beta_dep) {   // linear_bias on a reconstructed real-space ccf: V1 follows xi^r_0(beta) (ccf_model.py:358-370)
     for (int iq = threadIdx.x; iq < per_l; iq += kBlock) {
       const double* c = a.uni_vb + ((size_t)kb * per_l + iq) * 4;
-      recs[(iq >> 2) * stride + 4 + (iq & 3)] = fma(fma(fma(c[3], db, c[2]), db, c[1]), db, c[0]);
+      recs[(iq >> 2) * stride + 4 + (iq & 3)] = vs * fma(fma(fma(c[3], db, c[2]), db, c[1]), db, c[0]);
     }
   }
 }
@@ -173,10 +173,28 @@ __device__ __forceinline__ void rebuild_uni_xi(const TheoryArgs& a, double* recs
 // empirical_corr (ccf_model.py:451-455): v_r carries the factor (1 + Av delta), i.e. V = V1 + av V2 with the per-point
 // av; the kernels that own a point per workgroup rewrite the V half of the records for it
 template <int NLR>
-__device__ __forceinline__ void rebuild_uni_v_emp(const TheoryArgs& a, double* recs, double av) {
+__device__ __forceinline__ void rebuild_uni_v_emp(const TheoryArgs& a, double* recs, double av, double vs = 1.0) {
   constexpr int stride = uni_stride(NLR);
   for (int iq = threadIdx.x; iq < a.uni_n * 4; iq += kBlock)
-    recs[(iq >> 2) * stride + 4 + (iq & 3)] = fma(av, a.uni_v2[iq], a.uni_sv_v[(iq >> 2) * 8 + 4 + (iq & 3)]);
+    recs[(iq >> 2) * stride + 4 + (iq & 3)] = vs * fma(av, a.uni_v2[iq], a.uni_sv_v[(iq >> 2) * 8 + 4 + (iq & 3)]);
+}
+
+// V cubics of the records = vs * (batch-constant V1, kept unscaled in LDS at `v1`): the per-point amplitude of the mean
+// velocity (FastPoint::AVk) folded into the table once per work item instead of once per integrand point
+template <int NLR>
+__device__ __forceinline__ void scale_uni_v(int uni_n, double* recs, const double* v1, double vs) {
+  constexpr int stride = uni_stride(NLR);
+  for (int iq = threadIdx.x; iq < uni_n * 4; iq += kBlock) recs[(iq >> 2) * stride + 4 + (iq & 3)] = vs * v1[iq];
+}
+
+// Per-item tables of the kernels that own a point per workgroup.  PV: fold AVk into the V cubics (streaming modes).
+template <int NLR, int PV>
+__device__ __forceinline__ void rebuild_point_tables(const TheoryArgs& a, double* lds, int betar_off, int v1_off, double beta,
+                                                     double av, double AVk) {
+  const double vs = PV ? AVk : 1.0;
+  if (a.n_beta_r > 0) rebuild_uni_xi<NLR>(a, lds + kRecsOff, lds + betar_off, beta, vs);
+  if (a.empirical) rebuild_uni_v_emp<NLR>(a, lds + kRecsOff, av, vs);
+  else if (PV && !a.vr_beta_dep) scale_uni_v<NLR>(a.uni_n, lds + kRecsOff, lds + v1_off, vs);
 }
 
 // per-point factors of the index-unit formulation (wave-uniform in the point-major and cells kernels, per lane in
@@ -235,7 +253,9 @@ __device__ __forceinline__ const double* locate(const double* __restrict__ lds, 
 // FD = 1: realspace_ccf_from_data (ccf_model.py:618-619, 675-679) - xi^r is read at the fiducial coordinates
 // (r_par / apar, s_perp / aperp) on an abscissa that is not rescaled by c, i.e. at r_par' * fa and sperp2' * fp^2 with
 // fa = c/apar, fp = c/aperp (`sperp2x` carries the second product), through a second interval look-up.
-template <int NLR, int GRID, int FD>
+// PV = 1: the V cubics in the records already carry the per-point factor AVk (the kernels that own a point per workgroup
+// rescale them once per work item, scale_uni_v) - one multiply less per integrand point.
+template <int NLR, int GRID, int FD, int PV = 0>
 __device__ __forceinline__ double uni_value(const double* __restrict__ lds, const FastConsts& fc, double AVk,
                                             double r_par, double sperp2, double xk, double fa, double sperp2x) {
   const double r2 = fma(r_par, r_par, sperp2);
@@ -247,7 +267,7 @@ __device__ __forceinline__ double uni_value(const double* __restrict__ lds, cons
   const double* rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(r2, inv_r, fc.off) : r2 * inv_r, tq, qi);
   const double SV = cubic_b128(rec, tq);
   const double V = cubic_b128(rec + 4, tq);
-  const double ynum = fma(AVk * V, mu_r, xk);
+  const double ynum = PV ? fma(V, mu_r, xk) : fma(AVk * V, mu_r, xk);
   if (FD) {
     const double rp = r_par * fa;
     const double r2x = fma(rp, rp, sperp2x);
@@ -405,7 +425,7 @@ __device__ __forceinline__ void copy_image(double* lds, const double* __restrict
 }
 
 struct FastPlan {
-  int murec, xrec, betar, da, image_end, red, like, total;
+  int murec, xrec, betar, da, v1, image_end, red, like, total;
 };
 
 __host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int uni_n, int nlr, int n_beta_r, int lut_n,
@@ -417,6 +437,7 @@ __host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int uni_n,
   p.xrec = o;  o += n_x * 2;
   p.betar = o; o += (n_beta_r + 1) & ~1;
   p.da = o;    o += with_da ? uni_n * 4 : 0;  // Da table of the dispersion model
+  p.v1 = o;    o += with_da ? 0 : uni_n * 4;  // unscaled V1 cubics (streaming modes: the records hold AVk * V, see scale_uni_v)
   o = (o + 1) & ~1;
   p.image_end = o;                            // everything up to here is batch-constant (or rebuilt per point)
   p.red = o;   o += kWaves * kMaxEll;
@@ -446,6 +467,7 @@ __device__ __forceinline__ void stage_fast(const TheoryArgs& a, const FastPlan& 
   for (int e = tid; e < 2 * a.n_x; e += kBlock) lds[pl.xrec + e] = a.xw_scaled[e];     // {kExpScale x_k, w_k}
   stage_uni_records<NLR>(a, lds);
   if (with_da) stage_da<NLR>(a, lds + pl.da);
+  else for (int e = tid; e < a.uni_n * 4; e += kBlock) lds[pl.v1 + e] = a.uni_sv_v[(e >> 2) * 8 + 4 + (e & 3)];
   if (a.n_beta_r > 0)
     for (int i = tid; i < a.n_beta_r; i += kBlock) lds[pl.betar + i] = a.beta_r[i];
 }
@@ -495,14 +517,14 @@ __global__ __launch_bounds__(kBlock, 3) void vk_theory_fast_kernel(TheoryArgs a)
     const int q = (int)(item - pg * (unsigned)Q);
     const int g = (int)(pg - (unsigned)point * (unsigned)groups);
     const double* row = a.params + point * VK_NPAR;
-    if (a.n_beta_r > 0 || a.empirical) {
+    const FastPoint fp = make_fast_point(ps, fc);
+    constexpr int PV = mode_is_dispersion(MODE) ? 0 : 1;
+    if (PV || a.n_beta_r > 0 || a.empirical) {
       __syncthreads();  // previous item's readers are done with the per-point records
-      if (a.n_beta_r > 0) rebuild_uni_xi<NLR>(a, lds + kRecsOff, lds + pl.betar, row[VK_P_BETA]);
-      if (a.empirical) rebuild_uni_v_emp<NLR>(a, lds + kRecsOff, ps.av);
+      rebuild_point_tables<NLR, PV>(a, lds, pl.betar, pl.v1, row[VK_P_BETA], ps.av, fp.AVk);
       if (mode_is_dispersion(MODE) && a.empirical) rebuild_da_emp(a, lds + pl.da, ps.av);
       __syncthreads();
     }
-    const FastPoint fp = make_fast_point(ps, fc);
     VK_STAMP(a, 2);
     const int lo = (int)((long long)plane * q / Q), hi = (int)((long long)plane * (q + 1) / Q);
     const unsigned idx0 = (unsigned)(lo + lane + 64 * my_rank);
@@ -532,7 +554,7 @@ __global__ __launch_bounds__(kBlock, 3) void vk_theory_fast_kernel(TheoryArgs a)
           const double f = xw.y * (mode_is_dispersion(MODE)
                                        ? disp_value<NLR, GRID, MODE == kModeDispersionFromData>(lds, lds + pl.da, fc, fp, a.niter, num,
                                                                                               s_par, sperp2, xw.x)
-                                       : uni_value<NLR, GRID, MODE == kModeFromData>(lds, fc, fp.AVk, num, sperp2, xw.x, fp.fa,
+                                       : uni_value<NLR, GRID, MODE == kModeFromData, 1>(lds, fc, fp.AVk, num, sperp2, xw.x, fp.fa,
                                                                                     sperp2 * fp.fp2));
           const vk_d2 w01 = *reinterpret_cast<const vk_d2*>(mr + 2);
           acc[0] = fma(w01.x, f, acc[0]);
