@@ -18,6 +18,9 @@ from .ccf_model import CCFModel
 from .utils import InputError
 
 
+_SCALARS = (float, int, np.float64)     # the common types of a sampler's parameter values: no np.ndim() call needed
+
+
 class CCFFit(CCFModel):
     """Fits of the CCF model to measured redshift-space multipoles."""
 
@@ -240,7 +243,7 @@ class CCFFit(CCFModel):
     def log_likelihood(self, params, **kwargs):
         """(lnL, chi2) at one parameter point (reference: ccf_fit.py:356-483)."""
         plan = self._single_point_plan() if (not kwargs and type(params) is dict) else None
-        if plan is not None and not any(np.ndim(v) for v in params.values()):
+        if plan is not None and all(type(v) in _SCALARS or not np.ndim(v) for v in params.values()):
             eng, opts, need_beta, need_fs8 = plan
             if not self.fixed_data and params.get("beta", None) is None:
                 raise InputError("Need to supply a valid value of beta for interpolation")   # ccf_fit.py:188-189
