@@ -255,6 +255,24 @@ def test_general_s_grid_and_poles(synth_fit, oracle):
     assert np.max(np.abs(got["0"] - want["0"])) < RTOL * np.max(np.abs(want["0"]))
 
 
+def test_general_grid_batches_through_every_work_split(synth_fit, boss_fit):
+    """``theory_multipoles_batch`` on a caller's s grid (13 bins, not the data's 40 / 30; l = 0, 2, 4 or odd l on the full mu range)
+    for batch sizes that take the plane-split point-major kernel, the cell ranges and whole-point workgroups: every size must
+    reproduce the rows of one large batch (the partial-sum slots and counters are sized by the context's own grid)."""
+    s = np.linspace(4.0, 112.0, 13)
+    for fit, beta in ((synth_fit[3], False), (boss_fit["config"], True)):
+        hp = cases.halton_params(2100, with_beta=beta)
+        for poles in ([0, 2, 4], [0, 1]):
+            big = fit.theory_multipoles_batch(s, hp, poles)
+            assert big.shape == (2100, len(poles), 13) and np.all(np.isfinite(big))
+            for n in (1, 2, 7, 30, 200, 1500):
+                sub = fit.theory_multipoles_batch(s, {k: v[:n] for k, v in hp.items()}, poles)
+                assert np.max(np.abs(sub - big[:n])) <= 1e-12 * np.max(np.abs(big)), (beta, poles, n)
+    # and the reference-style scalar call
+    one = synth_fit[3].theory_multipoles(s, cases.point(cases.halton_params(3), 2), poles=[0, 2, 4])
+    assert set(one) == {"0", "2", "4"} and one["2"].shape == (13,)
+
+
 def test_large_batch_properties(synth_fit):
     """Full-size batch (BASELINE config 3: 65536 points): size-independent checks."""
     fit = synth_fit[3]
