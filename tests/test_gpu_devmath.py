@@ -27,5 +27,8 @@ def test_device_math_within_two_ulp(tmp_path):
     # 4M samples each: sqrt/rsqrt over x in [2e-9, 5e8], recip likewise, exp over [-760, 0]
     assert res["sqrt_ulp"] <= 2.0 and res["rsqrt_ulp"] <= 2.0 and res["recip_ulp"] <= 1.0
     assert res["exp_ulp_normal"] <= 2.5
+    # exp_gauss (clamped product, magic-number rounding, table + degree-4 polynomial): z in [-39, 39]; NaN in -> NaN out,
+    # saturated arguments -> exactly 0, exp(0) = 1
+    assert res["gauss_ulp_normal"] <= 3.0 and res["gauss_special_ok"] == 1
     # the raw hardware seeds are only ~2^-24, which is why each gets a third-order correction step
     assert 1e-9 < res["raw_v_rsq_f64_rel"] < 1e-6 and 1e-9 < res["raw_v_rcp_f64_rel"] < 1e-6

@@ -1,5 +1,5 @@
 // Standalone accuracy check of vk_devmath.h on the GPU:  hipcc --offload-arch=gfx950 -O3 -I victor_amd/csrc tools/devmath_check.hip -o /tmp/devmath_check
-// Prints the maximum error in ulp of sqrt_rsqrt, recip and exp_nonpos against the host's correctly rounded long-double values.
+// Prints the maximum error in ulp of sqrt_rsqrt, recip, exp_nonpos and exp_gauss against the host's correctly rounded long-double values.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -18,6 +18,16 @@ __global__ void run(const double* x, const double* a, double* g, double* ir, dou
   ex[i] = vkm::exp_nonpos(a[i], tab);
   raw_rsq[i] = __builtin_amdgcn_rsq(x[i]);
   raw_rcp[i] = __builtin_amdgcn_rcp(x[i]);
+}
+
+// vkm::exp_gauss: exp(-z^2/2) from (ynum, 1/SV) with y = kExpScale z; slots 0..3 of the inputs are special values
+__global__ void run_gauss(const double* yn, const double* isv, double* out, int n) {
+  __shared__ double tab[vkm::kExpTab];
+  vkm::clamp_keeps_nan();
+  for (int j = threadIdx.x; j < vkm::kExpTab; j += blockDim.x) tab[j] = vkm::exp2_frac_c4(j);
+  __syncthreads();
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = vkm::exp_gauss(yn[i], isv[i], tab);
 }
 
 // vkm::wave_sum (DPP reduction): every lane of a wavefront must receive the same total of the wave's 64 inputs
@@ -68,6 +78,34 @@ int main() {
     raw1 = fmax(raw1, fabs((double)((long double)r1[i] * sqrtl(xl) - 1.0L)));
     raw2 = fmax(raw2, fabs((double)((long double)r2[i] * xl - 1.0L)));
   }
+  // exp_gauss: z = ynum * inv_sv / kExpScale in [-12, 12] mostly (the kernels see |z| <~ 8), tails out to the underflow;
+  // the reference value is taken at the rounded product y' = fl(|ynum inv_sv|), which is an input of the range reduction
+  std::vector<double> yn(n), isv(n), eg(n);
+  for (int i = 0; i < n; ++i) {
+    const double z = ((i & 15) == 0 ? 39.0 : 12.0) * (rnd() * 2 - 1);
+    isv[i] = 0.5 + 1.5 * rnd();
+    yn[i] = z * vkm::kExpScale / isv[i];
+  }
+  yn[0] = NAN; isv[0] = 1.0;                       // NaN must propagate (clamp_keeps_nan)
+  yn[1] = 1e300; isv[1] = 1e5;                     // saturates at y' = 1: exactly 0
+  yn[2] = 0.0; isv[2] = 1.0;                       // exp(0) = 1
+  yn[3] = -3000.0 * vkm::kExpScale; isv[3] = 1.0;  // beyond the clamp: 0
+  double *dyn, *disv, *deg;
+  hipMalloc(&dyn, nb); hipMalloc(&disv, nb); hipMalloc(&deg, nb);
+  hipMemcpy(dyn, yn.data(), nb, hipMemcpyHostToDevice);
+  hipMemcpy(disv, isv.data(), nb, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(run_gauss, dim3(n / 256), dim3(256), 0, 0, dyn, disv, deg, n);
+  hipMemcpy(eg.data(), deg, nb, hipMemcpyDeviceToHost);
+  double m_gn = 0, m_gt = 0;
+  for (int i = 4; i < n; ++i) {
+    const double yp = fabs(yn[i] * isv[i]);                         // one rounding, as the device's v_mul_f64
+    const long double ys = (long double)yp * 32768.0L;
+    const long double el = expl(-ys * ys * (logl(2.0L) / 256.0L));
+    const double ue = ulp_err(eg[i], el);
+    if (el > 1e-300L) m_gn = fmax(m_gn, ue); else m_gt = fmax(m_gt, ue);
+  }
+  const int gauss_special_ok = std::isnan(eg[0]) && eg[1] == 0.0 && eg[2] == 1.0 && eg[3] == 0.0;
+
   // wave_sum on the first 2^16 samples of x and of a (signed), 64 consecutive values per wavefront
   const int nw = 1 << 16;
   double *dws;
@@ -86,7 +124,8 @@ int main() {
       ws_rel = fmax(ws_rel, (double)(fabsl((long double)w[g] - want) / mag));
     }
   }
-  printf("{\"wave_sum_rel\": %.3e, \"wave_sum_uniform\": %d, \"sqrt_ulp\": %.3f, \"rsqrt_ulp\": %.3f, \"recip_ulp\": %.3f, \"exp_ulp_normal\": %.3f, \"exp_ulp_denormal_tail\": %.3f, "
+  printf("{\"gauss_ulp_normal\": %.3f, \"gauss_ulp_denormal_tail\": %.3f, \"gauss_special_ok\": %d, ", m_gn, m_gt, gauss_special_ok);
+  printf("\"wave_sum_rel\": %.3e, \"wave_sum_uniform\": %d, \"sqrt_ulp\": %.3f, \"rsqrt_ulp\": %.3f, \"recip_ulp\": %.3f, \"exp_ulp_normal\": %.3f, \"exp_ulp_denormal_tail\": %.3f, "
          "\"raw_v_rsq_f64_rel\": %.3e, \"raw_v_rcp_f64_rel\": %.3e}\n", ws_rel, ws_uniform, m_g, m_ir, m_rc, m_exn, m_ex, raw1, raw2);
   return 0;
 }

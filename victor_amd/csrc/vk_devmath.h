@@ -102,27 +102,44 @@ __device__ __forceinline__ double fma_s(double p, double f, double c) {
   return r;
 }
 
-// exp(-z^2/2) for callers that carry y = kExpScale * z instead of z (kExpScale^2 = 128/ln2, folded into their
-// per-point and per-node constants): with yn = -y*y = -(z^2/2) * 256/ln2 the range reduction is n = rint(yn),
-// d = yn - n (exact), exp = 2^(n/256) * exp(d ln2/256).  The degree-4 Taylor polynomial in f = d ln2/256 is
-// evaluated in d with every coefficient divided by the leading one, c4 = (ln2/256)^4/24, so the Horner addends
-// are scalar constants and c4 lives in the table: `tab_c4[j]` = c4 * 2^(j/256) (exp2_frac_c4 below).
-// No clamp is needed: an fma-free exact d keeps the polynomial in [0.998, 1.002] for every finite argument, a huge
-// |yn| saturates v_cvt_i32 and v_ldexp then underflows to 0, and a NaN propagates.
-constexpr double kExpScale = 13.589148804608305;                 // sqrt(128/ln 2)
+// exp(-z^2/2) for callers that carry ynum and 1/SV with z = ynum / SV in units of kExpScale, i.e. y = kExpScale * z
+// (kExpScale^2 = 128/ln2 * 2^-30, folded into the per-point amplitude and the velocity nodes).
+//   * y' = min(|ynum| |inv_sv|, 1) comes out of ONE v_mul_f64: abs modifiers on the inputs and the VOP3 clamp bit on the
+//     result.  y' = 1 is |z| = 2^15 / sqrt(128/ln2) = 2411, where exp(-z^2/2) = 0 in double anyway (it underflows beyond
+//     |z| = 38.6), so the saturation is exact and bounds n below.
+//   * with yn = -(y' 2^15)^2 = -(z^2/2) 256/ln2 the range reduction is n = rint(yn), d = yn - n, exp = 2^(n/256) exp(d ln2/256).
+//     n comes from the add-a-magic-number rounding: nd = fma(-y', y', 1.5 2^22) has ulp 2^-30, i.e. it holds
+//     1.5 2^52 + n in its mantissa - the low word of nd IS n (two's complement, |n| <= 2^30) with no v_rndne / v_cvt -,
+//     nn = nd - magic = n 2^-30 exactly, and ds = fma(-y', y', -nn) = d 2^-30 is exact as before (|d| <= 1/2, up to a
+//     tie of the single rounding).
+//   * the degree-4 Taylor polynomial in f = d ln2/256 is evaluated in ds with every coefficient divided by the leading
+//     one, c4 2^120 with c4 = (ln2/256)^4/24, so the Horner addends are scalar constants and the leading one lives in
+//     the table: `tab_c4[j]` = c4 2^120 2^(j/256) (exp2_frac_c4 below).  Powers of two only rescale: same bits as a
+//     polynomial in d.
+// NaN: the clamp bit turns a NaN product into 0 when MODE.DX10_CLAMP is set (the HSA default); the kernels that use this
+// clear that bit at entry (clamp_keeps_nan) so a NaN still propagates, and their final multiply by inv_sv carries a NaN
+// 1/SV in any case.
+constexpr double kExpScale = 13.589148804608305 * 0x1p-15;       // sqrt(128/ln 2) 2^-15
+constexpr double kExpMagic = 0x1.8p22;                           // ulp 2^-30
 constexpr double kExpC1 = 0.0027076061740622863;                 // ln2/256
 constexpr double kExpC4 = kExpC1 * kExpC1 * kExpC1 * kExpC1 / 24.0;
-__device__ __forceinline__ double exp2_frac_c4(int j) { return kExpC4 * exp2((double)j * (1.0 / kExpTab)); }
+__device__ __forceinline__ double exp2_frac_c4(int j) { return kExpC4 * 0x1p120 * exp2((double)j * (1.0 / kExpTab)); }
 
-__device__ __forceinline__ double exp_scaled(double yn, const double* __restrict__ tab_c4) {
-  const double n = rint(yn);
-  const double d = yn - n;
-  const int ni = (int)n;
+// MODE.DX10_CLAMP = 0 for this wave: v_*_f64 ... clamp then returns NaN for a NaN result instead of 0
+__device__ __forceinline__ void clamp_keeps_nan() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 8, 1), 0"); }
+
+__device__ __forceinline__ double exp_gauss(double ynum, double inv_sv, const double* __restrict__ tab_c4) {
+  double yp;
+  asm("v_mul_f64 %0, |%1|, |%2| clamp" : "=v"(yp) : "v"(ynum), "v"(inv_sv));
+  const double nd = fma(-yp, yp, kExpMagic);
+  const double nn = nd - kExpMagic;
+  const double d = fma(-yp, yp, -nn);
+  const int ni = __double2loint(nd);
   const double t = tab_c4[ni & (kExpTab - 1)];
-  double q = d + 4.0 / kExpC1;                                   // (c3/c4)
-  q = fma_s(q, d, 12.0 / (kExpC1 * kExpC1));                     // c2/c4
-  q = fma_s(q, d, 24.0 / (kExpC1 * kExpC1 * kExpC1));            // c1/c4
-  q = fma_s(q, d, 24.0 / (kExpC1 * kExpC1 * kExpC1 * kExpC1));   // 1/c4
+  double q = d + 4.0 / kExpC1 * 0x1p-30;                                  // c3/c4
+  q = fma_s(q, d, 12.0 / (kExpC1 * kExpC1) * 0x1p-60);                    // c2/c4
+  q = fma_s(q, d, 24.0 / (kExpC1 * kExpC1 * kExpC1) * 0x1p-90);           // c1/c4
+  q = fma_s(q, d, 24.0 / (kExpC1 * kExpC1 * kExpC1 * kExpC1) * 0x1p-120); // 1/c4
   return ldexp(t * q, ni >> 8);
 }
 

@@ -95,6 +95,7 @@ __device__ __forceinline__ void finish_point_ranges(const TheoryArgs& a, long lo
 template <int NLR, int NL, int GRID, int MODE>
 __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_theory_cells_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
+  vkm::clamp_keeps_nan();
   warm_kernarg_lines<sizeof(TheoryArgs)>();
   const int N = a.n_ell * a.n_s;
   const int R = a.parts;
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
   typedef const vk_d2 __attribute__((address_space(4))) * cvec_ptr;
   const cvec_ptr cxw = (cvec_ptr)(unsigned long long)a.xw_scaled;
   const double* l_s = lds + pl.s;
+  const double x_max = fmax(fabs(cxw[0].x), fabs(cxw[a.n_x - 1].x));
   const int slots = min(cells_range_bins(a.n_mu, cpi), a.n_s) + 1;   // local bins of a range (+ one that only ever receives zeros)
   double* l_acc = lds + pl.acc;                              // [l][local bin][wave]: each entry touched by one wave only
   const unsigned items = (unsigned)a.n * (unsigned)R;                // the host keeps n * parts below 2^31
@@ -152,16 +154,27 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
       const double sperp2x = sperp2 * fp.fp2;      // from_data only
       const double s_par = sj * fp.k_par * mm.x;
       double g = 0.0;
-      for (int k = 0; k < a.n_x; ++k) {
-        const vk_d2 xw = cxw[k];             // scalar-cache read (wave-uniform), see vk_kernel_lanes.h
-        const double xk = xw.x;
-        const double num = fma(-xk, fp.Bk, s_par);
-        g = fma(xw.y,
-                mode_is_dispersion(MODE)
-                    ? disp_value<NLR, GRID, MODE == kModeDispersionFromData>(lds, lds + pl.da, fc, fp, a.niter, num, s_par, sperp2,
-                                                                           xk)
-                    : uni_value<NLR, GRID, MODE == kModeFromData, 1>(lds, fc, fp.AVk, num, sperp2, xk, fp.fa, sperp2x),
-                g);
+      // trips whose 64 x 50 radii all fall inside the table skip the clamp pair of the interval coordinate (see the lanes
+      // kernel; a trip that holds a mu = 1 cell reaches r < 0.01 and keeps it)
+      if (GRID == 0 && !mode_is_dispersion(MODE) && !__any(!cell_in_table(fc, s_par, sperp2, x_max * fabs(fp.Bk)))) {
+        for (int k = 0; k < a.n_x; ++k) {
+          const vk_d2 xw = cxw[k];
+          const double xk = xw.x;
+          g = fma(xw.y, uni_value<NLR, GRID, MODE == kModeFromData, 1, 0>(lds, fc, fp.AVk, fma(-xk, fp.Bk, s_par), sperp2, xk, fp.fa,
+                                                                         sperp2x), g);
+        }
+      } else {
+        for (int k = 0; k < a.n_x; ++k) {
+          const vk_d2 xw = cxw[k];             // scalar-cache read (wave-uniform), see vk_kernel_lanes.h
+          const double xk = xw.x;
+          const double num = fma(-xk, fp.Bk, s_par);
+          g = fma(xw.y,
+                  mode_is_dispersion(MODE)
+                      ? disp_value<NLR, GRID, MODE == kModeDispersionFromData>(lds, lds + pl.da, fc, fp, a.niter, num, s_par, sperp2,
+                                                                             xk)
+                      : uni_value<NLR, GRID, MODE == kModeFromData, 1>(lds, fc, fp.AVk, num, sperp2, xk, fp.fa, sperp2x),
+                  g);
+        }
       }
       if (!live) g = 0.0;
       // projection: this trip's cells belong to local bin jj0 or jj0 + 1 (the latter may be the spill bin)

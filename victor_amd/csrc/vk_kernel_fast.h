@@ -45,6 +45,7 @@ struct FastConsts {
   double off, t_lo, n_eps;        // GRID 0: t = r' + off, clamped to [t_lo, n_eps]; t_lo is u = 0.01, the first V knot
                                   // GRID 1: u = r' clamped to [t_lo, n_eps] = [first knot, last knot)
   double inv_g;                   // GRID 1: cells of the look-up table per unit length
+  double rlo2, rhi2;              // GRID 0: t stays inside (t_lo, n_eps) while rlo2 <= r'^2 < rhi2 (rows_in_table)
   int lut_off;                    // GRID 1: byte offset of the look-up table in LDS
 };
 
@@ -80,6 +81,7 @@ __device__ __forceinline__ FastConsts make_fast_consts(const TheoryArgs& a) {
     fc.t_lo = a.uni_knots[0];
     fc.n_eps = a.uni_knots[a.uni_n] * (1.0 - 0x1p-52);
     fc.inv_g = a.uni_lut_inv_g;
+    fc.rlo2 = fc.rhi2 = 0.0;
     fc.lut_off = (kRecsOff + (a.uni_n + 2) * uni_stride(NLR)) * 8;
   } else {
     fc.inv_h = a.uni_inv_h;
@@ -87,9 +89,21 @@ __device__ __forceinline__ FastConsts make_fast_consts(const TheoryArgs& a) {
     fc.t_lo = (a.vr.knots[0] - a.uni_u0) * a.uni_inv_h;
     fc.n_eps = (double)a.uni_n * (1.0 - 0x1p-52);
     fc.inv_g = 0.0;
+    // margins of 1e-9 relative: r' = r2 rsqrt(r2) is good to an ulp, so t cannot cross a bound the squares stay clear of
+    const double lo = fc.t_lo - fc.off, hi = fc.n_eps - fc.off;
+    fc.rlo2 = lo * lo * (1.0 + 1e-9);
+    fc.rhi2 = hi * hi * (1.0 - 1e-9);
     fc.lut_off = 0;
   }
   return fc;
+}
+
+// Is the interval coordinate of every velocity node of this lane's (s, mu) cell inside the table, so that the clamp pair of
+// `locate` is the identity?  s_perp'^2 <= r'^2 <= s_perp'^2 + (|s_par'| + max|x_k'| |Bk|)^2 by the monotonicity of the
+// roundings; `xi_max` = max|x_k'| |Bk|.  False for NaN operands (the clamped form then yields a valid index as before).
+__device__ __forceinline__ bool cell_in_table(const FastConsts& fc, double s_par, double sperp2, double xi_max) {
+  const double spx = fabs(s_par) + xi_max;
+  return (sperp2 >= fc.rlo2) && (fma(spx, spx, sperp2) < fc.rhi2);
 }
 
 // Stage the batch-constant parts of the records: sigma_v and V always, xi^r_l when it does not depend on beta;
@@ -224,12 +238,13 @@ __device__ __forceinline__ FastPoint make_fast_point(const PointScalars& ps, con
 
 // Record and local coordinate of a radius: `x` is the interval coordinate t = r' + off (GRID 0) or the radius u = r'
 // itself (GRID 1, union grid), not yet clamped.
-template <int NLR, int GRID>
+// CL = 0: the caller has shown that t lies inside [t_lo, n_eps] for every lane (rows_in_table below), the clamp pair is dropped.
+template <int NLR, int GRID, int CL = 1>
 __device__ __forceinline__ const double* locate(const double* __restrict__ lds, const FastConsts& fc, double x,
                                                 double& tq, int& qi) {
   constexpr int stride = uni_stride(NLR);
   if (GRID == 0) {
-    const double t = vmin_f64(vmax_f64(x, fc.t_lo), fc.n_eps);
+    const double t = CL ? vmin_f64(vmax_f64(x, fc.t_lo), fc.n_eps) : x;
     tq = __builtin_amdgcn_fract(t);
     qi = (int)t;
     return lds_at(lds + kRecsOff, __mul24(qi, stride * 8));
@@ -255,7 +270,7 @@ __device__ __forceinline__ const double* locate(const double* __restrict__ lds, 
 // fa = c/apar, fp = c/aperp (`sperp2x` carries the second product), through a second interval look-up.
 // PV = 1: the V cubics in the records already carry the per-point factor AVk (the kernels that own a point per workgroup
 // rescale them once per work item, scale_uni_v) - one multiply less per integrand point.
-template <int NLR, int GRID, int FD, int PV = 0>
+template <int NLR, int GRID, int FD, int PV = 0, int CL = 1>
 __device__ __forceinline__ double uni_value(const double* __restrict__ lds, const FastConsts& fc, double AVk,
                                             double r_par, double sperp2, double xk, double fa, double sperp2x) {
   const double r2 = fma(r_par, r_par, sperp2);
@@ -264,7 +279,7 @@ __device__ __forceinline__ double uni_value(const double* __restrict__ lds, cons
   double mu_x = mu_r;                           // the mu at which xi^r is read
   double tq;
   int qi;
-  const double* rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(r2, inv_r, fc.off) : r2 * inv_r, tq, qi);
+  const double* rec = locate<NLR, GRID, CL>(lds, fc, GRID == 0 ? fma(r2, inv_r, fc.off) : r2 * inv_r, tq, qi);
   const double SV = cubic_b128(rec, tq);
   const double V = cubic_b128(rec + 4, tq);
   const double ynum = PV ? fma(V, mu_r, xk) : fma(AVk * V, mu_r, xk);
@@ -285,8 +300,7 @@ __device__ __forceinline__ double uni_value(const double* __restrict__ lds, cons
     }
   }
   const double inv_sv = vkm::recip(SV);
-  const double y = ynum * inv_sv;
-  const double e = vkm::exp_scaled(-y * y, lds + kEtabOff);
+  const double e = vkm::exp_gauss(ynum, inv_sv, lds + kEtabOff);
   return inv_sv * fma(e, xir, e);
 }
 
@@ -330,8 +344,7 @@ __device__ __forceinline__ double disp_value(const double* __restrict__ lds, con
   if (NLR == 3) xir = fma(fma(cubic_b128(rec + 16, tq), mx2, cubic_b128(rec + 12, tq)), mx2, xir);
   const double inv_sv = vkm::recip(SV);
   const double jac = vkm::recip(1.0 + q + m2 * (dq - q));
-  const double y = xk * inv_sv;
-  const double e = vkm::exp_scaled(-y * y, lds + kEtabOff);
+  const double e = vkm::exp_gauss(xk, inv_sv, lds + kEtabOff);
   return inv_sv * jac * fma(e, xir, e);
 }
 
@@ -475,6 +488,7 @@ __device__ __forceinline__ void stage_fast(const TheoryArgs& a, const FastPlan& 
 template <int NLR, int NL, int GRID, int MODE>
 __global__ __launch_bounds__(kBlock, 3) void vk_theory_fast_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
+  vkm::clamp_keeps_nan();
   warm_kernarg_lines<sizeof(TheoryArgs)>();
   const int N = a.n_ell * a.n_s;
   const int Q = a.parts;

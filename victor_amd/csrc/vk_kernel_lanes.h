@@ -80,6 +80,7 @@ __device__ __forceinline__ PointScalars point_scalars_lane(const TheoryArgs& a, 
 template <int NLR, int NL, int GRID>
 __global__ __launch_bounds__(kBlock, 5) void vk_theory_lanes_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
+  vkm::clamp_keeps_nan();
   const LanesPlan pl = make_lanes_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.uni_lut_n);
   const int tid = threadIdx.x;
   if (a.image) copy_image(lds, a.image, pl.image_end);
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(kBlock, 5) void vk_theory_lanes_kernel(TheoryArgs a
   // tells the compiler so), which keeps them out of the VALU and LDS pipes
   typedef const vk_d2 __attribute__((address_space(4))) * cvec_ptr;
   const cvec_ptr cxw = (cvec_ptr)(unsigned long long)a.xw_scaled;
+  const double x_max = fmax(fabs(cxw[0].x), fabs(cxw[a.n_x - 1].x));
   const long long chunks = (a.n + 63) >> 6;
   const long long items = chunks * a.n_s;
   // XCD-aware block order: the n_s waves of a 64-point chunk read the same 6 KB of parameter rows; consecutive
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(kBlock, 5) void vk_theory_lanes_kernel(TheoryArgs a
     const FastPoint fp = make_fast_point(ps, fc);
     const double sj = a.s[j];
     const double sa = sj * fp.k_perp, sp = sj * fp.k_par;
+    const double xi_max = x_max * fabs(fp.Bk);
     double acc[NL];
 #pragma unroll
     for (int l = 0; l < NL; ++l) acc[l] = 0.0;
@@ -121,10 +124,20 @@ __global__ __launch_bounds__(kBlock, 5) void vk_theory_lanes_kernel(TheoryArgs a
       const double sperp2 = s_perp * s_perp;
       const double s_par = sp * mm.x;
       double g = 0.0;
-      for (int k = 0; k < a.n_x; ++k) {
-        const vk_d2 xw = cxw[k];
-        const double xk = xw.x;
-        g = fma(xw.y, uni_value<NLR, GRID, 0>(lds, fc, fp.AVk, fma(-xk, fp.Bk, s_par), sperp2, xk, 0.0, 0.0), g);
+      // rows whose 64 x 50 radii all fall inside the table (nearly all of them: the host extends the records past the last
+      // knot, and only the mu = 1 row reaches r < 0.01) skip the clamp pair of the interval coordinate
+      if (GRID == 0 && !__any(!cell_in_table(fc, s_par, sperp2, xi_max))) {
+        for (int k = 0; k < a.n_x; ++k) {
+          const vk_d2 xw = cxw[k];
+          const double xk = xw.x;
+          g = fma(xw.y, uni_value<NLR, GRID, 0, 0, 0>(lds, fc, fp.AVk, fma(-xk, fp.Bk, s_par), sperp2, xk, 0.0, 0.0), g);
+        }
+      } else {
+        for (int k = 0; k < a.n_x; ++k) {
+          const vk_d2 xw = cxw[k];
+          const double xk = xw.x;
+          g = fma(xw.y, uni_value<NLR, GRID, 0>(lds, fc, fp.AVk, fma(-xk, fp.Bk, s_par), sperp2, xk, 0.0, 0.0), g);
+        }
       }
 #pragma unroll
       for (int l = 0; l < NL; ++l) acc[l] = fma(a.w_ell[l * a.n_mu + i], g, acc[l]);
