@@ -124,8 +124,10 @@ __global__ __launch_bounds__(kBlock, 5) void vk_theory_lanes_kernel(TheoryArgs a
       const double sperp2 = s_perp * s_perp;
       const double s_par = sp * mm.x;
       double g = 0.0;
-      // rows whose 64 x 50 radii all fall inside the table (nearly all of them: the host extends the records past the last
-      // knot, and only the mu = 1 row reaches r < 0.01) skip the clamp pair of the interval coordinate
+      // rows whose 64 x 50 radii all fall inside the table (most of them: the records run to the last knot of the longest
+      // table, and only the mu = 1 row reaches r < 0.01) skip the clamp pair of the interval coordinate.  Extending the
+      // records past the last knot so that the top s bins qualify too was measured and dropped: nothing on config 3, and the
+      // larger LDS footprint costs BOSS a workgroup per CU (profiles/r02/i_clamp_exp_ab.txt)
       if (GRID == 0 && !__any(!cell_in_table(fc, s_par, sperp2, xi_max))) {
         for (int k = 0; k < a.n_x; ++k) {
           const vk_d2 xw = cxw[k];

@@ -8,8 +8,6 @@ tables; users normally do not touch it, except for the device-resident batch API
 
 import ctypes as C
 
-import os
-
 import numpy as np
 
 from . import _native as N
@@ -142,12 +140,6 @@ def build_tables(model, fit=None, matter_model=None, simpson_even=None):
                 u0, n = u0 - k0 * h, n + k0
                 if abs(u0) < 1e-9 * h:
                     u0 = 0.0
-                # ... and up past the last knot (constant records, i.e. the clamped evaluation) to where the radii of
-                # the top s bins reach for AP factors and dispersions at the edge of a wide prior: (s, mu) rows whose
-                # radii all stay inside the records skip the clamp of the interval coordinate (cell_in_table)
-                ext = os.environ.get("VICTOR_HIP_GRID_TOP", "1.3,40").split(",")
-                top = float(ext[0]) * float(s[-1]) + float(ext[1])
-                n = min(max(n, int(np.ceil((top - u0) / h))), max(n, 320))
                 grid = (u0 + h * np.arange(n), np.full(n, h))
                 t.uni_n, t.uni_u0, t.uni_inv_h = n, u0, 1.0 / h
         if grid is None:
