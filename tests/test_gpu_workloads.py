@@ -292,6 +292,37 @@ def _graph_replay_checks(fit, rows, hp):
     assert fit.log_likelihood(dict(p)) == single[0]
 
 
+def test_in_place_calls_poll_for_their_results():
+    """In-place host-buffer calls of up to 256 points do not wait for the end of the launch but for the results themselves
+    (slots pre-set to a NaN pattern, polled in pinned memory).  Same bits as the synchronised call for every size, rows
+    that fail (NaN parameter -> (-inf, inf)) included, through calls of changing size and content."""
+    import numpy as np
+    import victor_amd
+    from tests import cases
+    fit = victor_amd.CCFFit(*cases.boss_options("config"))
+    rows = fit._fit_rows(cases.halton_params(300, with_beta=True), fit.model)
+    rows[5, _native.P_SIGMAV] = np.nan
+    rows[200, _native.P_FSIGMA8] = np.inf
+    sizes = (1, 6, 64, 256, 300)
+    try:
+        _native.set_knob("VICTOR_HIP_SPIN_MAX", "0")
+        want = {n: fit.log_likelihood_batch(rows[:n]) for n in sizes}
+        want_tail = fit.log_likelihood_batch(rows[190:210])
+        _native.set_knob("VICTOR_HIP_SPIN_MAX", None)
+        for rep in range(3):
+            for n in sizes:
+                got = fit.log_likelihood_batch(rows[:n])
+                assert np.array_equal(got[0], want[n][0]) and np.array_equal(got[1], want[n][1]), (rep, n)
+            got = fit.log_likelihood_batch(rows[190:210])
+            assert np.array_equal(got[0], want_tail[0]) and np.array_equal(got[1], want_tail[1]), rep
+        assert np.isneginf(want[6][0][5]) and np.isposinf(want[6][1][5]) and np.isneginf(want_tail[0][10])
+        p = cases.point(cases.halton_params(4, with_beta=True), 3)
+        singles = {fit.log_likelihood(dict(p)) for _ in range(200)}
+        assert len(singles) == 1
+    finally:
+        _native.set_knob("VICTOR_HIP_SPIN_MAX", None)
+
+
 def test_one_process_driving_several_contexts():
     """victor_amd.sharding.MultiGPUFit: contiguous shards of a batch evaluated concurrently from host threads, one
     context per listed device (the one-GPU box lists device 0 three times); same as the single-context result."""

@@ -17,6 +17,7 @@
 // gather bandwidth, not for HBM or MFMA.  launch_theory() picks the K1 variant per call.
 
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <dlfcn.h>
 
@@ -115,6 +116,7 @@ struct Knobs {
   long long cells_min = -1;            // VICTOR_HIP_CELLS_MIN: smallest batch that takes the cells kernel (-1 = default)
   bool no_zero_copy = false;           // VICTOR_HIP_NO_ZERO_COPY: small host-buffer batches through the copy / graph path
   long long zero_copy_max = -1;        // VICTOR_HIP_ZERO_COPY_MAX: largest host-buffer batch on the in-place path (-1 = default)
+  long long spin_max = -1;             // VICTOR_HIP_SPIN_MAX: largest in-place batch whose results are polled for (-1 = default, 0 = never)
 };
 
 struct vk_ctx {
@@ -132,6 +134,7 @@ struct vk_ctx {
   const double *d_x1 = nullptr, *d_w1 = nullptr;  // single velocity node for the Kaiser-type models
   const double* d_vr_emp = nullptr;               // beta-dependent V2, Ge1, Ge2 (degree 6 in beta), see vk_tables.vr_emp
   const double* d_xws = nullptr;                  // [n_x + 1][2]: {kExpScale x_k, w_k}, scalar-cache reads (fast kernels)
+  double xw_max = 0.0;                            // max |kExpScale x_k|
   const double *d_s = nullptr, *d_mu = nullptr, *d_w = nullptr, *d_x = nullptr, *d_wx = nullptr, *d_beta_r = nullptr,
                *d_beta_d = nullptr, *d_data = nullptr, *d_beta_c = nullptr, *d_prec = nullptr, *d_logdet = nullptr,
                *d_eig = nullptr;
@@ -214,6 +217,7 @@ void load_knobs(vk_ctx* ctx) {
   if (const char* env = getenv("VICTOR_HIP_CELLS_MIN")) k.cells_min = atoll(env);
   k.no_zero_copy = getenv("VICTOR_HIP_NO_ZERO_COPY") != nullptr;
   if (const char* env = getenv("VICTOR_HIP_ZERO_COPY_MAX")) k.zero_copy_max = atoll(env);
+  if (const char* env = getenv("VICTOR_HIP_SPIN_MAX")) k.spin_max = atoll(env);
   k.force_generic = getenv("VICTOR_HIP_FORCE_GENERIC") != nullptr;
   if (const char* env = getenv("VICTOR_HIP_POINT_CAP")) k.point_cap = atoll(env);
   if (const char* env = getenv("VICTOR_HIP_LANES_CAP")) k.lanes_cap = atoll(env);
@@ -461,6 +465,7 @@ int theory_args(vk_ctx* ctx, const vk_eval_opts* o, TheoryArgs* a, int* nlr) {
     a->w_x = ctx->d_wx;
   }
   a->xw_scaled = ctx->d_xws;
+  a->xw_max = ctx->xw_max;
   *nlr = o->assume_isotropic ? 1 : ctx->n_ell_r;
   return VK_OK;
 }
@@ -942,6 +947,7 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
   for (int k = 0; k < t->n_x; ++k) {
     xw_scaled[2 * k] = t->x[k] * vkm::kExpScale;
     xw_scaled[2 * k + 1] = t->w_x[k];
+    ctx->xw_max = std::max(ctx->xw_max, std::fabs(xw_scaled[2 * k]));
   }
   const size_t o_xws = up.add(xw_scaled.data(), xw_scaled.size());
   const size_t o_br = t->n_beta_r > 0 ? up.add(t->beta_r, t->n_beta_r) : 0;
@@ -1302,6 +1308,8 @@ static int eval_batch_graph(vk_ctx* ctx, const vk_eval_opts* opts, const double*
   return 1;
 }
 
+constexpr int64_t kSpinMaxDefault = 256;         // in-place batches up to this size poll for their results (eval_batch_zero_copy)
+constexpr uint64_t kSpinSentinel = 0x7ff8dead5ca1ab1eULL;   // a quiet NaN with a payload no arithmetic produces
 constexpr int64_t kZeroCopyMaxDefault = 4096;   // host-buffer batches up to this size: parameters read in place, results written in place
 
 // Launch-bound host-buffer batches (the reference calls the likelihood with ONE point, CCFLikelihood.py:32-39): no copies at
@@ -1316,7 +1324,7 @@ static int eval_batch_zero_copy(vk_ctx* ctx, const vk_eval_opts* opts, const dou
   if (n > zc_max || ctx->knobs.no_zero_copy || ctx->zero_copy_off || ctx->timing || !(lnl || chi2)) return 0;
   if (!ctx->h_zc) {
     void* dev = nullptr;
-    if (hipHostMalloc((void**)&ctx->h_zc, (size_t)kZeroCopyCap * (VK_NPAR + 2) * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+    if (hipHostMalloc((void**)&ctx->h_zc, (size_t)kZeroCopyCap * (VK_NPAR + 2) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer(&dev, ctx->h_zc, 0) != hipSuccess) {
       (void)hipGetLastError();
       ctx->zero_copy_off = true;
@@ -1327,9 +1335,32 @@ static int eval_batch_zero_copy(vk_ctx* ctx, const vk_eval_opts* opts, const dou
   double* h_out = ctx->h_zc + (size_t)kZeroCopyCap * VK_NPAR;
   double* d_out = ctx->d_zc + (size_t)kZeroCopyCap * VK_NPAR;
   memcpy(ctx->h_zc, params, (size_t)n * VK_NPAR * sizeof(double));
+  // A handful of points: the host does not wait for the end of the launch (the command processor's end-of-kernel release and
+  // completion signal, then the runtime's wake-up) but for the results themselves - the slots are pre-set to a NaN pattern no
+  // kernel writes (failed rows report -inf / +inf) and polled in place; each slot is one 8-byte store of the thread that
+  // finishes its point.  The launch stays queued on the stream, which orders the next call behind it, and every workgroup
+  // has read its parameter row before the last result can appear, so the buffers may be reused at once.  Falls back to
+  // the stream synchronisation if nothing arrives within 2 ms (a failed launch reports its error there).
+  const int64_t spin_max = ctx->knobs.spin_max >= 0 ? ctx->knobs.spin_max : kSpinMaxDefault;
+  const bool spin = n <= spin_max;
+  volatile uint64_t* slots = reinterpret_cast<volatile uint64_t*>(h_out);
+  if (spin)
+    for (int64_t i = 0; i < 2 * n; ++i) slots[i] = kSpinSentinel;
   int rc = vk_eval_batch_device_async(ctx, opts, ctx->d_zc, n, d_out, d_out + n, d_th);
   if (rc) return rc;
-  VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  bool arrived = false;
+  if (spin) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned it = 1; !arrived; ++it) {
+      arrived = true;
+      for (int64_t i = 2 * n - 1; i >= 0; --i)
+        if (slots[i] == kSpinSentinel) { arrived = false; break; }
+      if (arrived) break;
+      __builtin_ia32_pause();
+      if ((it & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+  }
+  if (!arrived) VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (lnl) memcpy(lnl, h_out, (size_t)n * sizeof(double));
   if (chi2) memcpy(chi2, h_out + n, (size_t)n * sizeof(double));
   return 1;

@@ -7,6 +7,17 @@
 
 namespace vk {
 
+// threadIdx.x as a fresh value for code that runs once at the end of a work item (hand-over of partial sums, chi-square
+// tail): what such code derives from the thread index is then formed there instead of being hoisted to the top of the
+// kernel and carried - or spilled: 8 bytes per thread were 134 MB of scratch writes per 65536-point launch - through
+// the integrand loops.
+__device__ __forceinline__ int late_tid() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+
+
 constexpr int kBlock = 256;               // 4 wavefronts
 constexpr int kWaves = kBlock / 64;
 constexpr int kMaxEll = 3;
@@ -53,6 +64,7 @@ struct TheoryArgs {
   const double* x;        // [n_x]
   const double* w_x;      // [n_x]
   const double* xw_scaled;  // [n_x + 1][2]: {kExpScale x_k, w_k} (streaming fast kernels; last pair is padding)
+  double xw_max;            // max |kExpScale x_k| (cell_in_table)
   int n_beta_r;           // 0 = fixed xi tables
   const double* beta_r;
   PPView xi, vr, sv;

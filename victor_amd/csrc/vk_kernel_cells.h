@@ -74,7 +74,7 @@ template <int NL>
 __device__ __forceinline__ void finish_point_ranges(const TheoryArgs& a, long long point, double beta, double poison, double* th) {
   const int N = a.n_ell * a.n_s;
   const double w0 = a.wsum[0], w1 = a.wsum[1], w2 = a.wsum[2];
-  for (int e = threadIdx.x; e < N; e += kBlock) {
+  for (int e = late_tid(); e < N; e += kBlock) {
     const int l = (e >= 2 * a.n_s) ? 2 : (e >= a.n_s ? 1 : 0), j = e - l * a.n_s;
     const int q_first = (j * a.n_mu) / a.cells_per_item, q_last = (j * a.n_mu + a.n_mu - 1) / a.cells_per_item;
     double part[8];
@@ -112,13 +112,12 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
   VK_STAMP(a, 1);
 
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: a scalar register, not one VGPR per lane
   const double* l_mu = lds + pl.mu;
   const double* l_w = lds + pl.w;
   typedef const vk_d2 __attribute__((address_space(4))) * cvec_ptr;
   const cvec_ptr cxw = (cvec_ptr)(unsigned long long)a.xw_scaled;
   const double* l_s = lds + pl.s;
-  const double x_max = fmax(fabs(cxw[0].x), fabs(cxw[a.n_x - 1].x));
   const int slots = min(cells_range_bins(a.n_mu, cpi), a.n_s) + 1;   // local bins of a range (+ one that only ever receives zeros)
   double* l_acc = lds + pl.acc;                              // [l][local bin][wave]: each entry touched by one wave only
   const unsigned items = (unsigned)a.n * (unsigned)R;                // the host keeps n * parts below 2^31
@@ -156,7 +155,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
       double g = 0.0;
       // trips whose 64 x 50 radii all fall inside the table skip the clamp pair of the interval coordinate (see the lanes
       // kernel; a trip that holds a mu = 1 cell reaches r < 0.01 and keeps it)
-      if (GRID == 0 && !mode_is_dispersion(MODE) && !__any(!cell_in_table(fc, s_par, sperp2, x_max * fabs(fp.Bk)))) {
+      if (GRID == 0 && !mode_is_dispersion(MODE) && !__any(!cell_in_table(fc, s_par, sperp2, a.xw_max * fabs(fp.Bk)))) {
         for (int k = 0; k < a.n_x; ++k) {
           const vk_d2 xw = cxw[k];
           const double xk = xw.x;
@@ -194,7 +193,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
     // this range's share of the theory vector is complete in LDS once every wave has finished its trips
     __syncthreads();
     double* th = lds + pl.like;
-    for (int e = tid; e < NL * nb; e += kBlock) {
+    for (int e = late_tid(); e < NL * nb; e += kBlock) {
       const int l = e / nb, jl = e - l * nb;
       const int j = jf + jl;
       const double* pa = l_acc + (l * slots + jl) * kWaves;

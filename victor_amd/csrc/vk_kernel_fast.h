@@ -99,11 +99,14 @@ __device__ __forceinline__ FastConsts make_fast_consts(const TheoryArgs& a) {
 }
 
 // Is the interval coordinate of every velocity node of this lane's (s, mu) cell inside the table, so that the clamp pair of
-// `locate` is the identity?  s_perp'^2 <= r'^2 <= s_perp'^2 + (|s_par'| + max|x_k'| |Bk|)^2 by the monotonicity of the
-// roundings; `xi_max` = max|x_k'| |Bk|.  False for NaN operands (the clamped form then yields a valid index as before).
+// `locate` is the identity?  With r_par' = s_par' - x_k' Bk and `xi_max` = max|x_k'| |Bk|,
+//   s_perp'^2 + max(|s_par'| - xi_max, 0)^2 <= r'^2 <= s_perp'^2 + (|s_par'| + xi_max)^2
+// by the monotonicity of the roundings (the lower bound says that the mu = 1 cells, s_perp' = 0, only come near r = 0 in the
+// s bins the velocity nodes can reach).  False for NaN operands (the clamped form then yields a valid index as before).
 __device__ __forceinline__ bool cell_in_table(const FastConsts& fc, double s_par, double sperp2, double xi_max) {
   const double spx = fabs(s_par) + xi_max;
-  return (sperp2 >= fc.rlo2) && (fma(spx, spx, sperp2) < fc.rhi2);
+  const double spn = fmax(fabs(s_par) - xi_max, 0.0);
+  return (fma(spn, spn, sperp2) >= fc.rlo2) && (fma(spx, spx, sperp2) < fc.rhi2);
 }
 
 // Stage the batch-constant parts of the records: sigma_v and V always, xi^r_l when it does not depend on beta;

@@ -95,7 +95,6 @@ __global__ __launch_bounds__(kBlock, 5) void vk_theory_lanes_kernel(TheoryArgs a
   // tells the compiler so), which keeps them out of the VALU and LDS pipes
   typedef const vk_d2 __attribute__((address_space(4))) * cvec_ptr;
   const cvec_ptr cxw = (cvec_ptr)(unsigned long long)a.xw_scaled;
-  const double x_max = fmax(fabs(cxw[0].x), fabs(cxw[a.n_x - 1].x));
   const long long chunks = (a.n + 63) >> 6;
   const long long items = chunks * a.n_s;
   // XCD-aware block order: the n_s waves of a 64-point chunk read the same 6 KB of parameter rows; consecutive
@@ -114,7 +113,7 @@ __global__ __launch_bounds__(kBlock, 5) void vk_theory_lanes_kernel(TheoryArgs a
     const FastPoint fp = make_fast_point(ps, fc);
     const double sj = a.s[j];
     const double sa = sj * fp.k_perp, sp = sj * fp.k_par;
-    const double xi_max = x_max * fabs(fp.Bk);
+    const double xi_max = a.xw_max * fabs(fp.Bk);
     double acc[NL];
 #pragma unroll
     for (int l = 0; l < NL; ++l) acc[l] = 0.0;

@@ -130,7 +130,7 @@ __device__ __forceinline__ double like_quadratic(int N, const double* P0, const 
 // ccf_fit.py:349-354 (chi2), :166-193 (data vector), :195-260 (bracket), :444-481 (log det, forms, guards).
 __device__ __forceinline__ void like_point_workgroup(const LikeArgs& a, long long point, double beta, double* th, double* red) {
   typedef double d2 __attribute__((ext_vector_type(2)));
-  const int tid = threadIdx.x;
+  const int tid = late_tid();
   const double inf = __longlong_as_double(0x7ff0000000000000LL);
   // Interval searches on the (increasing) beta grids as counts over the threads - one grid value per thread, one
   // barrier each - instead of loops whose loads the compiler keeps in program order (31 dependent round trips each for
