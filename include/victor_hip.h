@@ -229,7 +229,9 @@ void vk_default_opts(vk_eval_opts* opts);
 
 /* Full likelihood for n parameter rows (host buffers).  Any of lnl/chi2/theory may be NULL.
  * lnl[i] = -inf, chi2[i] = +inf where the reference returns (-inf, inf) (ccf_fit.py:447-450,477-481).
- * theory is [n][n_ell*n_s]. */
+ * theory is [n][n_ell*n_s].  Synchronous for the caller: the results are in lnl / chi2 on return.  (Calls of a few
+ * hundred points that do not ask for `theory` return as soon as the results have arrived in pinned host memory, with
+ * the launch still retiring on the context's stream; every later call, vk_sync and vk_destroy are ordered behind it.) */
 int vk_eval_batch(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, int64_t n,
                   double* lnl, double* chi2, double* theory);
 

@@ -77,8 +77,11 @@ __device__ __forceinline__ PointScalars point_scalars_lane(const TheoryArgs& a, 
   return ps;
 }
 
+#ifndef VK_LANES_WG_PER_CU
+#define VK_LANES_WG_PER_CU 5
+#endif
 template <int NLR, int NL, int GRID>
-__global__ __launch_bounds__(kBlock, 5) void vk_theory_lanes_kernel(TheoryArgs a) {
+__global__ __launch_bounds__(kBlock, VK_LANES_WG_PER_CU) void vk_theory_lanes_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
   vkm::clamp_keeps_nan();
   const LanesPlan pl = make_lanes_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.uni_lut_n);
