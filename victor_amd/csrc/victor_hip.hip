@@ -185,6 +185,8 @@ struct vk_ctx {
   double* h_zc = nullptr;                       // pinned, device-mapped: params[kZeroCopyCap][VK_NPAR] | lnl, chi2 [2 kZeroCopyCap]
   double* d_zc = nullptr;                       // the same memory through the device's eyes
   bool zero_copy_off = false;
+  bool spin_off = false;               // results did not become visible to polling on this system (eval_batch_zero_copy)
+  int spin_timeouts = 0;
 };
 
 constexpr int64_t kGraphMaxN = 4096;
@@ -1342,7 +1344,7 @@ static int eval_batch_zero_copy(vk_ctx* ctx, const vk_eval_opts* opts, const dou
   // has read its parameter row before the last result can appear, so the buffers may be reused at once.  Falls back to
   // the stream synchronisation if nothing arrives within 2 ms (a failed launch reports its error there).
   const int64_t spin_max = ctx->knobs.spin_max >= 0 ? ctx->knobs.spin_max : kSpinMaxDefault;
-  const bool spin = n <= spin_max;
+  const bool spin = n <= spin_max && !ctx->spin_off;
   volatile uint64_t* slots = reinterpret_cast<volatile uint64_t*>(h_out);
   if (spin)
     for (int64_t i = 0; i < 2 * n; ++i) slots[i] = kSpinSentinel;
@@ -1360,7 +1362,14 @@ static int eval_batch_zero_copy(vk_ctx* ctx, const vk_eval_opts* opts, const dou
       if ((it & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
     }
   }
-  if (!arrived) VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (!arrived) {
+    VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // three small launches in a row took over 2 ms to show their results (the first call of a context, which also builds
+    // the LDS image, may): the stores evidently do not reach this memory before the launch ends - stop polling it
+    if (spin && n <= 64 && ++ctx->spin_timeouts >= 3) ctx->spin_off = true;
+  } else {
+    ctx->spin_timeouts = 0;
+  }
   if (lnl) memcpy(lnl, h_out, (size_t)n * sizeof(double));
   if (chi2) memcpy(chi2, h_out + n, (size_t)n * sizeof(double));
   return 1;
