@@ -22,8 +22,13 @@ Writes
                                              convention of the reference's published notebook numbers;
                                              same input files as above.
 
-    python oracle/make_golden.py             # both sets
+  tests/golden/ref_outputs_more.npz          (``--set more``) the remaining shipped combinations of model, data and
+                                             covariance files (fixed covariance, Patchy-mean data, anisotropic M+D
+                                             covariance), with boss/{cov_fixed,cov_md_aniso,patchy_data}.npy
+
+    python oracle/make_golden.py             # all sets
     python oracle/make_golden.py --set avg   # only the second one (inputs and ref_outputs.npz untouched)
+    python oracle/make_golden.py --set more  # only the third one
 """
 
 import json
@@ -207,6 +212,85 @@ def main_avg():
     for k in sorted(out):
         if k.startswith("boss_nb"):
             print("avg", k, np.array2string(out[k], precision=12))
+
+
+# the shipped combinations of model / data / covariance files (data/BOSS_DR12_CMASS_data/README.txt) beyond the two that
+# ``main`` covers; tests/cases.py::shipped_combination builds the same option dictionaries
+MORE_CASES = {
+    # CMASS data + PatchyMean model + the fixed (beta-independent) data-only covariance: beta-dependent data vector
+    # against ONE precision matrix, no log-det term
+    "fixedcov": dict(cov="boss/cov_fixed.npy", fixed_beta=True),
+    # mean of the 1000 Patchy mocks as the data vector, with its covariance: the shipped file is the CMASS stack times
+    # 1e-6 to within an ulp, so the test side rebuilds it from cov.npy (`cov_scale`) - chi2 of order 1e7
+    "patchy": dict(data="boss/patchy_data.npy", cov="boss/cov.npy", cov_scale=1e-6),
+    # measured real-space ccf with its ANISOTROPIC (M+D) covariance and the anisotropic sum
+    "fromdata_aniso": dict(model="boss/measured_model.npy", from_data=True, cov="boss/cov_md_aniso.npy",
+                           kwargs=dict(assume_isotropic=False)),
+    # Patchy mean data + PatchyMean template + isotropic (M+D) covariance of the mean (= the CMASS one / 1000 exactly)
+    "patchy_md": dict(data="boss/patchy_data.npy", cov="boss/cov_md_iso.npy", cov_scale=1e-3),
+}
+
+
+def more_options(case, gold, scratch):
+    """(model, data, kwargs) of one MORE_CASES entry; a rescaled covariance stack is written to ``scratch``."""
+    c = MORE_CASES[case]
+    model, data = boss_options("config")
+    model["dir"] = data["dir"] = gold
+    if "model" in c:
+        model["input_model_data_file"] = c["model"]
+    if c.get("from_data"):
+        model["realspace_ccf"]["from_data"] = True
+    if "data" in c:
+        data["redshift_space_ccf"]["data_file"] = c["data"]
+    cov = c["cov"]
+    if "cov_scale" in c:
+        d = np.load(os.path.join(gold, cov), allow_pickle=True).item()
+        d = dict(d, covmat=d["covmat"] * c["cov_scale"])
+        cov = os.path.join(scratch, f"cov_{case}.npy")
+        save_dict(cov, d)
+    data["covariance_matrix"]["data_file"] = cov
+    if c.get("fixed_beta"):
+        data["covariance_matrix"]["fixed_beta"] = True
+    return model, data, dict(c.get("kwargs", {}))
+
+
+def main_more():
+    """Third fixture set, ``tests/golden/ref_outputs_more.npz``: every remaining shipped combination of model, data and
+    covariance files, run through the unmodified reference (default ``simps`` rule).  Leaves the first two sets untouched."""
+    import tempfile
+    ref_shim.set_simpson_rule("simpson")
+    v = ref_shim.load()
+    meta = json.loads(str(np.load(os.path.join(GOLD, "ref_outputs.npz"))["meta_json"]))
+    boss_points = meta["boss_points"]
+    src = os.path.join(ref_shim.REFERENCE_ROOT, BOSS_DIR, BOSS_PREFIX)
+    save_dict(os.path.join(GOLD, "boss", "cov_fixed.npy"), ref_shim._h5_read(src + "fixed_D_covariance.hdf5"))
+    save_dict(os.path.join(GOLD, "boss", "cov_md_aniso.npy"),
+              ref_shim._h5_read(src + "variable_anisotropic_MD_covariance.hdf5"))
+    patchy = src.replace("CMASS_zobovVoids", "PatchyMean_zobovVoids")
+    save_dict(os.path.join(GOLD, "boss", "patchy_data.npy"), ref_shim._h5_read(patchy + "data.hdf5"))
+    # how close the rebuilt Patchy covariances are to the shipped files
+    for name, fac, ref_file in (("cov.npy", 1e-6, "variable_D_covariance.hdf5"),
+                                ("cov_md_iso.npy", 1e-3, "variable_isotropic_MD_covariance.hdf5")):
+        ours = np.load(os.path.join(GOLD, "boss", name), allow_pickle=True).item()["covmat"] * fac
+        theirs = ref_shim._h5_read(patchy + ref_file)["covmat"]
+        assert np.max(np.abs(ours / theirs - 1)) < 5e-16, name
+    out = {}
+    with tempfile.TemporaryDirectory() as scratch:
+        for case in MORE_CASES:
+            model, data, kw = more_options(case, GOLD, scratch)
+            fit = v.CCFFit(model, data)
+            out[f"{case}_theory"] = np.array([fit.theory_multipole_vector(fit.s, dict(q), fit.poles_s, **kw)
+                                              for q in boss_points])
+            for form in ("sellentin", "gaussian"):
+                ll = [fit.log_likelihood(dict(q), likelihood={"form": form, "nmocks": 1000, "nparams": 4}, **kw)
+                      for q in boss_points]
+                out[f"{case}_{form}_lnl"] = np.array([a for a, b in ll])
+                out[f"{case}_{form}_chi2"] = np.array([b for a, b in ll])
+    out["meta_json"] = np.array(json.dumps({"boss_points": boss_points, "cases": sorted(MORE_CASES)}))
+    np.savez_compressed(os.path.join(GOLD, "ref_outputs_more.npz"), **out)
+    for k in sorted(out):
+        if k.endswith(("chi2", "lnl")):
+            print("more", k, np.array2string(out[k], precision=10))
 
 
 def main():
@@ -415,9 +499,11 @@ def main():
 if __name__ == "__main__":
     import argparse
     ap = argparse.ArgumentParser()
-    ap.add_argument("--set", choices=["all", "default", "avg"], default="all")
+    ap.add_argument("--set", choices=["all", "default", "avg", "more"], default="all")
     which = ap.parse_args().set
     if which in ("all", "default"):
         main()
     if which in ("all", "avg"):
         main_avg()
+    if which in ("all", "more"):
+        main_more()

@@ -72,10 +72,45 @@ def synth_options(config):
     return model, data
 
 
+# The shipped combinations of model / data / covariance files (the reference's data/BOSS_DR12_CMASS_data/README.txt) beyond
+# boss_options() and the measured model + isotropic (M+D) covariance; same table as oracle/make_golden.py::MORE_CASES.
+SHIPPED_COMBINATIONS = {
+    "fixedcov": dict(cov="boss/cov_fixed.npy", fixed_beta=True),
+    "patchy": dict(data="boss/patchy_data.npy", cov="boss/cov.npy", cov_scale=1e-6),
+    "fromdata_aniso": dict(model="boss/measured_model.npy", from_data=True, cov="boss/cov_md_aniso.npy",
+                           kwargs=dict(assume_isotropic=False)),
+    "patchy_md": dict(data="boss/patchy_data.npy", cov="boss/cov_md_iso.npy", cov_scale=1e-3),
+}
+
+
+def shipped_combination(case, scratch):
+    """(model, data, call kwargs) of one SHIPPED_COMBINATIONS entry.  The Patchy-mean covariances are the CMASS stacks times
+    1e-6 / 1e-3 (to an ulp / exactly): they are rebuilt from the committed stacks into ``scratch`` instead of being stored."""
+    c = SHIPPED_COMBINATIONS[case]
+    model, data = boss_options("config")
+    if "model" in c:
+        model["input_model_data_file"] = c["model"]
+    if c.get("from_data"):
+        model["realspace_ccf"]["from_data"] = True
+    if "data" in c:
+        data["redshift_space_ccf"]["data_file"] = c["data"]
+    cov = c["cov"]
+    if "cov_scale" in c:
+        d = np.load(os.path.join(GOLDEN, cov), allow_pickle=True).item()
+        d = {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in dict(d, covmat=d["covmat"] * c["cov_scale"]).items()}
+        cov = os.path.join(str(scratch), f"cov_{case}.npy")
+        np.save(cov, d, allow_pickle=True)
+    data["covariance_matrix"]["data_file"] = cov
+    if c.get("fixed_beta"):
+        data["covariance_matrix"]["fixed_beta"] = True
+    return model, data, dict(c.get("kwargs", {}))
+
+
 def golden_outputs(simpson_even="simpson"):
     """Reference outputs: ``'simpson'`` = the reference with SciPy >= 1.11's ``simps`` (the default rule of this repo),
-    ``'avg'`` = with SciPy < 1.11's (oracle/make_golden.py --set avg); same inputs."""
-    name = {"simpson": "ref_outputs.npz", "avg": "ref_outputs_avg.npz"}[simpson_even]
+    ``'avg'`` = with SciPy < 1.11's (oracle/make_golden.py --set avg); same inputs.  ``'more'`` = the remaining shipped
+    combinations of model, data and covariance files (SHIPPED_COMBINATIONS; default rule)."""
+    name = {"simpson": "ref_outputs.npz", "avg": "ref_outputs_avg.npz", "more": "ref_outputs_more.npz"}[simpson_even]
     g = np.load(os.path.join(GOLDEN, name))
     meta = json.loads(str(g["meta_json"]))
     return g, meta

@@ -515,3 +515,37 @@ def test_dispersion_model_runs_on_the_fast_kernels(gold):
         for mapping in ("cells", "generic"):
             row_err = np.max(np.abs(res[mapping] - res["point"]), axis=1) / np.max(np.abs(res["point"]))
             assert np.quantile(row_err, 0.995) < 1e-10 and row_err.max() < 1e-5, (name, mapping, row_err.max())
+
+
+@pytest.mark.parametrize("case", sorted(cases.SHIPPED_COMBINATIONS))
+def test_shipped_file_combinations_on_gpu(case, tmp_path):
+    """The remaining combinations of the shipped model / data / covariance files against the reference's own outputs
+    (tests/golden/ref_outputs_more.npz; data/BOSS_DR12_CMASS_data/README.txt): fixed covariance with a beta-dependent data
+    vector (one precision matrix, no log-det term), the Patchy-mean data vector with its covariance (chi2 up to 1e9),
+    the measured real-space ccf with the anisotropic (M+D) covariance and the anisotropic sum, the Patchy mean with the
+    isotropic (M+D) covariance.  Single-point API, batch API and every chi-square kernel."""
+    import victor_amd
+    g, meta = cases.golden_outputs("more")
+    model, data, kw = cases.shipped_combination(case, tmp_path)
+    fit = victor_amd.CCFFit(model, data)
+    pts = meta["boss_points"]
+    rows = np.concatenate([fit._fit_rows(dict(p), fit._merged(kw)) for p in pts])
+    assert close(fit.theory_vector_batch(rows, **kw), g[f"{case}_theory"])
+    for form in ("sellentin", "gaussian"):
+        like = {"form": form, "nmocks": 1000, "nparams": 4}
+        want_l, want_c = g[f"{case}_{form}_lnl"], g[f"{case}_{form}_chi2"]
+        lnl, chi = fit.log_likelihood_batch(rows, likelihood=like, **kw)                   # fused chi-square
+        assert np.max(np.abs(chi / want_c - 1)) < RTOL and np.max(np.abs(lnl / want_l - 1)) < RTOL, form
+        one = [fit.log_likelihood(dict(p), likelihood=like, **kw) for p in pts[:3]]        # the reference's call
+        assert np.max(np.abs(np.array([a for a, b in one]) / want_l[:3] - 1)) < RTOL, form
+        big = np.tile(rows, (700, 1))                                                      # 5600 rows: separate K2 launch
+        for knob in ({}, {"VICTOR_HIP_LIKE_UNTILED": "1"}, {"VICTOR_HIP_NO_FUSE": "1"}):
+            for k, v in knob.items():
+                _native.set_knob(k, v)
+            try:
+                lb, cb = fit.log_likelihood_batch(big, likelihood=like, **kw)
+            finally:
+                for k in knob:
+                    _native.set_knob(k, None)
+            assert np.max(np.abs(cb.reshape(700, -1) / want_c - 1)) < RTOL, (form, knob)
+            assert np.max(np.abs(lb.reshape(700, -1) / want_l - 1)) < RTOL, (form, knob)

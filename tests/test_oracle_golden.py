@@ -202,3 +202,22 @@ def test_model_options_match_reference(boss, gold):
                 assert np.max(np.abs(t - g[key])) <= TOL * np.max(np.abs(g[key])), key
                 checked += 1
     assert checked >= 17
+
+
+@pytest.mark.parametrize("case", sorted(cases.SHIPPED_COMBINATIONS))
+def test_shipped_file_combinations(case, tmp_path):
+    """Every remaining combination of the shipped model / data / covariance files (data/BOSS_DR12_CMASS_data/README.txt):
+    the beta-independent covariance with the beta-dependent data vector, the Patchy-mean data vector with its (1e-6 x)
+    covariance - chi2 of order 1e7-1e9 -, the measured real-space ccf with the ANISOTROPIC (M+D) covariance, the Patchy mean
+    with the isotropic (M+D) covariance.  Reference outputs: tests/golden/ref_outputs_more.npz."""
+    g, meta = cases.golden_outputs("more")
+    model, data, kw = cases.shipped_combination(case, tmp_path)
+    fit = vo.OracleFit(model, data)
+    pts = meta["boss_points"]
+    th = np.array([fit.theory_multipole_vector(fit.s, dict(q), fit.poles_s, **kw) for q in pts])
+    assert np.max(np.abs(th - g[f"{case}_theory"])) <= TOL * np.max(np.abs(g[f"{case}_theory"]))
+    for form in ("sellentin", "gaussian"):
+        ll = [fit.log_likelihood(dict(q), likelihood={"form": form, "nmocks": 1000, "nparams": 4}, **kw) for q in pts]
+        lnl, chi = np.array([a for a, b in ll]), np.array([b for a, b in ll])
+        assert np.max(np.abs(chi / g[f"{case}_{form}_chi2"] - 1)) < 1e-10, form      # 1e4-1e9: precision stack x 1e3-1e6
+        assert np.max(np.abs(lnl / g[f"{case}_{form}_lnl"] - 1)) < 1e-10, form
