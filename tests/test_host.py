@@ -457,6 +457,28 @@ def test_anisotropic_dispersion_and_velocity_template_setup(tmp_path):
     assert np.max(np.abs(a / b - 1)) < 1e-12
 
 
+def test_dispersion_filter_options(tmp_path):
+    """velocity_pdf.dispersion: filter / filter_window / filter_order (ccf_model.py:278-283; the Savitzky-Golay pass along r
+    before the template is normalised): defaults (3, 1), a wider window with a higher order, and no filter at all give
+    three different tables, each equal to the oracle's (the oracle is checked against the reference on the same
+    options in tests/test_oracle_vs_reference.py)."""
+    import victor_amd
+    import victor_oracle as vo
+    seen = []
+    for opt in ({}, {"filter_window": 7, "filter_order": 3}, {"filter": False}):
+        for aniso in (True, False):
+            if aniso:
+                model, _ = _aniso_inputs(tmp_path)
+            else:
+                model, _ = cases.boss_options("config")
+            model = cases.clone(model)
+            model["velocity_pdf"]["dispersion"].update(opt)
+            m, o = victor_amd.CCFModel(model), vo.OracleModel(model)
+            assert np.max(np.abs(m.sv_rmu / o.sv_rmu - 1)) < 1e-13, (opt, aniso)
+            seen.append(m.sv_rmu)
+    assert not np.allclose(seen[0], seen[2], rtol=1e-6) and not np.allclose(seen[0], seen[4], rtol=1e-6)
+
+
 def test_background_cosmology_and_multipole_helpers(boss_fit):
     """victor.BackgroundCosmology (E(z) of the path, cosmology.py:27-45) and utils.fn_from_multipoles (utils.py:60-94)."""
     import victor

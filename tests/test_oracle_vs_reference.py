@@ -191,3 +191,18 @@ def test_package_reads_the_reference_yaml_and_hdf5_files_unchanged(ref):
         assert len(fa) == len(fb)
         for x, y in zip(fa, fb):
             assert x.shape == y.shape and np.array_equal(x, y)
+
+
+def test_dispersion_filter_options_against_the_reference(ref):
+    """velocity_pdf.dispersion filter / filter_window / filter_order (ccf_model.py:278-283): the oracle's normalised
+    sigma_v(r, mu) table and a likelihood through it equal the reference's for non-default options."""
+    import victor_oracle as vo
+    p = dict(cases.NOTEBOOK_POINT)
+    for opt in ({"filter_window": 7, "filter_order": 3}, {"filter": False}):
+        model, data = cases.boss_options("config")
+        model["velocity_pdf"]["dispersion"].update(opt)
+        rfit = ref.CCFFit(cases.clone(model), cases.clone(data))
+        ofit = vo.OracleFit(model, data)
+        assert np.max(np.abs(ofit.sv_rmu / rfit.sv_rmu - 1)) < 1e-14, opt
+        a, b = rfit.log_likelihood(dict(p)), ofit.log_likelihood(dict(p))
+        assert abs(a[0] - b[0]) <= 1e-12 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-12 * abs(a[1]), opt
