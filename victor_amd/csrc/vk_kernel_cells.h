@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
       double g = 0.0;
       // trips whose 64 x 50 radii all fall inside the table skip the clamp pair of the interval coordinate (see the lanes
       // kernel; a trip that holds a mu = 1 cell reaches r < 0.01 and keeps it)
-      if (GRID == 0 && !mode_is_dispersion(MODE) && !__any(!cell_in_table(fc, s_par, sperp2, a.xw_max * fabs(fp.Bk)))) {
+      if (!mode_is_dispersion(MODE) && !__any(!cell_in_table(fc, s_par, sperp2, a.xw_max * fabs(fp.Bk)))) {
         for (int k = 0; k < a.n_x; ++k) {
           const vk_d2 xw = cxw[k];
           const double xk = xw.x;

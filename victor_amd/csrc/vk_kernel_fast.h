@@ -45,7 +45,7 @@ struct FastConsts {
   double off, t_lo, n_eps;        // GRID 0: t = r' + off, clamped to [t_lo, n_eps]; t_lo is u = 0.01, the first V knot
                                   // GRID 1: u = r' clamped to [t_lo, n_eps] = [first knot, last knot)
   double inv_g;                   // GRID 1: cells of the look-up table per unit length
-  double rlo2, rhi2;              // GRID 0: t stays inside (t_lo, n_eps) while rlo2 <= r'^2 < rhi2 (rows_in_table)
+  double rlo2, rhi2;              // the clamped coordinate stays inside (t_lo, n_eps) while rlo2 <= r'^2 < rhi2 (cell_in_table)
   int lut_off;                    // GRID 1: byte offset of the look-up table in LDS
 };
 
@@ -81,7 +81,8 @@ __device__ __forceinline__ FastConsts make_fast_consts(const TheoryArgs& a) {
     fc.t_lo = a.uni_knots[0];
     fc.n_eps = a.uni_knots[a.uni_n] * (1.0 - 0x1p-52);
     fc.inv_g = a.uni_lut_inv_g;
-    fc.rlo2 = fc.rhi2 = 0.0;
+    fc.rlo2 = fc.t_lo * fc.t_lo * (1.0 + 1e-9);       // u = r' itself: inside [first knot, last knot) as for the lattice form below
+    fc.rhi2 = fc.n_eps * fc.n_eps * (1.0 - 1e-9);
     fc.lut_off = (kRecsOff + (a.uni_n + 2) * uni_stride(NLR)) * 8;
   } else {
     fc.inv_h = a.uni_inv_h;
@@ -252,7 +253,7 @@ __device__ __forceinline__ const double* locate(const double* __restrict__ lds, 
     qi = (int)t;
     return lds_at(lds + kRecsOff, __mul24(qi, stride * 8));
   }
-  const double u = vmin_f64(vmax_f64(x, fc.t_lo), fc.n_eps);
+  const double u = CL ? vmin_f64(vmax_f64(x, fc.t_lo), fc.n_eps) : x;
   const int cell = (int)(u * fc.inv_g);
   const int q0 = *reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(lds) + fc.lut_off + 2 * cell);
   const double* rec0 = lds_at(lds + kRecsOff, __mul24(q0, stride * 8));

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kBlock, VK_LANES_WG_PER_CU) void vk_theory_lanes_ke
       // table, and only the mu = 1 row reaches r < 0.01) skip the clamp pair of the interval coordinate.  Extending the
       // records past the last knot so that the top s bins qualify too was measured and dropped: nothing on config 3, and the
       // larger LDS footprint costs BOSS a workgroup per CU (profiles/r02/i_clamp_exp_ab.txt)
-      if (GRID == 0 && !__any(!cell_in_table(fc, s_par, sperp2, xi_max))) {
+      if (!__any(!cell_in_table(fc, s_par, sperp2, xi_max))) {
         for (int k = 0; k < a.n_x; ++k) {
           const vk_d2 xw = cxw[k];
           const double xk = xw.x;
