@@ -479,6 +479,47 @@ def test_dispersion_filter_options(tmp_path):
     assert not np.allclose(seen[0], seen[2], rtol=1e-6) and not np.allclose(seen[0], seen[4], rtol=1e-6)
 
 
+def test_no_kernel_of_the_library_spills(lib):
+    """The gfx950 code object inside libvictor_hip.so (clang offload bundle in .hip_fatbin), read with llvm-readelf: every
+    kernel's private segment is 0 bytes - no register spills, no scratch traffic (8 bytes per thread in the BOSS cells kernel
+    once were 134 MB of HBM writes per 65536-point launch) - and the large-batch theory kernels keep the registers of
+    five workgroups per CU."""
+    import re
+    import struct
+    import subprocess
+    from victor_amd.build import OUT
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.isfile(readelf):
+        pytest.skip("llvm-readelf not found")
+    sec = subprocess.run([readelf, "-S", OUT], capture_output=True, text=True).stdout
+    m = re.search(r"\.hip_fatbin\s+PROGBITS\s+[0-9a-f]+\s+([0-9a-f]+)\s+([0-9a-f]+)", sec)
+    assert m, "no .hip_fatbin section"
+    with open(OUT, "rb") as fh:
+        fh.seek(int(m.group(1), 16))
+        blob = fh.read(int(m.group(2), 16))
+    assert blob[:24] == b"__CLANG_OFFLOAD_BUNDLE__"
+    n, pos, code = struct.unpack_from("<Q", blob, 24)[0], 32, None
+    for _ in range(n):
+        off, size, idlen = struct.unpack_from("<QQQ", blob, pos)
+        ident = blob[pos + 24:pos + 24 + idlen].decode()
+        pos += 24 + idlen
+        if "gfx950" in ident:
+            code = blob[off:off + size]
+    assert code, "no gfx950 code object in the bundle"
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".co") as tmp:
+        tmp.write(code)
+        tmp.flush()
+        notes = subprocess.run([readelf, "--notes", tmp.name], capture_output=True, text=True).stdout
+    kernels = re.findall(r"\.name:\s+(\S+)[\s\S]*?\.private_segment_fixed_size:\s+(\d+)[\s\S]*?\.vgpr_count:\s+(\d+)", notes)
+    assert len(kernels) > 150
+    spilling = [k for k, priv, _ in kernels if int(priv) > 0]
+    assert not spilling, spilling
+    for k, _, vgpr in kernels:
+        if "vk_theory_lanes_kernel" in k or ("vk_theory_cells_kernel" in k and k.endswith("Li0EEEvNS_10TheoryArgsE")):
+            assert int(vgpr) <= 96, (k, vgpr)          # 512 / 5 workgroups of four waves, in granules of 8
+
+
 def test_background_cosmology_and_multipole_helpers(boss_fit):
     """victor.BackgroundCosmology (E(z) of the path, cosmology.py:27-45) and utils.fn_from_multipoles (utils.py:60-94)."""
     import victor

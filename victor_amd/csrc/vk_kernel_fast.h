@@ -490,7 +490,7 @@ __device__ __forceinline__ void stage_fast(const TheoryArgs& a, const FastPlan& 
 }
 
 template <int NLR, int NL, int GRID, int MODE>
-__global__ __launch_bounds__(kBlock, 3) void vk_theory_fast_kernel(TheoryArgs a) {
+__global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 3 : 2) void vk_theory_fast_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
   vkm::clamp_keeps_nan();
   warm_kernarg_lines<sizeof(TheoryArgs)>();
