@@ -15,21 +15,27 @@ namespace vkm {
 // Cross-lane traffic goes through DPP (quad permutes, row mirrors, row broadcasts), not through ds_bpermute: the LDS pipe
 // is the second-busiest unit of the theory kernels and a reduction there costs 12 LDS instructions per sum.
 // Fixed association order: pairs, quads, half rows, rows of 16, then rows 0+1, 2+3, and the two halves.
-template <int CTRL, int ROW_MASK>
+// BOUND_CTRL: lanes without a source read 0 instead of keeping the old value of the destination.  The permutes within a
+// row give every lane a source, so nothing is ever kept - but only with bound_ctrl set may the compiler drop the two
+// v_mov_b32 that materialise the "old" operand in front of every pair of DPP moves (32 of them per wave_sum pair of a trip).
+template <int CTRL, int ROW_MASK, bool BOUND_CTRL = false>
 __device__ __forceinline__ double dpp_move(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, BOUND_CTRL);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, BOUND_CTRL);
   return __hiloint2double(hi, lo);
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
-  v += dpp_move<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
-  v += dpp_move<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
-  v += dpp_move<0x141, 0xF>(v);   // row_half_mirror
-  v += dpp_move<0x140, 0xF>(v);   // row_mirror: every lane of a row of 16 holds the row's sum
-  v += dpp_move<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3 (disabled rows receive 0)
-  v += dpp_move<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+  v += dpp_move<0xB1, 0xF, true>(v);    // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E, 0xF, true>(v);    // quad_perm [2,3,0,1]
+  v += dpp_move<0x141, 0xF, true>(v);   // row_half_mirror
+  v += dpp_move<0x140, 0xF, true>(v);   // row_mirror: every lane of a row of 16 holds the row's sum
+  // row_bcast:15 (lane 15 of a row to the next row; row 0 has no source and reads 0) and row_bcast:31 (lane 31 to rows 2
+  // and 3; rows 0 and 1 read 0), all rows enabled: row 2 also picks up row 1's sum in the first step, which only lane 63's
+  // chain (r3 + r2) + (r1 + r0) never sees - same association order as the row-masked form, no "old" operand to set up
+  v += dpp_move<0x142, 0xF, true>(v);
+  v += dpp_move<0x143, 0xF, true>(v);   // lane 63 holds the total
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
   return __hiloint2double(hi, lo);
