@@ -27,6 +27,8 @@ def test_device_math_within_two_ulp(tmp_path):
     # 4M samples each: sqrt/rsqrt over x in [2e-9, 5e8], recip likewise, exp over [-760, 0]
     assert res["sqrt_ulp"] <= 2.0 and res["rsqrt_ulp"] <= 2.0 and res["recip_ulp"] <= 1.0
     assert res["exp_ulp_normal"] <= 2.5
+    # the one-step 1/sqrt of the streaming integrand: 3/8 e^2 with |e| <= 1.05e-7 - 20 ulp (4.4e-15) at worst, one on average
+    assert res["rsqrt_nr_ulp_max"] <= 22.0 and res["rsqrt_nr_ulp_mean"] <= 1.5
     # exp_gauss (clamped product, magic-number rounding, table + degree-4 polynomial): z in [-39, 39]; NaN in -> NaN out,
     # saturated arguments -> exactly 0, exp(0) = 1
     assert res["gauss_ulp_normal"] <= 3.0 and res["gauss_special_ok"] == 1

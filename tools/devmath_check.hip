@@ -6,6 +6,11 @@
 #include <vector>
 #include "vk_devmath.h"
 
+__global__ void run_nr(const double* x, double* out, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = vkm::rsqrt_nr(x[i]);
+}
+
 __global__ void run(const double* x, const double* a, double* g, double* ir, double* rc, double* ex, double* raw_rsq,
                     double* raw_rcp, int n) {
   __shared__ double tab[vkm::kExpTab];
@@ -78,6 +83,17 @@ int main() {
     raw1 = fmax(raw1, fabs((double)((long double)r1[i] * sqrtl(xl) - 1.0L)));
     raw2 = fmax(raw2, fabs((double)((long double)r2[i] * xl - 1.0L)));
   }
+  // rsqrt_nr (one Newton step): worst case and mean error in ulp
+  std::vector<double> nr(n);
+  hipLaunchKernelGGL(run_nr, dim3(n / 256), dim3(256), 0, 0, dx, dg, n);
+  hipMemcpy(nr.data(), dg, nb, hipMemcpyDeviceToHost);
+  double m_nr = 0, s_nr = 0;
+  for (int i = 0; i < n; ++i) {
+    const double u = ulp_err(nr[i], 1.0L / sqrtl((long double)x[i]));
+    m_nr = fmax(m_nr, u);
+    s_nr += u;
+  }
+
   // exp_gauss: z = ynum * inv_sv / kExpScale in [-12, 12] mostly (the kernels see |z| <~ 8), tails out to the underflow;
   // the reference value is taken at the rounded product y' = fl(|ynum inv_sv|), which is an input of the range reduction
   std::vector<double> yn(n), isv(n), eg(n);
@@ -124,7 +140,8 @@ int main() {
       ws_rel = fmax(ws_rel, (double)(fabsl((long double)w[g] - want) / mag));
     }
   }
-  printf("{\"gauss_ulp_normal\": %.3f, \"gauss_ulp_denormal_tail\": %.3f, \"gauss_special_ok\": %d, ", m_gn, m_gt, gauss_special_ok);
+  printf("{\"rsqrt_nr_ulp_max\": %.3f, \"rsqrt_nr_ulp_mean\": %.3f, ", m_nr, s_nr / n);
+  printf("\"gauss_ulp_normal\": %.3f, \"gauss_ulp_denormal_tail\": %.3f, \"gauss_special_ok\": %d, ", m_gn, m_gt, gauss_special_ok);
   printf("\"wave_sum_rel\": %.3e, \"wave_sum_uniform\": %d, \"sqrt_ulp\": %.3f, \"rsqrt_ulp\": %.3f, \"recip_ulp\": %.3f, \"exp_ulp_normal\": %.3f, \"exp_ulp_denormal_tail\": %.3f, "
          "\"raw_v_rsq_f64_rel\": %.3e, \"raw_v_rcp_f64_rel\": %.3e}\n", ws_rel, ws_uniform, m_g, m_ir, m_rc, m_exn, m_ex, raw1, raw2);
   return 0;

@@ -53,12 +53,29 @@ __device__ __forceinline__ void sqrt_rsqrt(double x, double& g, double& ir) {
   g = x * ir;
 }
 
-// 1/sqrt(x) alone, same scheme (callers that need sqrt(x) fold x * ir into their next fma)
+// 1/sqrt(x) alone, third-order like sqrt_rsqrt (the dispersion model's fixed-point iteration, which amplifies rounding)
 __device__ __forceinline__ double rsqrt3(double x) {
   const double y = __builtin_amdgcn_rsq(x);
   const double e = fma(-(x * y), y, 1.0);
   const double p = fma(0.375, e, 0.5);
   return fma(y * e, p, y);
+}
+
+// 1/sqrt(x) for the streaming integrand of the fast kernels (callers fold x * ir into their next fma): ONE Newton step
+// from the hardware seed, y' = y (1 + e/2), e = 1 - x y^2.  The seed is good to 5.3e-8, i.e. |e| <= 1.05e-7, so the result
+// is good to 3/8 e^2 <= 4.4e-15 - 20 ulp at worst, 1.0 ulp on average (measured on the hardware, tools/devmath_check.hip) -
+// against one ulp for the third-order step of sqrt_rsqrt / rsqrt3.  It feeds mu_r = r_par / r and the interval coordinate
+// r / (c h), where an error of that size is of the order of what the conditioning of the Gaussian factor already makes of
+// the last-bit errors of 1/sigma (2 y^2 eps).  Measured end to end: 200 oracle-checked points per configuration, max rel
+// dchi2 7.3e-15 -> 1.1e-14 (config 3) and 1.2e-14 -> 1.7e-14 (BOSS), medians unchanged; 131072 points of the wide fuzz box
+// against the generic kernel (third order throughout), theory vectors 1.7e-14 -> 2.6e-14 (config 3), 1.3e-15 -> 3.1e-15
+// (BOSS) of their maximum; bench batch max rel dchi2 vs the oracle 2.6e-14 -> 3.6e-14 - for one instruction of ~53 per
+// integrand point (same-box A/B: config 3 25.50 -> 25.10 ms, BOSS 15.30 -> 15.00 ms; profiles/r02/p_rsq_second_order.txt).
+// 1/sigma keeps its third-order step (recip): its error enters the exponent at full weight.
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(-(x * y), y, 1.0);
+  return fma(y * e, 0.5, y);
 }
 
 // 1/x for a normal x of either sign (velocity dispersion, Jacobians): y' = y (1 + e + e^2), e = 1 - x y, error ~ e^3

@@ -278,7 +278,7 @@ template <int NLR, int GRID, int FD, int PV = 0, int CL = 1>
 __device__ __forceinline__ double uni_value(const double* __restrict__ lds, const FastConsts& fc, double AVk,
                                             double r_par, double sperp2, double xk, double fa, double sperp2x) {
   const double r2 = fma(r_par, r_par, sperp2);
-  const double inv_r = vkm::rsqrt3(r2);
+  const double inv_r = vkm::rsqrt_nr(r2);
   const double mu_r = r_par * inv_r;
   double mu_x = mu_r;                           // the mu at which xi^r is read
   double tq;
@@ -290,7 +290,7 @@ __device__ __forceinline__ double uni_value(const double* __restrict__ lds, cons
   if (FD) {
     const double rp = r_par * fa;
     const double r2x = fma(rp, rp, sperp2x);
-    const double inv_rx = vkm::rsqrt3(r2x);
+    const double inv_rx = vkm::rsqrt_nr(r2x);
     mu_x = rp * inv_rx;
     rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(r2x, inv_rx, fc.off) : r2x * inv_rx, tq, qi);
   }
