@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 13
+#define VK_ABI_VERSION 14
 
 /* error codes */
 #define VK_OK 0
@@ -225,6 +225,8 @@ void vk_destroy(vk_ctx* ctx);
 const char* vk_last_error(const vk_ctx* ctx);
 /* name of the theory-kernel variant the most recent evaluation launched (diagnostics / benchmarks) */
 const char* vk_last_kernel(const vk_ctx* ctx);
+/* 1 when that launch also took the chi-square / log-likelihood (fused tail), 0 when K2 ran as its own launch */
+int vk_last_fused(const vk_ctx* ctx);
 void vk_default_opts(vk_eval_opts* opts);
 
 /* Full likelihood for n parameter rows (host buffers).  Any of lnl/chi2/theory may be NULL.

@@ -673,3 +673,47 @@ def test_fused_path_keeps_the_failure_guards(boss_fit):
             lnl, chi = fit.log_likelihood_batch(rows)
         assert np.all(np.isneginf(lnl[[2, 4]])) and np.all(np.isposinf(chi[[2, 4]])), kn
         assert np.all(np.isfinite(lnl[[0, 1, 3, 5]])) and np.all(chi[[0, 1, 3, 5]] > 0), kn
+
+
+def test_point_major_fused_launch_beyond_the_counter_array(boss_fit):
+    """A BOSS batch larger than the completion-counter array (16384 points) through the point-major kernel, whose chi-square
+    is fused from 8192 points on when the covariance depends on beta: one workgroup owns a whole point there and must not
+    touch counters[point] (round-2 advisor finding: an out-of-bounds atomic for point >= 16384).  Same results as the
+    two-launch path, twice in a row (nothing may be left behind in foreign memory), and as the cells kernel."""
+    fit = boss_fit["config"]
+    n = 20000
+    rows = fit._fit_rows(cases.halton_params(n, with_beta=True), fit.model)
+    eng = fit._get_engine()
+    with knobs(NO_FUSE="1"):
+        ref_l, ref_c = fit.log_likelihood_batch(rows)
+    with knobs(MAPPING="point"):
+        for rep in range(2):
+            lnl, chi = fit.log_likelihood_batch(rows)
+            assert eng.last_kernel() == "vk_theory_fast_kernel" and eng.last_fused()
+            assert np.max(np.abs(chi / ref_c - 1)) < 1e-12 and np.max(np.abs(lnl / ref_l - 1)) < 1e-12, rep
+    lnl, chi = fit.log_likelihood_batch(rows[:700])            # counters still zero: a split launch right after
+    assert np.max(np.abs(chi / ref_c[:700] - 1)) < 1e-12
+
+
+def test_nan_beta_reports_a_failed_row_in_every_chi_square_kernel(synth_fit):
+    """beta entering only through the covariance bracket (fixed data vector, fixed real-space ccf; reachable through the C ABI,
+    not through the reference's option files): a NaN beta must give (-inf, inf) from the fused tail, the workgroup-per-point
+    kernel and the wave-per-point kernel alike (round-2 advisor finding: the count-based bracket took it for "below the grid";
+    the reference raises IndexError for it, ccf_fit.py:213-228)."""
+    import victor_amd
+    model, data = cases.synth_options(3)
+    fit = victor_amd.CCFFit(model, data)
+    base = np.array(fit.covmat, dtype=float)
+    fit.fixed_covmat = False                                   # plain attributes, read by engine.build_tables
+    fit.beta_covmat = np.array([0.3, 0.4, 0.5])
+    fit.covmat = np.stack([base, 1.1 * base, 1.2 * base])
+    fit.icov = np.linalg.inv(fit.covmat)
+    rows = fit._fit_rows(cases.halton_params(6), fit.model)
+    rows[:, _native.P_BETA] = [0.35, np.nan, 0.45, 0.3, np.nan, 0.6]
+    for kn in ({}, {"NO_FUSE": "1"}, {"NO_FUSE": "1", "LIKE_WIDE": "0"}, {"MAPPING": "cells"}, {"MAPPING": "point"}):
+        with knobs(NO_GRAPH="1", **kn):
+            lnl, chi = fit.log_likelihood_batch(rows)
+        assert np.all(np.isneginf(lnl[[1, 4]])) and np.all(np.isposinf(chi[[1, 4]])), kn
+        assert np.all(np.isfinite(lnl[[0, 2, 3, 5]])), kn
+    ref = synth_fit[3].log_likelihood_batch(rows)              # fixed covariance = slice 0: the row ON the first grid value
+    assert abs(chi[3] / ref[1][3] - 1) < 1e-12

@@ -479,11 +479,8 @@ def test_dispersion_filter_options(tmp_path):
     assert not np.allclose(seen[0], seen[2], rtol=1e-6) and not np.allclose(seen[0], seen[4], rtol=1e-6)
 
 
-def test_no_kernel_of_the_library_spills(lib):
-    """The gfx950 code object inside libvictor_hip.so (clang offload bundle in .hip_fatbin), read with llvm-readelf: every
-    kernel's private segment is 0 bytes - no register spills, no scratch traffic (8 bytes per thread in the BOSS cells kernel
-    once were 134 MB of HBM writes per 65536-point launch) - and the large-batch theory kernels keep the registers of
-    five workgroups per CU."""
+def _gfx950_code_object(tmp_dir):
+    """Extract the gfx950 code object from libvictor_hip.so (clang offload bundle in .hip_fatbin) into a file."""
     import re
     import struct
     import subprocess
@@ -506,11 +503,20 @@ def test_no_kernel_of_the_library_spills(lib):
         if "gfx950" in ident:
             code = blob[off:off + size]
     assert code, "no gfx950 code object in the bundle"
-    import tempfile
-    with tempfile.NamedTemporaryFile(suffix=".co") as tmp:
-        tmp.write(code)
-        tmp.flush()
-        notes = subprocess.run([readelf, "--notes", tmp.name], capture_output=True, text=True).stdout
+    path = os.path.join(str(tmp_dir), "victor_gfx950.co")
+    with open(path, "wb") as fh:
+        fh.write(code)
+    return path
+
+
+def test_no_kernel_of_the_library_spills(lib, tmp_path):
+    """The gfx950 code object inside libvictor_hip.so, read with llvm-readelf: every kernel's private segment is 0 bytes -
+    no register spills, no scratch traffic (8 bytes per thread in the BOSS cells kernel once were 134 MB of HBM writes per
+    65536-point launch) - and the large-batch theory kernels keep the registers of five workgroups per CU."""
+    import re
+    import subprocess
+    co = _gfx950_code_object(tmp_path)
+    notes = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
     kernels = re.findall(r"\.name:\s+(\S+)[\s\S]*?\.private_segment_fixed_size:\s+(\d+)[\s\S]*?\.vgpr_count:\s+(\d+)", notes)
     assert len(kernels) > 150
     spilling = [k for k, priv, _ in kernels if int(priv) > 0]
@@ -518,6 +524,56 @@ def test_no_kernel_of_the_library_spills(lib):
     for k, _, vgpr in kernels:
         if "vk_theory_lanes_kernel" in k or ("vk_theory_cells_kernel" in k and k.endswith("Li0EEEvNS_10TheoryArgsE")):
             assert int(vgpr) <= 96, (k, vgpr)          # 512 / 5 workgroups of four waves, in granules of 8
+
+
+def test_cross_workgroup_handoff_is_ordered_in_the_code_object(lib, tmp_path):
+    """Partial sums and theory vectors handed from one workgroup to another inside a launch (vk_common.h: point_completed)
+    are write-through (sc1) stores published by a device-scope counter increment.  On gfx950 nothing but an explicit
+    `s_waitcnt vmcnt(0)` makes a wave wait for its stores before the barrier that precedes the increment (the back-off barrier
+    carries no vmcnt wait, a workgroup-scope release fence emits lgkmcnt(0) only), so the shipped ISA is checked: in every
+    kernel that contains the counter's returning `global_atomic_add`, walking back from the atomic there is an s_barrier, and
+    walking back from that barrier an `s_waitcnt vmcnt(0)` comes before any global store; the finishing workgroup's reads
+    of the handed-over data are sc1 loads."""
+    import re
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.isfile(objdump):
+        pytest.skip("llvm-objdump not found")
+    co = _gfx950_code_object(tmp_path)
+    asm = subprocess.run([objdump, "-d", "--mcpu=gfx950", co], capture_output=True, text=True).stdout
+    funcs, cur = {}, None
+    for ln in asm.split("\n"):
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", ln)
+        if m:
+            cur = funcs.setdefault(m.group(1), [])
+        elif cur is not None and ln.strip():
+            cur.append(ln.strip())
+    checked = 0
+    for name, body in funcs.items():
+        atomics = [i for i, ins in enumerate(body) if ins.startswith("global_atomic_add")]
+        if not atomics:
+            continue
+        assert "vk_theory_cells_kernel" in name or "vk_theory_fast_kernel" in name, name    # only the fused / split theory kernels
+        for i in atomics:
+            assert " sc0" in body[i], (name, body[i])            # returning form: the finishing workgroup is told by the value
+            j = i
+            while j >= 0 and not body[j].startswith("s_barrier"):
+                j -= 1
+            assert j >= 0, (name, "no s_barrier in front of the counter increment")
+            k, drained = j - 1, False
+            while k >= 0:
+                ins = body[k]
+                if ins.startswith("s_waitcnt") and "vmcnt(0)" in ins:
+                    drained = True
+                    break
+                assert not re.match(r"(global|buffer|flat|scratch)_store", ins), (name, "store between the wait and the barrier", ins)
+                k -= 1
+            assert drained, (name, "no s_waitcnt vmcnt(0) in front of the barrier")
+            checked += 1
+        stores = [ins for ins in body if ins.startswith("global_store") and " sc1" in ins]
+        loads = [ins for ins in body if ins.startswith("global_load") and " sc1" in ins]
+        assert stores and loads, (name, len(stores), len(loads))
+    assert checked >= 100, checked
 
 
 def test_background_cosmology_and_multipole_helpers(boss_fit):

@@ -643,7 +643,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
     if (a.parts > kMaxParts) a.parts = kMaxParts;
     if (a.parts > 1 && ((size_t)a.n * a.n_s * kMaxParts * kMaxEll > ctx->partial_doubles || a.n > kCounterCap)) a.parts = 1;
     const bool need_counters = groups * a.parts > 1;
-    a.fuse = want_fuse && (!need_counters || a.n <= kCounterCap) ? 1 : 0;
+    a.fuse = want_fuse && (!need_counters || a.n <= kCounterCap) ? 1 : 0;   // counters[point] exists for point < kCounterCap only
     const bool tail = a.fuse || a.parts > 1;
     const FastPlan plf = make_fast_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, disp, tail ? N : 0);
     const size_t lds = (size_t)plf.total * sizeof(double);
@@ -831,6 +831,8 @@ void vk_default_opts(vk_eval_opts* o) {
 const char* vk_last_error(const vk_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
 const char* vk_last_kernel(const vk_ctx* ctx) { return ctx ? ctx->last_kernel : "none"; }
+
+int vk_last_fused(const vk_ctx* ctx) { return ctx && ctx->last_fused ? 1 : 0; }
 
 static int check_pp(const vk_pp* p, const char* name, std::string* err) {
   char buf[256];
@@ -1310,6 +1312,17 @@ static int eval_batch_graph(vk_ctx* ctx, const vk_eval_opts* opts, const double*
   return 1;
 }
 
+// spin-wait hint of the polling loop below
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield" ::: "memory");
+#else
+  asm volatile("" ::: "memory");
+#endif
+}
+
 constexpr int64_t kSpinMaxDefault = 256;         // in-place batches up to this size poll for their results (eval_batch_zero_copy)
 constexpr uint64_t kSpinSentinel = 0x7ff8dead5ca1ab1eULL;   // a quiet NaN with a payload no arithmetic produces
 constexpr int64_t kZeroCopyMaxDefault = 4096;   // host-buffer batches up to this size: parameters read in place, results written in place
@@ -1342,7 +1355,9 @@ static int eval_batch_zero_copy(vk_ctx* ctx, const vk_eval_opts* opts, const dou
   // kernel writes (failed rows report -inf / +inf) and polled in place; each slot is one 8-byte store of the thread that
   // finishes its point.  The launch stays queued on the stream, which orders the next call behind it, and every workgroup
   // has read its parameter row before the last result can appear, so the buffers may be reused at once.  Falls back to
-  // the stream synchronisation if nothing arrives within 2 ms (a failed launch reports its error there).
+  // the stream synchronisation if nothing arrives within 2 ms (a failed launch reports its error there).  A result that
+  // happens to carry the sentinel's bit pattern - only a caller's NaN parameter with exactly that payload, propagated
+  // into lnL, can - looks like "not arrived": the call then returns the correct values after the 2 ms timeout.
   const int64_t spin_max = ctx->knobs.spin_max >= 0 ? ctx->knobs.spin_max : kSpinMaxDefault;
   const bool spin = n <= spin_max && !ctx->spin_off;
   volatile uint64_t* slots = reinterpret_cast<volatile uint64_t*>(h_out);
@@ -1358,7 +1373,7 @@ static int eval_batch_zero_copy(vk_ctx* ctx, const vk_eval_opts* opts, const dou
       for (int64_t i = 2 * n - 1; i >= 0; --i)
         if (slots[i] == kSpinSentinel) { arrived = false; break; }
       if (arrived) break;
-      __builtin_ia32_pause();
+      cpu_relax();
       if ((it & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
     }
   }

@@ -240,11 +240,21 @@ __device__ __forceinline__ void load_shared_x8(const double* p, double (&v)[8]) 
 
 // "This workgroup finished one of the `total` work items of `point`": returns true (to every thread) in the workgroup
 // that finished the last one.  Everything the workgroups stored with store_shared() before their call is then readable
-// with load_shared() (stores complete - s_waitcnt at the barrier - before the device-scope counter increment; the reader's
-// loads are issued after its own increment returned).  The finishing workgroup resets counters[point] for the next launch.
-// `flag`: one int of LDS.
+// with load_shared().  The ordering is spelled out, not implied: EVERY thread first waits for its own write-through (sc1)
+// stores - `s_waitcnt vmcnt(0)`; a workgroup-scope release fence emits only lgkmcnt(0) on gfx950 and the back-off barrier
+// puts no vmcnt wait in front of s_barrier -, the barrier then orders thread 0's device-scope counter increment behind the
+// waits of all four waves, and the finishing workgroup's sc1 loads are issued after its own increment has returned and a
+// second barrier (MI355X_MICROARCH.md, "Valid forms": sc1 stores, every storing wave drained, one lane signalling behind a
+// workgroup barrier, sc1 loads after the returned add).  tests/test_host.py checks the wait in the shipped code object.
+// The finishing workgroup resets counters[point] for the next launch.  `flag`: one int of LDS.
+#ifndef VK_AB_NO_DRAIN
+__device__ __forceinline__ void drain_shared_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#else   // A/B build of the round-2 form (tools/, never shipped): a workgroup-scope release fence, no vmcnt wait
+__device__ __forceinline__ void drain_shared_stores() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+#endif
+
 __device__ __forceinline__ bool point_completed(unsigned* counters, long long point, unsigned total, int* flag) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  drain_shared_stores();
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned done = __hip_atomic_fetch_add(counters + point, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;

@@ -624,7 +624,15 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 3 : 2) void vk_the
       // live after the tail, so its registers (the chi-square needs ~100) do not spill the state of the loop above.
       double* th = lds + pl.like;
       int* flag = reinterpret_cast<int*>(th + ((N + 1) & ~1) + kWaves + 2);
-      const bool last = point_completed(a.counters, point, (unsigned)(groups * Q), flag);
+      // a point owned by this workgroup alone needs no counter (and batches beyond the counter array have none): its theory
+      // vector is re-read from L2 once this workgroup's own write-through stores have landed
+      bool last = true;
+      if (groups * Q == 1) {
+        drain_shared_stores();
+        __syncthreads();
+      } else {
+        last = point_completed(a.counters, point, (unsigned)(groups * Q), flag);
+      }
       VK_STAMP(a, 4);
       if (last) {
         finish_point<NL>(a, point, row[VK_P_BETA], ps.poison, th, Q > 1);

@@ -146,8 +146,10 @@ __device__ __forceinline__ void like_point_workgroup(const LikeArgs& a, long lon
       const int n_lt = __syncthreads_count(tid < a.n_beta_c && g < beta);
       const int n_eq = __syncthreads_count(tid < a.n_beta_c && g == beta);
       const int last = a.n_beta_c - 1;
-      if (n_lt == 0 && !n_eq) {
-        lo = 0;                           // below the grid (or NaN): first slice
+      if (beta != beta) {
+        t = beta;                         // NaN beta: the blend weight of cov_bracket, i.e. the row reports (-inf, inf) in every K2 variant
+      } else if (n_lt == 0 && !n_eq) {
+        lo = 0;                           // below the grid: first slice
       } else if (n_lt == a.n_beta_c) {
         lo = last;                        // above the grid: last slice
       } else if (n_eq) {

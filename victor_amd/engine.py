@@ -229,10 +229,15 @@ def build_tables(model, fit=None, matter_model=None, simpson_even=None):
                     except np.linalg.LinAlgError:
                         # slice k has a positive determinant but is not positive definite (an even number of negative
                         # eigenvalues): the identity above does not hold through eigh.  The reference constructs such a
-                        # fit and decides point by point from slogdet of the blend (ccf_fit.py:447-450); here every point
-                        # bracketed by this slice reports a failed evaluation (-inf, inf) - a covariance matrix that is
-                        # not positive definite is an input error in any case.
-                        logdet[kk] = np.nan
+                        # fit and decides point by point from slogdet of the blend (ccf_fit.py:447-450).  Here the slice
+                        # keeps its own log det - a point ON this grid value (t = 0, no blend) evaluates as in the
+                        # reference - and NaN factors mark every BLENDED evaluation that starts from it as failed
+                        # (-inf, inf): a covariance matrix that is not positive definite is an input error in any case.
+                        import warnings
+                        warnings.warn("covariance slice %d (beta = %g) has a positive determinant but is not positive "
+                                      "definite: likelihood evaluations that interpolate from it (beta between this grid "
+                                      "value and the next) will report -inf" % (kk, float(bc[kk])), RuntimeWarning)
+                        eig[kk] = np.nan
             logdet = arr(logdet)
             eig = arr(eig)
             t.n_beta_c = nb
@@ -450,6 +455,9 @@ class Engine:
 
     def last_kernel(self):
         return self._lib.vk_last_kernel(self._ctx).decode()
+
+    def last_fused(self):
+        return bool(self._lib.vk_last_fused(self._ctx))
 
     def sync(self):
         self._check(self._lib.vk_sync(self._ctx))
