@@ -1,5 +1,6 @@
 // Standalone accuracy check of vk_devmath.h on the GPU:  hipcc --offload-arch=gfx950 -O3 -I victor_amd/csrc tools/devmath_check.hip -o /tmp/devmath_check
-// Prints the maximum error in ulp of sqrt_rsqrt, recip, exp_nonpos and exp_gauss against the host's correctly rounded long-double values.
+// Prints the maximum error in ulp of sqrt_rsqrt, recip and exp_nonpos, and the relative errors of the streaming integrand's cheaper forms
+// (recip_nr, rsqrt_nr_x2, exp_gauss<0>, exp_gauss<1>), against the host's long-double values.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -13,8 +14,8 @@ __global__ void run_nr(const double* x, double* out, int n) {
 
 __global__ void run(const double* x, const double* a, double* g, double* ir, double* rc, double* ex, double* raw_rsq,
                     double* raw_rcp, int n) {
-  __shared__ double tab[vkm::kExpTab];
-  for (int j = threadIdx.x; j < vkm::kExpTab; j += blockDim.x) tab[j] = vkm::exp2_frac(j);
+  __shared__ double tab[vkm::kExpNonposTab];
+  for (int j = threadIdx.x; j < vkm::kExpNonposTab; j += blockDim.x) tab[j] = vkm::exp2_frac(j);
   __syncthreads();
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -25,14 +26,24 @@ __global__ void run(const double* x, const double* a, double* g, double* ir, dou
   raw_rcp[i] = __builtin_amdgcn_rcp(x[i]);
 }
 
-// vkm::exp_gauss: exp(-z^2/2) from (ynum, 1/SV) with y = kExpScale z; slots 0..3 of the inputs are special values
+// vkm::exp_gauss<EXPT>: exp(-z^2/2) from (ynum, 1/SV) with y = kExpScale z; slots 0..3 of the inputs are special values
+template <int EXPT>
 __global__ void run_gauss(const double* yn, const double* isv, double* out, int n) {
-  __shared__ double tab[vkm::kExpTab];
+  extern __shared__ double tab[];
   vkm::clamp_keeps_nan();
-  for (int j = threadIdx.x; j < vkm::kExpTab; j += blockDim.x) tab[j] = vkm::exp2_frac_c4(j);
+  for (int j = threadIdx.x; j < vkm::ExpCfg<EXPT>::kDoubles; j += blockDim.x) tab[j] = vkm::exp_table_slot<EXPT>(j);
   __syncthreads();
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = vkm::exp_gauss(yn[i], isv[i], tab);
+  if (i < n) out[i] = vkm::exp_gauss<EXPT>(yn[i], isv[i], tab, (unsigned)(threadIdx.x & 31) << 3);
+}
+
+// the one-step reciprocal and the doubled one-step 1/sqrt of the streaming integrand
+__global__ void run_nr2(const double* x, double* rc, double* rs, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    rc[i] = vkm::recip_nr(x[i]);
+    rs[i] = vkm::rsqrt_nr_x2(x[i]);
+  }
 }
 
 // vkm::wave_sum (DPP reduction): every lane of a wavefront must receive the same total of the wave's 64 inputs
@@ -103,24 +114,48 @@ int main() {
     yn[i] = z * vkm::kExpScale / isv[i];
   }
   yn[0] = NAN; isv[0] = 1.0;                       // NaN must propagate (clamp_keeps_nan)
-  yn[1] = 1e300; isv[1] = 1e5;                     // saturates at y' = 1: exactly 0
+  yn[1] = 1e300; isv[1] = 1e5;                     // saturates at y' = 1 (|z| = 37.7): below the normal range, not NaN
   yn[2] = 0.0; isv[2] = 1.0;                       // exp(0) = 1
-  yn[3] = -3000.0 * vkm::kExpScale; isv[3] = 1.0;  // beyond the clamp: 0
+  yn[3] = -3000.0 * vkm::kExpScale; isv[3] = 1.0;  // beyond the clamp: likewise
   double *dyn, *disv, *deg;
   hipMalloc(&dyn, nb); hipMalloc(&disv, nb); hipMalloc(&deg, nb);
   hipMemcpy(dyn, yn.data(), nb, hipMemcpyHostToDevice);
   hipMemcpy(disv, isv.data(), nb, hipMemcpyHostToDevice);
-  hipLaunchKernelGGL(run_gauss, dim3(n / 256), dim3(256), 0, 0, dyn, disv, deg, n);
-  hipMemcpy(eg.data(), deg, nb, hipMemcpyDeviceToHost);
-  double m_gn = 0, m_gt = 0;
-  for (int i = 4; i < n; ++i) {
-    const double yp = fabs(yn[i] * isv[i]);                         // one rounding, as the device's v_mul_f64
-    const long double ys = (long double)yp * 32768.0L;
-    const long double el = expl(-ys * ys * (logl(2.0L) / 256.0L));
-    const double ue = ulp_err(eg[i], el);
-    if (el > 1e-300L) m_gn = fmax(m_gn, ue); else m_gt = fmax(m_gt, ue);
+  double g_rel[2] = {0, 0}, g_mean[2] = {0, 0};
+  int gauss_special_ok = 1;
+  for (int expt = 0; expt < 2; ++expt) {
+    if (expt == 0) hipLaunchKernelGGL(run_gauss<0>, dim3(n / 256), dim3(256), vkm::ExpCfg<0>::kDoubles * 8, 0, dyn, disv, deg, n);
+    else hipLaunchKernelGGL(run_gauss<1>, dim3(n / 256), dim3(256), vkm::ExpCfg<1>::kDoubles * 8, 0, dyn, disv, deg, n);
+    hipMemcpy(eg.data(), deg, nb, hipMemcpyDeviceToHost);
+    long double sum = 0;
+    long cnt = 0;
+    for (int i = 4; i < n; ++i) {
+      const double yp = fabs(yn[i] * isv[i]);                         // one rounding, as the device's v_mul_f64
+      const long double ys = (long double)yp * 512.0L;                 // = z sqrt(128/ln2)
+      const long double el = expl(-ys * ys * (logl(2.0L) / 256.0L));
+      if (el > 1e-290L) {                                              // |z| <= 36.5; beyond, only "tiny" is asserted (specials)
+        const long double rel = ((long double)eg[i] - el) / el;
+        g_rel[expt] = fmax(g_rel[expt], (double)fabsl(rel));
+        sum += rel;
+        ++cnt;
+      } else if (!(eg[i] >= 0.0 && eg[i] < 1e-280)) {
+        gauss_special_ok = 0;
+      }
+    }
+    g_mean[expt] = (double)(sum / cnt);
+    gauss_special_ok &= std::isnan(eg[0]) && eg[1] >= 0.0 && eg[1] < 1e-300 && eg[2] == 1.0 && eg[3] >= 0.0 && eg[3] < 1e-300;
   }
-  const int gauss_special_ok = std::isnan(eg[0]) && eg[1] == 0.0 && eg[2] == 1.0 && eg[3] == 0.0;
+  // recip_nr / rsqrt_nr_x2: relative errors
+  std::vector<double> rc2(n), rs2(n);
+  hipLaunchKernelGGL(run_nr2, dim3(n / 256), dim3(256), 0, 0, dx, dg, dir, n);
+  hipMemcpy(rc2.data(), dg, nb, hipMemcpyDeviceToHost);
+  hipMemcpy(rs2.data(), dir, nb, hipMemcpyDeviceToHost);
+  double m_rc2 = 0, m_rs2 = 0;
+  for (int i = 0; i < n; ++i) {
+    const long double xl = x[i];
+    m_rc2 = fmax(m_rc2, (double)fabsl((long double)rc2[i] * xl - 1.0L));
+    m_rs2 = fmax(m_rs2, (double)fabsl((long double)rs2[i] * sqrtl(xl) * 0.5L - 1.0L));
+  }
 
   // wave_sum on the first 2^16 samples of x and of a (signed), 64 consecutive values per wavefront
   const int nw = 1 << 16;
@@ -141,7 +176,8 @@ int main() {
     }
   }
   printf("{\"rsqrt_nr_ulp_max\": %.3f, \"rsqrt_nr_ulp_mean\": %.3f, ", m_nr, s_nr / n);
-  printf("\"gauss_ulp_normal\": %.3f, \"gauss_ulp_denormal_tail\": %.3f, \"gauss_special_ok\": %d, ", m_gn, m_gt, gauss_special_ok);
+  printf("\"gauss_rel_max\": [%.3e, %.3e], \"gauss_rel_mean\": [%.3e, %.3e], \"gauss_special_ok\": %d, \"recip_nr_rel\": %.3e, \"rsqrt_nr_x2_rel\": %.3e, ",
+         g_rel[0], g_rel[1], g_mean[0], g_mean[1], gauss_special_ok, m_rc2, m_rs2);
   printf("\"wave_sum_rel\": %.3e, \"wave_sum_uniform\": %d, \"sqrt_ulp\": %.3f, \"rsqrt_ulp\": %.3f, \"recip_ulp\": %.3f, \"exp_ulp_normal\": %.3f, \"exp_ulp_denormal_tail\": %.3f, "
          "\"raw_v_rsq_f64_rel\": %.3e, \"raw_v_rcp_f64_rel\": %.3e}\n", ws_rel, ws_uniform, m_g, m_ir, m_rc, m_exn, m_ex, raw1, raw2);
   return 0;

@@ -82,8 +82,10 @@ __global__ void vk_joint_sum_kernel(const double* ws, long long n, int n_ctx, lo
 // vk_create: the tables every launch copies into LDS unchanged - the scaled exp table of vk_devmath.h and the mu records
 // {mu, sqrt(1 - mu^2), W_0, W_1, W_2, 0} of the context's own grid - computed once, on the device (same bits as the
 // in-kernel staging of the general-grid entry points)
-__global__ void vk_init_stage_kernel(const double* mu, const double* w_ell, int n_mu, int n_ell, double* exp_tab, double* stage_mu) {
-  for (int j = threadIdx.x; j < vkm::kExpTab; j += blockDim.x) exp_tab[j] = vkm::exp2_frac_c4(j);
+__global__ void vk_init_stage_kernel(const double* mu, const double* w_ell, int n_mu, int n_ell, double* exp_tab, double* exp_tab_rep,
+                                     double* stage_mu) {
+  for (int j = threadIdx.x; j < vkm::ExpCfg<0>::kDoubles; j += blockDim.x) exp_tab[j] = vkm::exp_table_slot<0>(j);
+  for (int j = threadIdx.x; j < vkm::ExpCfg<1>::kDoubles; j += blockDim.x) exp_tab_rep[j] = vkm::exp_table_slot<1>(j);
   for (int i = threadIdx.x; i < n_mu; i += blockDim.x) {
     const double m = mu[i];
     double* rec = stage_mu + i * kMuRec;
@@ -133,7 +135,8 @@ struct vk_ctx {
   // device pointers into d_tables
   const double *d_x1 = nullptr, *d_w1 = nullptr;  // single velocity node for the Kaiser-type models
   const double* d_vr_emp = nullptr;               // beta-dependent V2, Ge1, Ge2 (degree 6 in beta), see vk_tables.vr_emp
-  const double* d_xws = nullptr;                  // [n_x + 1][2]: {kExpScale x_k, w_k}, scalar-cache reads (fast kernels)
+  const double* d_xws = nullptr;                  // [n_x + 1][2]: {kExpScale x_k, w_k} (point-major fast kernel)
+  const double* d_xgw = nullptr;                  // velocity nodes grouped by quadrature weight (TheoryArgs::xgw)
   double xw_max = 0.0;                            // max |kExpScale x_k|
   const double *d_s = nullptr, *d_mu = nullptr, *d_w = nullptr, *d_x = nullptr, *d_wx = nullptr, *d_beta_r = nullptr,
                *d_beta_d = nullptr, *d_data = nullptr, *d_beta_c = nullptr, *d_prec = nullptr, *d_logdet = nullptr,
@@ -152,7 +155,8 @@ struct vk_ctx {
   const double* d_uni_knots = nullptr;
   // batch-independent staging tables and the bookkeeping of the fused / split launches (one device allocation)
   double* d_aux = nullptr;
-  const double* d_exp_tab = nullptr;   // [vkm::kExpTab]
+  const double* d_exp_tab = nullptr;   // [ExpCfg<0>::kDoubles]
+  const double* d_exp_tab_rep = nullptr;   // [ExpCfg<1>::kDoubles]
   const double* d_stage_mu = nullptr;  // [n_mu][kMuRec]
   unsigned* d_counters = nullptr;      // [kCounterCap], zero between launches
   double* d_partial = nullptr;         // [partial_doubles]
@@ -323,14 +327,22 @@ void choose_split(const vk_ctx* ctx, long long n, int n_s, int* spi, int* team, 
   *parts = (int)(q < 1 ? 1 : (q > 4 ? 4 : q));
 }
 
+// VK_LITE: development build that compiles only the instantiations the two bench workloads (BOSS: isotropic xi^r, l = 0,2;
+// config 3: three real-space multipoles, l = 0,2,4; lattice grid, streaming) reach - a tenth of the compile time.  Never shipped.
+#ifdef VK_LITE
+#define VK_LITE_KEEP(NLR, NL, GRID, MODE) (((NLR) == 1 && (NL) == 2) || ((NLR) == 3 && (NL) == 3)) && (GRID) == 0 && (MODE) == 0
+#else
+#define VK_LITE_KEEP(NLR, NL, GRID, MODE) true
+#endif
+
 template <int RSD, int NLR>
 int launch_generic_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: return launch_on_stream(ctx, vk_theory_kernel<RSD, NLR, 1>, grid, lds, a);
-    case 2: return launch_on_stream(ctx, vk_theory_kernel<RSD, NLR, 2>, grid, lds, a);
-    case 3: return launch_on_stream(ctx, vk_theory_kernel<RSD, NLR, 3>, grid, lds, a);
+    case 1: if constexpr (VK_LITE_KEEP(NLR, 1, 0, RSD)) return launch_on_stream(ctx, vk_theory_kernel<RSD, NLR, 1>, grid, lds, a); break;
+    case 2: if constexpr (VK_LITE_KEEP(NLR, 2, 0, RSD)) return launch_on_stream(ctx, vk_theory_kernel<RSD, NLR, 2>, grid, lds, a); break;
+    case 3: if constexpr (VK_LITE_KEEP(NLR, 3, 0, RSD)) return launch_on_stream(ctx, vk_theory_kernel<RSD, NLR, 3>, grid, lds, a); break;
   }
-  return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
+  return fail(ctx, VK_E_ARG, "n_ell must be 1..3 (or a VK_LITE development build)");
 }
 
 template <int RSD>
@@ -346,11 +358,11 @@ int launch_generic(vk_ctx* ctx, const TheoryArgs& a, int nlr, int grid, size_t l
 template <int NLR, int GRID, int MODE>
 int launch_fast_ngf(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 1, GRID, MODE>, grid, lds, a);
-    case 2: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 2, GRID, MODE>, grid, lds, a);
-    case 3: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 3, GRID, MODE>, grid, lds, a);
+    case 1: if constexpr (VK_LITE_KEEP(NLR, 1, GRID, MODE)) return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 1, GRID, MODE>, grid, lds, a); break;
+    case 2: if constexpr (VK_LITE_KEEP(NLR, 2, GRID, MODE)) return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 2, GRID, MODE>, grid, lds, a); break;
+    case 3: if constexpr (VK_LITE_KEEP(NLR, 3, GRID, MODE)) return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 3, GRID, MODE>, grid, lds, a); break;
   }
-  return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
+  return fail(ctx, VK_E_ARG, "n_ell must be 1..3 (or a VK_LITE development build)");
 }
 
 template <int NLR, int GRID>
@@ -370,11 +382,11 @@ int launch_fast_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
 template <int NLR, int GRID>
 int launch_lanes_ng(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: return launch_on_stream(ctx, vk_theory_lanes_kernel<NLR, 1, GRID>, grid, lds, a);
-    case 2: return launch_on_stream(ctx, vk_theory_lanes_kernel<NLR, 2, GRID>, grid, lds, a);
-    case 3: return launch_on_stream(ctx, vk_theory_lanes_kernel<NLR, 3, GRID>, grid, lds, a);
+    case 1: if constexpr (VK_LITE_KEEP(NLR, 1, GRID, 0)) return launch_on_stream(ctx, vk_theory_lanes_kernel<NLR, 1, GRID>, grid, lds, a); break;
+    case 2: if constexpr (VK_LITE_KEEP(NLR, 2, GRID, 0)) return launch_on_stream(ctx, vk_theory_lanes_kernel<NLR, 2, GRID>, grid, lds, a); break;
+    case 3: if constexpr (VK_LITE_KEEP(NLR, 3, GRID, 0)) return launch_on_stream(ctx, vk_theory_lanes_kernel<NLR, 3, GRID>, grid, lds, a); break;
   }
-  return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
+  return fail(ctx, VK_E_ARG, "n_ell must be 1..3 (or a VK_LITE development build)");
 }
 
 template <int NLR>
@@ -385,11 +397,11 @@ int launch_lanes_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
 template <int NLR, int GRID, int MODE>
 int launch_cells_ngf(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 1, GRID, MODE>, grid, lds, a);
-    case 2: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 2, GRID, MODE>, grid, lds, a);
-    case 3: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 3, GRID, MODE>, grid, lds, a);
+    case 1: if constexpr (VK_LITE_KEEP(NLR, 1, GRID, MODE)) return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 1, GRID, MODE>, grid, lds, a); break;
+    case 2: if constexpr (VK_LITE_KEEP(NLR, 2, GRID, MODE)) return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 2, GRID, MODE>, grid, lds, a); break;
+    case 3: if constexpr (VK_LITE_KEEP(NLR, 3, GRID, MODE)) return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 3, GRID, MODE>, grid, lds, a); break;
   }
-  return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
+  return fail(ctx, VK_E_ARG, "n_ell must be 1..3 (or a VK_LITE development build)");
 }
 
 template <int NLR, int GRID>
@@ -409,9 +421,9 @@ int launch_cells_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
 template <int RSD>
 int launch_xi_smu(vk_ctx* ctx, const TheoryArgs& a, int nlr, int grid, size_t lds) {
   switch (nlr) {
-    case 1: return launch_on_stream(ctx, vk_xi_smu_kernel<RSD, 1>, grid, lds, a);
-    case 2: return launch_on_stream(ctx, vk_xi_smu_kernel<RSD, 2>, grid, lds, a);
-    case 3: return launch_on_stream(ctx, vk_xi_smu_kernel<RSD, 3>, grid, lds, a);
+    case 1: if constexpr (VK_LITE_KEEP(1, 2, 1, 0)) return launch_on_stream(ctx, vk_xi_smu_kernel<RSD, 1>, grid, lds, a); break;
+    case 2: if constexpr (VK_LITE_KEEP(1, 2, 1, 0)) return launch_on_stream(ctx, vk_xi_smu_kernel<RSD, 2>, grid, lds, a); break;
+    case 3: if constexpr (VK_LITE_KEEP(1, 2, 1, 0)) return launch_on_stream(ctx, vk_xi_smu_kernel<RSD, 3>, grid, lds, a); break;
   }
   return fail(ctx, VK_E_ARG, "bad number of real-space multipoles %d", nlr);
 }
@@ -468,6 +480,7 @@ int theory_args(vk_ctx* ctx, const vk_eval_opts* o, TheoryArgs* a, int* nlr) {
   }
   a->xw_scaled = ctx->d_xws;
   a->xw_max = ctx->xw_max;
+  a->xgw = ctx->d_xgw;
   *nlr = o->assume_isotropic ? 1 : ctx->n_ell_r;
   return VK_OK;
 }
@@ -519,6 +532,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
   const int N = a.n_ell * a.n_s;
   choose_split(ctx, a.n, a.n_s, &a.sbins_per_item, &a.team, &a.parts);
   a.exp_tab = ctx->d_exp_tab;
+  a.exp_tab_rep = ctx->d_exp_tab_rep;
   a.nx_magic = div_magic(a.n_x);
   a.nmu_magic = div_magic(a.n_mu);
   a.counters = ctx->d_counters;
@@ -954,6 +968,24 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
     ctx->xw_max = std::max(ctx->xw_max, std::fabs(xw_scaled[2 * k]));
   }
   const size_t o_xws = up.add(xw_scaled.data(), xw_scaled.size());
+  // the same nodes in groups of equal weight, first occurrence first, original order inside a group; the weight travels with
+  // the group's last node (the lanes and cells kernels multiply a group's sum by it once)
+  std::vector<double> xgw;
+  {
+    std::vector<char> taken(t->n_x, 0);
+    for (int k0 = 0; k0 < t->n_x; ++k0) {
+      if (taken[k0]) continue;
+      for (int k = k0; k < t->n_x; ++k)
+        if (!taken[k] && t->w_x[k] == t->w_x[k0]) {
+          taken[k] = 1;
+          xgw.push_back(t->x[k] * vkm::kExpScale);
+          xgw.push_back(0.0);
+        }
+      xgw.back() = t->w_x[k0];
+    }
+    xgw.resize(xgw.size() + 2, 0.0);      // pad pair
+  }
+  const size_t o_xgw = up.add(xgw.data(), xgw.size());
   const size_t o_br = t->n_beta_r > 0 ? up.add(t->beta_r, t->n_beta_r) : 0;
   const size_t xi_coef_n = t->n_beta_r > 0 ? (size_t)t->n_ell_r * (t->n_beta_r - 1) * t->xi.n_int * 16
                                            : (size_t)t->n_ell_r * t->xi.n_int * 4;
@@ -983,6 +1015,22 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
                                               : (size_t)t->n_ell_r * t->uni_n * 4);
     o_uxc = up.add(t->uni_xic, t->n_beta_r > 0 ? (size_t)t->n_ell_r * (t->n_beta_r - 1) * t->uni_n * 16
                                                : (size_t)t->n_ell_r * t->uni_n * 4);
+    // What the fast kernels read is 1 + xi^r as a polynomial in (2 mu_r)^2 (vk_kernel_fast.h: uni_point): the "+1" of
+    // ccf_model.py:690 goes into the constant coefficient of the l = 0 set (for beta polynomials: the beta-constant one), and
+    // the sets of mu_r^2 and mu_r^4 are divided by 4 and 16 - exact rescalings, done here so that vk_tables keeps its meaning
+    {
+      const size_t per_l = t->n_beta_r > 0 ? (size_t)(t->n_beta_r - 1) * t->uni_n * 16 : (size_t)t->uni_n * 4;
+      const size_t step = t->n_beta_r > 0 ? 16 : 4;          // doubles per (interval): [4 powers of tau] x [4 powers of d beta] or [4]
+      for (size_t o : {o_uxi, o_uxc}) {
+        double* x0 = up.host.data() + o;
+        for (size_t e = 0; e < per_l; e += step) x0[e] += 1.0;
+      }
+      double* xc = up.host.data() + o_uxc;
+      for (int l = 1; l < t->n_ell_r; ++l) {
+        const double f = l == 1 ? 0.25 : 0.0625;
+        for (size_t e = 0; e < per_l; ++e) xc[(size_t)l * per_l + e] *= f;
+      }
+    }
     if (t->vr_beta_dep && t->uni_vb) o_uvb = up.add(t->uni_vb, (size_t)(t->n_beta_r - 1) * t->uni_n * 16);
     if (!t->vr_beta_dep && t->uni_v2) o_uv2 = up.add(t->uni_v2, (size_t)t->uni_n * 4);
     if (!t->vr_beta_dep && t->uni_da) o_uda = up.add(t->uni_da, (size_t)t->uni_n * 4);
@@ -1012,6 +1060,7 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
   const double* base = ctx->d_tables;
   ctx->d_x1 = base + o_x1; ctx->d_w1 = base + o_x1 + 1;
   ctx->d_xws = base + o_xws;
+  ctx->d_xgw = base + o_xgw;
   ctx->d_s = base + o_s; ctx->d_mu = base + o_mu; ctx->d_w = base + o_w; ctx->d_x = base + o_x; ctx->d_wx = base + o_wx;
   ctx->d_beta_r = t->n_beta_r > 0 ? base + o_br : nullptr;
   auto view = [&](const vk_pp& p, size_t ok, size_t oc) {
@@ -1051,19 +1100,22 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
     // batch-independent staging tables + bookkeeping of the split / fused launches
     const size_t n_stage = (size_t)t->n_mu * kMuRec;
     ctx->partial_doubles = (size_t)kPartialPoints * t->n_s * kMaxParts * kMaxEll;
-    const size_t aux_doubles = vkm::kExpTab + n_stage + ctx->partial_doubles + (kCounterCap * sizeof(unsigned) + 7) / 8 + 2;
+    const size_t n_exp = vkm::ExpCfg<0>::kDoubles + vkm::ExpCfg<1>::kDoubles;
+    const size_t aux_doubles = n_exp + n_stage + ctx->partial_doubles + (kCounterCap * sizeof(unsigned) + 7) / 8 + 2;
     if ((rc = hipMalloc((void**)&ctx->d_aux, aux_doubles * sizeof(double))) != hipSuccess) return hip_bail(rc, "hipMalloc(aux)");
     if ((rc = hipMemsetAsync(ctx->d_aux, 0, aux_doubles * sizeof(double), ctx->stream)) != hipSuccess)
       return hip_bail(rc, "hipMemset(aux)");
     double* exp_tab = ctx->d_aux;
-    double* stage_mu = exp_tab + vkm::kExpTab;
+    double* exp_tab_rep = exp_tab + vkm::ExpCfg<0>::kDoubles;
+    double* stage_mu = exp_tab + n_exp;
     ctx->d_partial = stage_mu + n_stage;
     ctx->d_counters = reinterpret_cast<unsigned*>(ctx->d_partial + ctx->partial_doubles);
     hipLaunchKernelGGL(vk_init_stage_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->d_mu, ctx->d_w, t->n_mu, t->n_ell, exp_tab,
-                       stage_mu);
+                       exp_tab_rep, stage_mu);
     if ((rc = hipGetLastError()) != hipSuccess) return hip_bail(rc, "vk_init_stage_kernel");
     if ((rc = hipStreamSynchronize(ctx->stream)) != hipSuccess) return hip_bail(rc, "vk_init_stage_kernel");
     ctx->d_exp_tab = exp_tab;
+    ctx->d_exp_tab_rep = exp_tab_rep;
     ctx->d_stage_mu = stage_mu;
     for (int l = 0; l < t->n_ell; ++l) {
       double ws = 0.0;
@@ -1436,7 +1488,7 @@ static int general_grid(vk_ctx* ctx, const vk_eval_opts* opts, const double* par
   int rc = check_opts(ctx, opts);
   if (rc) return rc;
   if (n < 0 || n_s < 1 || n_mu < 2 || !params || !s || !mu || !out) return fail(ctx, VK_E_ARG, "bad arguments");
-  if (project && (n_ell < 1 || n_ell > kMaxEll || !w_ell)) return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
+  if (project && (n_ell < 1 || n_ell > kMaxEll || !w_ell)) return fail(ctx, VK_E_ARG, "n_ell must be 1..3 (or a VK_LITE development build)");
   if (n == 0) return VK_OK;
   VK_HIP(ctx, hipSetDevice(ctx->device));
   const int ne = project ? n_ell : 1;

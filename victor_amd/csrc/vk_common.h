@@ -63,8 +63,11 @@ struct TheoryArgs {
   const double* w_ell;    // [n_ell][n_mu]
   const double* x;        // [n_x]
   const double* w_x;      // [n_x]
-  const double* xw_scaled;  // [n_x + 1][2]: {kExpScale x_k, w_k} (streaming fast kernels; last pair is padding)
+  const double* xw_scaled;  // [n_x + 1][2]: {kExpScale x_k, w_k} (point-major fast kernel; last pair is padding)
   double xw_max;            // max |kExpScale x_k| (cell_in_table)
+  // velocity nodes in groups of equal quadrature weight (Simpson: a handful of distinct values) for the kernels whose node
+  // loop is wave-uniform (lanes, cells): the weight multiplies the group's sum once instead of every integrand point
+  const double* xgw;        // [n_x + 1][2]: {kExpScale x_k in group order, the group's weight at its LAST node else 0} (scalar-cache reads)
   int n_beta_r;           // 0 = fixed xi tables
   const double* beta_r;
   PPView xi, vr, sv;
@@ -103,7 +106,8 @@ struct TheoryArgs {
   int team;               // waves cooperating on one s bin (1, 2 or 4)
   double* out;            // theory: [n][n_ell*n_s];  xi_smu: [n][n_mu][n_s]
   // ---- staging tables that do not depend on the batch (built once in vk_create) --------------------------------
-  const double* exp_tab;  // [vkm::kExpTab] c4 2^(j/256) (vk_devmath.h), computed on the device so every launch copies the same bits
+  const double* exp_tab;  // [ExpCfg<0>::kDoubles] exp table, plain form (vk_devmath.h), computed on the device so every launch copies the same bits
+  const double* exp_tab_rep;  // [ExpCfg<1>::kDoubles] 64 entries x 32 lane replicas (the lanes kernel with the anisotropic sum)
   const double* stage_mu; // [n_mu][kMuRec] {mu, sqrt(1-mu^2), W_0, W_1, W_2, 0} of the context's own (mu, W) grid, or NULL
   const double* image;    // LDS image of this kernel variant's batch-constant tables (vk_kernel_fast.h: copy_image), or NULL
   double wsum[3];         // sum_i W_l[i]: the "-1" of ccf_model.py:690 projects to -sum_i W_l[i] (not 0 for l > 0)

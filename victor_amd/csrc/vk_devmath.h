@@ -85,9 +85,9 @@ __device__ __forceinline__ double recip(double x) {
   return fma(y, fma(e, e, e), y);
 }
 
-// 2^(j/256), j = 0..255, to be staged in LDS by the caller (2 KB)
-constexpr int kExpTab = 256;
-__device__ __forceinline__ double exp2_frac(int j) { return exp2((double)j * (1.0 / kExpTab)); }
+// 2^(j/256), j = 0..255, to be staged in LDS by the caller (2 KB): table of exp_nonpos
+constexpr int kExpNonposTab = 256;
+__device__ __forceinline__ double exp2_frac(int j) { return exp2((double)j * (1.0 / kExpNonposTab)); }
 
 // p*f + c as ONE v_fma_f64.  hipcc prefers the two-address v_fmac_f64 and then needs a v_mov_b64 per step to
 // re-materialise the constant addend it overwrites; naming the three-address form keeps Horner steps at one
@@ -109,7 +109,7 @@ __device__ __forceinline__ double exp_nonpos(double a, const double* __restrict_
   double f = fma(n, -0x1.62e42fee00000p-9, a);                   // ln2/256, high 32 bits: n*hi is exact
   f = fma(n, -0x1.a39ef35793c76p-41, f);                         //          remainder
   const int ni = (int)n;
-  const double t = tab[ni & (kExpTab - 1)];
+  const double t = tab[ni & (kExpNonposTab - 1)];
   double p = fma3(f, 1.0 / 24.0, 1.0 / 6.0);
   p = fma(p, f, 0.5);
   p = fma(p, f, 1.0);
@@ -125,45 +125,115 @@ __device__ __forceinline__ double fma_s(double p, double f, double c) {
   return r;
 }
 
+// 1/x from ONE Newton step, y' = y (1 + e), e = 1 - x y: error e^2.  The v_rcp_f64 seed is good to 2^-24-ish (measured:
+// tools/devmath_check.hip), so the result is good to ~3e-15 - the streaming integrand's 1/sigma_v, whose error enters the
+// Gaussian's exponent as z^2 eps, i.e. <= 1e-13 relative where the integrand has any weight (z^2 <= 36), against the
+// end-to-end budget of 1e-10 on chi2 / xi_l ("accuracy budget"; the contract is 1e-6).
+__device__ __forceinline__ double recip_nr(double x) {
+  const double y = __builtin_amdgcn_rcp(x);
+  const double e = fma(-x, y, 1.0);
+  return fma(y, e, y);
+}
+
+// Twice the refined 1/sqrt(x) in four instructions: y' = y (3 - x y^2) / 2 is Newton's step, and the callers want 2 y' anyway
+// once every length they feed in is halved (an exact power-of-two rescaling on the host side of the loop: X = r'^2 / 4,
+// 2 y' = 4 / r', X * 2y' = r', (num / 2) * 2y' = 2 mu_r - see vk_kernel_fast.h: uni_accum).  Same accuracy as rsqrt_nr.
+__device__ __forceinline__ double rsqrt_nr_x2(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double h = x * y;
+  const double w = fma(-h, y, 3.0);
+  return y * w;
+}
+
 // exp(-z^2/2) for callers that carry ynum and 1/SV with z = ynum / SV in units of kExpScale, i.e. y = kExpScale * z
-// (kExpScale^2 = 128/ln2 * 2^-30, folded into the per-point amplitude and the velocity nodes).
+// (kExpScale^2 = 128/ln2 * 2^-18, folded into the per-point amplitude and the velocity nodes).
 //   * y' = min(|ynum| |inv_sv|, 1) comes out of ONE v_mul_f64: abs modifiers on the inputs and the VOP3 clamp bit on the
-//     result.  y' = 1 is |z| = 2^15 / sqrt(128/ln2) = 2411, where exp(-z^2/2) = 0 in double anyway (it underflows beyond
-//     |z| = 38.6), so the saturation is exact and bounds n below.
-//   * with yn = -(y' 2^15)^2 = -(z^2/2) 256/ln2 the range reduction is n = rint(yn), d = yn - n, exp = 2^(n/256) exp(d ln2/256).
-//     n comes from the add-a-magic-number rounding: nd = fma(-y', y', 1.5 2^22) has ulp 2^-30, i.e. it holds
-//     1.5 2^52 + n in its mantissa - the low word of nd IS n (two's complement, |n| <= 2^30) with no v_rndne / v_cvt -,
-//     nn = nd - magic = n 2^-30 exactly, and ds = fma(-y', y', -nn) = d 2^-30 is exact as before (|d| <= 1/2, up to a
-//     tie of the single rounding).
-//   * the degree-4 Taylor polynomial in f = d ln2/256 is evaluated in ds with every coefficient divided by the leading
-//     one, c4 2^120 with c4 = (ln2/256)^4/24, so the Horner addends are scalar constants and the leading one lives in
-//     the table: `tab_c4[j]` = c4 2^120 2^(j/256) (exp2_frac_c4 below).  Powers of two only rescale: same bits as a
-//     polynomial in d.
+//     result.  y' = 1 is |z| = 2^9 / sqrt(128/ln2) = 37.7, where exp(-z^2/2) = 4e-309 is below the normal range anyway:
+//     the saturation returns a denormal-sized value instead of the true denormal-or-zero, and it bounds n below, which is
+//     what lets the power of two be applied by integer arithmetic on the exponent field (no v_ldexp_f64, no v_ashr).
+//   * with yn = -(y' 2^9)^2 = -(z^2/2) 256/ln2 the range reduction is n = rint(yn / step), d = yn - n step, with a table of
+//     T = 256 / step entries per octave.  n comes from the add-a-magic-number rounding: nd = fma(-y', y', 1.5 2^34 step)
+//     has ulp 2^-18 step, i.e. it holds 1.5 2^52 + n in its mantissa - the low word of nd IS n (two's complement,
+//     |n| <= 2^18) with no v_rndne / v_cvt -, nn = nd - magic = n 2^-18 step exactly, and ds = fma(-y', y', -nn) is exact as
+//     well (|d| <= 1/2, up to a tie of the single rounding).
+//   * exp = 2^(n >> log2 T) 2^(j/T) p(d), j = n mod T.  The table entry t_j = L 2^(j/T) (L = the polynomial's leading
+//     coefficient, so that the Horner form is monic and its addends are scalar constants) is stored with j 2^(20 - log2 T)
+//     subtracted from its high word: adding n 2^(20 - log2 T) to that word - ONE v_lshl_add_u32 - then adds exactly
+//     (n - j) / T = n >> log2 T to the exponent field.  The field cannot underflow: n >> log2 T >= -1024 and L puts t_j at
+//     2^25 or above.
+//   * two table forms, chosen per kernel (template parameter EXPT of the fast kernels):
+//       EXPT 0: T = 256, degree-3 Taylor polynomial (|f| <= ln2/512: remainder f^4/24 <= 1.4e-13, always positive,
+//               2.8e-14 on average); 2 KB; its byte offset (j << 3) is one SDWA shift of the low byte of n.  The reads are
+//               random over the 32 bank pairs: ~3.5 LDS cycles per group of 32 lanes instead of 1.
+//       EXPT 1: T = 64, degree 4 (|f| <= ln2/128: remainder f^5/120 <= 3.9e-14), each entry replicated for the 32 lanes of
+//               a ds_read_b64 group, entry j of lane l at byte (j << 8) + ((l & 31) << 3): 16 KB, conflict-free by
+//               construction.  Two more vector instructions than EXPT 0; for the kernels whose LDS pipe is the co-limiter
+//               (lanes kernel with the anisotropic sum: 10 ds_read_b128 per integrand point).
 // NaN: the clamp bit turns a NaN product into 0 when MODE.DX10_CLAMP is set (the HSA default); the kernels that use this
 // clear that bit at entry (clamp_keeps_nan) so a NaN still propagates, and their final multiply by inv_sv carries a NaN
 // 1/SV in any case.
-constexpr double kExpScale = 13.589148804608305 * 0x1p-15;       // sqrt(128/ln 2) 2^-15
-constexpr double kExpMagic = 0x1.8p22;                           // ulp 2^-30
-constexpr double kExpC1 = 0.0027076061740622863;                 // ln2/256
-constexpr double kExpC4 = kExpC1 * kExpC1 * kExpC1 * kExpC1 / 24.0;
-__device__ __forceinline__ double exp2_frac_c4(int j) { return kExpC4 * 0x1p120 * exp2((double)j * (1.0 / kExpTab)); }
+constexpr double kExpScale = 13.589148804608305 * 0x1p-9;        // sqrt(128/ln 2) 2^-9
+constexpr double kExpC = 709.782712893383996843;                 // 1024 ln 2: f = ds * kExpC for both table forms
+template <int EXPT> struct ExpCfg;
+template <> struct ExpCfg<0> {
+  static constexpr int kBits = 8, kEntries = 256, kDoubles = 256, kDegree = 3;
+  static constexpr double kMagic = 0x1.8p34;                     // ulp 2^-18
+  static constexpr double kLead = kExpC * kExpC * kExpC / 6.0;
+};
+template <> struct ExpCfg<1> {
+  static constexpr int kBits = 6, kEntries = 64, kDoubles = 64 * 32, kDegree = 4;
+  static constexpr double kMagic = 0x1.8p36;                     // ulp 2^-16: one step = four steps of the 256-entry form
+  static constexpr double kLead = kExpC * kExpC * kExpC * kExpC / 24.0;
+};
+constexpr int kExpTab = ExpCfg<0>::kDoubles;                      // legacy name: doubles of the plain table
+
+// entry j of the table, as stored: L 2^(j/T) with j << (20 - log2 T) taken off the high word (see above)
+template <int EXPT>
+__device__ __forceinline__ double exp_table_entry(int j) {
+  typedef ExpCfg<EXPT> C;
+  const double t = C::kLead * exp2((double)j * (1.0 / C::kEntries));
+  return __hiloint2double(__double2hiint(t) - (j << (20 - C::kBits)), __double2loint(t));
+}
+// slot e of the staged table (EXPT 1: [entry][lane of the group of 32])
+template <int EXPT>
+__device__ __forceinline__ double exp_table_slot(int e) { return exp_table_entry<EXPT>(EXPT == 1 ? (e >> 5) : e); }
 
 // MODE.DX10_CLAMP = 0 for this wave: v_*_f64 ... clamp then returns NaN for a NaN result instead of 0
 __device__ __forceinline__ void clamp_keeps_nan() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 8, 1), 0"); }
 
-__device__ __forceinline__ double exp_gauss(double ynum, double inv_sv, const double* __restrict__ tab_c4) {
+// `tab`: LDS address of the staged table; `lane_off` = (lane & 31) << 3 (EXPT 1 only)
+template <int EXPT>
+__device__ __forceinline__ double exp_gauss(double ynum, double inv_sv, const double* __restrict__ tab, unsigned lane_off = 0) {
+  typedef ExpCfg<EXPT> C;
   double yp;
   asm("v_mul_f64 %0, |%1|, |%2| clamp" : "=v"(yp) : "v"(ynum), "v"(inv_sv));
-  const double nd = fma(-yp, yp, kExpMagic);
-  const double nn = nd - kExpMagic;
+  const double nd = fma(-yp, yp, C::kMagic);
+  const double nn = nd - C::kMagic;
   const double d = fma(-yp, yp, -nn);
-  const int ni = __double2loint(nd);
-  const double t = tab_c4[ni & (kExpTab - 1)];
-  double q = d + 4.0 / kExpC1 * 0x1p-30;                                  // c3/c4
-  q = fma_s(q, d, 12.0 / (kExpC1 * kExpC1) * 0x1p-60);                    // c2/c4
-  q = fma_s(q, d, 24.0 / (kExpC1 * kExpC1 * kExpC1) * 0x1p-90);           // c1/c4
-  q = fma_s(q, d, 24.0 / (kExpC1 * kExpC1 * kExpC1 * kExpC1) * 0x1p-120); // 1/c4
-  return ldexp(t * q, ni >> 8);
+  const int n = __double2loint(nd);
+  unsigned off;
+  if (EXPT == 0) {
+    // (n & 255) << 3 as one SDWA shift of the low byte of n
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(off) : "v"(3), "v"(n));
+    __builtin_assume(off < 2048u);       // lets the table's LDS base fold into the ds_read offset field
+  } else {
+    // ((n & 63) << 8) | lane_off in two instructions (left to itself the compiler shifts, masks and adds: three)
+    asm("v_and_b32 %0, 63, %1\n\tv_lshl_or_b32 %0, %0, 8, %2" : "=&v"(off) : "v"(n), "v"(lane_off));
+  }
+  const double t = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(tab) + off);
+  const double ts = __hiloint2double(__double2hiint(t) + (n << (20 - C::kBits)), __double2loint(t));
+  double q;
+  if (C::kDegree == 3) {
+    q = d + 3.0 / kExpC;
+    q = fma_s(q, d, 6.0 / (kExpC * kExpC));
+    q = fma_s(q, d, 6.0 / (kExpC * kExpC * kExpC));
+  } else {
+    q = d + 4.0 / kExpC;
+    q = fma_s(q, d, 12.0 / (kExpC * kExpC));
+    q = fma_s(q, d, 24.0 / (kExpC * kExpC * kExpC));
+    q = fma_s(q, d, 24.0 / (kExpC * kExpC * kExpC * kExpC));
+  }
+  return ts * q;
 }
 
 }  // namespace vkm

@@ -107,7 +107,8 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
   VK_STAMP(a, 0);
   if (a.image) copy_image(lds, a.image, pl.image_end);
   else stage_cells<NLR>(a, pl, lds, mode_is_dispersion(MODE));
-  const FastConsts fc = make_fast_consts<NLR>(a);
+  constexpr bool kHalf = !mode_is_dispersion(MODE);       // streaming modes: half units (vk_kernel_fast.h: FastPoint)
+  const FastConsts fc = make_fast_consts<NLR>(a, kHalf);
   __syncthreads();
   VK_STAMP(a, 1);
 
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
   const double* l_mu = lds + pl.mu;
   const double* l_w = lds + pl.w;
   typedef const vk_d2 __attribute__((address_space(4))) * cvec_ptr;
-  const cvec_ptr cxw = (cvec_ptr)(unsigned long long)a.xw_scaled;
+  const cvec_ptr cxg = (cvec_ptr)(unsigned long long)a.xgw;    // velocity nodes in groups of equal weight (see the lanes kernel), scalar-cache reads
   const double* l_s = lds + pl.s;
   const int slots = min(cells_range_bins(a.n_mu, cpi), a.n_s) + 1;   // local bins of a range (+ one that only ever receives zeros)
   double* l_acc = lds + pl.acc;                              // [l][local bin][wave]: each entry touched by one wave only
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
     const int nb = (int)__umulhi((unsigned)(c1 - 1), a.nmu_magic) - jf + 1;
     const double* row = a.params + point * VK_NPAR;
     const PointScalars ps = point_scalars(a, row);
-    const FastPoint fp = make_fast_point(ps, fc);
+    const FastPoint fp = make_fast_point(ps, fc, kHalf);
     constexpr int PV = mode_is_dispersion(MODE) ? 0 : 1;
     __syncthreads();      // every wave is done with the previous item's records and accumulators
     rebuild_point_tables<NLR, PV>(a, lds, pl.betar, pl.v1, row[VK_P_BETA], ps.av, fp.AVk);
@@ -155,24 +156,44 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
       double g = 0.0;
       // trips whose 64 x 50 radii all fall inside the table skip the clamp pair of the interval coordinate (see the lanes
       // kernel; a trip that holds a mu = 1 cell reaches r < 0.01 and keeps it)
-      if (!mode_is_dispersion(MODE) && !__any(!cell_in_table(fc, s_par, sperp2, a.xw_max * fabs(fp.Bk)))) {
+      const bool inside = !mode_is_dispersion(MODE) && !__any(!cell_in_table(fc, s_par, sperp2, a.xw_max * fabs(fp.Bk)));
+      double gs = 0.0;
+      if (mode_is_dispersion(MODE)) {
         for (int k = 0; k < a.n_x; ++k) {
-          const vk_d2 xw = cxw[k];
-          const double xk = xw.x;
-          g = fma(xw.y, uni_value<NLR, GRID, MODE == kModeFromData, 1, 0>(lds, fc, fp.AVk, fma(-xk, fp.Bk, s_par), sperp2, xk, fp.fa,
-                                                                         sperp2x), g);
+          const vk_d2 xw = cxg[k];
+          gs += disp_value<NLR, GRID, MODE == kModeDispersionFromData>(lds, lds + pl.da, fc, fp, a.niter, fma(-xw.x, fp.Bk, s_par), s_par,
+                                                                     sperp2, xw.x);
+          if (__double2hiint(xw.y) != 0) {            // wave-uniform: a scalar branch, taken at the last node of a group
+            asm volatile("" ::: "memory");            // (keeps the compiler from turning it into per-lane selects)
+            g = fma(xw.y, gs, g);
+            gs = 0.0;
+          }
+        }
+      } else if (inside) {
+        for (int k = 0; k < a.n_x; ++k) {
+          const vk_d2 xw = cxg[k];
+          double inv_sv;
+          const double p = uni_point<NLR, GRID, MODE == kModeFromData, 1, 0>(lds, fc, 0.0, fma(-xw.x, fp.Bk, s_par), sperp2, xw.x, fp.fa,
+                                                                            sperp2x, 0u, inv_sv);
+          gs = fma(inv_sv, p, gs);
+          if (__double2hiint(xw.y) != 0) {            // wave-uniform: a scalar branch, taken at the last node of a group
+            asm volatile("" ::: "memory");            // (keeps the compiler from turning it into per-lane selects)
+            g = fma(xw.y, gs, g);
+            gs = 0.0;
+          }
         }
       } else {
         for (int k = 0; k < a.n_x; ++k) {
-          const vk_d2 xw = cxw[k];             // scalar-cache read (wave-uniform), see vk_kernel_lanes.h
-          const double xk = xw.x;
-          const double num = fma(-xk, fp.Bk, s_par);
-          g = fma(xw.y,
-                  mode_is_dispersion(MODE)
-                      ? disp_value<NLR, GRID, MODE == kModeDispersionFromData>(lds, lds + pl.da, fc, fp, a.niter, num, s_par, sperp2,
-                                                                             xk)
-                      : uni_value<NLR, GRID, MODE == kModeFromData, 1>(lds, fc, fp.AVk, num, sperp2, xk, fp.fa, sperp2x),
-                  g);
+          const vk_d2 xw = cxg[k];
+          double inv_sv;
+          const double p = uni_point<NLR, GRID, MODE == kModeFromData, 1, 1>(lds, fc, 0.0, fma(-xw.x, fp.Bk, s_par), sperp2, xw.x, fp.fa,
+                                                                            sperp2x, 0u, inv_sv);
+          gs = fma(inv_sv, p, gs);
+          if (__double2hiint(xw.y) != 0) {            // wave-uniform: a scalar branch, taken at the last node of a group
+            asm volatile("" ::: "memory");            // (keeps the compiler from turning it into per-lane selects)
+            g = fma(xw.y, gs, g);
+            gs = 0.0;
+          }
         }
       }
       if (!live) g = 0.0;

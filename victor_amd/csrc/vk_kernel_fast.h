@@ -27,12 +27,14 @@ namespace vk {
 typedef double vk_d2 __attribute__((ext_vector_type(2)));
 constexpr int kMuRec = 6;   // {mu, sqrt(1-mu^2), W_0, W_1, W_2, pad}
 constexpr int kEtabOff = 0;                  // doubles
-constexpr int kRecsOff = vkm::kExpTab;
+// EXPT: form of the exp table at the start of LDS (vk_devmath.h: ExpCfg); the records follow it
+template <int EXPT> __host__ __device__ constexpr int recs_off() { return vkm::ExpCfg<EXPT>::kDoubles; }
+__host__ __device__ constexpr int recs_off_rt(int expt) { return expt ? vkm::ExpCfg<1>::kDoubles : vkm::ExpCfg<0>::kDoubles; }
 
 __host__ __device__ constexpr int uni_stride(int nlr) { return 4 * (2 + nlr) + 2; }   // doubles per refined interval
 // exp table + records (+ two sentinel records and the u16 look-up table of the union-grid mode), at fixed offsets
-__host__ __device__ constexpr int fast_fixed_doubles(int uni_n, int nlr, int lut_n) {
-  return kRecsOff + (uni_n + (lut_n > 0 ? 2 : 0)) * uni_stride(nlr) + (lut_n + 3) / 4;
+__host__ __device__ constexpr int fast_fixed_doubles(int uni_n, int nlr, int lut_n, int expt = 0) {
+  return recs_off_rt(expt) + (uni_n + (lut_n > 0 ? 2 : 0)) * uni_stride(nlr) + (lut_n + 3) / 4;
 }
 
 // GRID = 0: the unified grid is a uniform lattice (index arithmetic).  GRID = 1: it is the union of arbitrary knot
@@ -45,7 +47,8 @@ struct FastConsts {
   double off, t_lo, n_eps;        // GRID 0: t = r' + off, clamped to [t_lo, n_eps]; t_lo is u = 0.01, the first V knot
                                   // GRID 1: u = r' clamped to [t_lo, n_eps] = [first knot, last knot)
   double inv_g;                   // GRID 1: cells of the look-up table per unit length
-  double rlo2, rhi2;              // the clamped coordinate stays inside (t_lo, n_eps) while rlo2 <= r'^2 < rhi2 (cell_in_table)
+  double rlo2, rhi2;              // the clamped coordinate stays inside (t_lo, n_eps) while rlo2 <= X < rhi2 (cell_in_table),
+                                  // X = r'^2 (full units) or r'^2 / 4 (half units, the streaming modes)
   int lut_off;                    // GRID 1: byte offset of the look-up table in LDS
 };
 
@@ -72,28 +75,30 @@ __device__ __forceinline__ double cubic_b128(const double* rec, double t) {
   return fma(fma(fma(hi.y, t, hi.x), t, lo.y), t, lo.x);
 }
 
-template <int NLR>
-__device__ __forceinline__ FastConsts make_fast_consts(const TheoryArgs& a) {
+// HALF: the caller works in half units (every length times k/2, see uni_point), so the squares it tests are r'^2 / 4
+template <int NLR, int EXPT = 0>
+__device__ __forceinline__ FastConsts make_fast_consts(const TheoryArgs& a, bool half) {
   FastConsts fc;
+  const double sq = half ? 0.25 : 1.0;
   if (a.uni_lut_n > 0) {
     fc.inv_h = 1.0;
     fc.off = 0.0;
     fc.t_lo = a.uni_knots[0];
     fc.n_eps = a.uni_knots[a.uni_n] * (1.0 - 0x1p-52);
     fc.inv_g = a.uni_lut_inv_g;
-    fc.rlo2 = fc.t_lo * fc.t_lo * (1.0 + 1e-9);       // u = r' itself: inside [first knot, last knot) as for the lattice form below
-    fc.rhi2 = fc.n_eps * fc.n_eps * (1.0 - 1e-9);
-    fc.lut_off = (kRecsOff + (a.uni_n + 2) * uni_stride(NLR)) * 8;
+    fc.rlo2 = sq * fc.t_lo * fc.t_lo * (1.0 + 1e-9);       // u = r' itself: inside [first knot, last knot) as for the lattice form below
+    fc.rhi2 = sq * fc.n_eps * fc.n_eps * (1.0 - 1e-9);
+    fc.lut_off = (recs_off<EXPT>() + (a.uni_n + 2) * uni_stride(NLR)) * 8;
   } else {
     fc.inv_h = a.uni_inv_h;
     fc.off = -a.uni_u0 * a.uni_inv_h;
     fc.t_lo = (a.vr.knots[0] - a.uni_u0) * a.uni_inv_h;
     fc.n_eps = (double)a.uni_n * (1.0 - 0x1p-52);
     fc.inv_g = 0.0;
-    // margins of 1e-9 relative: r' = r2 rsqrt(r2) is good to an ulp, so t cannot cross a bound the squares stay clear of
+    // margins of 1e-9 relative: r' = X * (4 / r') is good to a few ulp, so t cannot cross a bound the squares stay clear of
     const double lo = fc.t_lo - fc.off, hi = fc.n_eps - fc.off;
-    fc.rlo2 = lo * lo * (1.0 + 1e-9);
-    fc.rhi2 = hi * hi * (1.0 - 1e-9);
+    fc.rlo2 = sq * lo * lo * (1.0 + 1e-9);
+    fc.rhi2 = sq * hi * hi * (1.0 - 1e-9);
     fc.lut_off = 0;
   }
   return fc;
@@ -104,6 +109,7 @@ __device__ __forceinline__ FastConsts make_fast_consts(const TheoryArgs& a) {
 //   s_perp'^2 + max(|s_par'| - xi_max, 0)^2 <= r'^2 <= s_perp'^2 + (|s_par'| + xi_max)^2
 // by the monotonicity of the roundings (the lower bound says that the mu = 1 cells, s_perp' = 0, only come near r = 0 in the
 // s bins the velocity nodes can reach).  False for NaN operands (the clamped form then yields a valid index as before).
+// All lengths in the caller's units (half units: fc was made with half = true).
 __device__ __forceinline__ bool cell_in_table(const FastConsts& fc, double s_par, double sperp2, double xi_max) {
   const double spx = fabs(s_par) + xi_max;
   const double spn = fmax(fabs(s_par) - xi_max, 0.0);
@@ -112,10 +118,10 @@ __device__ __forceinline__ bool cell_in_table(const FastConsts& fc, double s_par
 
 // Stage the batch-constant parts of the records: sigma_v and V always, xi^r_l when it does not depend on beta;
 // also the exp table.  All threads of the workgroup; `lds` is the start of dynamic LDS.
-template <int NLR>
+template <int NLR, int EXPT = 0>
 __device__ __forceinline__ void stage_uni_records(const TheoryArgs& a, double* lds) {
   constexpr int stride = uni_stride(NLR);
-  double* recs = lds + kRecsOff;
+  double* recs = lds + recs_off<EXPT>();
   const int tid = threadIdx.x;
   for (int e = tid; e < a.uni_n * 8; e += kBlock) recs[(e >> 3) * stride + (e & 7)] = a.uni_sv_v[e];
   if (a.n_beta_r == 0) {
@@ -126,7 +132,8 @@ __device__ __forceinline__ void stage_uni_records(const TheoryArgs& a, double* l
       recs[(iq >> 2) * stride + 8 + 4 * l + (iq & 3)] = src[e];
     }
   }
-  for (int j = tid; j < vkm::kExpTab; j += kBlock) lds[kEtabOff + j] = a.exp_tab[j];
+  const double* etab = EXPT ? a.exp_tab_rep : a.exp_tab;
+  for (int j = tid; j < vkm::ExpCfg<EXPT>::kDoubles; j += kBlock) lds[kEtabOff + j] = etab[j];
   if (a.uni_lut_n > 0) {
     // union-grid mode: pad slots {left knot, 1/width}; two sentinel records whose left knot is the last knot; the table
     for (int q = tid; q <= a.uni_n + 1; q += kBlock) {
@@ -146,10 +153,11 @@ __device__ __forceinline__ void stage_uni_records(const TheoryArgs& a, double* l
 template <int NLR>
 __device__ __forceinline__ void rebuild_uni_xi(const TheoryArgs& a, double* recs, const double* bg, double beta, double vs = 1.0) {
   constexpr int stride = uni_stride(NLR);
+  const int tid = late_tid();        // fresh per work item: nothing derived from it is carried through the integrand loops
   // PCHIP piece: last i in [1, n-2] with beta >= bg[i], else 0 - a count over the lanes for grids of up to 64 nodes
   int kb = 0;
   if (a.n_beta_r <= 64) {
-    const int lane = threadIdx.x & 63;
+    const int lane = tid & 63;
     kb = __popcll(__ballot(lane >= 1 && lane < a.n_beta_r - 1 && beta >= bg[lane < a.n_beta_r ? lane : 0]));
   } else {
     for (int i = 1; i < a.n_beta_r - 1; ++i) kb = (beta >= bg[i]) ? i : kb;
@@ -160,7 +168,7 @@ __device__ __forceinline__ void rebuild_uni_xi(const TheoryArgs& a, double* recs
   const double* src = ((NLR > 1) ? a.uni_xic : a.uni_xi) + (size_t)kb * per_l * 4;
   const int total = NLR * per_l;
   // four entries per thread per pass, their eight 16-byte coefficient loads in flight together
-  for (int base = threadIdx.x; base < total; base += 4 * kBlock) {
+  for (int base = tid; base < total; base += 4 * kBlock) {
     vk_d2 c01[4], c23[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -181,7 +189,7 @@ __device__ __forceinline__ void rebuild_uni_xi(const TheoryArgs& a, double* recs
     }
   }
   if (a.vr_beta_dep) {   // linear_bias on a reconstructed real-space ccf: V1 follows xi^r_0(beta) (ccf_model.py:358-370)
-    for (int iq = threadIdx.x; iq < per_l; iq += kBlock) {
+    for (int iq = tid; iq < per_l; iq += kBlock) {
       const double* c = a.uni_vb + ((size_t)kb * per_l + iq) * 4;
       recs[(iq >> 2) * stride + 4 + (iq & 3)] = vs * fma(fma(fma(c[3], db, c[2]), db, c[1]), db, c[0]);
     }
@@ -193,7 +201,7 @@ __device__ __forceinline__ void rebuild_uni_xi(const TheoryArgs& a, double* recs
 template <int NLR>
 __device__ __forceinline__ void rebuild_uni_v_emp(const TheoryArgs& a, double* recs, double av, double vs = 1.0) {
   constexpr int stride = uni_stride(NLR);
-  for (int iq = threadIdx.x; iq < a.uni_n * 4; iq += kBlock)
+  for (int iq = late_tid(); iq < a.uni_n * 4; iq += kBlock)
     recs[(iq >> 2) * stride + 4 + (iq & 3)] = vs * fma(av, a.uni_v2[iq], a.uni_sv_v[(iq >> 2) * 8 + 4 + (iq & 3)]);
 }
 
@@ -202,7 +210,7 @@ __device__ __forceinline__ void rebuild_uni_v_emp(const TheoryArgs& a, double* r
 template <int NLR>
 __device__ __forceinline__ void scale_uni_v(int uni_n, double* recs, const double* v1, double vs) {
   constexpr int stride = uni_stride(NLR);
-  for (int iq = threadIdx.x; iq < uni_n * 4; iq += kBlock) recs[(iq >> 2) * stride + 4 + (iq & 3)] = vs * v1[iq];
+  for (int iq = late_tid(); iq < uni_n * 4; iq += kBlock) recs[(iq >> 2) * stride + 4 + (iq & 3)] = vs * v1[iq];
 }
 
 // Per-item tables of the kernels that own a point per workgroup.  PV: fold AVk into the V cubics (streaming modes).
@@ -210,28 +218,35 @@ template <int NLR, int PV>
 __device__ __forceinline__ void rebuild_point_tables(const TheoryArgs& a, double* lds, int betar_off, int v1_off, double beta,
                                                      double av, double AVk) {
   const double vs = PV ? AVk : 1.0;
-  if (a.n_beta_r > 0) rebuild_uni_xi<NLR>(a, lds + kRecsOff, lds + betar_off, beta, vs);
-  if (a.empirical) rebuild_uni_v_emp<NLR>(a, lds + kRecsOff, av, vs);
-  else if (PV && !a.vr_beta_dep) scale_uni_v<NLR>(a.uni_n, lds + kRecsOff, lds + v1_off, vs);
+  double* recs = lds + recs_off<0>();                        // the kernels that own a point per workgroup use the plain exp table
+  if (a.n_beta_r > 0) rebuild_uni_xi<NLR>(a, recs, lds + betar_off, beta, vs);
+  if (a.empirical) rebuild_uni_v_emp<NLR>(a, recs, av, vs);
+  else if (PV && !a.vr_beta_dep) scale_uni_v<NLR>(a.uni_n, recs, lds + v1_off, vs);
 }
 
 // per-point factors of the index-unit formulation (wave-uniform in the point-major and cells kernels, per lane in
-// the lanes kernel)
+// the lanes kernel).  The streaming modes work in HALF units - every length times k/2, so that twice the refined 1/sqrt comes
+// out of four instructions (vkm::rsqrt_nr_x2) and the factors of two land where they cost nothing: X = r'^2/4,
+// yy = 4/r', X yy = r', (num/2) yy = 2 mu_r, AVk halved, and the mu_r^2-power coefficients of the records divided by 4 and
+// 16 on the host (vk_tables.uni_xic) - all exact.  The dispersion modes keep full units (their fixed-point iteration
+// needs r itself).
 struct FastPoint {
-  double fa, fp2;         // from_data: c/apar and (c/aperp)^2 (fiducial coordinates of xi^r, see uni_value)
+  double fa, fp2;         // from_data: c/apar and (c/aperp)^2 (fiducial coordinates of xi^r, see uni_point)
   double Gk, gD;          // dispersion model: aH^-1 v_r/r = -Gk V(u) / r' and aH^-1 v_r' = -gD Da(u) (see disp_value)
   double k_perp, k_par;   // aperp k, apar k: s_perp' = s sqrt(1-mu^2) k_perp, s_par' = s mu k_par
   double Bk;              // sigma_v iaH_true k / kExpScale: r_par' = s_par' - x_k' Bk with x_k' = kExpScale x_k
   double AVk;             // kExpScale g / (3 iaH_true sigma_v): y = (x_k' + AVk V mu_r) / SV
 };
 
-__device__ __forceinline__ FastPoint make_fast_point(const PointScalars& ps, const FastConsts& fc) {
+__device__ __forceinline__ FastPoint make_fast_point(const PointScalars& ps, const FastConsts& fc, bool half) {
   FastPoint fp;
+  const double hs = half ? 0.5 : 1.0;
   const double k = ps.inv_c * fc.inv_h;
-  fp.k_perp = ps.aperp * k;
-  fp.k_par = ps.apar * k;
-  fp.Bk = ps.B * k * (1.0 / vkm::kExpScale);
-  fp.AVk = ps.A * vkm::kExpScale;
+  const double kl = k * hs;                                // the scale of the lengths that enter the integrand
+  fp.k_perp = ps.aperp * kl;
+  fp.k_par = ps.apar * kl;
+  fp.Bk = ps.B * kl * (1.0 / vkm::kExpScale);
+  fp.AVk = ps.A * vkm::kExpScale * hs;                     // multiplies V * (2 mu_r) in half units
   const double c = 1.0 / ps.inv_c;
   fp.fa = c * ps.inv_apar;
   fp.fp2 = (c * ps.inv_aperp) * (c * ps.inv_aperp);
@@ -242,77 +257,86 @@ __device__ __forceinline__ FastPoint make_fast_point(const PointScalars& ps, con
 
 // Record and local coordinate of a radius: `x` is the interval coordinate t = r' + off (GRID 0) or the radius u = r'
 // itself (GRID 1, union grid), not yet clamped.
-// CL = 0: the caller has shown that t lies inside [t_lo, n_eps] for every lane (rows_in_table below), the clamp pair is dropped.
-template <int NLR, int GRID, int CL = 1>
+// CL = 0: the caller has shown that t lies inside [t_lo, n_eps] for every lane (cell_in_table), the clamp pair is dropped.
+template <int NLR, int GRID, int CL = 1, int EXPT = 0>
 __device__ __forceinline__ const double* locate(const double* __restrict__ lds, const FastConsts& fc, double x,
                                                 double& tq, int& qi) {
   constexpr int stride = uni_stride(NLR);
+  constexpr int roff = recs_off<EXPT>();
   if (GRID == 0) {
     const double t = CL ? vmin_f64(vmax_f64(x, fc.t_lo), fc.n_eps) : x;
     tq = __builtin_amdgcn_fract(t);
     qi = (int)t;
-    return lds_at(lds + kRecsOff, __mul24(qi, stride * 8));
+    return lds_at(lds + roff, __mul24(qi, stride * 8));
   }
   const double u = CL ? vmin_f64(vmax_f64(x, fc.t_lo), fc.n_eps) : x;
   const int cell = (int)(u * fc.inv_g);
   const int q0 = *reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(lds) + fc.lut_off + 2 * cell);
-  const double* rec0 = lds_at(lds + kRecsOff, __mul24(q0, stride * 8));
+  const double* rec0 = lds_at(lds + roff, __mul24(q0, stride * 8));
   const double k1 = rec0[2 * stride - 2], k2 = rec0[3 * stride - 2];      // left knots of the next two records
   const int q = q0 + (u >= k1) + (u >= k2);
   qi = q;
-  const double* rec = lds_at(lds + kRecsOff, __mul24(q, stride * 8));
+  const double* rec = lds_at(lds + roff, __mul24(q, stride * 8));
   const vk_d2 kw = *reinterpret_cast<const vk_d2*>(rec + stride - 2);
   tq = (u - kw.x) * kw.y;
   return rec;
 }
 
-// (1 + xi^r) * exp(-z^2/2) / SV at one integrand point, given r_par' and s_perp'^2 in index units and the scaled
-// velocity node xk' (ccf_model.py:648-657, 681-690).  For NLR > 1 the records hold the Legendre sum regrouped in
-// powers of m = mu_r^2 (A, B, C of vk_tables.uni_xic), so xi^r = A + m (B + m C).
+// One integrand point of the streaming model (ccf_model.py:648-657, 681-690): returns p = (1 + xi^r) exp(-z^2/2) and
+// 1/SV in `inv_sv`; the caller accumulates inv_sv * p (times the velocity node's weight, taken per weight group where the
+// node loop is wave-uniform).  HALF units (see FastPoint): `num` = r_par'/2, `sperp2` = s_perp'^2/4, `AVh` = AVk/2 (or
+// unused with PV), `xk` the scaled velocity node.
+//   geometry   X = num^2 + sperp2, yy = 4/r' (four instructions), mu2 = num yy = 2 mu_r, t = X yy + off
+//   records    sigma_v and V cubics at (interval, tq); xi^r with the constant "+1" of 1 + xi^r already in its constant
+//              coefficient, and for NLR > 1 the Legendre sum regrouped in powers of mu2^2 = 4 mu_r^2 (A + 1, B/4, C/16 of
+//              vk_tables.uni_xic), so xi^r + 1 = A' + mu2^2 (B' + mu2^2 C')
+//   Gaussian   1/SV from one Newton step (vkm::recip_nr), exp from vkm::exp_gauss<EXPT>
 // FD = 1: realspace_ccf_from_data (ccf_model.py:618-619, 675-679) - xi^r is read at the fiducial coordinates
-// (r_par / apar, s_perp / aperp) on an abscissa that is not rescaled by c, i.e. at r_par' * fa and sperp2' * fp^2 with
+// (r_par / apar, s_perp / aperp) on an abscissa that is not rescaled by c, i.e. at num * fa and sperp2 * fp^2 with
 // fa = c/apar, fp = c/aperp (`sperp2x` carries the second product), through a second interval look-up.
-// PV = 1: the V cubics in the records already carry the per-point factor AVk (the kernels that own a point per workgroup
+// PV = 1: the V cubics in the records already carry the per-point factor AVh (the kernels that own a point per workgroup
 // rescale them once per work item, scale_uni_v) - one multiply less per integrand point.
-template <int NLR, int GRID, int FD, int PV = 0, int CL = 1>
-__device__ __forceinline__ double uni_value(const double* __restrict__ lds, const FastConsts& fc, double AVk,
-                                            double r_par, double sperp2, double xk, double fa, double sperp2x) {
-  const double r2 = fma(r_par, r_par, sperp2);
-  const double inv_r = vkm::rsqrt_nr(r2);
-  const double mu_r = r_par * inv_r;
-  double mu_x = mu_r;                           // the mu at which xi^r is read
+template <int NLR, int GRID, int FD, int PV = 0, int CL = 1, int EXPT = 0>
+__device__ __forceinline__ double uni_point(const double* __restrict__ lds, const FastConsts& fc, double AVh,
+                                            double num, double sperp2, double xk, double fa, double sperp2x,
+                                            unsigned lane_off, double& inv_sv) {
+  const double X = fma(num, num, sperp2);
+  const double yy = vkm::rsqrt_nr_x2(X);
+  const double mu2 = num * yy;
+  double mu_x = mu2;                            // (twice) the mu at which xi^r is read
   double tq;
   int qi;
-  const double* rec = locate<NLR, GRID, CL>(lds, fc, GRID == 0 ? fma(r2, inv_r, fc.off) : r2 * inv_r, tq, qi);
+  const double* rec = locate<NLR, GRID, CL, EXPT>(lds, fc, GRID == 0 ? fma(X, yy, fc.off) : X * yy, tq, qi);
   const double SV = cubic_b128(rec, tq);
   const double V = cubic_b128(rec + 4, tq);
-  const double ynum = PV ? fma(V, mu_r, xk) : fma(AVk * V, mu_r, xk);
+  const double ynum = PV ? fma(V, mu2, xk) : fma(AVh * V, mu2, xk);
   if (FD) {
-    const double rp = r_par * fa;
-    const double r2x = fma(rp, rp, sperp2x);
-    const double inv_rx = vkm::rsqrt_nr(r2x);
-    mu_x = rp * inv_rx;
-    rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(r2x, inv_rx, fc.off) : r2x * inv_rx, tq, qi);
+    const double rp = num * fa;
+    const double Xx = fma(rp, rp, sperp2x);
+    const double yyx = vkm::rsqrt_nr_x2(Xx);
+    mu_x = rp * yyx;
+    rec = locate<NLR, GRID, 1, EXPT>(lds, fc, GRID == 0 ? fma(Xx, yyx, fc.off) : Xx * yyx, tq, qi);
   }
-  double xir = cubic_b128(rec + 8, tq);
+  double xi1 = cubic_b128(rec + 8, tq);
   if (NLR > 1) {
     const double m2 = mu_x * mu_x;
     if (NLR == 2) {
-      xir = fma(cubic_b128(rec + 12, tq), m2, xir);
+      xi1 = fma(cubic_b128(rec + 12, tq), m2, xi1);
     } else {
-      xir = fma(fma(cubic_b128(rec + 16, tq), m2, cubic_b128(rec + 12, tq)), m2, xir);
+      xi1 = fma(fma(cubic_b128(rec + 16, tq), m2, cubic_b128(rec + 12, tq)), m2, xi1);
     }
   }
-  const double inv_sv = vkm::recip(SV);
-  const double e = vkm::exp_gauss(ynum, inv_sv, lds + kEtabOff);
-  return inv_sv * fma(e, xir, e);
+  inv_sv = vkm::recip_nr(SV);
+  const double e = vkm::exp_gauss<EXPT>(ynum, inv_sv, lds + kEtabOff, lane_off);
+  return e * xi1;
 }
 
 // The dispersion model (ccf_model.py:658-671) on the same records: zero-mean Gaussian pdf of width sigma_v SV(r), the
 // real-space coordinate from the reference's fixed-point iteration r_par <- (s_par - v/aH) / (1 + q(r)),
 // q(r) = aH^-1 v_r(r)/r, started at the redshift-space separation and repeated `niter` more times, and the Jacobian
 // 1 / (1 + q + mu_r^2 (dq - q)) with dq = aH^-1 v_r'(r).  `da` = LDS table of Da = delta - 2 Delta/3 on the unified
-// grid, [uni_n][4].  All lengths in index units; `num` = s_par' - x_k' Bk.
+// grid, [uni_n][4].  All lengths in index units (FULL units: fc and fp made with half = false); `num` = s_par' - x_k' Bk.
+// The fixed-point iteration amplifies rounding, so 1/r and the reciprocals keep their third-order refinements here.
 template <int NLR, int GRID, int FD>
 __device__ __forceinline__ double disp_value(const double* __restrict__ lds, const double* __restrict__ da,
                                              const FastConsts& fc, const FastPoint& fp, int niter, double num,
@@ -334,22 +358,22 @@ __device__ __forceinline__ double disp_value(const double* __restrict__ lds, con
   const double q = -fp.Gk * cubic_b128(rec + 4, tq) * inv_r;
   const double dq = -fp.gD * cubic_b128(da + 4 * qi, tq);
   const double m2 = mu_r * mu_r;
-  double mx2 = m2;
-  if (FD) {   // xi^r at the fiducial coordinates, as in uni_value
+  double mx2 = 4.0 * m2;                        // the records hold the coefficients of powers of (2 mu)^2, see uni_point
+  if (FD) {   // xi^r at the fiducial coordinates, as in uni_point
     const double rp = r_par * fp.fa;
     const double r2x = fma(rp, rp, sperp2 * fp.fp2);
     const double inv_rx = vkm::rsqrt3(r2x);
     const double mu_x = rp * inv_rx;
-    mx2 = mu_x * mu_x;
+    mx2 = 4.0 * (mu_x * mu_x);
     rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(r2x, inv_rx, fc.off) : r2x * inv_rx, tq, qi);
   }
-  double xir = cubic_b128(rec + 8, tq);
-  if (NLR == 2) xir = fma(cubic_b128(rec + 12, tq), mx2, xir);
-  if (NLR == 3) xir = fma(fma(cubic_b128(rec + 16, tq), mx2, cubic_b128(rec + 12, tq)), mx2, xir);
+  double xi1 = cubic_b128(rec + 8, tq);          // 1 + xi^r_0 (the "+1" sits in the constant coefficient)
+  if (NLR == 2) xi1 = fma(cubic_b128(rec + 12, tq), mx2, xi1);
+  if (NLR == 3) xi1 = fma(fma(cubic_b128(rec + 16, tq), mx2, cubic_b128(rec + 12, tq)), mx2, xi1);
   const double inv_sv = vkm::recip(SV);
   const double jac = vkm::recip(1.0 + q + m2 * (dq - q));
-  const double e = vkm::exp_gauss(xk, inv_sv, lds + kEtabOff);
-  return inv_sv * jac * fma(e, xir, e);
+  const double e = vkm::exp_gauss<0>(xk, inv_sv, lds + kEtabOff);
+  return inv_sv * jac * (e * xi1);
 }
 
 // MODE of the kernels that own a point per workgroup: streaming, streaming on a measured real-space ccf, dispersion
@@ -510,7 +534,8 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 3 : 2) void vk_the
   // ---- batch-constant tables: from the context's LDS image when there is one ------------------------
   if (a.image) copy_image(lds, a.image, pl.image_end);
   else stage_fast<NLR>(a, pl, lds, mode_is_dispersion(MODE));
-  const FastConsts fc = make_fast_consts<NLR>(a);
+  constexpr bool kHalf = !mode_is_dispersion(MODE);       // streaming modes: half units (FastPoint)
+  const FastConsts fc = make_fast_consts<NLR>(a, kHalf);
   __syncthreads();
   VK_STAMP(a, 1);
 
@@ -535,7 +560,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 3 : 2) void vk_the
     const int q = (int)(item - pg * (unsigned)Q);
     const int g = (int)(pg - (unsigned)point * (unsigned)groups);
     const double* row = a.params + point * VK_NPAR;
-    const FastPoint fp = make_fast_point(ps, fc);
+    const FastPoint fp = make_fast_point(ps, fc, kHalf);
     constexpr int PV = mode_is_dispersion(MODE) ? 0 : 1;
     if (PV || a.n_beta_r > 0 || a.empirical) {
       __syncthreads();  // previous item's readers are done with the per-point records
@@ -569,11 +594,14 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 3 : 2) void vk_the
           const double sperp2 = s_perp * s_perp;
           const double s_par = s_apar * m01.x;
           const double num = fma(-xw.x, fp.Bk, s_par);
-          const double f = xw.y * (mode_is_dispersion(MODE)
-                                       ? disp_value<NLR, GRID, MODE == kModeDispersionFromData>(lds, lds + pl.da, fc, fp, a.niter, num,
-                                                                                              s_par, sperp2, xw.x)
-                                       : uni_value<NLR, GRID, MODE == kModeFromData, 1>(lds, fc, fp.AVk, num, sperp2, xw.x, fp.fa,
-                                                                                    sperp2 * fp.fp2));
+          double f;
+          if (mode_is_dispersion(MODE)) {
+            f = xw.y * disp_value<NLR, GRID, MODE == kModeDispersionFromData>(lds, lds + pl.da, fc, fp, a.niter, num, s_par, sperp2, xw.x);
+          } else {
+            double inv_sv;
+            const double p = uni_point<NLR, GRID, MODE == kModeFromData, 1>(lds, fc, 0.0, num, sperp2, xw.x, fp.fa, sperp2 * fp.fp2, 0u, inv_sv);
+            f = (xw.y * inv_sv) * p;
+          }
           const vk_d2 w01 = *reinterpret_cast<const vk_d2*>(mr + 2);
           acc[0] = fma(w01.x, f, acc[0]);
           if (NL > 1) acc[1] = fma(w01.y, f, acc[1]);

@@ -29,7 +29,7 @@ __host__ __device__ inline LdsPlan make_plan(int n_mu, int n_x, int n_ell, int s
   p.betar = o; o += n_beta_r;
   p.red = o;  o += kWaves * kMaxEll;
   o = (o + 1) & ~1;
-  p.etab = o; o += vkm::kExpTab;
+  p.etab = o; o += vkm::kExpNonposTab;
   p.total = o;
   return p;
 }
@@ -188,7 +188,7 @@ __device__ void stage_tables(const TheoryArgs& a, const LdsPlan& pl, double* lds
     lds[pl.x + i] = a.x[i];
     lds[pl.wx + i] = a.w_x[i];
   }
-  for (int j = tid; j < vkm::kExpTab; j += kBlock) lds[pl.etab + j] = vkm::exp2_frac(j);
+  for (int j = tid; j < vkm::kExpNonposTab; j += kBlock) lds[pl.etab + j] = vkm::exp2_frac(j);
   for (int i = tid; i <= a.sv.n_int; i += kBlock) lds[pl.svk + i] = a.sv.knots[i];
   for (int i = tid; i < a.sv.n_int * 4; i += kBlock) lds[pl.svc + i] = a.sv_n_mu ? 0.0 : a.sv.coef[i];
   for (int i = tid; i <= a.vr.n_int; i += kBlock) lds[pl.vrk + i] = a.vr.knots[i];

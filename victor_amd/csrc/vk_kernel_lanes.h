@@ -18,9 +18,20 @@ struct LanesPlan {
   int smu, image_end, total;
 };
 
+// exp-table form of the lanes kernel (vk_devmath.h: ExpCfg).  With the anisotropic sum the kernel reads ten 16-byte record
+// pieces per integrand point and the LDS array is ~80 % busy, a sixth of it bank conflicts of the random exp-table reads; the
+// replicated table (EXPT 1) halves those conflicts (16.4 % -> 9.4 % of the LDS cycles, command-FIFO-full cycles 1.1e9 -> 0.4e9
+// per launch) but costs two vector instructions, 14 KB of LDS and with it the fifth workgroup per CU: 25.8 ms against 24.7 ms
+// for the plain table on config 3 (same box, profiles/r03/c_*) - the vector ALU, 89-90 % busy, is what bounds the launch.
+// The plain table is the default for every NLR; -D'VK_LANES_EXPT(NLR)=((NLR)>=2)' rebuilds the A/B.
+#ifndef VK_LANES_EXPT
+#define VK_LANES_EXPT(NLR) 0
+#endif
+__host__ __device__ constexpr int lanes_expt(int nlr) { return VK_LANES_EXPT(nlr); }
+
 __host__ __device__ inline LanesPlan make_lanes_plan(int n_mu, int n_x, int uni_n, int nlr, int lut_n) {
   LanesPlan p;
-  int o = fast_fixed_doubles(uni_n, nlr, lut_n);   // exp table + records first (fixed offsets)
+  int o = fast_fixed_doubles(uni_n, nlr, lut_n, lanes_expt(nlr));   // exp table + records first (fixed offsets)
   o = (o + 1) & ~1;
   p.smu = o;   o += 2 * n_mu;           // {mu_i, sqrt(1 - mu_i^2)}
   p.image_end = o;                      // all of it is batch-constant (LDS image, see vk_kernel_fast.h)
@@ -35,7 +46,7 @@ __device__ __forceinline__ void stage_lanes(const TheoryArgs& a, const LanesPlan
     lds[pl.smu + 2 * i] = m;
     lds[pl.smu + 2 * i + 1] = sqrt(1.0 - m * m);
   }
-  stage_uni_records<NLR>(a, lds);
+  stage_uni_records<NLR, lanes_expt(NLR)>(a, lds);
 }
 
 // per-lane version of point_scalars (each lane integrates its own AP rescaling factor, ccf_model.py:609-611)
@@ -80,6 +91,7 @@ __device__ __forceinline__ PointScalars point_scalars_lane(const TheoryArgs& a, 
 #ifndef VK_LANES_WG_PER_CU
 #define VK_LANES_WG_PER_CU 5
 #endif
+
 template <int NLR, int NL, int GRID>
 __global__ __launch_bounds__(kBlock, VK_LANES_WG_PER_CU) void vk_theory_lanes_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
@@ -88,16 +100,18 @@ __global__ __launch_bounds__(kBlock, VK_LANES_WG_PER_CU) void vk_theory_lanes_ke
   const int tid = threadIdx.x;
   if (a.image) copy_image(lds, a.image, pl.image_end);
   else stage_lanes<NLR>(a, pl, lds);
-  const FastConsts fc = make_fast_consts<NLR>(a);
+  constexpr int EXPT = lanes_expt(NLR);
+  const FastConsts fc = make_fast_consts<NLR, EXPT>(a, true);
   __syncthreads();
 
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  const unsigned lane_off = (unsigned)(lane & 31) << 3;      // this lane's replica of the exp table (EXPT 1)
   const double* l_smu = lds + pl.smu;
   // velocity nodes through the scalar cache: wave-uniform, read-only for the whole launch (constant address space
   // tells the compiler so), which keeps them out of the VALU and LDS pipes
   typedef const vk_d2 __attribute__((address_space(4))) * cvec_ptr;
-  const cvec_ptr cxw = (cvec_ptr)(unsigned long long)a.xw_scaled;
+  const cvec_ptr cxg = (cvec_ptr)(unsigned long long)a.xgw;
   const long long chunks = (a.n + 63) >> 6;
   const long long items = chunks * a.n_s;
   // XCD-aware block order: the n_s waves of a 64-point chunk read the same 6 KB of parameter rows; consecutive
@@ -113,7 +127,7 @@ __global__ __launch_bounds__(kBlock, VK_LANES_WG_PER_CU) void vk_theory_lanes_ke
     const bool valid = point < a.n;
     if (!valid) point = a.n - 1;
     const PointScalars ps = point_scalars_lane(a, a.params + point * VK_NPAR);
-    const FastPoint fp = make_fast_point(ps, fc);
+    const FastPoint fp = make_fast_point(ps, fc, true);     // half units (vk_kernel_fast.h: FastPoint)
     const double sj = a.s[j];
     const double sa = sj * fp.k_perp, sp = sj * fp.k_par;
     const double xi_max = a.xw_max * fabs(fp.Bk);
@@ -130,19 +144,34 @@ __global__ __launch_bounds__(kBlock, VK_LANES_WG_PER_CU) void vk_theory_lanes_ke
       // table, and only the mu = 1 row reaches r < 0.01) skip the clamp pair of the interval coordinate.  Extending the
       // records past the last knot so that the top s bins qualify too was measured and dropped: nothing on config 3, and the
       // larger LDS footprint costs BOSS a workgroup per CU (profiles/r02/i_clamp_exp_ab.txt)
-      if (!__any(!cell_in_table(fc, s_par, sperp2, xi_max))) {
+      const bool inside = !__any(!cell_in_table(fc, s_par, sperp2, xi_max));
+      // nodes in groups of equal quadrature weight: `gs` sums a group, its weight arrives with the group's last node
+      // (a wave-uniform test on a scalar register) - one multiply per group instead of one per integrand point
+      double gs = 0.0;
+#define VK_GROUP_END(xw)                                                                                                  \
+  if (__double2hiint((xw).y) != 0) {            /* wave-uniform: a scalar branch, taken at the last node of a group */   \
+    asm volatile("" ::: "memory");              /* (keeps the compiler from turning it into per-lane selects) */        \
+    g = fma((xw).y, gs, g);                                                                                               \
+    gs = 0.0;                                                                                                             \
+  }
+      if (inside) {
         for (int k = 0; k < a.n_x; ++k) {
-          const vk_d2 xw = cxw[k];
-          const double xk = xw.x;
-          g = fma(xw.y, uni_value<NLR, GRID, 0, 0, 0>(lds, fc, fp.AVk, fma(-xk, fp.Bk, s_par), sperp2, xk, 0.0, 0.0), g);
+          const vk_d2 xw = cxg[k];
+          double inv_sv;
+          const double p = uni_point<NLR, GRID, 0, 0, 0, EXPT>(lds, fc, fp.AVk, fma(-xw.x, fp.Bk, s_par), sperp2, xw.x, 0.0, 0.0, lane_off, inv_sv);
+          gs = fma(inv_sv, p, gs);
+          VK_GROUP_END(xw)
         }
       } else {
         for (int k = 0; k < a.n_x; ++k) {
-          const vk_d2 xw = cxw[k];
-          const double xk = xw.x;
-          g = fma(xw.y, uni_value<NLR, GRID, 0>(lds, fc, fp.AVk, fma(-xk, fp.Bk, s_par), sperp2, xk, 0.0, 0.0), g);
+          const vk_d2 xw = cxg[k];
+          double inv_sv;
+          const double p = uni_point<NLR, GRID, 0, 0, 1, EXPT>(lds, fc, fp.AVk, fma(-xw.x, fp.Bk, s_par), sperp2, xw.x, 0.0, 0.0, lane_off, inv_sv);
+          gs = fma(inv_sv, p, gs);
+          VK_GROUP_END(xw)
         }
       }
+#undef VK_GROUP_END
 #pragma unroll
       for (int l = 0; l < NL; ++l) acc[l] = fma(a.w_ell[l * a.n_mu + i], g, acc[l]);
     }

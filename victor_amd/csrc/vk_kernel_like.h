@@ -70,6 +70,20 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return s;
 }
 
+// number of threads of the workgroup whose predicate holds, to every thread; `red` as for block_sum.  (Not __syncthreads_count:
+// HIP implements that through a static __shared__ word, which moves the base of dynamic LDS off zero for the whole kernel -
+// every LDS address of the theory loops then carries an addend the ds_read offset field could have held.)
+__device__ __forceinline__ int block_count(bool pred, double* red) {
+  const int c = __popcll(__ballot(pred));
+  __syncthreads();                       // `red` may still be read from a previous call
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = (double)c;
+  __syncthreads();
+  double s = red[0];
+#pragma unroll
+  for (int w = 1; w < kWaves; ++w) s += red[w];
+  return (int)s;
+}
+
 // sum_b (sum_{r in [r0, r1)} th[r] P[r][b]) th[b] over this lane's column pairs b = 2 lane, 2 lane + 128, ... (N even), with
 // P = (1-t) P0 + t P1 when BLEND.  The rows of a column pair are streamed through a rolling window of D 16-byte loads:
 // D in flight at any time, so the whole column costs one exposed round trip to L2 plus issue time, in 4 D registers.
@@ -140,11 +154,11 @@ __device__ __forceinline__ void like_point_workgroup(const LikeArgs& a, long lon
   int lo = 0;
   double t = 0.0;
   if (by_count) {
-    if (a.n_beta_d > 0) k = __syncthreads_count(tid >= 1 && tid < a.n_beta_d - 1 && beta >= a.beta_d[tid]);
+    if (a.n_beta_d > 0) k = block_count(tid >= 1 && tid < a.n_beta_d - 1 && beta >= a.beta_d[tid < a.n_beta_d ? tid : 0], red);
     if (a.n_beta_c > 0) {
       const double g = tid < a.n_beta_c ? a.beta_c[tid] : inf;
-      const int n_lt = __syncthreads_count(tid < a.n_beta_c && g < beta);
-      const int n_eq = __syncthreads_count(tid < a.n_beta_c && g == beta);
+      const int n_lt = block_count(tid < a.n_beta_c && g < beta, red);
+      const int n_eq = block_count(tid < a.n_beta_c && g == beta, red);
       const int last = a.n_beta_c - 1;
       if (beta != beta) {
         t = beta;                         // NaN beta: the blend weight of cov_bracket, i.e. the row reports (-inf, inf) in every K2 variant
@@ -208,8 +222,8 @@ __device__ __forceinline__ void like_point_workgroup(const LikeArgs& a, long lon
       for (int e = tid; e < a.N; e += kBlock) ld += logdet_term(fma(t, ev[e], omt), &n_neg, &n_bad);
     }
     ld = block_sum(ld, red);
-    const int neg = __syncthreads_count(n_neg & 1);       // parity of the number of negative factors
-    const int bad = __syncthreads_count(n_bad);
+    const int neg = block_count(n_neg & 1, red);       // parity of the number of negative factors
+    const int bad = block_count(n_bad != 0, red);
     singular = (neg & 1) || bad || !(fabs(a.logdet[lo]) < inf);
     factor = -0.5 * (a.logdet[lo] + ld);
   }
