@@ -10,17 +10,18 @@ anisotropic real-space xi (l = 0,2,4), AP-dependent template rescaling, sigma_v(
 Halton points PER GPU (weak scaling: rank g evaluates points [g*B, (g+1)*B) of one global sequence).
 Inputs are resident in HBM before the timed region; outputs stay in HBM.
 
-For N > 1 the driver launches one process per GPU with torch.distributed.run; torch is used only for the
-host-side rendezvous (gloo: barriers, the RCCL unique id, max-over-ranks of the time).  The data path
-is libvictor_hip.so + RCCL.  After the weak-scaling line's timed loop a multi-rank run also times a fixed global batch
-(65536 points in total, `strong_scaling`) and every rank checks the whole gathered lnL vector against its own
-recomputation of rows from every other rank's shard.
+For N > 1 the driver launches one process per GPU with torch.distributed.run; the ranks themselves never import torch:
+RANK / WORLD_SIZE come from the environment, the rendezvous (RCCL unique id, barriers, max-over-ranks of the time) is a
+standard-library socket group (victor_amd/rendezvous.py), the data path is libvictor_hip.so + RCCL.  Started on its own,
+`python bench.py --gpus N` drives N contexts from ONE process (ncclCommInitAll, one grouped ncclAllGather per step).
+After the weak-scaling line's timed loop a multi-GPU run also times a fixed global batch (65536 points in total,
+`strong_scaling`) and every GPU's copy of the gathered lnL vector is checked against local recomputation of rows from every
+other shard.
 """
 
 import argparse
 import json
 import os
-import subprocess
 import sys
 import time
 
@@ -129,13 +130,6 @@ def cpu_single_thread(sample_pts, rule):
     with mp.get_context("spawn").Pool(1) as pool:
         _, busy, out, _ = pool.map(cpu_worker, [(0, sample_pts, rule)])[0]
     return {"evals_per_s": len(sample_pts) / busy, "busy_s": busy, "n": len(sample_pts)}
-
-
-def free_port():
-    import socket
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        return sock.getsockname()[1]
 
 
 def warm_up(eng, launch, seconds=0.3):
@@ -270,6 +264,32 @@ def dsplit_measurement(batch=16384, steps=10):
             "max_rel_dchi2_vs_reference_golden": float(np.max(np.abs(chi6 / g["dsplit_chi2"] - 1)))}
 
 
+class Slot:
+    """One GPU of the run: a context with its shard of the global Halton sequence resident in HBM."""
+
+    def __init__(self, g, device, model, data, hp_all, B, total):
+        import victor_amd
+        self.g = g
+        self.fit = victor_amd.CCFFit(model, data, device=device)
+        self.eng = self.fit._get_engine()
+        self.opts = self.eng.make_opts(self.fit.model, self.fit.fit_options)
+        self.mine = {k: v[g * B:(g + 1) * B] for k, v in hp_all.items()}
+        rows = self.fit._fit_rows(self.mine, self.fit.model)
+        eng = self.eng
+        self.d_rows, self.d_lnl, self.d_chi = eng.alloc(rows.size), eng.alloc(B), eng.alloc(B)
+        self.d_ws = eng.alloc(B * eng.n_data)
+        self.d_all = eng.alloc(B * total) if total > 1 else None
+        eng.upload(self.d_rows, rows)
+
+    def launch(self, n):
+        self.eng.eval_device_async(self.opts, self.d_rows, n, self.d_lnl, self.d_chi, self.d_ws)
+
+    def free(self):
+        for p in (self.d_rows, self.d_lnl, self.d_chi, self.d_ws, self.d_all):
+            if p:
+                self.eng.free(p)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -284,26 +304,26 @@ def main():
                          "'avg' (SciPy < 1.11); same cost, recorded in config.simpson_even")
     args = ap.parse_args()
 
-    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
-    if args.gpus > 1 and not launched:
-        # start one rank per GPU as child processes (never exec: this process may already hold the GPU)
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT") or str(free_port()),
-               os.path.abspath(__file__)] + sys.argv[1:]
-        sys.exit(subprocess.call(cmd))
-
+    # Two ways to several GPUs, no torch and no MPI binding in either (victor_amd/rendezvous.py, vk_comm_*):
+    #   launched   one process per GPU under a launcher (the driver: torch.distributed.run; mpirun / srun work the same) -
+    #              RANK / WORLD_SIZE from the environment, a standard-library socket group for the rendezvous and the barriers,
+    #              ncclCommInitRank + ncclAllGather on the context's stream;
+    #   standalone `python bench.py --gpus N`: ONE process, N contexts, ncclCommInitAll + a grouped ncclAllGather per step.
     from victor_amd.sharding import Dist
     dist = Dist()
+    launched = dist.launched
     if launched:
-        with stdout_to_stderr():
-            dist.init_process_group("gloo")
+        dist.connect()
     rank, world = dist.rank, dist.world
     if launched and world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    n_local = 1 if launched else max(args.gpus, 1)       # contexts this process drives
+    total = world * n_local                              # GPUs of the run
 
     import numpy as np
-    import victor_amd
+    import victor_amd  # noqa: F401
     from victor_amd.build import build_native
+    from victor_amd.engine import Engine
     from tests import cases
     if rank == 0:
         build_native()
@@ -312,152 +332,164 @@ def main():
     model, data = cases.synth_options(CONFIG)
     model["numerics"] = {"simpson_even": args.simpson_even}
     B = args.batch
-    hp_all = cases.halton_params(B * world)
-    mine = {k: v[rank * B:(rank + 1) * B] for k, v in hp_all.items()}
+    hp_all = cases.halton_params(B * total)
 
     # CPU baseline first: it spawns worker processes, which must happen before this process touches the GPU
     base = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and total == 1 and not args.no_cpu_baseline:
         cores = host_cores()
         ns = min(args.cpu_sample or max(16, 40 * cores), B)      # ~40 oracle evaluations per core (~50 ms each): ~30 core-seconds of CPU work
         sel = np.linspace(0, B - 1, ns).astype(int)
-        sample = [cases.point(mine, int(i)) for i in sel]
+        sample = [cases.point(hp_all, int(i)) for i in sel]
         base, vals, theory_o = cpu_baseline(sample, args.simpson_even)
         base["single_thread"] = cpu_single_thread(sample[:: max(1, len(sample) // 64)][:64], args.simpson_even)
 
-    # one rank per GPU; on a box with fewer GPUs than ranks (rehearsals) ranks share devices and the RCCL communicator
-    # cannot be built, which exercises the host-gather fallback below
+    # one context per GPU; on a box with fewer GPUs than contexts (rehearsals) contexts share devices and no RCCL
+    # communicator can be built, which exercises the host-gather fallback below
     from victor_amd import _native
     n_dev = max(_native.load().vk_device_count(), 1)
-    fit = victor_amd.CCFFit(model, data, device=(dist.local_rank % n_dev) if launched else 0)
-    eng = fit._get_engine()
-    opts = eng.make_opts(fit.model, fit.fit_options)
-    rows = fit._fit_rows(mine, fit.model)
+    slots = [Slot(rank * n_local + i, ((dist.local_rank if launched else i) % n_dev), model, data, hp_all, B, total)
+             for i in range(n_local)]
+    engines = [s.eng for s in slots]
+    lead = slots[0]
+    fit, eng = lead.fit, lead.eng
     N = eng.n_data
 
-    d_rows = eng.alloc(rows.size)
-    d_lnl = eng.alloc(B)
-    d_chi = eng.alloc(B)
-    d_ws = eng.alloc(B * N)
-    d_all = eng.alloc(B * world) if world > 1 or launched else None
-    eng.upload(d_rows, rows)
-    use_comm = launched
-    host_gather = False
-    if use_comm:
-        # RCCL logs (version banner, topology warnings) go to stdout by default; stdout is reserved for the JSON line
-        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
+    # the gather: "rank" = one communicator per process, "group" = one process, grouped calls, "host" = degraded mode
+    # (RCCL unavailable or refused), "none" = a single GPU started without a launcher
+    gather = "none"
+    if total > 1 or launched:
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")   # RCCL logs go to stdout by default; stdout is the JSON line's
         with stdout_to_stderr():
             rccl_ok = 1.0
             try:
-                uid = eng.comm_unique_id() if rank == 0 else None
-            except Exception as exc:                        # librccl missing: every rank must learn about it
-                print(f"rank {rank}: RCCL unavailable ({exc})", file=sys.stderr)
-                uid, rccl_ok = bytes(128), 0.0
-            uid = dist.broadcast_bytes(uid, src=0, nbytes=128)
+                if launched:
+                    from victor_amd.sharding import one_device_per_rank
+                    if not one_device_per_rank(dist, eng):
+                        raise RuntimeError("two ranks share a GPU: RCCL needs one device per rank")
+                    try:
+                        uid = eng.comm_unique_id() if rank == 0 else None
+                    except Exception as exc:                # librccl missing: every rank must learn about it
+                        print(f"rank {rank}: RCCL unavailable ({exc})", file=sys.stderr)
+                        uid, rccl_ok = bytes(128), 0.0
+                    uid = dist.broadcast_bytes(uid, src=0, nbytes=128)
+                    rccl_ok = dist.min_float(rccl_ok)
+                    if rccl_ok:
+                        try:
+                            eng.comm_init(uid, rank, world)
+                        except Exception as exc:
+                            print(f"rank {rank}: ncclCommInitRank failed ({exc})", file=sys.stderr)
+                            rccl_ok = 0.0
+                        rccl_ok = dist.min_float(rccl_ok)    # no collective before every rank holds a communicator
+                        if rccl_ok:
+                            eng.comm_allgather_async(lead.d_lnl, lead.d_all, B)   # first collective builds the rings (and logs) here
+                            eng.sync()
+                else:
+                    Engine.comm_init_all(engines)
+                    Engine.comm_allgather_group_async(engines, [s.d_lnl for s in slots], [s.d_all for s in slots], B)
+                    for e in engines:
+                        e.sync()
+            except Exception as exc:
+                print(f"rank {rank}: RCCL communicator failed ({exc})", file=sys.stderr)
+                rccl_ok = 0.0
             rccl_ok = dist.min_float(rccl_ok)
-            if rccl_ok:
-                try:
-                    eng.comm_init(uid, rank, world)
-                    eng.comm_allgather_async(d_lnl, d_all, B)  # first collective builds the rings (and logs) here
-                    eng.sync()
-                except Exception as exc:
-                    print(f"rank {rank}: RCCL communicator failed ({exc})", file=sys.stderr)
-                    rccl_ok = 0.0
-                rccl_ok = dist.min_float(rccl_ok)
-        if not rccl_ok:
-            # degraded mode, reported as such in the JSON line: gather lnL through the host process group
-            use_comm = False
-            host_gather = True
+        gather = ("rank" if launched else "group") if rccl_ok else "host"
 
-    def step():
-        eng.eval_device_async(opts, d_rows, B, d_lnl, d_chi, d_ws)
-        if use_comm:
-            eng.comm_allgather_async(d_lnl, d_all, B)
-        elif host_gather:
-            eng.sync()
-            step.gathered = dist.allgather_host(eng.download(d_lnl, B), B)
+    state = {}
+
+    def gather_step(n):
+        if gather == "rank":
+            eng.comm_allgather_async(lead.d_lnl, lead.d_all, n)
+        elif gather == "group":
+            Engine.comm_allgather_group_async(engines, [s.d_lnl for s in slots], [s.d_all for s in slots], n)
+        elif gather == "host":
+            for e in engines:
+                e.sync()
+            local = np.concatenate([s.eng.download(s.d_lnl, n) for s in slots])
+            state["gathered"] = dist.allgather_host(local, len(local)) if launched else local
+
+    def step(n=B):
+        for s in slots:
+            s.launch(n)
+        gather_step(n)
+
+    def sync_all():
+        for e in engines:
+            e.sync()
+
+    def timed(n):
+        """K steps bracketed by sync + barrier on both sides; returns (max-over-ranks seconds, theory ms per launch per slot)."""
+        sync_all()
+        dist.barrier()
+        for e in engines:
+            e.timing(True)
+            e.read_timing(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(n)
+        sync_all()
+        dist.barrier()
+        el = time.perf_counter() - t0
+        per = []
+        for e in engines:
+            th, lk, launches = e.read_timing(reset=True)
+            e.timing(False)
+            per.append((th / max(launches, 1), lk / max(launches, 1)))
+        return dist.max_float(el), per
 
     warm_up(eng, step)                 # untimed pre-warm (runtime's one-off post-allocation stall), then the W steps
     for _ in range(args.warmup):
         step()
-    eng.sync()
-    dist.barrier()
-    eng.timing(True)
-    eng.read_timing(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    eng.sync()
-    dist.barrier()
-    elapsed = time.perf_counter() - t0
-    theory_ms, like_ms, launches = eng.read_timing(reset=True)
-    eng.timing(False)
-    elapsed = dist.max_float(elapsed)
+    elapsed, per_slot = timed(B)
+    theory_ms, like_ms = per_slot[0]
 
     kernel_name = eng.last_kernel()
-    lnl = eng.download(d_lnl, B)
-    chi2 = eng.download(d_chi, B)
-    ok = bool(np.all(np.isfinite(lnl)) and np.all(chi2 > 0))
-    # Every rank checks the WHOLE gathered vector: its own slot bit for bit, every other rank's slot finite and - for a few
-    # rows spread over that rank's shard - equal to this rank's own evaluation of the same global Halton points (another
-    # batch size, hence possibly another kernel mapping: agreement to rounding).
+    lnl = eng.download(lead.d_lnl, B)
+    chi2 = eng.download(lead.d_chi, B)
+    ok = True
     gathered_ok = None
-    gathered = None
-    if use_comm:
-        gathered = eng.download(d_all, B * world)
-    elif host_gather:
-        gathered = step.gathered
-    if gathered is not None:
-        good = bool(np.array_equal(gathered[rank * B:(rank + 1) * B], lnl)) and bool(np.all(np.isfinite(gathered)))
+    # Every slot checks the WHOLE gathered vector: its own part bit for bit, every other slot's part finite and - for a few
+    # rows spread over that slot's shard - equal to this slot's own evaluation of the same global Halton points (another
+    # batch size, hence possibly another kernel mapping: agreement to rounding).
+    good = True
+    for s in slots:
+        mine_l = s.eng.download(s.d_lnl, B)
+        ok = ok and bool(np.all(np.isfinite(mine_l)) and np.all(s.eng.download(s.d_chi, B) > 0))
+        if gather == "none":
+            continue
+        gathered = s.eng.download(s.d_all, B * total) if gather in ("rank", "group") else state["gathered"]
+        good = good and bool(np.array_equal(gathered[s.g * B:(s.g + 1) * B], mine_l)) and bool(np.all(np.isfinite(gathered)))
         probe = np.unique(np.linspace(0, B - 1, 6).astype(int))
-        for other in range(world):
-            if other == rank:
+        for other in range(total):
+            if other == s.g:
                 continue
             theirs = {k: v[other * B + probe] for k, v in hp_all.items()}
-            mine_l, _ = fit.log_likelihood_batch(theirs)
-            good = good and bool(np.max(np.abs(gathered[other * B + probe] - mine_l)) <= 1e-9 * np.max(np.abs(mine_l)))
+            own_l, _ = s.fit.log_likelihood_batch(theirs)
+            good = good and bool(np.max(np.abs(gathered[other * B + probe] - own_l)) <= 1e-9 * np.max(np.abs(own_l)))
+    if gather != "none":
         gathered_ok = bool(dist.min_float(1.0 if good else 0.0))
-    kernel_ms_ranks = dist.allgather_host(np.array([theory_ms / max(launches, 1)]), 1).tolist() if launched else None
+    k_local = np.array([p[0] for p in per_slot])
+    kernel_ms_ranks = (dist.allgather_host(k_local, len(k_local)) if launched else k_local).tolist() if total > 1 or launched else None
 
-    # fixed global batch next to the weak-scaling line: BATCH_PER_GPU points in total, B / world per rank
+    # fixed global batch next to the weak-scaling line: BATCH_PER_GPU points in total, B / total per GPU
     strong = None
-    if world > 1:
-        Bs = max(1, args.batch // world)
-        mine_s = {k: v[rank * Bs:(rank + 1) * Bs] for k, v in hp_all.items()}
-        eng.upload(d_rows, fit._fit_rows(mine_s, fit.model))
-
-        def step_s():
-            eng.eval_device_async(opts, d_rows, Bs, d_lnl, d_chi, d_ws)
-            if use_comm:
-                eng.comm_allgather_async(d_lnl, d_all, Bs)
-            elif host_gather:
-                eng.sync()
-                step_s.gathered = dist.allgather_host(eng.download(d_lnl, Bs), Bs)
-
+    if total > 1:
+        Bs = max(1, args.batch // total)
+        for s in slots:
+            mine_s = {k: v[s.g * Bs:(s.g + 1) * Bs] for k, v in hp_all.items()}
+            s.eng.upload(s.d_rows, s.fit._fit_rows(mine_s, s.fit.model))
         for _ in range(max(args.warmup, 1)):
-            step_s()
-        eng.sync()
-        dist.barrier()
-        eng.timing(True)
-        eng.read_timing(reset=True)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step_s()
-        eng.sync()
-        dist.barrier()
-        el_s = dist.max_float(time.perf_counter() - t0)
-        th_s, _, n_s = eng.read_timing(reset=True)
-        eng.timing(False)
-        ks = dist.allgather_host(np.array([th_s / max(n_s, 1)]), 1).tolist()
-        strong = {"global_batch": Bs * world, "batch_per_gpu": Bs, "value": Bs * world * args.steps / el_s, "unit": "evals/s",
+            step(Bs)
+        el_s, per_s = timed(Bs)
+        ks_local = np.array([p[0] for p in per_s])
+        ks = (dist.allgather_host(ks_local, len(ks_local)) if launched else ks_local).tolist()
+        strong = {"global_batch": Bs * total, "batch_per_gpu": Bs, "value": Bs * total * args.steps / el_s, "unit": "evals/s",
                   "ms_per_step": 1e3 * el_s / args.steps, "scaling": "strong", "kernel": eng.last_kernel(),
                   "theory_kernel_ms_per_rank": ks}
 
     if rank == 0:
-        total = B * world * args.steps
-        value = total / elapsed
-        k1_ms = theory_ms / max(launches, 1)
-        k2_ms = like_ms / max(launches, 1)
+        value = B * total * args.steps / elapsed
+        k1_ms, k2_ms = theory_ms, like_ms
         aniso = not fit.model["assume_isotropic"]
         F = flops_per_eval(len(fit.s), 100, 50, len(fit.poles_s), aniso)
         achieved_tf = F * B / (k1_ms * 1e-3) / 1e12 if k1_ms > 0 else None
@@ -474,16 +506,20 @@ def main():
         alg_bytes = (8 * 10 + 16) * B     # 80 B of parameters in, lnL + chi2 out, per evaluation
         out = {
             "metric": "likelihood evals/sec (40 s-bins, 100 mu, l=0,2,4)",
-            "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "evals/s", "n_gpus": total, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE config 3: synthetic 40 s x 100 mu x 50 v grid, xi_r l=0,2,4, data l=0,2,4 "
                                    "(N=120), AP-dependent rescale, sigma_v(r) template, gaussian likelihood",
                        "simpson_even": eng.simpson_even + (" (SciPy >= 1.11 simps rule; 'avg' = SciPy < 1.11)"
                                                            if eng.simpson_even == "simpson" else " (SciPy < 1.11 simps rule)"),
-                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"batch-sharded x{world}",
-                       "gather": "rccl allgather of lnL" if use_comm else
-                       ("host allgather of lnL (RCCL unavailable)" if host_gather else "none (single process)")},
+                       "batch_per_gpu": B, "global_batch": B * total, "parallelism": f"batch-sharded x{total}",
+                       "processes": world, "contexts_per_process": n_local,
+                       "rendezvous": "standard-library socket group (victor_amd/rendezvous.py)" if launched else "none (one process)",
+                       "gather": {"rank": "rccl allgather of lnL (ncclCommInitRank, one process per GPU)",
+                                  "group": "rccl allgather of lnL (ncclCommInitAll, grouped calls, one process)",
+                                  "host": "host allgather of lnL (RCCL unavailable or refused)",
+                                  "none": "none (single GPU)"}[gather]},
             "roofline": {"bound": "fp64-valu", "kernel": kernel_name + "<3,3>",
                          "achieved": achieved_tf, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / PEAK_FP64_VALU_TFLOPS if achieved_tf else None,
@@ -499,12 +535,12 @@ def main():
         }
         if gathered_ok is not None:
             out["gather_matches_local"] = gathered_ok       # every rank, every slot (see above)
-        if launched:
+        if kernel_ms_ranks is not None:
             out["config"]["rccl"] = _native.comm_info()
             out["theory_kernel_ms_per_rank"] = kernel_ms_ranks
         if strong is not None:
             out["strong_scaling"] = strong
-        if world == 1 and not args.no_boss:
+        if total == 1 and not args.no_boss:
             out["boss_cmass"] = boss_measurement(args)
             out["batch_sweep"] = batch_sweep()
             out["dsplit5"] = dsplit_measurement()
@@ -524,21 +560,20 @@ def main():
             out["max_abs_dchi2_vs_oracle"] = float(np.max(np.abs(chi2[sel] - chi_o)))
             out["max_rel_dlnl_vs_oracle"] = float(np.max(np.abs(lnl[sel] / lnl_o - 1)))
             kk = sorted(theory_o)
-            th_g = fit.theory_vector_batch({k: v[sel[kk]] for k, v in mine.items()})
+            th_g = fit.theory_vector_batch({k: v[sel[kk]] for k, v in lead.mine.items()})
             th_o = np.array([theory_o[k] for k in kk])
             scale = np.max(np.abs(th_o.reshape(len(kk), len(fit.poles_s), -1)), axis=2, keepdims=True)
             dxi = np.abs(th_g - th_o).reshape(len(kk), len(fit.poles_s), -1) / scale
             out["max_rel_dxi_ell_vs_oracle"] = float(dxi.max())      # relative to max|xi_l| of each multipole
         print(json.dumps(out))
 
-    for p in (d_rows, d_lnl, d_chi, d_ws, d_all):
-        if p:
-            eng.free(p)
-    if use_comm:
-        eng.comm_destroy()
+    if gather in ("rank", "group"):
+        for e in engines:
+            e.comm_destroy()
+    for s_ in slots:
+        s_.free()
     dist.barrier()
-    if dist.pg is not None:
-        dist.pg.destroy_process_group()
+    dist.close()
     if not ok or gathered_ok is False:
         sys.exit(1)
 

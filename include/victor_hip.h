@@ -281,6 +281,17 @@ int vk_comm_init(vk_ctx* ctx, const char* id, int rank, int nranks);
 /* all ranks contribute count doubles at d_send, every rank receives nranks*count at d_recv */
 int vk_comm_allgather_async(vk_ctx* ctx, const double* d_send, double* d_recv, int64_t count);
 int vk_comm_destroy(vk_ctx* ctx);
+/* PCI bus id of the context's GPU ("0000:c1:00.0"): ranks compare these (with their host names) before building a
+ * communicator - RCCL needs one device per rank, and a launcher may give two ranks the same GPU under different ordinals. */
+int vk_device_bus_id(const vk_ctx* ctx, char* buf, size_t len);
+/* One process driving several GPUs (one context per device, any host thread): communicators for all n contexts at once
+ * (ncclCommInitAll - no unique id, no rendezvous), context i being rank i.  Fails with VK_E_RCCL when two contexts share a
+ * device (RCCL refuses that; callers then gather through the host). */
+int vk_comm_init_all(vk_ctx* const* ctxs, int32_t n);
+/* The all-gather of such a group in one call: ncclGroupStart, one ncclAllGather per context on that context's stream
+ * (d_send[i]: count doubles on device i, d_recv[i]: n*count doubles on device i), ncclGroupEnd.  Enqueued. */
+int vk_comm_allgather_group_async(vk_ctx* const* ctxs, int32_t n, const double* const* d_send, double* const* d_recv,
+                                  int64_t count);
 /* Writes a JSON object naming the HIP runtime this process mapped (path, runtime/driver version, the HIP version the
  * library was built with) and the RCCL that vk_comm_* uses (path, ncclGetVersion).  RCCL is looked up next to the mapped
  * HIP runtime first, so both come from one ROCm install (PyTorch's bundled pair when torch was imported before this

@@ -29,6 +29,8 @@ Writes
     python oracle/make_golden.py             # all sets
     python oracle/make_golden.py --set avg   # only the second one (inputs and ref_outputs.npz untouched)
     python oracle/make_golden.py --set more  # only the third one
+    python oracle/make_golden.py --set disp  # only the fourth one: tests/golden/ref_outputs_disp.npz from
+                                             # tests/golden/disp_worst_rows.json (see main_disp)
 """
 
 import json
@@ -293,6 +295,64 @@ def main_more():
             print("more", k, np.array2string(out[k], precision=10))
 
 
+def ulp_step(x, direction):
+    """x moved by one unit in the last place (towards +inf for direction > 0, -inf otherwise)."""
+    return float(np.nextafter(x, np.inf if direction > 0 else -np.inf))
+
+
+def main_disp():
+    """Fourth fixture set, ``tests/golden/ref_outputs_disp.npz``: the dispersion model (ccf_model.py:658-671) where it is
+    ill-conditioned.  ``tests/golden/disp_worst_rows.json`` lists parameter rows, found on the GPU by
+    tools/gpu_find_disp_rows.py as the rows on which the three GPU mappings disagree most (a velocity node next to r = 0 at
+    mu = 1: the five fixed-point iterations amplify rounding).  The unmodified reference is run on each row AND on copies
+    with one input moved by one ulp in either direction, so the fixture records the reference's own spread next to its
+    outputs: ``<case>_theory`` (n, N), ``<case>_chi2``, ``<case>_lnl``, ``<case>_spread_theory`` = max over the perturbed
+    copies of max|d xi_l| / max|xi_l|, ``<case>_spread_chi2`` = max relative change of chi2, ``<case>_rows`` = the inputs.
+    A row on which the reference itself returns NaN (one integrand point where the iteration collapses to r = 0 and the
+    Jacobian 1 + q + mu_r^2 (dq - q) cancels to exactly 0 makes xi(s, mu) infinite there, and the global bicubic fit of
+    utils.py:45-56 spreads it over every multipole bin; chi2 = inf) is kept as such, spreads 0."""
+    ref_shim.set_simpson_rule("simpson")
+    v = ref_shim.load()
+    with open(os.path.join(GOLD, "disp_worst_rows.json")) as fh:
+        worst = json.load(fh)
+    cases = {"synth3": (synth_options(3), {}), "boss": (boss_options("config"), {}),
+             "boss_emp": (boss_options("config"), {"empirical_corr": True})}
+    out, meta = {}, {}
+    for name, rows in worst.items():
+        (model, data), kw = cases[name]
+        kw = dict(kw, rsd_model="dispersion")
+        model["dir"] = data["dir"] = GOLD
+        fit = v.CCFFit(model, data)
+        keys = sorted(rows[0]["params"])
+        th, chi, lnl, sp_t, sp_c, inputs = [], [], [], [], [], []
+        for row in rows:
+            p = {k: float.fromhex(x) for k, x in row["params"].items()}
+            t0 = fit.theory_multipole_vector(fit.s, dict(p), fit.poles_s, **kw)
+            l0, c0 = fit.log_likelihood(dict(p), **kw)
+            dt, dc = 0.0, 0.0
+            for k in keys:
+                for direction in (+1, -1):
+                    q = dict(p)
+                    q[k] = ulp_step(p[k], direction)
+                    t1 = fit.theory_multipole_vector(fit.s, dict(q), fit.poles_s, **kw)
+                    _, c1 = fit.log_likelihood(dict(q), **kw)
+                    if np.all(np.isfinite(t0)) and np.all(np.isfinite(t1)):
+                        dt = max(dt, float(np.max(np.abs(t1 - t0)) / np.max(np.abs(t0))))
+                        dc = max(dc, abs(c1 / c0 - 1))
+                    elif np.all(np.isfinite(t0)) != np.all(np.isfinite(t1)):
+                        dt = dc = np.inf                 # finite on one side of a 1-ulp move only
+            th.append(t0); chi.append(c0); lnl.append(l0); sp_t.append(dt); sp_c.append(dc)
+            inputs.append([p[k] for k in keys])
+            print(f"disp {name}: gpu mapping spread {row['gpu_mapping_spread']:.1e}  reference spread under 1-ulp input moves: "
+                  f"theory {dt:.1e}, chi2 {dc:.1e}  (chi2 {c0:.6f})", flush=True)
+        out[f"{name}_theory"], out[f"{name}_chi2"], out[f"{name}_lnl"] = np.array(th), np.array(chi), np.array(lnl)
+        out[f"{name}_spread_theory"], out[f"{name}_spread_chi2"] = np.array(sp_t), np.array(sp_c)
+        out[f"{name}_rows"] = np.array(inputs)
+        meta[name] = {"keys": keys, "kwargs": kw, "gpu_mapping_spread": [r["gpu_mapping_spread"] for r in rows]}
+    out["meta_json"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(GOLD, "ref_outputs_disp.npz"), **out)
+
+
 def main():
     ref_shim.set_simpson_rule("simpson")
     v = ref_shim.load()
@@ -499,7 +559,7 @@ def main():
 if __name__ == "__main__":
     import argparse
     ap = argparse.ArgumentParser()
-    ap.add_argument("--set", choices=["all", "default", "avg", "more"], default="all")
+    ap.add_argument("--set", choices=["all", "default", "avg", "more", "disp"], default="all")
     which = ap.parse_args().set
     if which in ("all", "default"):
         main()
@@ -507,3 +567,5 @@ if __name__ == "__main__":
         main_avg()
     if which in ("all", "more"):
         main_more()
+    if which in ("all", "disp"):
+        main_disp()

@@ -174,3 +174,13 @@ def cobaya_info():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(root, "config", "boss_cobaya_config.yaml")) as fh:
         return yaml.full_load(fh)
+
+
+def dispersion_fixture():
+    """The reference's outputs on the rows where the dispersion model's fixed-point iteration is ill-conditioned, with the
+    reference's own spread under 1-ulp moves of the inputs (oracle/make_golden.py --set disp).  Returns (npz, meta,
+    {case: (model, data)})."""
+    g = np.load(os.path.join(GOLDEN, "ref_outputs_disp.npz"))
+    meta = json.loads(str(g["meta_json"]))
+    options = {"synth3": synth_options(3), "boss": boss_options("config"), "boss_emp": boss_options("config")}
+    return g, meta, options

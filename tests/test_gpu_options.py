@@ -468,11 +468,63 @@ def test_empirical_corr_runs_on_the_fast_kernels(gold):
             assert close(res[mapping][:3], g[key]), (name, mapping)
         # Mapping against mapping: rounding-level agreement, except for the isolated rows where a velocity node puts the
         # fixed-point iteration of ccf_model.py:660-664 next to r = 0 (mu = 1): there the five iterations amplify a 1-ulp
-        # difference in any input to 1e-9 ... 1e-6 - in the reference as much as here (DESIGN.md section 2,
-        # tools/gpu_fuzz_disp_check.py) - so the bound is on the bulk of the rows plus a loose cap on the worst one.
+        # difference in any input - in the reference as much as here (test_dispersion_model_where_it_is_ill_conditioned pins
+        # that against the reference's own 1-ulp spread) - so the bound is on the bulk of the rows plus the contract's 1e-6
+        # on the worst one of this batch.
         for mapping in ("cells", "generic"):
             row_err = np.max(np.abs(res[mapping] - res["point"]), axis=1) / np.max(np.abs(res["point"]))
-            assert np.quantile(row_err, 0.995) < 1e-10 and row_err.max() < 1e-5, (name, mapping, row_err.max())
+            assert np.quantile(row_err, 0.995) < 1e-10 and row_err.max() < 1e-6, (name, mapping, row_err.max())
+
+
+def test_dispersion_model_where_it_is_ill_conditioned():
+    """Parity against the REFERENCE on the rows where the dispersion model is ill-conditioned (a velocity node that lets the
+    fixed-point iteration of ccf_model.py:660-664 collapse towards r = 0 at mu = 1).  tests/golden/ref_outputs_disp.npz
+    holds the reference's outputs on the worst rows of two 131072-point scans per configuration (tools/gpu_find_disp_rows.py)
+    AND its own spread when one input moves by one ulp (oracle/make_golden.py --set disp).  Every GPU mapping must
+      * meet the contract (1e-6 of max|xi_l|, 1e-6 relative on chi2) wherever the reference is itself stable at that level,
+      * deviate by more than 1e-9 only where the reference does too, and by a comparable amount (the amplification is chaotic:
+        a factor 50 on the recorded 1-ulp spread, measured worst case 6),
+      * on the row where the reference returns NaN for every bin (an integrand point whose Jacobian cancels to exactly 0,
+        smeared over all bins by its global bicubic fit - and finite again after a 1-ulp move), agree between its mappings or
+        report the failure pair."""
+    import victor_amd
+    g, meta, options = cases.dispersion_fixture()
+    worst = 0.0
+    for name, m in meta.items():
+        fit = victor_amd.CCFFit(*options[name])
+        kw = dict(m["kwargs"])
+        model = fit._merged(kw)
+        pd = {k: g[f"{name}_rows"][:, j] for j, k in enumerate(m["keys"])}
+        rows = fit._fit_rows(pd, model)
+        ref_t, ref_c = g[f"{name}_theory"], g[f"{name}_chi2"]
+        sp_t, sp_c = g[f"{name}_spread_theory"], g[f"{name}_spread_chi2"]
+        res = {}
+        for mapping in ("point", "cells", "generic"):
+            env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
+            _native.set_knob(env, "1" if mapping == "generic" else mapping)
+            try:
+                th = fit.theory_vector_batch(rows, **kw)
+                lnl, chi = fit.log_likelihood_batch(rows, **kw)
+            finally:
+                _native.set_knob(env, None)
+            res[mapping] = th
+            for i in range(len(rows)):
+                if not np.all(np.isfinite(ref_t[i])):
+                    assert np.isposinf(ref_c[i])
+                    assert (np.isneginf(lnl[i]) and np.isposinf(chi[i])) or np.all(np.isfinite(th[i])), (name, mapping, i)
+                    continue
+                scale = np.max(np.abs(ref_t[i]))
+                dev = np.max(np.abs(th[i] - ref_t[i])) / scale
+                dchi = abs(chi[i] / ref_c[i] - 1)
+                worst = max(worst, dev / max(sp_t[i], 1e-16))
+                assert dev <= max(1e-9, 50 * sp_t[i]), (name, mapping, i, dev, sp_t[i])
+                assert dchi <= max(1e-9, 50 * sp_c[i], 50 * sp_t[i]), (name, mapping, i, dchi, sp_c[i])
+                if sp_t[i] <= 2e-8:                      # the reference is stable at the contract's level here
+                    assert dev <= 1e-6 and dchi <= 1e-6, (name, mapping, i, dev, dchi)
+        for i in range(len(rows)):
+            if not np.all(np.isfinite(ref_t[i])) and all(np.all(np.isfinite(res[mp][i])) for mp in res):
+                scale = np.max(np.abs(res["generic"][i]))
+                assert max(np.max(np.abs(res[mp][i] - res["generic"][i])) for mp in ("point", "cells")) <= 1e-6 * scale, (name, i)
 
 
 def test_dispersion_model_runs_on_the_fast_kernels(gold):
@@ -510,11 +562,12 @@ def test_dispersion_model_runs_on_the_fast_kernels(gold):
                 assert close(res[mapping][:npts], g[key]), (name, mapping)
         # Mapping against mapping: rounding-level agreement, except for the isolated rows where a velocity node puts the
         # fixed-point iteration of ccf_model.py:660-664 next to r = 0 (mu = 1): there the five iterations amplify a 1-ulp
-        # difference in any input to 1e-9 ... 1e-6 - in the reference as much as here (DESIGN.md section 2,
-        # tools/gpu_fuzz_disp_check.py) - so the bound is on the bulk of the rows plus a loose cap on the worst one.
+        # difference in any input - in the reference as much as here (test_dispersion_model_where_it_is_ill_conditioned pins
+        # that against the reference's own 1-ulp spread) - so the bound is on the bulk of the rows plus the contract's 1e-6
+        # on the worst one of this batch.
         for mapping in ("cells", "generic"):
             row_err = np.max(np.abs(res[mapping] - res["point"]), axis=1) / np.max(np.abs(res["point"]))
-            assert np.quantile(row_err, 0.995) < 1e-10 and row_err.max() < 1e-5, (name, mapping, row_err.max())
+            assert np.quantile(row_err, 0.995) < 1e-10 and row_err.max() < 1e-6, (name, mapping, row_err.max())
 
 
 @pytest.mark.parametrize("case", sorted(cases.SHIPPED_COMBINATIONS))

@@ -106,52 +106,104 @@ def test_density_split_joint_fit():
     assert abs(one[1] / g["dsplit_chi2"][0] - 1) < 1e-9
 
 
-def test_walker_example_under_torchrun_single_rank():
-    """examples/run_walkers.py as one rank of a torch.distributed.run launch: exercises the RCCL communicator
-    (unique id broadcast, ncclCommInitRank, ncclAllGather on the context's stream) end to end."""
-    import json
+def _launch_ranks(script_args, world, extra_env=None, timeout=240):
+    """Start ``world`` ranks the way any launcher does - RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* in the environment - as plain
+    child processes (no torchrun, no mpirun); returns their CompletedProcess-like (returncode, stdout, stderr) tuples."""
     import socket
-    import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(root, "examples", "run_walkers.py"), "--steps", "40"]
-    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
-    assert out.returncode == 0, out.stderr.decode()[-2000:]
-    res = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), **(extra_env or {}))
+        procs.append(subprocess.Popen([sys.executable] + script_args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    out = []
+    try:
+        for p in procs:
+            o, e = p.communicate(timeout=timeout)
+            out.append((p.returncode, o, e))
+    finally:
+        for p in procs:                     # a rank that is still there (a hung rendezvous) must not outlive the test
+            if p.poll() is None:
+                p.kill()
+    return out
+
+
+def test_walker_example_as_one_launched_rank():
+    """examples/run_walkers.py as the single rank of a launcher-style start (RANK=0, WORLD_SIZE=1): with one rank no gather is
+    built; the chain itself must behave."""
+    import json
+    (rc, out, err), = _launch_ranks([os.path.join(ROOT, "examples", "run_walkers.py"), "--steps", "40"], 1)
+    assert rc == 0, err[-2000:]
+    res = json.loads(out.strip().splitlines()[-1])
     assert res["walkers_total"] == 8 and res["gathered_shape"] == [40, 8]
     assert 0.02 < res["acceptance"] < 0.95
     assert 0.2 <= res["mean"]["beta"] <= 0.6 and 100 <= res["mean"]["sigma_v"] <= 500
     assert res["best_lnl_over_all_ranks"] > 250          # the reference point alone gives lnL = 284.8
 
 
-def test_bench_two_rank_rehearsal_on_one_gpu():
-    """``bench.py --gpus 2`` on the one-GPU box: the launcher picks a free rendezvous port, both ranks share device 0, the
-    RCCL communicator cannot be built (two ranks on one device) and the gather falls back to the host process group -
-    which exercises everything around the collective: every rank's check of EVERY slot of the gathered vector against its
-    own recomputation of the other rank's rows, the fixed-global-batch leg with per-rank kernel times, and the library
-    diagnostics in the JSON line."""
+def test_walker_example_two_ranks_and_two_contexts_on_one_gpu():
+    """The same example with two launched ranks (socket rendezvous, RCCL refused for two ranks on one device -> gather through
+    the socket group) and as ONE process with two contexts (``--gpus 2``: ncclCommInitAll refused for a shared device -> host
+    concatenation): both layouts end to end on the one-GPU box."""
     import json
-    env = dict(os.environ)
-    env.pop("MASTER_PORT", None)
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                          "--batch", "4096", "--no-cpu-baseline", "--no-boss"], env=env, capture_output=True, text=True,
-                         timeout=600)
-    assert res.returncode == 0, res.stderr[-2000:]
-    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, res.stdout[-2000:]
-    out = json.loads(lines[0])
+    res = _launch_ranks([os.path.join(ROOT, "examples", "run_walkers.py"), "--steps", "20"], 2)
+    for rc, out, err in res:
+        assert rc == 0, err[-2000:]
+    r0 = json.loads(res[0][1].strip().splitlines()[-1])
+    assert r0["walkers_total"] == 16 and r0["gathered_shape"] == [20, 16] and r0["gather"] in ("host", "rccl")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "run_walkers.py"), "--steps", "20", "--gpus", "2"],
+                         capture_output=True, text=True, timeout=240)
+    assert one.returncode == 0, one.stderr[-2000:]
+    r1 = json.loads(one.stdout.strip().splitlines()[-1])
+    assert r1["walkers_total"] == 16 and r1["gathered_shape"] == [20, 16] and r1["best_lnl_over_all_ranks"] > 200
+
+
+def _check_two_gpu_line(out):
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8192 and out["scaling"] == "weak"
     assert out["gather_matches_local"] is True and out["outputs_finite"] is True
     assert "host allgather" in out["config"]["gather"] or "rccl" in out["config"]["gather"]
     rccl = out["config"]["rccl"]
     assert rccl["hip_runtime"] and rccl["rccl"] and rccl["rccl_version"] > 0 and rccl["rccl_next_to_hip_runtime"] is True
+    assert "torch" not in rccl["hip_runtime"]            # /opt/rocm's runtime: nothing imported torch's bundled copy first
     assert len(out["theory_kernel_ms_per_rank"]) == 2 and all(t > 0 for t in out["theory_kernel_ms_per_rank"])
     strong = out["strong_scaling"]
     assert strong["global_batch"] == 4096 and strong["batch_per_gpu"] == 2048 and strong["value"] > 0
     assert len(strong["theory_kernel_ms_per_rank"]) == 2
+
+
+def test_bench_two_launched_ranks_on_one_gpu():
+    """``bench.py --gpus 2`` as two launched ranks on the one-GPU box (what the driver's torchrun start looks like to the
+    ranks): standard-library rendezvous, both ranks on device 0, RCCL refuses the communicator and the gather falls back to
+    the socket group - which exercises everything around the collective: every rank's check of EVERY slot of the gathered
+    vector against its own recomputation of the other rank's rows, the fixed-global-batch leg with per-rank kernel times, and
+    the library diagnostics in the JSON line."""
+    import json
+    res = _launch_ranks([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4096",
+                         "--no-cpu-baseline", "--no-boss"], 2)
+    for rc, out, err in res:
+        assert rc == 0, err[-2000:]
+    lines = [ln for ln in res[0][1].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not [ln for ln in res[1][1].splitlines() if ln.startswith("{")], res[0][1][-2000:]
+    out = json.loads(lines[0])
+    _check_two_gpu_line(out)
+    assert out["config"]["processes"] == 2 and out["config"]["contexts_per_process"] == 1
+    assert "socket" in out["config"]["rendezvous"]
+
+
+def test_bench_one_process_two_contexts_on_one_gpu():
+    """``python bench.py --gpus 2`` started on its own: ONE process drives both contexts (no launcher, no rendezvous); on the
+    one-GPU box ncclCommInitAll is refused for the shared device and the gather is the host concatenation."""
+    import json
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--batch", "4096", "--no-cpu-baseline", "--no-boss"], capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    _check_two_gpu_line(out)
+    assert out["config"]["processes"] == 1 and out["config"]["contexts_per_process"] == 2
 
 
 def test_integration_stub_runs_as_written():

@@ -624,3 +624,17 @@ def test_table_dump_covers_every_field_and_c_client_compiles(boss_fit, tmp_path)
                     os.path.join(ROOT, "examples", "c_abi_client.c"), "-ldl", "-o", exe], check=True)
     done = subprocess.run([exe], capture_output=True, text=True)
     assert done.returncode == 2 and "usage" in done.stderr
+
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_no_torch_in_the_product_or_the_bench():
+    """The north star's "no PyTorch": nothing in the package, the bench or the examples imports torch - the multi-process
+    rendezvous is victor_amd/rendezvous.py (standard library), the multi-GPU data path libvictor_hip.so + RCCL."""
+    import glob
+    import re
+    files = glob.glob(os.path.join(_ROOT, "victor_amd", "**", "*.py"), recursive=True) + glob.glob(os.path.join(_ROOT, "victor", "**", "*.py"), recursive=True) + \
+        glob.glob(os.path.join(_ROOT, "examples", "*.py")) + [os.path.join(_ROOT, "bench.py"), os.path.join(_ROOT, "__graft_entry__.py")]
+    for f in files:
+        assert not re.search(r"^\s*(import torch|from torch)", open(f).read(), flags=re.M), f

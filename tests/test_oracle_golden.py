@@ -221,3 +221,23 @@ def test_shipped_file_combinations(case, tmp_path):
         lnl, chi = np.array([a for a, b in ll]), np.array([b for a, b in ll])
         assert np.max(np.abs(chi / g[f"{case}_{form}_chi2"] - 1)) < 1e-10, form      # 1e4-1e9: precision stack x 1e3-1e6
         assert np.max(np.abs(lnl / g[f"{case}_{form}_lnl"] - 1)) < 1e-10, form
+
+
+def test_dispersion_model_where_it_is_ill_conditioned():
+    """The rows of tests/golden/ref_outputs_disp.npz (reference outputs where five fixed-point iterations amplify rounding,
+    ccf_model.py:658-671, with the reference's own spread under 1-ulp input moves): the oracle performs the reference's
+    arithmetic operation for operation, so it follows the reference even there - including the row on which the reference
+    returns NaN for every bin."""
+    g, meta, options = cases.dispersion_fixture()
+    for name, m in meta.items():
+        fit = vo.OracleFit(*options[name])
+        kw = dict(m["kwargs"])
+        for i, row in enumerate(g[f"{name}_rows"]):
+            p = dict(zip(m["keys"], (float(x) for x in row)))
+            t = fit.theory_multipole_vector(fit.s, dict(p), fit.poles_s, **kw)
+            ref = g[f"{name}_theory"][i]
+            if not np.all(np.isfinite(ref)):
+                assert not np.all(np.isfinite(t)), (name, i)
+                continue
+            spread = float(g[f"{name}_spread_theory"][i])
+            assert np.max(np.abs(t - ref)) <= max(1e-10, 20 * spread) * np.max(np.abs(ref)), (name, i)

@@ -1,4 +1,4 @@
-"""Multi-GPU path on CPU: batch sharding + gather with world_size 2 over gloo (no GPU needed).
+"""Multi-GPU path on CPU: batch sharding + gather with world_size 2 over the standard-library socket group (no GPU needed).
 
 The device evaluation is replaced by a deterministic stand-in (the sharding layer only needs
 ``rows -> (lnl, chi2)``); what is under test is the partitioning, the padding to equal counts, the gather
@@ -52,7 +52,7 @@ def evaluate(rows):                       # stand-in for CCFFit.log_likelihood_b
     return -0.5 * chi2, chi2
 
 dist = Dist()
-dist.init_process_group("gloo")
+dist.connect()
 assert dist.world == 2
 rng = np.random.default_rng(5)
 out = []
@@ -66,7 +66,10 @@ assert dist.min_float(1.0 + dist.rank) == 1.0
 assert t == 2.0
 payload = dist.broadcast_bytes(bytes(range(128)) if dist.rank == 0 else None, src=0, nbytes=128)
 assert payload == bytes(range(128))
+got = dist.group.allgather_doubles(np.arange(3 + dist.rank, dtype=float))       # unequal lengths
+assert np.array_equal(got, np.array([0., 1., 2., 0., 1., 2., 3.]))
 dist.barrier()
+dist.close()
 print("rank", dist.rank, "ok")
 '''
 
@@ -77,7 +80,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_two_rank_gloo_gather(tmp_path):
+def test_two_rank_socket_gather(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
     port = str(_free_port())
@@ -104,7 +107,7 @@ def evaluate(batch):
     return -0.5 * ((batch["a"] - 0.2) ** 2 / 0.01 + (batch["b"] + 1.0) ** 2 / 0.25)
 
 dist = Dist()
-dist.init_process_group("gloo")
+dist.connect()
 specs = [ParamSpec("a", -1, 1, 0.2, 0.05, 0.1), ParamSpec("b", -4, 2, -1.0, 0.2, 0.5)]
 ens = DistributedEnsemble(evaluate, specs, walkers_per_rank=8, dist=dist, seed=5)
 chain, lnl, all_lnl = ens.run(25)
@@ -143,3 +146,86 @@ def test_default_device_follows_the_launcher():
     assert default_device({"OMPI_COMM_WORLD_LOCAL_RANK": "3"}, 8) == 3
     assert default_device({"SLURM_LOCALID": "9"}, 8) == 1
     assert default_device({"LOCAL_RANK": "2"}, 1) == 0
+
+
+def test_rendezvous_endpoint_and_launcher_environment():
+    """Where the ranks meet and who they are, for every launcher the plug-in is run under (rendezvous.py docstring)."""
+    from victor_amd import rendezvous as rz
+    assert rz.launcher_ranks({}) is None
+    assert rz.launcher_ranks({"RANK": "3", "WORLD_SIZE": "8", "LOCAL_RANK": "1"}) == (3, 8, 1)
+    assert rz.launcher_ranks({"OMPI_COMM_WORLD_RANK": "2", "OMPI_COMM_WORLD_SIZE": "4", "OMPI_COMM_WORLD_LOCAL_RANK": "0"}) == (2, 4, 0)
+    assert rz.launcher_ranks({"PMI_RANK": "1", "PMI_SIZE": "2"}) == (1, 2, 1)
+    assert rz.launcher_ranks({"SLURM_PROCID": "5", "SLURM_NTASKS": "16", "SLURM_LOCALID": "5"}) == (5, 16, 5)
+    assert rz.endpoint({"VICTOR_RDZV": "node17:4711"}) == ("tcp", ("node17", 4711))
+    assert rz.endpoint({"VICTOR_RDZV": "unix:/tmp/x.sock"}) == ("unix", "/tmp/x.sock")
+    kind, path = rz.endpoint({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29511", "TORCHELASTIC_RUN_ID": "none"})
+    assert kind == "unix" and "29511" in path and path.endswith(".sock")      # the launcher's own store owns the TCP port
+    assert rz.endpoint({"MASTER_ADDR": "10.1.2.3", "MASTER_PORT": "29511"}) == ("tcp", ("10.1.2.3", 29512))
+
+
+def test_socket_group_collectives_with_three_ranks(tmp_path):
+    """Three ranks as threads of one process over a Unix socket and over TCP: all-gather of bytes, broadcast, barrier,
+    max / min, doubles of unequal lengths; a stray connection that does not speak the protocol is ignored."""
+    import threading
+    from victor_amd.rendezvous import SocketGroup
+    for where in (("unix", str(tmp_path / "g.sock")), ("tcp", ("127.0.0.1", _free_port()))):
+        results, errors = {}, []
+
+        def run(rank):
+            try:
+                g = SocketGroup(rank, 3, where=where, timeout=30)
+                parts = g.allgather_bytes(bytes([rank]) * (rank + 1))
+                uid = g.broadcast_bytes(bytes(range(128)) if rank == 0 else None)
+                g.barrier()
+                results[rank] = (parts, uid, g.max_float(rank), g.min_float(rank), g.allgather_doubles(np.full(rank, rank)).tolist())
+                g.close()
+            except Exception as exc:            # pragma: no cover
+                errors.append((rank, repr(exc)))
+
+        threads = [threading.Thread(target=run, args=(r,)) for r in range(3)]
+        threads[0].start()
+        if where[0] == "tcp":                   # a port scanner's connect: closed without the greeting
+            import socket as so
+            import time
+            time.sleep(0.2)
+            stray = so.create_connection(where[1])
+            stray.sendall(b"\x03\x00\x00\x00\x00\x00\x00\x00abc")
+            stray.close()
+        for t in threads[1:]:
+            t.start()
+        for t in threads:
+            t.join(60)
+        assert not errors, errors
+        for rank in range(3):
+            parts, uid, mx, mn, dbl = results[rank]
+            assert parts == [b"\x00", b"\x01\x01", b"\x02\x02\x02"] and uid == bytes(range(128))
+            assert (mx, mn) == (2.0, 0.0) and dbl == [1.0, 2.0, 2.0]
+
+
+def test_socket_group_reports_ranks_that_are_out_of_step(tmp_path):
+    """One rank calls a barrier where the other calls max_float (a branch only one of them took): both get a RuntimeError
+    naming the two calls, instead of hanging or reading each other's payload as their own."""
+    import threading
+    from victor_amd.rendezvous import SocketGroup
+    where = ("unix", str(tmp_path / "oos.sock"))
+    errors = {}
+
+    def run(rank):
+        g = SocketGroup(rank, 2, where=where, timeout=30)
+        g.barrier()
+        try:
+            if rank == 0:
+                g.barrier()
+            else:
+                g.max_float(1.0)
+        except RuntimeError as exc:
+            errors[rank] = str(exc)
+        g.close()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(60)
+    assert set(errors) == {0, 1} and all("out of step" in e for e in errors.values()), errors
+    assert "barrier" in errors[0] and "max" in errors[0]

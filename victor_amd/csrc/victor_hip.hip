@@ -757,6 +757,8 @@ typedef int (*fn_get_id)(rccl_id_t*);
 typedef int (*fn_init_rank)(void**, int, rccl_id_t, int);
 typedef int (*fn_allgather)(const void*, void*, size_t, int, void*, hipStream_t);
 typedef int (*fn_destroy)(void*);
+typedef int (*fn_init_all)(void**, int, const int*);
+typedef int (*fn_group)(void);
 typedef const char* (*fn_errstr)(int);
 
 // Path of the shared object that defines `addr` (empty if unknown)
@@ -1599,6 +1601,61 @@ int vk_comm_allgather_async(vk_ctx* ctx, const double* d_send, double* d_recv, i
   const int kNcclDouble = 8;  // ncclFloat64 in rccl.h
   int rc = ag(d_send, d_recv, (size_t)count, kNcclDouble, ctx->comm, ctx->stream);
   if (rc != 0) return fail(ctx, VK_E_RCCL, "ncclAllGather failed (%d)", rc);
+  return VK_OK;
+}
+
+int vk_device_bus_id(const vk_ctx* ctx, char* buf, size_t len) {
+  if (!ctx || !buf || len < 16) return VK_E_ARG;
+  if (hipDeviceGetPCIBusId(buf, (int)len, ctx->device) != hipSuccess) {
+    (void)hipGetLastError();
+    snprintf(buf, len, "device%d", ctx->device);
+  }
+  return VK_OK;
+}
+
+int vk_comm_init_all(vk_ctx* const* ctxs, int32_t n) {
+  if (!ctxs || n < 1 || !ctxs[0]) return VK_E_ARG;
+  vk_ctx* lead = ctxs[0];
+  std::vector<int> devs(n);
+  for (int i = 0; i < n; ++i) {
+    if (!ctxs[i]) return fail(lead, VK_E_ARG, "context %d is NULL", i);
+    if (ctxs[i]->comm) return fail(lead, VK_E_ARG, "context %d already has a communicator", i);
+    devs[i] = ctxs[i]->device;
+    for (int j = 0; j < i; ++j)
+      if (devs[j] == devs[i]) return fail(lead, VK_E_RCCL, "contexts %d and %d share device %d: RCCL needs one device per rank", j, i, devs[i]);
+  }
+  void* lib = open_rccl();
+  if (!lib) return fail(lead, VK_E_RCCL, "cannot load librccl (looked next to %s first): %s", hip_runtime_path().c_str(), dlerror());
+  auto init = (fn_init_all)dlsym(lib, "ncclCommInitAll");
+  if (!init) return fail(lead, VK_E_RCCL, "ncclCommInitAll not found");
+  std::vector<void*> comms(n, nullptr);
+  const int rc = init(comms.data(), n, devs.data());
+  if (rc != 0) {
+    auto es = (fn_errstr)dlsym(lib, "ncclGetErrorString");
+    return fail(lead, VK_E_RCCL, "ncclCommInitAll failed: %s", es ? es(rc) : "?");
+  }
+  for (int i = 0; i < n; ++i) {
+    ctxs[i]->comm = comms[i];
+    ctxs[i]->rccl_lib = lib;
+  }
+  return VK_OK;
+}
+
+int vk_comm_allgather_group_async(vk_ctx* const* ctxs, int32_t n, const double* const* d_send, double* const* d_recv,
+                                  int64_t count) {
+  if (!ctxs || n < 1 || !ctxs[0] || !d_send || !d_recv || count < 0) return VK_E_ARG;
+  vk_ctx* lead = ctxs[0];
+  for (int i = 0; i < n; ++i)
+    if (!ctxs[i] || !ctxs[i]->comm) return fail(lead, VK_E_RCCL, "context %d has no communicator", i);
+  auto ag = (fn_allgather)dlsym(lead->rccl_lib, "ncclAllGather");
+  auto gs = (fn_group)dlsym(lead->rccl_lib, "ncclGroupStart");
+  auto ge = (fn_group)dlsym(lead->rccl_lib, "ncclGroupEnd");
+  if (!ag || !gs || !ge) return fail(lead, VK_E_RCCL, "ncclAllGather / ncclGroupStart / ncclGroupEnd not found");
+  const int kNcclDouble = 8;  // ncclFloat64 in rccl.h
+  int rc = gs();
+  for (int i = 0; i < n && rc == 0; ++i) rc = ag(d_send[i], d_recv[i], (size_t)count, kNcclDouble, ctxs[i]->comm, ctxs[i]->stream);
+  const int rc_end = ge();
+  if (rc != 0 || rc_end != 0) return fail(lead, VK_E_RCCL, "grouped ncclAllGather failed (%d, %d)", rc, rc_end);
   return VK_OK;
 }
 

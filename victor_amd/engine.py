@@ -478,11 +478,48 @@ class Engine:
             raise N.NativeError("vk_comm_unique_id failed (is librccl available?)")
         return buf.raw
 
-    def comm_init(self, uid, rank, nranks):
-        self._check(self._lib.vk_comm_init(self._ctx, uid, int(rank), int(nranks)))
+    def bus_id(self):
+        buf = C.create_string_buffer(64)
+        self._check(self._lib.vk_device_bus_id(self._ctx, buf, len(buf)))
+        return buf.value.decode()
+
+    def comm_init(self, uid, rank, nranks, timeout=120.0):
+        """ncclCommInitRank for this context.  The call blocks until every rank has joined; it runs on a helper thread so that a
+        rendezvous that never completes (a rank that died, a fabric problem) surfaces as an error after ``timeout`` seconds
+        instead of a silent hang - the caller then gathers through the host."""
+        import threading
+        box = {}
+
+        def work():
+            box["rc"] = self._lib.vk_comm_init(self._ctx, uid, int(rank), int(nranks))
+
+        t = threading.Thread(target=work, daemon=True)
+        t.start()
+        t.join(timeout)
+        if t.is_alive():
+            raise N.NativeError(f"ncclCommInitRank did not complete within {timeout:.0f} s")
+        self._check(box["rc"])
 
     def comm_allgather_async(self, d_send, d_recv, count):
         self._check(self._lib.vk_comm_allgather_async(self._ctx, d_send, d_recv, int(count)))
 
     def comm_destroy(self):
         self._check(self._lib.vk_comm_destroy(self._ctx))
+
+    # one process driving several GPUs: the engines of a group, context i = rank i (vk_comm_init_all)
+    @staticmethod
+    def comm_init_all(engines):
+        lead = engines[0]
+        ctxs = (C.c_void_p * len(engines))(*[e._ctx for e in engines])
+        lead._check(lead._lib.vk_comm_init_all(ctxs, len(engines)))
+
+    @staticmethod
+    def comm_allgather_group_async(engines, d_send, d_recv, count):
+        """One grouped all-gather: ``d_send[i]`` (count doubles) and ``d_recv[i]`` (len(engines) * count doubles) live on
+        engine i's device; enqueued on every engine's stream."""
+        lead = engines[0]
+        n = len(engines)
+        ctxs = (C.c_void_p * n)(*[e._ctx for e in engines])
+        snd = (C.c_void_p * n)(*d_send)
+        rcv = (C.c_void_p * n)(*d_recv)
+        lead._check(lead._lib.vk_comm_allgather_group_async(ctxs, n, snd, rcv, int(count)))

@@ -197,7 +197,7 @@ def gelman_rubin(chain):
 class DistributedEnsemble:
     """One :class:`EnsembleMetropolis` per rank plus an all-gather of every step's log-likelihoods.
 
-    ``gather(local_lnl) -> all_lnl`` is ``Dist.allgather_host`` (gloo) or an RCCL gather through the engine;
+    ``gather(local_lnl) -> all_lnl`` is ``Dist.allgather_host`` (the ranks' socket group) or an RCCL gather through the engine;
     the walkers themselves never interact, so the collective is monitoring traffic only (W doubles per rank).
     """
 

@@ -5,7 +5,8 @@ parallelism: one process per GPU, rank ``g`` of ``G`` evaluates rows ``[lo_g, hi
 its own replica of the tables (< 1.5 MB), and the only exchange is one all-gather of ``lnL`` (and
 optionally ``chi2``) per batch - 8 KiB per rank at 8 GPUs x 1024 points, latency-bound on xGMI.  The gather
 runs through RCCL on the context's stream (``vk_comm_allgather_async``) when a communicator exists;
-``gather="host"`` uses the process group directly (gloo) and is what the CPU tests exercise.
+``gather="host"`` uses the ranks' socket group (:mod:`victor_amd.rendezvous`) and is what the CPU tests exercise.
+A single process can drive all GPUs of a node as well (:class:`MultiGPUFit`; RCCL group calls, ``vk_comm_init_all``).
 
 The reference has no counterpart: it relies on independent MCMC chains under ``mpirun`` (README.md:30).
 """
@@ -48,70 +49,66 @@ def padded_chunk(n, world):
 
 
 class Dist:
-    """Rank / world size from the launcher's environment (torchrun / torch.distributed.run)."""
+    """The ranks of a multi-process run: rank / world size from the launcher's environment (torchrun, Open MPI, MPICH,
+    Slurm - :func:`victor_amd.rendezvous.launcher_ranks`) and the host-side collectives the data path needs around it
+    (barriers, the RCCL unique id, a few scalars), carried by a standard-library socket group
+    (:class:`victor_amd.rendezvous.SocketGroup`).  No torch, no MPI binding."""
 
     def __init__(self, rank=None, world=None, local_rank=None):
-        env = os.environ
-        self.rank = int(env.get("RANK", 0)) if rank is None else rank
-        self.world = int(env.get("WORLD_SIZE", 1)) if world is None else world
-        self.local_rank = int(env.get("LOCAL_RANK", self.rank)) if local_rank is None else local_rank
-        self.pg = None
+        from .rendezvous import launcher_ranks
+        found = launcher_ranks()
+        self.launched = found is not None
+        r, w, l = found if found else (0, 1, 0)
+        self.rank = r if rank is None else rank
+        self.world = w if world is None else world
+        self.local_rank = (l if rank is None else self.rank) if local_rank is None else local_rank
+        self.group = None
 
-    @property
-    def launched(self):
-        return "RANK" in os.environ and "WORLD_SIZE" in os.environ
-
-    def init_process_group(self, backend="gloo"):
-        """Host-side rendezvous (barriers, the RCCL unique id, timing reductions).  gloo on CPU tensors: the
-        data path itself never goes through torch."""
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
-        self.pg = dist
-        return dist
+    def connect(self, where=None, timeout=120.0):
+        """Meet the other ranks (a collective; no-op for a single rank)."""
+        from .rendezvous import SocketGroup
+        if self.group is None:
+            self.group = SocketGroup(self.rank, self.world, where=where, timeout=timeout)
+        return self
 
     def barrier(self):
-        if self.pg is not None and self.world > 1:
-            self.pg.barrier()
+        if self.group is not None and self.world > 1:
+            self.group.barrier()
 
     def broadcast_bytes(self, payload, src=0, nbytes=None):
-        if self.pg is None or self.world == 1:
+        if self.group is None or self.world == 1:
             return payload
-        import torch
-        n = len(payload) if payload is not None else nbytes
-        buf = torch.zeros(n, dtype=torch.uint8)
-        if self.rank == src:
-            buf = torch.frombuffer(bytearray(payload), dtype=torch.uint8).clone()
-        self.pg.broadcast(buf, src=src)
-        return bytes(buf.numpy().tobytes())
+        return self.group.broadcast_bytes(payload, src=src)
 
     def max_float(self, x):
-        if self.pg is None or self.world == 1:
-            return float(x)
-        import torch
-        t = torch.tensor([float(x)], dtype=torch.float64)
-        self.pg.all_reduce(t, op=self.pg.ReduceOp.MAX)
-        return float(t[0])
+        return float(x) if self.group is None or self.world == 1 else self.group.max_float(x)
 
     def min_float(self, x):
-        if self.pg is None or self.world == 1:
-            return float(x)
-        import torch
-        t = torch.tensor([float(x)], dtype=torch.float64)
-        self.pg.all_reduce(t, op=self.pg.ReduceOp.MIN)
-        return float(t[0])
+        return float(x) if self.group is None or self.world == 1 else self.group.min_float(x)
 
     def allgather_host(self, local, chunk):
         """All-gather equal-size host arrays of ``chunk`` doubles per rank -> (world*chunk,)."""
         local = np.ascontiguousarray(local, dtype=np.float64)
         assert local.shape == (chunk,)
-        if self.pg is None or self.world == 1:
+        if self.group is None or self.world == 1:
             return local.copy()
-        import torch
-        outs = [torch.empty(chunk, dtype=torch.float64) for _ in range(self.world)]
-        self.pg.all_gather(outs, torch.from_numpy(local))
-        return torch.cat(outs).numpy()
+        return self.group.allgather_doubles(local)
+
+    def close(self):
+        if self.group is not None:
+            self.group.close()
+            self.group = None
+
+
+def one_device_per_rank(dist, engine):
+    """True when no two ranks of the run sit on the same GPU (host name + PCI bus id, exchanged over the socket group): the
+    precondition of an RCCL communicator.  A collective - every rank gets the same answer."""
+    import socket
+    if dist.world == 1 or dist.group is None:
+        return True
+    mine = f"{socket.gethostname()}|{engine.bus_id()}".encode()
+    ids = dist.group.allgather_bytes(mine, "devices")
+    return len(set(ids)) == len(ids)
 
 
 def unpad(gathered, n, world):
@@ -179,6 +176,8 @@ class RcclGather:
 
     def __init__(self, engine, dist, count):
         self.engine, self.dist, self.count = engine, dist, int(count)
+        if not one_device_per_rank(dist, engine):
+            raise RuntimeError("two ranks share a GPU: RCCL needs one device per rank")
         uid = engine.comm_unique_id() if dist.rank == 0 else None
         uid = dist.broadcast_bytes(uid, src=0, nbytes=128)
         engine.comm_init(uid, dist.rank, dist.world)
@@ -241,6 +240,61 @@ class MultiGPUFit:
             return np.empty(0), np.empty(0)
         return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
 
+    def enable_rccl(self):
+        """Build RCCL communicators for the GPUs of this fit (``vk_comm_init_all``: one process, no rendezvous).  Returns
+        False - and :meth:`log_likelihood_gathered` then goes through the host - when RCCL is missing or refuses (two
+        contexts on one device)."""
+        from .engine import Engine
+        engines = [f._get_engine() for f in self.fits]
+        try:
+            Engine.comm_init_all(engines)
+            self._rccl = True
+        except Exception as exc:
+            self._rccl_error = str(exc)
+            self._rccl = False
+        return self._rccl
+
+    def log_likelihood_gathered(self, params, **kwargs):
+        """lnL[n] of a batch sharded over the GPUs with the result all-gathered ON the GPUs (every device ends up holding the
+        whole vector, as the ranks of a multi-process run do) and read back from the first one: parameter shards uploaded,
+        one launch per device, one grouped RCCL all-gather over xGMI, one download.  Falls back to the host-side
+        concatenation of :meth:`log_likelihood_batch` without communicators."""
+        if not getattr(self, "_rccl", False):
+            return self.log_likelihood_batch(params, **kwargs)[0]
+        from . import _native as N
+        from .engine import Engine
+        rows = self._rows(params, kwargs)
+        n, g = len(rows), len(self.fits)
+        if n == 0:
+            return np.empty(0)
+        chunk = padded_chunk(n, g)
+        fit0 = self.fits[0]
+        model = fit0._merged(kwargs)
+        fit_options = fit0._merged_fit(kwargs)
+        engines = [f._get_engine(f._engine_key(model), model["simpson_even"]) for f in self.fits]
+        if engines != [f._get_engine() for f in self.fits]:
+            return self.log_likelihood_batch(params, **kwargs)[0]      # another table set than the one the communicators belong to
+        bufs = getattr(self, "_gather_bufs", None)
+        if bufs is None or bufs[0] < chunk:
+            if bufs is not None:
+                for e, ptrs in zip(engines, bufs[1]):
+                    for p in ptrs:
+                        e.free(p)
+            cap = max(chunk, 64)
+            bufs = self._gather_bufs = (cap, [(e.alloc(cap * N.VK_NPAR), e.alloc(cap), e.alloc(cap), e.alloc(cap * e.n_data),
+                                               e.alloc(cap * g)) for e in engines])
+        for r, (f, e, (d_rows, d_lnl, d_chi, d_ws, d_all)) in enumerate(zip(self.fits, engines, bufs[1])):
+            lo, hi = shard_bounds(n, g, r)
+            shard = np.empty((chunk, N.VK_NPAR))
+            shard[: hi - lo] = rows[lo:hi]
+            shard[hi - lo:] = rows[hi - 1 if hi > lo else 0]          # padding rows: valid parameters, results dropped by unpad
+            e.upload(d_rows, shard)
+            e.eval_device_async(e.make_opts(model, fit_options), d_rows, chunk, d_lnl, d_chi, d_ws)
+        Engine.comm_allgather_group_async(engines, [b[1] for b in bufs[1]], [b[4] for b in bufs[1]], chunk)
+        for e in engines:
+            e.sync()
+        return unpad(engines[0].download(bufs[1][0][4], chunk * g), n, g)
+
     def theory_vector_batch(self, params, **kwargs):
         rows = self._rows(params, kwargs)
         n, g = len(rows), len(self.fits)
@@ -254,3 +308,7 @@ class MultiGPUFit:
         if self._pool is not None:
             self._pool.shutdown()
             self._pool = None
+        if getattr(self, "_rccl", False):
+            for f in self.fits:
+                f._get_engine().comm_destroy()
+            self._rccl = False
