@@ -234,6 +234,37 @@ def api_latency():
     return res
 
 
+def walker_rates(steps=150):
+    """BASELINE config 4's workload on one GPU: lock-step Metropolis walkers on config/boss_cobaya_config.yaml (priors, start
+    distributions and proposal widths from the file cobaya reads), proposals made on the host, one host-buffer likelihood
+    batch per step.  Likelihood evaluations per second of wall-clock for 8, 64 and 512 walkers; the first evaluation of the
+    process (runtime, code object, tables) is timed apart."""
+    import victor_amd
+    from victor_amd.sampler import EnsembleMetropolis, parse_cobaya_params
+    from tests import cases
+    info = cases.cobaya_info()
+    lk = info["likelihood"]["CCFLikelihood"]
+    cwd = os.getcwd()
+    os.chdir(ROOT)                       # the data paths in the config are relative to the repository root
+    try:
+        fit = victor_amd.CCFFit(lk["model"], lk["data"])
+    finally:
+        os.chdir(cwd)
+    specs, fixed = parse_cobaya_params(info["params"])
+    res = {}
+    for walkers in (8, 64, 512):
+        ens = EnsembleMetropolis(lambda batch: fit.log_likelihood_batch(batch)[0], specs, walkers, seed=1, fixed=fixed)
+        ens.initialise()
+        ens.run(10)                      # past the first call's one-off costs (LDS image, pinned buffers, captured graph)
+        e0 = ens.n_evals
+        t0 = time.perf_counter()
+        ens.run(steps)
+        dt = time.perf_counter() - t0
+        res[f"{walkers}_walkers"] = {"evals_per_s": (ens.n_evals - e0) / dt, "steps_per_s": steps / dt,
+                                     "acceptance": ens.n_accept / max(ens.n_steps * walkers, 1)}
+    return res
+
+
 def dsplit_measurement(batch=16384, steps=10):
     """BASELINE config 5 on one GPU: five table sets sharing one parameter batch (block-diagonal covariance, N = 5 x 120),
     one upload, the blocks on their own streams, sums on the device (vk_joint_eval_device_async)."""
@@ -545,6 +576,7 @@ def main():
             out["batch_sweep"] = batch_sweep()
             out["dsplit5"] = dsplit_measurement()
             out["host_api"] = api_latency()
+            out["walker_ensembles"] = walker_rates()
         if base is not None:
             chi_o = np.array([v[1] for v in vals])
             lnl_o = np.array([v[0] for v in vals])

@@ -58,6 +58,7 @@ int main(int argc, char** argv) {
       {"uni_n", 0, &t.uni_n}, {"uni_u0", 1, &t.uni_u0}, {"uni_inv_h", 1, &t.uni_inv_h},
       {"uni_sv_v", 2, &t.uni_sv_v}, {"uni_xi", 2, &t.uni_xi}, {"uni_xic", 2, &t.uni_xic}, {"uni_vb", 2, &t.uni_vb},
       {"uni_v2", 2, &t.uni_v2}, {"uni_da", 2, &t.uni_da}, {"uni_ge", 2, &t.uni_ge},
+      {"uni_dab", 2, &t.uni_dab}, {"uni_empb", 2, &t.uni_empb},
       {"uni_lut_n", 0, &t.uni_lut_n}, {"uni_lut_inv_g", 1, &t.uni_lut_inv_g}, {"uni_lut", 3, &t.uni_lut},
       {"uni_knots", 2, &t.uni_knots},
       {"iaH", 1, &t.iaH}, {"template_sigma8", 1, &t.template_sigma8},

@@ -167,6 +167,11 @@ typedef struct vk_tables {
   const double* uni_ge; /* fixed velocity tables only (else NULL): the numerical-gradient tables Ge1, Ge2 of the
                            empirical_corr branch on the unified grid, [2][uni_n][4]: the dispersion model then uses
                            Ge1 + Av Ge2 in place of Da (ccf_model.py:455-459)                                    */
+  const double* uni_dab;/* vr_beta_dep only (else NULL): Da on the unified grid as beta polynomials,
+                           [n_beta_r-1][uni_n][4][4]: the dispersion model on the fast kernels with linear_bias on a
+                           reconstructed real-space ccf (ccf_model.py:358-370, 658-671)                           */
+  const double* uni_empb;/* vr_beta_dep only (else NULL): V2, Ge1, Ge2 of the empirical_corr branch on the unified grid,
+                           degree 6 in beta (vr_emp refined): [3][n_beta_r-1][uni_n][4][7]                        */
   /* Union-grid form of the same tables for knots that are not uniform or not commensurate: uni_n intervals between
    * the sorted distinct knots uni_knots[0..uni_n] of vr (uni_knots[0] = vr.knots[0] = 0.01), xi and sv; the
    * coefficient arrays above are then in units of each interval's own width.  A uniform look-up table of

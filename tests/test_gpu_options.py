@@ -56,6 +56,49 @@ def test_boss_beta_dependent_tables(gold):
         assert close(got, want), beta
 
 
+def test_beta_dependent_velocity_tables_run_on_the_fast_kernels(gold):
+    """linear_bias on a reconstructed real-space ccf makes the velocity profile beta-dependent (ccf_model.py:358-370).  Its
+    dispersion model (Da as beta polynomials, vk_tables.uni_dab) and its empirical_corr branch in both RSD models (V2, Ge1, Ge2
+    of degree 6 in beta, ccf_model.py:451-459, vk_tables.uni_empb) are rebuilt per point in LDS like V1, so these combinations
+    run on the cells / point-major kernels, not only on the generic one: reference goldens in every mapping, then a batch
+    with a different Av per point through the three mappings."""
+    import victor_amd
+    g, meta = gold
+    fit = victor_amd.CCFFit(*cases.boss_options("config"))
+    pts = [dict(q, bias=2.1, Av=0.7, M=1.05, Q=0.95) for q in meta["boss_points"][:3]]
+    combos = {"lb_disp": dict(matter_model="linear_bias", rsd_model="dispersion"),
+              "lb_emp_stream": dict(matter_model="linear_bias", empirical_corr=True),
+              "lb_emp_disp": dict(matter_model="linear_bias", empirical_corr=True, rsd_model="dispersion")}
+    hp = dict(cases.halton_params(1000, with_beta=True), bias=np.linspace(1.6, 2.4, 1000), Av=np.linspace(-1.0, 1.0, 1000))
+    for tag, kw in combos.items():
+        model = fit._merged(kw)
+        eng = fit._get_engine(fit._engine_key(model))
+        batch = np.vstack([fit._fit_rows(dict(p), model) for p in pts] + [fit._fit_rows(hp, model)])
+        res = {}
+        for mapping in ("point", "cells", "generic"):
+            env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
+            _native.set_knob(env, "1" if mapping == "generic" else mapping)
+            try:
+                res[mapping] = fit.theory_vector_batch(batch, **kw)
+                assert eng.last_kernel().endswith({"point": "fast_kernel", "cells": "cells_kernel", "generic": "vk_theory_kernel"}[mapping]), (tag, mapping)
+            finally:
+                _native.set_knob(env, None)
+            assert close(res[mapping][:3], g[f"opt_boss_{tag}"]), (tag, mapping)
+        fit.theory_vector_batch(batch, **kw)                               # the default choice at this size
+        assert eng.last_kernel() == "vk_theory_cells_kernel", (tag, eng.last_kernel())
+        for mapping in ("cells", "generic"):
+            row_err = np.max(np.abs(res[mapping] - res["point"]), axis=1) / np.max(np.abs(res["point"]))
+            assert np.quantile(row_err, 0.995) < 1e-10 and row_err.max() < 1e-6, (tag, mapping, row_err.max())
+        # and the likelihood through the fused tail of the fast kernels against the generic path
+        a = fit.log_likelihood_batch(batch[:200], **kw)
+        _native.set_knob("VICTOR_HIP_FORCE_GENERIC", "1")
+        try:
+            b = fit.log_likelihood_batch(batch[:200], **kw)
+        finally:
+            _native.set_knob("VICTOR_HIP_FORCE_GENERIC", None)
+        assert np.max(np.abs(a[1] / b[1] - 1)) < 1e-8, tag
+
+
 def test_synthetic_fixed_tables(gold):
     import victor_amd
     g, meta = gold

@@ -59,6 +59,62 @@ def test_cobaya_plugin_calculate_on_gpu():
     assert abs(lnl[0] - state["logp"]) < 1e-12 * abs(lnl[0]) and lnl.shape == (2,)
 
 
+def _cobaya_inputs(lk, sampled):
+    """What cobaya's model hands to ``calculate``: EVERY input parameter the plug-in's YAML declares - sampled ones, fixed
+    numbers, and the dynamically defined ones (``value: "lambda alpha, epsilon: ..."``) evaluated from the others."""
+    import inspect
+    known, later = dict(sampled), {}
+    for name in lk.input_params:
+        spec = lk.params[name]
+        if name in known:
+            continue
+        if isinstance(spec, dict) and isinstance(spec.get("value"), str) and spec["value"].lstrip().startswith("lambda"):
+            later[name] = eval(spec["value"])            # the plug-in's own YAML, as cobaya evaluates it
+        elif isinstance(spec, dict) and "value" in spec:
+            known[name] = float(spec["value"])
+        elif spec is None:
+            raise KeyError(f"sampled parameter {name} needs a value")
+        else:
+            known[name] = float(spec)
+    for name, fn in later.items():
+        known[name] = float(fn(*[known[a] for a in inspect.signature(fn).parameters]))
+    return known
+
+
+def test_cobaya_shaped_construction_and_full_parameter_set():
+    """The plug-in driven the way cobaya drives it (CCFLikelihood.py:32-42 of the reference, its YAML lines 9-41): constructed
+    as ``Class(info, name, timing, packages_path, initialize, standalone)`` with its class defaults coming from
+    CCFLikelihood.yaml, and ``calculate(state, want_derived, **params)`` receiving every declared input - the
+    lambda-derived aperp / apar / alpha NEXT TO epsilon, bias, the excursion-set and cosmology extras.  logp must be
+    bit-identical to the four-parameter call (epsilon takes precedence over aperp / apar, ccf_model.py:589-596; unknown
+    names are ignored) and equal to the reference's golden."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "victor", "likelihoods"))
+    from CCFLikelihood import CCFLikelihood
+    run = cases.cobaya_info()["likelihood"]["CCFLikelihood"]
+    lk = CCFLikelihood({"model": run["model"], "data": run["data"]}, "CCFLikelihood", None, None, True, False)
+    assert lk.get_name() == "CCFLikelihood" and lk.config_file == "config/boss_config.yaml"      # a class default
+    assert "chi2_ccf_correct" in lk.output_params and "chi2_ccf_correct" not in lk.input_params
+    declared = {"fsigma8", "beta", "epsilon", "b", "alpha", "aperp", "apar", "astar", "sigma_v", "Av", "f", "sigma_8_0", "b10",
+                "b01", "Rp", "Rx", "Omega_m", "Omega_b", "H0", "ns", "mnu", "Omega_k", "delta_c", "M", "Q"}
+    assert set(lk.input_params) == declared                       # the reference YAML's list, name for name
+    g, meta = cases.golden_outputs()
+    for i, pt in enumerate(meta["boss_points"][:2]):              # epsilon = 1.0 and epsilon = 1.04
+        sampled = {k: pt[k] for k in ("fsigma8", "beta", "epsilon")}
+        full = _cobaya_inputs(lk, dict(sampled, sigma_v=pt["sigma_v"]))
+        assert set(full) == declared
+        assert abs(full["aperp"] - full["alpha"] * full["epsilon"] ** (1 / 3)) < 1e-15 and "apar" in full
+        s_full, s_four = {}, {}
+        lk.calculate(s_full, want_derived=True, **full)
+        lk.calculate(s_four, want_derived=True, **dict(sampled, sigma_v=pt["sigma_v"]))
+        assert s_full["logp"] == s_four["logp"] and s_full["derived"] == s_four["derived"]          # bit for bit
+        assert abs(s_full["logp"] - g["boss_cobaya_lnl"][i]) < 1e-9 * abs(s_full["logp"])
+        assert abs(s_full["derived"]["chi2_ccf_correct"] - g["boss_cobaya_chi2"][i]) < 1e-9 * g["boss_cobaya_chi2"][i]
+    # initialize=False leaves the object unbuilt, as in cobaya
+    bare = CCFLikelihood({"model": run["model"], "data": run["data"]}, initialize=False)
+    assert not hasattr(bare, "ccf")
+
+
 def test_config_file_route_of_plugin(tmp_path, monkeypatch):
     """model/data omitted -> the plug-in loads config/boss_config.yaml relative to the working directory."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -638,3 +638,22 @@ def test_no_torch_in_the_product_or_the_bench():
         glob.glob(os.path.join(_ROOT, "examples", "*.py")) + [os.path.join(_ROOT, "bench.py"), os.path.join(_ROOT, "__graft_entry__.py")]
     for f in files:
         assert not re.search(r"^\s*(import torch|from torch)", open(f).read(), flags=re.M), f
+
+
+def test_plugin_stand_in_has_cobayas_shape():
+    """Without cobaya the plug-in's base class is a stand-in with cobaya's constructor signature and defaults mechanism
+    (class defaults from CCFLikelihood.yaml, overridden by the run's info); initialize=False builds nothing, so this runs
+    without a GPU.  The GPU side is tests/test_gpu_workloads.py::test_cobaya_shaped_construction_and_full_parameter_set."""
+    import inspect
+    import yaml
+    sys.path.insert(0, os.path.join(_ROOT, "victor", "likelihoods"))
+    from CCFLikelihood import CCFLikelihood
+    sig = list(inspect.signature(CCFLikelihood.__init__).parameters)
+    assert sig[:7] == ["self", "info", "name", "timing", "packages_path", "initialize", "standalone"]
+    lk = CCFLikelihood({"model": {"x": 1}, "config_file": "elsewhere.yaml"}, "like", None, None, False, False)
+    assert lk.get_name() == "like" and lk.model == {"x": 1} and lk.data is None and lk.config_file == "elsewhere.yaml"
+    with open(os.path.join(_ROOT, "victor", "likelihoods", "CCFLikelihood.yaml")) as fh:
+        defaults = yaml.full_load(fh)
+    assert lk.params == defaults["params"] and lk.output_params == ["chi2_ccf_correct"]
+    assert {"fsigma8", "beta", "epsilon", "aperp", "apar", "alpha"} <= set(lk.input_params)
+    assert lk.get_can_provide_params() == ["fsigma8"]

@@ -41,3 +41,12 @@ for name, opts, beta in (("config3", cases.synth_options(3), False), ("boss", ca
     for kw in ({}, {"rsd_model": "dispersion"}, {"rsd_model": "kaiser"}, {"rsd_model": "euclid_special"},
                {"empirical_corr": True}, {"matter_model": "linear_bias"}):
         run(fit, f"{name} {kw}", 16384, beta, **kw)
+
+# the beta-dependent velocity profile (linear_bias on the reconstructed BOSS ccf) in the combinations that used to be generic-only
+boss = victor_amd.CCFFit(*cases.boss_options("config"))
+for kw in ({"matter_model": "linear_bias", "rsd_model": "dispersion"}, {"matter_model": "linear_bias", "empirical_corr": True},
+           {"matter_model": "linear_bias", "empirical_corr": True, "rsd_model": "dispersion"}):
+    run(boss, f"boss {kw}", 16384, True, **kw)
+    _native.set_knob("VICTOR_HIP_FORCE_GENERIC", "1")
+    run(boss, f"boss {kw}, generic kernel", 16384, True, **kw)
+    _native.set_knob("VICTOR_HIP_FORCE_GENERIC", None)

@@ -12,16 +12,36 @@ import yaml
 
 try:  # pragma: no cover - cobaya is optional
     from cobaya.likelihood import Likelihood
-except ImportError:  # minimal stand-in with cobaya's attribute-injection behaviour
+except ImportError:
     class Likelihood:
-        model = None
-        data = None
-        config_file = "config/boss_config.yaml"
+        """Stand-in for ``cobaya.likelihood.Likelihood`` when cobaya is not installed, shaped like the real one: the same
+        constructor signature, class defaults read from ``<ClassName>.yaml`` next to the class's module and overridden by
+        ``info`` (cobaya's defaults mechanism), every top-level option set as an attribute, the ``params`` block kept as
+        ``params`` / ``input_params`` / ``output_params``, then ``initialize()``."""
 
-        def __init__(self, info=None, **kwargs):
-            for key, value in dict(info or {}, **kwargs).items():
+        def __init__(self, info=None, name=None, timing=None, packages_path=None, initialize=True, standalone=True,
+                     **kwargs):
+            import inspect
+            merged = {}
+            path = os.path.splitext(inspect.getfile(type(self)))[0] + ".yaml"
+            if os.path.isfile(path):
+                with open(path) as fh:
+                    merged.update(yaml.full_load(fh) or {})
+            merged.update(info or {})
+            merged.update(kwargs)
+            self._name = name or type(self).__name__
+            self.packages_path = packages_path
+            self.params = dict(merged.pop("params", None) or {})
+            derived = {k for k, v in self.params.items() if isinstance(v, dict) and v.get("derived")}
+            self.input_params = [k for k in self.params if k not in derived]
+            self.output_params = sorted(derived)
+            for key, value in merged.items():
                 setattr(self, key, value)
-            self.initialize()
+            if initialize:
+                self.initialize()
+
+        def get_name(self):
+            return self._name
 
 from victor import CCFFit
 

@@ -35,7 +35,7 @@ class vk_tables(C.Structure):
         ("matter_model", C.c_int32), ("vr_beta_dep", C.c_int32), ("vr", vk_pp), ("vr_emp", C.POINTER(C.c_double)),
         ("vt_amp", C.c_double),
         ("sv", vk_pp), ("sv_n_mu", C.c_int32), ("sv_mu_inv_h", C.c_double), ("sv_mu", _dp), ("sv2d", _dp),
-        ("uni_n", C.c_int32), ("uni_u0", C.c_double), ("uni_inv_h", C.c_double), ("uni_sv_v", _dp), ("uni_xi", _dp), ("uni_xic", _dp), ("uni_vb", _dp), ("uni_v2", _dp), ("uni_da", _dp), ("uni_ge", _dp),
+        ("uni_n", C.c_int32), ("uni_u0", C.c_double), ("uni_inv_h", C.c_double), ("uni_sv_v", _dp), ("uni_xi", _dp), ("uni_xic", _dp), ("uni_vb", _dp), ("uni_v2", _dp), ("uni_da", _dp), ("uni_ge", _dp), ("uni_dab", _dp), ("uni_empb", _dp),
         ("uni_lut_n", C.c_int32), ("uni_lut_inv_g", C.c_double), ("uni_lut", C.POINTER(C.c_uint16)), ("uni_knots", _dp),
         ("iaH", C.c_double), ("template_sigma8", C.c_double),
         ("n_beta_d", C.c_int32), ("beta_d", _dp), ("data", _dp),

@@ -148,7 +148,7 @@ struct vk_ctx {
   const double *d_sv_mu = nullptr, *d_sv2d = nullptr;
   int uni_n = 0;             // unified refined grid (fast kernels need it)
   double uni_u0 = 0, uni_inv_h = 0;
-  const double *d_uni_sv_v = nullptr, *d_uni_xi = nullptr, *d_uni_xic = nullptr, *d_uni_vb = nullptr, *d_uni_v2 = nullptr, *d_uni_da = nullptr, *d_uni_ge = nullptr;
+  const double *d_uni_sv_v = nullptr, *d_uni_xi = nullptr, *d_uni_xic = nullptr, *d_uni_vb = nullptr, *d_uni_v2 = nullptr, *d_uni_da = nullptr, *d_uni_ge = nullptr, *d_uni_dab = nullptr, *d_uni_empb = nullptr;
   int uni_lut_n = 0;         // > 0: union-grid form of the unified tables
   double uni_lut_inv_g = 0;
   const unsigned short* d_uni_lut = nullptr;
@@ -455,6 +455,8 @@ int theory_args(vk_ctx* ctx, const vk_eval_opts* o, TheoryArgs* a, int* nlr) {
   a->uni_v2 = ctx->d_uni_v2;
   a->uni_da = ctx->d_uni_da;
   a->uni_ge = ctx->d_uni_ge;
+  a->uni_dab = ctx->d_uni_dab;
+  a->uni_empb = ctx->d_uni_empb;
   a->uni_lut_n = ctx->uni_lut_n;
   a->uni_lut_inv_g = ctx->uni_lut_inv_g;
   a->uni_lut = ctx->d_uni_lut;
@@ -550,8 +552,12 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
 #endif
   // the fast kernel (streaming only) packs LDS byte offsets of the mu and (x, w) records into 16 bits each
   // fast kernels: the streaming model, and the dispersion model on fixed velocity tables (cells / point-major only)
-  const bool disp = a.rsd == VK_RSD_DISPERSION && a.uni_da && (!a.empirical || a.uni_ge) && !a.vr_beta_dep;
-  const bool fast = (a.rsd == VK_RSD_STREAMING || disp) && ctx->fast_ok && (!a.empirical || a.uni_v2) &&
+  // (fixed velocity tables: Da / Ge staged once; beta-dependent ones - linear_bias on a reconstructed real-space ccf - rebuilt
+  // per point from their beta polynomials, uni_dab / uni_empb)
+  const bool disp = a.rsd == VK_RSD_DISPERSION &&
+                    (a.vr_beta_dep ? (a.uni_dab && (!a.empirical || a.uni_empb)) : (a.uni_da && (!a.empirical || a.uni_ge)));
+  const bool emp_ok = !a.empirical || (a.vr_beta_dep ? a.uni_empb != nullptr : a.uni_v2 != nullptr);
+  const bool fast = (a.rsd == VK_RSD_STREAMING || disp) && ctx->fast_ok && emp_ok &&
                     a.n_mu <= 1024 && a.n_x <= 2048 && !ctx->knobs.force_generic;
   // chi-square inside the theory kernel: point-major and cells kernels only, up to fuse_max points (A/B: DESIGN.md section 5)
   // A/B (tools/gpu_small_batch_ab.py, config 3 / BOSS, resident): the fused launch wins up to ~256 points (64 points: 41.2 vs
@@ -1003,7 +1009,7 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
     o_svmu = up.add(t->sv_mu, t->sv_n_mu);
     o_sv2d = up.add(t->sv2d, (size_t)t->sv.n_int * (t->sv_n_mu - 1) * 16);
   }
-  size_t o_usv = 0, o_uxi = 0, o_uxc = 0, o_ulut = 0, o_uk = 0, o_uvb = 0, o_uv2 = 0, o_uda = 0, o_uge = 0;
+  size_t o_usv = 0, o_uxi = 0, o_uxc = 0, o_ulut = 0, o_uk = 0, o_uvb = 0, o_uv2 = 0, o_uda = 0, o_uge = 0, o_udab = 0, o_uempb = 0;
   const bool have_lut = t->uni_n > 0 && t->uni_lut_n > 0 && t->uni_lut && t->uni_knots;
   if (have_lut) {
     std::vector<double> packed(((size_t)t->uni_lut_n + 3) / 4, 0.0);        // u16 cells travel inside the double arena
@@ -1037,6 +1043,8 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
     if (!t->vr_beta_dep && t->uni_v2) o_uv2 = up.add(t->uni_v2, (size_t)t->uni_n * 4);
     if (!t->vr_beta_dep && t->uni_da) o_uda = up.add(t->uni_da, (size_t)t->uni_n * 4);
     if (!t->vr_beta_dep && t->uni_ge) o_uge = up.add(t->uni_ge, (size_t)t->uni_n * 8);
+    if (t->vr_beta_dep && t->uni_dab) o_udab = up.add(t->uni_dab, (size_t)(t->n_beta_r - 1) * t->uni_n * 16);
+    if (t->vr_beta_dep && t->uni_empb) o_uempb = up.add(t->uni_empb, (size_t)3 * (t->n_beta_r - 1) * t->uni_n * 28);
   }
   size_t o_bd = 0, o_data = 0, o_bc = 0, o_prec = 0, o_ld = 0, o_eig = 0;
   if (t->data) {
@@ -1085,6 +1093,8 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
     if (!t->vr_beta_dep && t->uni_v2) ctx->d_uni_v2 = base + o_uv2;
     if (!t->vr_beta_dep && t->uni_da) ctx->d_uni_da = base + o_uda;
     if (!t->vr_beta_dep && t->uni_ge) ctx->d_uni_ge = base + o_uge;
+    if (t->vr_beta_dep && t->uni_dab) ctx->d_uni_dab = base + o_udab;
+    if (t->vr_beta_dep && t->uni_empb) ctx->d_uni_empb = base + o_uempb;
     if (have_lut) {
       ctx->uni_lut_n = t->uni_lut_n;
       ctx->uni_lut_inv_g = t->uni_lut_inv_g;

@@ -89,6 +89,8 @@ struct TheoryArgs {
   const double* uni_v2;   // V2 = r Delta delta on the unified grid (fixed velocity tables), [uni_n][4]
   const double* uni_da;   // Da = delta - 2 Delta/3 on the unified grid (fixed velocity tables), [uni_n][4]
   const double* uni_ge;   // Ge1, Ge2 (empirical_corr gradient tables) on the unified grid, [2][uni_n][4]
+  const double* uni_dab;  // beta-dependent Da on the unified grid (vr_beta_dep), [n_beta_r-1][uni_n][4][4]
+  const double* uni_empb; // beta-dependent V2, Ge1, Ge2 (vr_beta_dep), degree 6 in beta: [3][n_beta_r-1][uni_n][4][7]
   int uni_lut_n;          // > 0: union-grid form (arbitrary knots), cells of the look-up table
   double uni_lut_inv_g;
   const unsigned short* uni_lut;

@@ -135,8 +135,8 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
     const FastPoint fp = make_fast_point(ps, fc, kHalf);
     constexpr int PV = mode_is_dispersion(MODE) ? 0 : 1;
     __syncthreads();      // every wave is done with the previous item's records and accumulators
-    rebuild_point_tables<NLR, PV>(a, lds, pl.betar, pl.v1, row[VK_P_BETA], ps.av, fp.AVk);
-    if (mode_is_dispersion(MODE) && a.empirical) rebuild_da_emp(a, lds + pl.da, ps.av);
+    rebuild_point_tables<NLR, PV>(a, lds, pl.betar, pl.v1, row[VK_P_BETA], ps.av, fp.AVk, mode_is_dispersion(MODE) ? lds + pl.da : nullptr);
+    if (mode_is_dispersion(MODE) && a.empirical && !a.vr_beta_dep) rebuild_da_emp(a, lds + pl.da, ps.av);
     for (int e = lane; e < kMaxEll * slots; e += 64) l_acc[e * kWaves + wave] = 0.0;
     __syncthreads();
     VK_STAMP(a, 2);

@@ -150,8 +150,18 @@ __device__ __forceinline__ void stage_uni_records(const TheoryArgs& a, double* l
 
 // Per-point xi^r records when the real-space input depends on the reconstruction beta (PCHIP piece kb, extrapolating
 // with the end pieces as PchipInterpolator does; ccf_model.py:323-326).  `bg` = beta grid in LDS.
+// degree-6 polynomial in db, coefficients c[0..6] (the empirical_corr tables of a beta-dependent velocity profile)
+__device__ __forceinline__ double poly6(const double* __restrict__ c, double db) {
+  double v = c[6];
+#pragma unroll
+  for (int p = 5; p >= 0; --p) v = fma(v, db, c[p]);
+  return v;
+}
+
+// `da`: LDS table of the dispersion model's v_r' (NULL in the streaming modes); `av`: the point's empirical_corr amplitude.
 template <int NLR>
-__device__ __forceinline__ void rebuild_uni_xi(const TheoryArgs& a, double* recs, const double* bg, double beta, double vs = 1.0) {
+__device__ __forceinline__ void rebuild_uni_xi(const TheoryArgs& a, double* recs, const double* bg, double beta, double vs = 1.0,
+                                               double av = 0.0, double* da = nullptr) {
   constexpr int stride = uni_stride(NLR);
   const int tid = late_tid();        // fresh per work item: nothing derived from it is carried through the integrand loops
   // PCHIP piece: last i in [1, n-2] with beta >= bg[i], else 0 - a count over the lanes for grids of up to 64 nodes
@@ -189,9 +199,23 @@ __device__ __forceinline__ void rebuild_uni_xi(const TheoryArgs& a, double* recs
     }
   }
   if (a.vr_beta_dep) {   // linear_bias on a reconstructed real-space ccf: V1 follows xi^r_0(beta) (ccf_model.py:358-370)
+    // with empirical_corr, V = V1 + av V2 and (dispersion model) v_r' from Ge1 + av Ge2 instead of Da (ccf_model.py:451-459):
+    // products of PCHIP cubics, degree 6 in beta (vk_tables.uni_empb)
+    const size_t var6 = (size_t)(a.n_beta_r - 1) * per_l * 7;
+    const double* e6 = a.uni_empb + (size_t)kb * per_l * 7;
     for (int iq = tid; iq < per_l; iq += kBlock) {
       const double* c = a.uni_vb + ((size_t)kb * per_l + iq) * 4;
-      recs[(iq >> 2) * stride + 4 + (iq & 3)] = vs * fma(fma(fma(c[3], db, c[2]), db, c[1]), db, c[0]);
+      double v = fma(fma(fma(c[3], db, c[2]), db, c[1]), db, c[0]);
+      if (a.empirical) v = fma(av, poly6(e6 + (size_t)iq * 7, db), v);
+      recs[(iq >> 2) * stride + 4 + (iq & 3)] = vs * v;
+      if (da) {
+        if (a.empirical) {
+          da[iq] = fma(av, poly6(e6 + 2 * var6 + (size_t)iq * 7, db), poly6(e6 + var6 + (size_t)iq * 7, db));
+        } else {
+          const double* d = a.uni_dab + ((size_t)kb * per_l + iq) * 4;
+          da[iq] = fma(fma(fma(d[3], db, d[2]), db, d[1]), db, d[0]);
+        }
+      }
     }
   }
 }
@@ -214,13 +238,14 @@ __device__ __forceinline__ void scale_uni_v(int uni_n, double* recs, const doubl
 }
 
 // Per-item tables of the kernels that own a point per workgroup.  PV: fold AVk into the V cubics (streaming modes).
+// `da`: the dispersion modes' LDS table of v_r' (NULL in the streaming modes) - rebuilt here when the velocity profile depends on beta.
 template <int NLR, int PV>
 __device__ __forceinline__ void rebuild_point_tables(const TheoryArgs& a, double* lds, int betar_off, int v1_off, double beta,
-                                                     double av, double AVk) {
+                                                     double av, double AVk, double* da = nullptr) {
   const double vs = PV ? AVk : 1.0;
   double* recs = lds + recs_off<0>();                        // the kernels that own a point per workgroup use the plain exp table
-  if (a.n_beta_r > 0) rebuild_uni_xi<NLR>(a, recs, lds + betar_off, beta, vs);
-  if (a.empirical) rebuild_uni_v_emp<NLR>(a, recs, av, vs);
+  if (a.n_beta_r > 0) rebuild_uni_xi<NLR>(a, recs, lds + betar_off, beta, vs, av, a.vr_beta_dep ? da : nullptr);
+  if (a.empirical && !a.vr_beta_dep) rebuild_uni_v_emp<NLR>(a, recs, av, vs);
   else if (PV && !a.vr_beta_dep) scale_uni_v<NLR>(a.uni_n, recs, lds + v1_off, vs);
 }
 
@@ -382,6 +407,7 @@ __host__ __device__ constexpr bool mode_is_dispersion(int mode) { return mode >=
 
 template <int NLR>
 __device__ __forceinline__ void stage_da(const TheoryArgs& a, double* da) {
+  if (!a.uni_da) return;                                     // beta-dependent velocity profile: rebuilt per point (rebuild_uni_xi)
   for (int e = threadIdx.x; e < a.uni_n * 4; e += kBlock) da[e] = a.uni_da[e];
 }
 
@@ -564,8 +590,8 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 3 : 2) void vk_the
     constexpr int PV = mode_is_dispersion(MODE) ? 0 : 1;
     if (PV || a.n_beta_r > 0 || a.empirical) {
       __syncthreads();  // previous item's readers are done with the per-point records
-      rebuild_point_tables<NLR, PV>(a, lds, pl.betar, pl.v1, row[VK_P_BETA], ps.av, fp.AVk);
-      if (mode_is_dispersion(MODE) && a.empirical) rebuild_da_emp(a, lds + pl.da, ps.av);
+      rebuild_point_tables<NLR, PV>(a, lds, pl.betar, pl.v1, row[VK_P_BETA], ps.av, fp.AVk, mode_is_dispersion(MODE) ? lds + pl.da : nullptr);
+      if (mode_is_dispersion(MODE) && a.empirical && !a.vr_beta_dep) rebuild_da_emp(a, lds + pl.da, ps.av);
       __syncthreads();
     }
     VK_STAMP(a, 2);

@@ -162,6 +162,13 @@ def build_tables(model, fit=None, matter_model=None, simpson_even=None):
                 uni_vb = arr(np.moveaxis(vb, -1, 0))                                       # (n_beta-1, n, 4, 4)
                 t.uni_vb = N.as_dp(uni_vb)
                 v_ref = np.zeros_like(sv_ref)
+                # Da likewise (dispersion model), and the degree-6 beta polynomials of the empirical_corr branch (V2, Ge1, Ge2)
+                dab = T.refine_pp_on(r_ext, np.moveaxis(vr_coef[1], 0, -1), left, width)
+                uni_dab = arr(np.moveaxis(dab, -1, 0))
+                t.uni_dab = N.as_dp(uni_dab)
+                uni_empb = arr(np.stack([np.moveaxis(T.refine_pp_on(r_ext, np.moveaxis(vr_emp[v], 0, -1), left, width), -1, 0)
+                                         for v in range(3)]))                               # (3, n_beta-1, n, 4, 7)
+                t.uni_empb = N.as_dp(uni_empb)
             else:
                 v_ref = T.refine_pp_on(r_ext, vr_coef[0], left, width)
                 uni_v2 = arr(T.refine_pp_on(r_ext, vr_coef[2], left, width))              # empirical_corr: V = V1 + Av V2
@@ -268,6 +275,8 @@ def table_array_lengths(t):
         "uni_v2": t.uni_n * 4 if (t.uni_n and t.uni_v2) else 0,
         "uni_da": t.uni_n * 4 if (t.uni_n and t.uni_da) else 0,
         "uni_ge": t.uni_n * 8 if (t.uni_n and t.uni_ge) else 0,
+        "uni_dab": (nb - 1) * t.uni_n * 16 if (t.uni_n and t.vr_beta_dep and t.uni_dab) else 0,
+        "uni_empb": 3 * (nb - 1) * t.uni_n * 28 if (t.uni_n and t.vr_beta_dep and t.uni_empb) else 0,
         "uni_lut": t.uni_lut_n, "uni_knots": t.uni_n + 1 if t.uni_lut_n else 0,
         "beta_d": t.n_beta_d, "data": (t.n_beta_d - 1) * N_ * 4 if t.n_beta_d else (N_ if t.data else 0),
         "beta_c": t.n_beta_c, "prec": (max(t.n_beta_c, 1) * N_ * N_) if t.prec else 0,
