@@ -493,3 +493,23 @@ def test_c_abi_rejects_bad_calls_without_crashing():
     # the context is still healthy
     lnl, chi2 = fit.log_likelihood_batch(rows)
     assert np.all(np.isfinite(lnl))
+
+
+def test_ten_million_point_batch_is_chunked_inside_the_library():
+    """A batch beyond the 32-bit work-item range of one launch (6.7 M points at 40 s bins; round 2 returned VK_E_ARG there):
+    the library cuts it into launches of whole 65536-point blocks on the context's stream.  10 M points of config 2 in ONE call
+    against the same rows in two calls of 5 M: bit for bit, every row finite."""
+    import victor_amd
+    fit = victor_amd.CCFFit(*cases.synth_options(2))
+    n = 10_000_000
+    rows = fit._fit_rows(cases.halton_params(n), fit.model)
+    lnl, chi2 = fit.log_likelihood_batch(rows)
+    assert lnl.shape == (n,) and np.all(np.isfinite(lnl)) and np.all(chi2 > 0)
+    half = n // 2
+    for lo, hi in ((0, half), (half, n)):
+        l2, c2 = fit.log_likelihood_batch(rows[lo:hi])
+        assert np.array_equal(l2, lnl[lo:hi]) and np.array_equal(c2, chi2[lo:hi])
+    # and it is the same function of the row as a small batch through another kernel mapping (to rounding)
+    probe = np.linspace(0, n - 1, 50).astype(int)
+    l3, c3 = fit.log_likelihood_batch(rows[probe])
+    assert np.max(np.abs(c3 / chi2[probe] - 1)) < 1e-11

@@ -110,6 +110,7 @@ struct Knobs {
   int mapping = 0;                     // VICTOR_HIP_MAPPING: 0 auto, 1 point, 2 cells, 3 lanes, -1 unknown name
   bool like_untiled = false;           // VICTOR_HIP_LIKE_UNTILED
   bool no_graph = false;               // VICTOR_HIP_NO_GRAPH
+  bool lanes_by_chunk = false;         // VICTOR_HIP_LANES_BY_CHUNK: a workgroup takes all s bins of a 64-point chunk (A/B)
   bool no_fuse = false;                // VICTOR_HIP_NO_FUSE: keep chi2 in its own launch (A/B of the fused path)
   long long fuse_max = -1;             // VICTOR_HIP_FUSE_MAX: largest batch whose chi2 is taken inside the theory kernel (-1 = default)
   int split_q = 0;                     // third field of VICTOR_HIP_SPLIT "spi,team,parts": workgroups per (mu, v) plane
@@ -232,6 +233,7 @@ void load_knobs(vk_ctx* ctx) {
   k.like_untiled = getenv("VICTOR_HIP_LIKE_UNTILED") != nullptr;
   k.no_graph = getenv("VICTOR_HIP_NO_GRAPH") != nullptr;
   k.no_fuse = getenv("VICTOR_HIP_NO_FUSE") != nullptr;
+  k.lanes_by_chunk = getenv("VICTOR_HIP_LANES_BY_CHUNK") != nullptr;
   ctx->knobs = k;
   ctx->knob_gen = g_knob_gen.load(std::memory_order_relaxed);
 }
@@ -592,7 +594,8 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
     ctx->last_kernel = "vk_theory_lanes_kernel";
     a.parts = 1;
     a.image = get_image(ctx, a, 2, nlr, false, make_lanes_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.uni_lut_n).image_end);
-    const long long blocks = blocks_l;
+    a.lanes_per_block = ctx->knobs.lanes_by_chunk ? a.n_s : kWaves;
+    const long long blocks = ctx->knobs.lanes_by_chunk ? (a.n + 63) >> 6 : blocks_l;
     // One workgroup per four items, never a grid-stride loop by default: letting the dispatcher refill CUs as
     // workgroups retire measured 38.1 / 36.0 / 34.6 / 33.8 ms at 4 / 8 / 16 / 64 workgroups per CU on the bench workload
     // (5 are resident), and a cap that makes workgroups loop leaves a ragged tail of 0.6 ms items - 131072 points ran at
@@ -1246,22 +1249,34 @@ int vk_eval_batch_device_async(vk_ctx* ctx, const vk_eval_opts* opts, const doub
   a.s = ctx->d_s; a.mu = ctx->d_mu; a.w_ell = ctx->d_w;
   a.stage_mu = ctx->d_stage_mu;
   for (int l = 0; l < 3; ++l) a.wsum[l] = ctx->wsum[l];
-  a.out = d_theory_ws;
-  LikeArgs la;
-  if (want_like) fill_like_args(ctx, opts, d_params, d_theory_ws, n, d_lnl, d_chi2, &la);
+  // One launch addresses its work items with 32 bits (n * n_s * kMaxParts < 2^31): larger batches - 6.7 M points at 40 s bins -
+  // are cut into chunks of whole 65536-point blocks here, each with its own pair of launches on the same stream.  Points are
+  // independent and every kernel's arithmetic per point is independent of its neighbours, so the results are bit-identical to
+  // calls the caller chunks himself.
+  const long long chunk_max = std::max<long long>(65536, ((1LL << 31) / ((long long)ctx->n_s * kMaxParts) - 1) & ~65535LL);
+  if (n > chunk_max && ctx->timing) return fail(ctx, VK_E_ARG, "kernel timing is per launch pair: disable it for batches above %lld points", chunk_max);
   const bool timed = ctx->timing && want_like;
   if (timed) {
     harvest_timing(ctx);
     VK_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   }
-  bool fused = false;
-  rc = launch_theory(ctx, a, nlr, want_like ? &la : nullptr, &fused);
-  if (rc) return rc;
-  ctx->last_fused = fused;
-  if (timed) VK_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-  if (want_like && !fused) {
-    rc = launch_like(ctx, la);
+  for (long long off = 0; off < n; off += chunk_max) {
+    const long long m = std::min<long long>(chunk_max, n - off);
+    a.params = d_params + off * VK_NPAR;
+    a.n = m;
+    a.out = d_theory_ws + off * ctx->N;
+    LikeArgs la;
+    if (want_like)
+      fill_like_args(ctx, opts, a.params, a.out, m, d_lnl ? d_lnl + off : nullptr, d_chi2 ? d_chi2 + off : nullptr, &la);
+    bool fused = false;
+    rc = launch_theory(ctx, a, nlr, want_like ? &la : nullptr, &fused);
     if (rc) return rc;
+    ctx->last_fused = fused;
+    if (timed) VK_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    if (want_like && !fused) {
+      rc = launch_like(ctx, la);
+      if (rc) return rc;
+    }
   }
   if (timed) {
     VK_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));

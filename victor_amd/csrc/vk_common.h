@@ -104,6 +104,7 @@ struct TheoryArgs {
   int niter;              // fixed-point iterations of the dispersion / Kaiser coordinate shift
   int kaiser_approx;      // ccf_model.py:730-738
   int coord_shift;        // ccf_model.py:698-707
+  int lanes_per_block;    // lanes kernel: consecutive work items per workgroup (kWaves, or n_s: a 64-point chunk per workgroup)
   int sbins_per_item;     // s bins handled by one workgroup visit
   int team;               // waves cooperating on one s bin (1, 2 or 4)
   double* out;            // theory: [n][n_ell*n_s];  xi_smu: [n][n_mu][n_s]

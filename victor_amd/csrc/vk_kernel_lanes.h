@@ -120,7 +120,16 @@ __global__ __launch_bounds__(kBlock, VK_LANES_WG_PER_CU) void vk_theory_lanes_ke
   const unsigned nwg = gridDim.x, orig = blockIdx.x;
   const unsigned xq = nwg >> 3, xr = nwg & 7, xcd = orig & 7;
   const unsigned bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (orig >> 3);
-  for (long long item = (long long)bid * kWaves + wave; item < items; item += (long long)gridDim.x * kWaves) {
+  // Work items (chunk-major: item = chunk * n_s + s bin) are dealt to the workgroups in blocks of `per_block` consecutive
+  // items, a wave taking every fourth one of its block: per_block = 4 is one item per wave (the default); per_block = n_s
+  // gives a workgroup ALL s bins of one 64-point chunk - the mapping a chi-square fused into this kernel would need (its
+  // theory vectors would then sit in one workgroup's LDS) - kept as an A/B knob: see DESIGN.md "Measured and rejected".
+  const int per_block = a.lanes_per_block;
+  const long long nblocks = (items + per_block - 1) / per_block;
+  for (long long blk = bid; blk < nblocks; blk += gridDim.x)
+  for (int sub = wave; sub < per_block; sub += kWaves) {
+    const long long item = blk * per_block + sub;
+    if (item >= items) break;
     const long long chunk = item / a.n_s;
     const int j = (int)(item - chunk * a.n_s);
     long long point = chunk * 64 + lane;
