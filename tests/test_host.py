@@ -524,6 +524,11 @@ def test_no_kernel_of_the_library_spills(lib, tmp_path):
     for k, _, vgpr in kernels:
         if "vk_theory_lanes_kernel" in k or ("vk_theory_cells_kernel" in k and k.endswith("Li0EEEvNS_10TheoryArgsE")):
             assert int(vgpr) <= 96, (k, vgpr)          # 512 / 5 workgroups of four waves, in granules of 8
+    # no static LDS in the fast theory kernels: their dynamic LDS then starts at address 0, which vkm::exp_gauss relies on
+    # when it reads its table (at the start of dynamic LDS) with the byte offset as the address
+    static = re.findall(r"\.group_segment_fixed_size:\s+(\d+)[\s\S]*?\.name:\s+(\S+)", notes)
+    fast = [(k, int(sz)) for sz, k in static if re.search(r"vk_theory_(lanes|cells|fast)_kernel|vk_image_kernel", k)]
+    assert len(fast) > 100 and all(sz == 0 for _, sz in fast), [x for x in fast if x[1]][:5]
 
 
 def test_cross_workgroup_handoff_is_ordered_in_the_code_object(lib, tmp_path):

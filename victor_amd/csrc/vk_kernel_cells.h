@@ -101,8 +101,11 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
   const int R = a.parts;
   const int cpi = a.cells_per_item;
   const bool tail = a.fuse || R > 1;
-  const CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, mode_is_dispersion(MODE), cpi,
-                                       tail ? N : 0);
+  CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, mode_is_dispersion(MODE), cpi,
+                                 tail ? N : 0);
+  // the offset behind the accumulators depends on an integer division by n_mu, which the compiler evaluates on the vector ALU:
+  // wave-uniform, but held - and once spilled - as a vector register unless it is made a scalar here
+  pl.like = __builtin_amdgcn_readfirstlane(pl.like);
   const int tid = threadIdx.x;
   VK_STAMP(a, 0);
   if (a.image) copy_image(lds, a.image, pl.image_end);

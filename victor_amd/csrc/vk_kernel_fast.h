@@ -26,7 +26,7 @@ namespace vk {
 // --------------------------------------------------------------------------------------------------
 typedef double vk_d2 __attribute__((ext_vector_type(2)));
 constexpr int kMuRec = 6;   // {mu, sqrt(1-mu^2), W_0, W_1, W_2, pad}
-constexpr int kEtabOff = 0;                  // doubles
+constexpr int kEtabOff = 0;                  // doubles; must stay 0: vkm::exp_gauss addresses the table from LDS address 0
 // EXPT: form of the exp table at the start of LDS (vk_devmath.h: ExpCfg); the records follow it
 template <int EXPT> __host__ __device__ constexpr int recs_off() { return vkm::ExpCfg<EXPT>::kDoubles; }
 __host__ __device__ constexpr int recs_off_rt(int expt) { return expt ? vkm::ExpCfg<1>::kDoubles : vkm::ExpCfg<0>::kDoubles; }
