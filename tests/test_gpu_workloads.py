@@ -248,6 +248,34 @@ def test_bench_two_launched_ranks_on_one_gpu():
     assert "socket" in out["config"]["rendezvous"]
 
 
+def test_bench_under_the_drivers_launcher_command():
+    """The driver's own N > 1 command line - ``python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
+    127.0.0.1 --master-port P bench.py --gpus 2 ...`` - on the one-GPU box.  torch is the LAUNCHER only (its agent owns TCP port
+    P, which is why the ranks meet on a Unix socket named after it); the ranks must produce the same record as under the plain
+    launcher of the test above, and must not have mapped torch's HIP runtime."""
+    import json
+    import socket
+    try:
+        import importlib.util
+        if importlib.util.find_spec("torch") is None:
+            pytest.skip("torch (the driver's launcher) is not installed")
+    except ImportError:
+        pytest.skip("torch (the driver's launcher) is not installed")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "4096", "--no-cpu-baseline", "--no-boss"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=360)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    _check_two_gpu_line(out)
+    assert out["config"]["processes"] == 2 and "socket" in out["config"]["rendezvous"]
+
+
 def test_bench_one_process_two_contexts_on_one_gpu():
     """``python bench.py --gpus 2`` started on its own: ONE process drives both contexts (no launcher, no rendezvous); on the
     one-GPU box ncclCommInitAll is refused for the shared device and the gather is the host concatenation."""
