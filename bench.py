@@ -255,12 +255,14 @@ def walker_rates(steps=150):
     for walkers in (8, 64, 512):
         ens = EnsembleMetropolis(lambda batch: fit.log_likelihood_batch(batch)[0], specs, walkers, seed=1, fixed=fixed)
         ens.initialise()
-        ens.run(10)                      # past the first call's one-off costs (LDS image, pinned buffers, captured graph)
+        t_end = time.perf_counter() + 0.4    # past the first call's one-off costs and the runtime's stall after fresh allocations (see warm_up)
+        while time.perf_counter() < t_end:
+            ens.run(10)
         e0 = ens.n_evals
         t0 = time.perf_counter()
         ens.run(steps)
         dt = time.perf_counter() - t0
-        res[f"{walkers}_walkers"] = {"evals_per_s": (ens.n_evals - e0) / dt, "steps_per_s": steps / dt,
+        res[f"{walkers}_walkers"] = {"evals_per_s": (ens.n_evals - e0) / dt, "us_per_step": 1e6 * dt / steps,
                                      "acceptance": ens.n_accept / max(ens.n_steps * walkers, 1)}
     return res
 

@@ -126,7 +126,7 @@ def test_all_five_published_pairs_under_the_legacy_simpson_rule(boss_fit, oracle
         assert vec_close(fit.theory_vector_batch(rows), ga[f"synth{config}_theory"])
         big = np.tile(rows, (4096, 1))
         lnl_b, chi_b = fit.log_likelihood_batch(big)
-        assert fit._get_engine().last_kernel() == "vk_theory_lanes_kernel"
+        assert fit._get_engine().last_kernel() == "vk_theory_cells_kernel"        # the large-batch default since round 3
         assert np.max(np.abs(chi_b.reshape(4096, 9) / ga[f"synth{config}_chi2"] - 1)) < RTOL
         # live oracle on a fresh point under the same rule
         ofit = oracle.OracleFit(model, data)

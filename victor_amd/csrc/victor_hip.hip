@@ -588,8 +588,16 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
   const long long blocks_l = (waves + kWaves - 1) / kWaves;
   const size_t lds_l = (size_t)make_lanes_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.uni_lut_n).total * sizeof(double);
   const long long wg_per_cu = std::max<long long>(1, std::min<long long>(5, (160 * 1024) / (lds_l ? lds_l : 1)));
+  // cells variant: one workgroup per point with the velocity loop innermost; needs n_mu >= 64 (a wave's 64 cells must not
+  // straddle more than two s bins)
+  const bool cells_ok = fast && a.n_mu >= 64 && a.n_mu <= 4096 && a.n_x <= 2048;
+  // Round 3: with the shorter integrand loop the cells kernel is ahead of the lanes kernel at EVERY batch size, also for
+  // batch-constant tables (tools/gpu_lanes_vs_cells.py, same box, M evals/s at 8192 / 65536 / 262144 points: config 3
+  // 2.58 / 2.66 / 2.66 against 2.23 / 2.58 / 2.65, config 2 3.38 / 3.50 / 3.50 against 2.75 / 3.21 / 3.37): it carries the
+  // point's velocity amplitude in its table (one instruction less per integrand point) and has no ragged tail of 0.6 ms
+  // items.  The lanes kernel remains for grids the cells kernel cannot take (n_mu < 64) and as VICTOR_HIP_MAPPING=lanes.
   const bool lanes = lanes_ok && lds_l <= 160 * 1024 &&
-                     (mapping ? mapping == 3 : blocks_l * ctx->depth_mult >= 4 * wg_per_cu * ctx->n_cu);
+                     (mapping ? mapping == 3 : (!cells_ok && blocks_l * ctx->depth_mult >= 4 * wg_per_cu * ctx->n_cu));
   if (lanes) {
     ctx->last_kernel = "vk_theory_lanes_kernel";
     a.parts = 1;
@@ -608,9 +616,6 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
       case 3: return launch_lanes_nl<3>(ctx, a, grid_l, lds_l);
     }
   }
-  // cells variant: one workgroup per point with the velocity loop innermost; needs enough points to fill the chip
-  // and n_mu >= 64 (a wave's 64 cells must not straddle more than two s bins)
-  const bool cells_ok = fast && a.n_mu >= 64 && a.n_mu <= 4096 && a.n_x <= 2048;
   // crossover against the point-major kernel measured between 512 and 768 points (config 3) and near 500 (BOSS),
   // tools/gpu_small_batch_ab.py: one workgroup per point needs ~2.5 workgroups per CU to keep the SIMDs fed
   // crossover against the point-major kernel (whose finer split wins for a handful of points): config 3 / BOSS 8 points
