@@ -300,7 +300,7 @@ def dsplit_measurement(batch=16384, steps=10):
 class Slot:
     """One GPU of the run: a context with its shard of the global Halton sequence resident in HBM."""
 
-    def __init__(self, g, device, model, data, hp_all, B, total):
+    def __init__(self, g, device, model, data, hp_all, B, total, gathered):
         import victor_amd
         self.g = g
         self.fit = victor_amd.CCFFit(model, data, device=device)
@@ -311,7 +311,7 @@ class Slot:
         eng = self.eng
         self.d_rows, self.d_lnl, self.d_chi = eng.alloc(rows.size), eng.alloc(B), eng.alloc(B)
         self.d_ws = eng.alloc(B * eng.n_data)
-        self.d_all = eng.alloc(B * total) if total > 1 else None
+        self.d_all = eng.alloc(B * total) if gathered else None        # every GPU's copy of the gathered lnL vector
         eng.upload(self.d_rows, rows)
 
     def launch(self, n):
@@ -381,8 +381,8 @@ def main():
     # communicator can be built, which exercises the host-gather fallback below
     from victor_amd import _native
     n_dev = max(_native.load().vk_device_count(), 1)
-    slots = [Slot(rank * n_local + i, ((dist.local_rank if launched else i) % n_dev), model, data, hp_all, B, total)
-             for i in range(n_local)]
+    slots = [Slot(rank * n_local + i, ((dist.local_rank if launched else i) % n_dev), model, data, hp_all, B, total,
+                  total > 1 or launched) for i in range(n_local)]
     engines = [s.eng for s in slots]
     lead = slots[0]
     fit, eng = lead.fit, lead.eng

@@ -276,6 +276,20 @@ def test_bench_under_the_drivers_launcher_command():
     assert out["config"]["processes"] == 2 and "socket" in out["config"]["rendezvous"]
 
 
+def test_bench_single_launched_rank_gathers_through_rccl():
+    """One launched rank: the whole RCCL path of the multi-process layout - unique id, ncclCommInitRank on the watchdog thread,
+    ncclAllGather on the context's stream in every timed step, every slot checked - with /opt/rocm's RCCL next to /opt/rocm's HIP
+    runtime (no torch in the process)."""
+    import json
+    (rc, out, err), = _launch_ranks([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "4096",
+                                     "--no-cpu-baseline", "--no-boss"], 1)
+    assert rc == 0, err[-2000:]
+    line = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == 1 and line["gather_matches_local"] is True
+    assert line["config"]["gather"].startswith("rccl allgather of lnL (ncclCommInitRank"), line["config"]["gather"]
+    assert "torch" not in line["config"]["rccl"]["hip_runtime"] and line["config"]["rccl"]["rccl_next_to_hip_runtime"] is True
+
+
 def test_bench_one_process_two_contexts_on_one_gpu():
     """``python bench.py --gpus 2`` started on its own: ONE process drives both contexts (no launcher, no rendezvous); on the
     one-GPU box ncclCommInitAll is refused for the shared device and the gather is the host concatenation."""

@@ -234,8 +234,8 @@ class CCFFit(CCFModel):
             made = None                                         # two evaluations per point: the general path
         else:
             eng = self._get_engine(self._engine_key(model), model["simpson_even"])
-            made = (eng, C.byref(eng.make_opts(model, fit_options)), self._needs_beta(model) or not self.fixed_data,
-                    self._needs_fsigma8(model))
+            opts = eng.make_opts(model, fit_options)
+            made = (eng, C.byref(opts), self._needs_beta(model) or not self.fixed_data, self._needs_fsigma8(model), opts)
         import copy
         self._plan = (copy.deepcopy(self.model), copy.deepcopy(self.fit_options), made)
         return made
@@ -244,7 +244,7 @@ class CCFFit(CCFModel):
         """(lnL, chi2) at one parameter point (reference: ccf_fit.py:356-483)."""
         plan = self._single_point_plan() if (not kwargs and type(params) is dict) else None
         if plan is not None and all(type(v) in _SCALARS or not np.ndim(v) for v in params.values()):
-            eng, opts, need_beta, need_fs8 = plan
+            eng, opts, need_beta, need_fs8 = plan[:4]
             if not self.fixed_data and params.get("beta", None) is None:
                 raise InputError("Need to supply a valid value of beta for interpolation")   # ccf_fit.py:188-189
             lnl, chi2 = eng.eval_point(opts, self._scalar_row(params, need_beta, need_fs8))
@@ -258,6 +258,14 @@ class CCFFit(CCFModel):
     def log_likelihood_batch(self, params, **kwargs):
         """(lnL[n], chi2[n]) for a batch: ``params`` is a dict of equal-length arrays (scalars broadcast) or an
         ``(n, VK_NPAR)`` array of rows in the column order of ``include/victor_hip.h``."""
+        plan = self._single_point_plan() if not kwargs else None
+        if plan is not None:
+            # plain call (a sampler's step): the cached (engine, option block) pair of log_likelihood, no option merging
+            eng, _, need_beta, need_fs8, opts = plan
+            if not isinstance(params, np.ndarray) and not self.fixed_data and params.get("beta", None) is None:
+                raise InputError("Need to supply a valid value of beta for interpolation")   # ccf_fit.py:188-189
+            lnl, chi2, _ = eng.eval_batch(opts, self._param_rows(params, need_beta, need_fs8))
+            return lnl, chi2
         lnl, chi2, _ = self._run(params, kwargs)
         return lnl, chi2
 

@@ -28,6 +28,9 @@ def _ez(z, cosmology):
     return BackgroundCosmology(cosmology).Ez(z)
 
 
+_SCALARS = (float, int, np.float64, np.int64)
+
+
 class CCFModel:
     """Model calculations for void-galaxy / density-split cross-correlation functions."""
 
@@ -363,53 +366,58 @@ class CCFModel:
             if rows.ndim != 2 or rows.shape[1] != N.VK_NPAR:
                 raise InputError(f"parameter array must have shape (n, {N.VK_NPAR})")
             return rows
-        get = params.get
-        lengths = {len(v) for v in params.values() if np.ndim(v) > 0}
+        arrays, scalars = {}, {}
+        for key, v in params.items():                 # one pass; np.ndim only for what is neither a number nor an ndarray
+            if type(v) in _SCALARS or v is None:
+                scalars[key] = v
+            elif (v.ndim if isinstance(v, np.ndarray) else np.ndim(v)) > 0:
+                arrays[key] = v
+            else:
+                scalars[key] = v
+        lengths = {len(v) for v in arrays.values()}
         if len(lengths) > 1:
             raise InputError(f"parameter arrays have different lengths: {sorted(lengths)}")
-        is_batch = bool(lengths)
-        n = next(iter(lengths)) if is_batch else 1    # an empty batch (length 0) is legal
+        n = next(iter(lengths)) if arrays else 1      # an empty batch (length 0) is legal
         rows = np.empty((n, N.VK_NPAR))
 
-        if not is_batch:
+        if not arrays:
             # one point given as scalars (the reference's calling convention, one call per MCMC step): plain Python
             # floats, one assignment into the row
             rows[0] = self._scalar_row(params, need_beta, need_fsigma8)
             return rows
 
-        def col(v):                                   # arrays of length n, scalars broadcast
-            v = np.asarray(v, dtype=float)
-            if v.ndim > 1:
-                raise InputError("parameter arrays must be one-dimensional")
-            return np.broadcast_to(v, (n,))
+        # Batches: the scalar entries (fixed parameters of a sampler, defaults) fill every row at once from the same Python
+        # floats the single-point path uses; only the parameters given as arrays are assigned column by column (a walker
+        # ensemble's step spends as long here as on the GPU, so the numpy calls are counted)
 
-        if need_fsigma8:
-            rows[:, N.P_FSIGMA8] = col(params["fsigma8"])        # KeyError if absent, as ccf_model.py:432-435
-        else:
-            rows[:, N.P_FSIGMA8] = col(get("fsigma8", 0.0))      # growth term is beta*bias (ccf_model.py:430)
-        rows[:, N.P_SIGMAV] = col(get("sigma_v", 380))
+        def col(name, default=None):                  # the parameter as a float or a length-n float array
+            if name in arrays:
+                v = np.asarray(arrays[name], dtype=float)
+                if v.ndim > 1:
+                    raise InputError("parameter arrays must be one-dimensional")
+                return v
+            v = scalars.get(name, default)
+            return None if v is None else float(v)
+
+        if need_fsigma8 and "fsigma8" not in params:
+            raise KeyError("fsigma8")                                # as ccf_model.py:432-435
+        if need_beta and "beta" not in params:
+            raise KeyError("beta")                                   # as ccf_model.py:587
         if "epsilon" in params:
-            eps = col(params["epsilon"])
-            apar = col(get("alpha", 1)) * eps ** (-2 / 3)
+            eps = col("epsilon")
+            apar = col("alpha", 1) * eps ** (-2 / 3)
             aperp = eps * apar
         else:
-            aperp = col(get("aperp", 1))
-            apar = col(get("apar", 1))
+            aperp = col("aperp", 1)
+            apar = col("apar", 1)
             eps = aperp / apar
-        rows[:, N.P_APERP] = aperp
-        rows[:, N.P_APAR] = apar
-        rows[:, N.P_EPSILON] = eps
-        if need_beta:
-            rows[:, N.P_BETA] = col(params["beta"])               # KeyError if absent, as ccf_model.py:587
-        else:
-            beta = get("beta", None)
-            rows[:, N.P_BETA] = col(0.40 if beta is None else beta)
-        rows[:, N.P_ASTAR] = col(get("astar", 1))
-        rows[:, N.P_M] = col(get("M", 1.0))
-        rows[:, N.P_Q] = col(get("Q", 1.0))
-        rows[:, N.P_BIAS] = col(get("bias", self.model["bias"]))
-        rows[:, N.P_AV] = col(get("Av", 0))
-        rows[:, N.P_SPARE] = 0.0
+        beta = col("beta")
+        cols = (col("fsigma8", 0.0), col("sigma_v", 380), aperp, apar, eps, 0.40 if beta is None else beta, col("astar", 1),
+                col("M", 1.0), col("Q", 1.0), col("bias", self.model["bias"]), col("Av", 0), 0.0)
+        rows[:] = [c if isinstance(c, float) else 0.0 for c in cols]
+        for k, c in enumerate(cols):
+            if not isinstance(c, float):
+                rows[:, k] = c
         return rows
 
     def _scalar_row(self, params, need_beta, need_fsigma8=True):

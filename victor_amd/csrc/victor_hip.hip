@@ -1626,6 +1626,7 @@ int vk_comm_init(vk_ctx* ctx, const char* id, int rank, int nranks) {
 
 int vk_comm_allgather_async(vk_ctx* ctx, const double* d_send, double* d_recv, int64_t count) {
   if (!ctx || !ctx->comm) return fail(ctx, VK_E_RCCL, "communicator not initialised");
+  if (!d_send || !d_recv || count < 0) return fail(ctx, VK_E_ARG, "vk_comm_allgather_async: NULL buffer or negative count");
   auto ag = (fn_allgather)dlsym(ctx->rccl_lib, "ncclAllGather");
   if (!ag) return fail(ctx, VK_E_RCCL, "ncclAllGather not found");
   const int kNcclDouble = 8;  // ncclFloat64 in rccl.h
@@ -1675,8 +1676,10 @@ int vk_comm_allgather_group_async(vk_ctx* const* ctxs, int32_t n, const double* 
                                   int64_t count) {
   if (!ctxs || n < 1 || !ctxs[0] || !d_send || !d_recv || count < 0) return VK_E_ARG;
   vk_ctx* lead = ctxs[0];
-  for (int i = 0; i < n; ++i)
+  for (int i = 0; i < n; ++i) {
     if (!ctxs[i] || !ctxs[i]->comm) return fail(lead, VK_E_RCCL, "context %d has no communicator", i);
+    if (!d_send[i] || !d_recv[i]) return fail(lead, VK_E_ARG, "vk_comm_allgather_group_async: NULL buffer for context %d", i);
+  }
   auto ag = (fn_allgather)dlsym(lead->rccl_lib, "ncclAllGather");
   auto gs = (fn_group)dlsym(lead->rccl_lib, "ncclGroupStart");
   auto ge = (fn_group)dlsym(lead->rccl_lib, "ncclGroupEnd");
