@@ -184,7 +184,8 @@ def test_rmu_real_space_input_on_gpu(tmp_path, with_beta):
 
 @pytest.mark.parametrize("non_uniform_mu", [False, True])
 def test_anisotropic_sigma_v_template_on_gpu(tmp_path, non_uniform_mu):
-    """3-key sigma_v(r, mu) template (bicubic, box-clamped) through the generic kernels vs the oracle."""
+    """3-key sigma_v(r, mu) template (bicubic, box-clamped; uniform and non-uniform mu knots) vs the oracle: streaming model on
+    the fast kernels (patches in LDS, SVA instantiations), dispersion model on the generic kernel."""
     import sys
     import os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
@@ -195,12 +196,42 @@ def test_anisotropic_sigma_v_template_on_gpu(tmp_path, non_uniform_mu):
     fit = victor_amd.CCFFit(model, data)
     ora = vo.OracleFit(model, data)
     hp = cases.halton_params(40)
-    for i, kw in ((3, {}), (11, {"rsd_model": "dispersion"}), (29, {"assume_isotropic": True})):
+    for i, kw, kernel in ((3, {}, "vk_theory_fast_kernel"), (11, {"rsd_model": "dispersion"}, "vk_theory_kernel"),
+                          (29, {"assume_isotropic": True}, "vk_theory_fast_kernel")):
         p = cases.point(hp, i)
         got = fit.log_likelihood(dict(p), **kw)
         want = ora.log_likelihood(dict(p), **kw)
         assert abs(got[1] / want[1] - 1) < RTOL and abs(got[0] / want[0] - 1) < RTOL, (i, kw)
-    assert fit._get_engine().last_kernel() == "vk_theory_kernel"          # not a fast-path configuration
+        # streaming: the patches ride in LDS on the fast kernels (uniform r grid, lattice form); dispersion: generic kernel
+        assert fit._get_engine().last_kernel() == kernel, (kw, fit._get_engine().last_kernel())
+    # a batch through every mapping that can take it: oracle on a few rows, mapping against mapping on all of them
+    # (rows with |mu_r| beyond the template's box and r beyond its r range are clamped as FITPACK's bispeu does)
+    hb = cases.halton_params(600)
+    rows = fit._fit_rows(hb, fit.model)
+    res = {}
+    for mapping in ("point", "cells", "generic"):
+        env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
+        _native.set_knob(env, "1" if mapping == "generic" else mapping)
+        try:
+            res[mapping] = fit.theory_vector_batch(rows)
+            assert fit._get_engine().last_kernel().endswith(
+                {"point": "fast_kernel", "cells": "cells_kernel", "generic": "vk_theory_kernel"}[mapping]), mapping
+        finally:
+            _native.set_knob(env, None)
+    for i in (0, 17, 599):
+        want = ora.theory_multipole_vector(ora.s, cases.point(hb, i), ora.poles_s)
+        for mapping in res:
+            assert close(res[mapping][i], want), (mapping, i)
+    for mapping in ("cells", "generic"):
+        assert np.max(np.abs(res[mapping] - res["point"])) < 1e-10 * np.max(np.abs(res["point"])), mapping
+    fit.theory_vector_batch(rows)
+    assert fit._get_engine().last_kernel() == "vk_theory_cells_kernel"        # the default at this size
+    _native.set_knob("VICTOR_HIP_MAPPING", "lanes")                            # the lanes kernel cannot take it: generic
+    try:
+        fit.theory_vector_batch(rows[:64])
+        assert fit._get_engine().last_kernel() != "vk_theory_lanes_kernel"
+    finally:
+        _native.set_knob("VICTOR_HIP_MAPPING", None)
 
 
 def test_velocity_template_mean_model_on_gpu(tmp_path):

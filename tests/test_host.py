@@ -522,7 +522,7 @@ def test_no_kernel_of_the_library_spills(lib, tmp_path):
     spilling = [k for k, priv, _ in kernels if int(priv) > 0]
     assert not spilling, spilling
     for k, _, vgpr in kernels:
-        if "vk_theory_lanes_kernel" in k or ("vk_theory_cells_kernel" in k and k.endswith("Li0EEEvNS_10TheoryArgsE")):
+        if "vk_theory_lanes_kernel" in k or ("vk_theory_cells_kernel" in k and k.endswith("Li0ELi0EEEvNS_10TheoryArgsE")):   # MODE = streaming, SVA = 0
             assert int(vgpr) <= 96, (k, vgpr)          # 512 / 5 workgroups of four waves, in granules of 8
     # no static LDS in the fast theory kernels: their dynamic LDS then starts at address 0, which vkm::exp_gauss relies on
     # when it reads its table (at the start of dynamic LDS) with the byte offset as the address

@@ -50,10 +50,12 @@ __global__ __launch_bounds__(kBlock) void vk_image_kernel(TheoryArgs a, int kind
   extern __shared__ double lds[];
   for (int e = threadIdx.x; e < n; e += kBlock) lds[e] = 0.0;
   __syncthreads();
+  const int n_sva = (with_da & 2) ? a.sva_doubles : 0;        // bit 1: the SVA instantiation's layout
+  with_da &= 1;
   if (kind == 0) {
-    stage_fast<NLR>(a, make_fast_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, with_da, 0), lds, with_da != 0);
+    stage_fast<NLR>(a, make_fast_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, with_da, 0, n_sva), lds, with_da != 0);
   } else if (kind == 1) {
-    stage_cells<NLR>(a, make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, with_da, 64, 0), lds, with_da != 0);
+    stage_cells<NLR>(a, make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, with_da, 64, 0, n_sva), lds, with_da != 0);
   } else {
     stage_lanes<NLR>(a, make_lanes_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.uni_lut_n), lds);
   }
@@ -137,6 +139,8 @@ struct vk_ctx {
   const double *d_x1 = nullptr, *d_w1 = nullptr;  // single velocity node for the Kaiser-type models
   const double* d_vr_emp = nullptr;               // beta-dependent V2, Ge1, Ge2 (degree 6 in beta), see vk_tables.vr_emp
   const double* d_xws = nullptr;                  // [n_x + 1][2]: {kExpScale x_k, w_k} (point-major fast kernel)
+  const double* d_sva = nullptr;                  // anisotropic sigma_v block for the fast kernels (TheoryArgs::sva)
+  int sva_doubles = 0;
   const double* d_xgw = nullptr;                  // velocity nodes grouped by quadrature weight (TheoryArgs::xgw)
   double xw_max = 0.0;                            // max |kExpScale x_k|
   const double *d_s = nullptr, *d_mu = nullptr, *d_w = nullptr, *d_x = nullptr, *d_wx = nullptr, *d_beta_r = nullptr,
@@ -367,8 +371,30 @@ int launch_fast_ngf(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   return fail(ctx, VK_E_ARG, "n_ell must be 1..3 (or a VK_LITE development build)");
 }
 
+// anisotropic sigma_v(r, mu) template on the fast kernels (SVA instantiations): streaming model, lattice form
+template <int NLR>
+int launch_fast_sva(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
+  switch (a.n_ell) {
+    case 1: if constexpr (VK_LITE_KEEP(NLR, 1, 1, 0)) return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 1, 0, kModeStreaming, 1>, grid, lds, a); break;
+    case 2: if constexpr (VK_LITE_KEEP(NLR, 2, 1, 0)) return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 2, 0, kModeStreaming, 1>, grid, lds, a); break;
+    case 3: if constexpr (VK_LITE_KEEP(NLR, 3, 1, 0)) return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 3, 0, kModeStreaming, 1>, grid, lds, a); break;
+  }
+  return fail(ctx, VK_E_ARG, "n_ell must be 1..3 (or a VK_LITE development build)");
+}
+
+template <int NLR>
+int launch_cells_sva(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
+  switch (a.n_ell) {
+    case 1: if constexpr (VK_LITE_KEEP(NLR, 1, 1, 0)) return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 1, 0, kModeStreaming, 1>, grid, lds, a); break;
+    case 2: if constexpr (VK_LITE_KEEP(NLR, 2, 1, 0)) return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 2, 0, kModeStreaming, 1>, grid, lds, a); break;
+    case 3: if constexpr (VK_LITE_KEEP(NLR, 3, 1, 0)) return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 3, 0, kModeStreaming, 1>, grid, lds, a); break;
+  }
+  return fail(ctx, VK_E_ARG, "n_ell must be 1..3 (or a VK_LITE development build)");
+}
+
 template <int NLR, int GRID>
 int launch_fast_ng(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
+  if (a.sv_n_mu > 0) return launch_fast_sva<NLR>(ctx, a, grid, lds);
   if (a.rsd == VK_RSD_DISPERSION)
     return a.from_data ? launch_fast_ngf<NLR, GRID, kModeDispersionFromData>(ctx, a, grid, lds)
                        : launch_fast_ngf<NLR, GRID, kModeDispersion>(ctx, a, grid, lds);
@@ -408,6 +434,7 @@ int launch_cells_ngf(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
 
 template <int NLR, int GRID>
 int launch_cells_ng(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
+  if (a.sv_n_mu > 0) return launch_cells_sva<NLR>(ctx, a, grid, lds);
   if (a.rsd == VK_RSD_DISPERSION)
     return a.from_data ? launch_cells_ngf<NLR, GRID, kModeDispersionFromData>(ctx, a, grid, lds)
                        : launch_cells_ngf<NLR, GRID, kModeDispersion>(ctx, a, grid, lds);
@@ -447,6 +474,8 @@ int theory_args(vk_ctx* ctx, const vk_eval_opts* o, TheoryArgs* a, int* nlr) {
   a->sv_mu_inv_h = ctx->sv_mu_inv_h;
   a->sv_mu = ctx->d_sv_mu;
   a->sv2d = ctx->d_sv2d;
+  a->sva = ctx->d_sva;
+  a->sva_doubles = ctx->sva_doubles;
   a->uni_n = ctx->uni_n;
   a->uni_u0 = ctx->uni_u0;
   a->uni_inv_h = ctx->uni_inv_h;
@@ -491,9 +520,9 @@ int theory_args(vk_ctx* ctx, const vk_eval_opts* o, TheoryArgs* a, int* nlr) {
 
 // LDS image for launches on the context's own grid (NULL: the kernel stages entry by entry).  Built on first use, never
 // while the stream is being captured into a graph (the first, eager call of a shape has built it by then).
-const double* get_image(vk_ctx* ctx, const TheoryArgs& a, int kind, int nlr, bool with_da, int image_end) {
+const double* get_image(vk_ctx* ctx, const TheoryArgs& a, int kind, int nlr, bool with_da, int image_end, bool sva = false) {
   if (!a.stage_mu || image_end <= 0) return nullptr;
-  const int key = kind * 100 + nlr * 10 + (with_da ? 1 : 0);
+  const int key = kind * 100 + nlr * 10 + (with_da ? 1 : 0) + (sva ? 2 : 0);
   auto hit = ctx->images.find(key);
   if (hit != ctx->images.end()) return hit->second;
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
@@ -505,15 +534,15 @@ const double* get_image(vk_ctx* ctx, const TheoryArgs& a, int kind, int nlr, boo
   switch (nlr) {
     case 1:
       if (lds > 64 * 1024) ok = hipFuncSetAttribute(reinterpret_cast<const void*>(vk_image_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-      if (ok) hipLaunchKernelGGL(vk_image_kernel<1>, dim3(1), dim3(kBlock), lds, ctx->stream, a, kind, with_da ? 1 : 0, img, image_end);
+      if (ok) hipLaunchKernelGGL(vk_image_kernel<1>, dim3(1), dim3(kBlock), lds, ctx->stream, a, kind, (with_da ? 1 : 0) | (sva ? 2 : 0), img, image_end);
       break;
     case 2:
       if (lds > 64 * 1024) ok = hipFuncSetAttribute(reinterpret_cast<const void*>(vk_image_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-      if (ok) hipLaunchKernelGGL(vk_image_kernel<2>, dim3(1), dim3(kBlock), lds, ctx->stream, a, kind, with_da ? 1 : 0, img, image_end);
+      if (ok) hipLaunchKernelGGL(vk_image_kernel<2>, dim3(1), dim3(kBlock), lds, ctx->stream, a, kind, (with_da ? 1 : 0) | (sva ? 2 : 0), img, image_end);
       break;
     default:
       if (lds > 64 * 1024) ok = hipFuncSetAttribute(reinterpret_cast<const void*>(vk_image_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-      if (ok) hipLaunchKernelGGL(vk_image_kernel<3>, dim3(1), dim3(kBlock), lds, ctx->stream, a, kind, with_da ? 1 : 0, img, image_end);
+      if (ok) hipLaunchKernelGGL(vk_image_kernel<3>, dim3(1), dim3(kBlock), lds, ctx->stream, a, kind, (with_da ? 1 : 0) | (sva ? 2 : 0), img, image_end);
       break;
   }
   if (!ok || hipGetLastError() != hipSuccess) {
@@ -559,7 +588,11 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
   const bool disp = a.rsd == VK_RSD_DISPERSION &&
                     (a.vr_beta_dep ? (a.uni_dab && (!a.empirical || a.uni_empb)) : (a.uni_da && (!a.empirical || a.uni_ge)));
   const bool emp_ok = !a.empirical || (a.vr_beta_dep ? a.uni_empb != nullptr : a.uni_v2 != nullptr);
-  const bool fast = (a.rsd == VK_RSD_STREAMING || disp) && ctx->fast_ok && emp_ok &&
+  // anisotropic sigma_v(r, mu): its bicubic patches ride in LDS for the streaming model on the lattice form (SVA instantiations)
+  const bool sva = a.sv_n_mu > 0;
+  const bool sva_ok = !sva || (a.sva_doubles > 0 && a.rsd == VK_RSD_STREAMING && !a.from_data && a.uni_lut_n == 0);
+  const int n_sva = sva ? a.sva_doubles : 0;
+  const bool fast = (a.rsd == VK_RSD_STREAMING || disp) && ctx->fast_ok && emp_ok && sva_ok &&
                     a.n_mu <= 1024 && a.n_x <= 2048 && !ctx->knobs.force_generic;
   // chi-square inside the theory kernel: point-major and cells kernels only, up to fuse_max points (A/B: DESIGN.md section 5)
   // A/B (tools/gpu_small_batch_ab.py, config 3 / BOSS, resident): the fused launch wins up to ~256 points (64 points: 41.2 vs
@@ -578,7 +611,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
   const long long cap = (ctx->knobs.point_cap > 0 ? ctx->knobs.point_cap : kDefaultCap) * ctx->n_cu;
   // lanes-over-batch variant: batch-constant tables and enough points to fill the chip with n_s * n/64 waves
   const int mapping = ctx->knobs.mapping;                           // VICTOR_HIP_MAPPING: 0 = choose by batch size
-  const bool lanes_ok = fast && a.n_beta_r == 0 && !a.empirical && !a.from_data && !disp;   // per-point tables need a workgroup per point
+  const bool lanes_ok = fast && a.n_beta_r == 0 && !a.empirical && !a.from_data && !disp && !sva;   // per-point tables need a workgroup per point
   // One wave per (s bin, 64-point chunk), one workgroup per four of them; 5 workgroups are resident per CU.  Every item
   // runs for ~0.6 ms, so the launch ends with a ragged tail about one residency round long, while the cells kernel
   // (one workgroup per point, 2.20-2.25 M evals/s on config 3 from 2000 points on) has none: measured, the lanes kernel
@@ -652,10 +685,10 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
     a.cells_per_item = cpi;
     a.fuse = want_fuse ? 1 : 0;
     const bool tail = a.fuse || R > 1;
-    const CellsPlan plc = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, disp, cpi, tail ? N : 0);
+    const CellsPlan plc = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, disp, cpi, tail ? N : 0, n_sva);
     const size_t lds_c = (size_t)plc.total * sizeof(double);
     if (lds_c > 160 * 1024) return fail(ctx, VK_E_ARG, "tables need %zu bytes of LDS (> 160 KiB)", lds_c);
-    a.image = get_image(ctx, a, 1, nlr, disp, plc.image_end);
+    a.image = get_image(ctx, a, 1, nlr, disp, plc.image_end, sva);
     const long long items_c = a.n * R;
     const int grid_c = (int)((tail || items_c < cap) ? items_c : cap);     // fused / split launches: one item per workgroup
     if (fused) *fused = a.fuse != 0;
@@ -673,10 +706,10 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
     const bool need_counters = groups * a.parts > 1;
     a.fuse = want_fuse && (!need_counters || a.n <= kCounterCap) ? 1 : 0;   // counters[point] exists for point < kCounterCap only
     const bool tail = a.fuse || a.parts > 1;
-    const FastPlan plf = make_fast_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, disp, tail ? N : 0);
+    const FastPlan plf = make_fast_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, disp, tail ? N : 0, n_sva);
     const size_t lds = (size_t)plf.total * sizeof(double);
     if (lds > 160 * 1024) return fail(ctx, VK_E_ARG, "tables need %zu bytes of LDS (> 160 KiB)", lds);
-    a.image = get_image(ctx, a, 0, nlr, disp, plf.image_end);
+    a.image = get_image(ctx, a, 0, nlr, disp, plf.image_end, sva);
     const long long items = a.n * groups * a.parts;
     const int grid = (int)((tail || items < cap) ? items : cap);            // fused / split launches: one item per workgroup
     if (fused) *fused = a.fuse != 0;
@@ -939,7 +972,11 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
   {
     // the fast theory kernels need the unified tables: either the uniform-lattice form (uniform, commensurate knot
     // sets sharing the r grid between xi and V) or the union-grid form (any knots) located through a look-up table
-    bool ok = (!t->vr_beta_dep || t->uni_vb) && t->sv_n_mu == 0 && t->uni_n > 0 && t->uni_sv_v && t->uni_xi && t->uni_xic &&
+    // an anisotropic sigma_v(r, mu) template rides along as bicubic patches when its r grid is uniform, the unified tables are in
+    // lattice form and the patches fit beside them in LDS (48 KB)
+    const bool sva_fits = t->sv_n_mu == 0 || (t->sv.inv_h > 0 && t->sv.lead == 0 && t->uni_lut_n == 0 &&
+                                              (size_t)t->sv.n_int * (t->sv_n_mu - 1) * 16 + t->sv_n_mu <= 6144);
+    bool ok = (!t->vr_beta_dep || t->uni_vb) && sva_fits && t->uni_n > 0 && t->uni_sv_v && t->uni_xi && t->uni_xic &&
               t->xi.knots[0] > t->vr.knots[0] && t->sv.knots[0] >= t->vr.knots[0];
     if (ok && t->uni_lut_n > 0) {
       ok = t->uni_lut && t->uni_knots && t->uni_lut_n <= 4097 && t->uni_n < 4096 && t->uni_lut_inv_g > 0 &&
@@ -1012,10 +1049,24 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
   const size_t o_vre = have_vr_emp ? up.add(t->vr_emp, (size_t)3 * (t->n_beta_r - 1) * t->vr.n_int * 28) : 0;
   const size_t o_svk = up.add(t->sv.knots, t->sv.n_int + 1),
                o_svc = up.add(t->sv.coef, t->sv_n_mu ? 4 : (size_t)t->sv.n_int * 4);   // 1-D coefficients unused with sv2d
-  size_t o_svmu = 0, o_sv2d = 0;
+  size_t o_svmu = 0, o_sv2d = 0, o_sva = 0;
   if (t->sv_n_mu) {
     o_svmu = up.add(t->sv_mu, t->sv_n_mu);
     o_sv2d = up.add(t->sv2d, (size_t)t->sv.n_int * (t->sv_n_mu - 1) * 16);
+    if (ctx->fast_ok) {
+      // the same patches for the fast kernels: powers of the r interval's local coordinate in [0, 1) instead of (u - knot),
+      // followed by the mu knots - one contiguous block that the kernels copy into LDS
+      const int nm = t->sv_n_mu - 1;
+      const double h = 1.0 / t->sv.inv_h;
+      std::vector<double> blk((size_t)t->sv.n_int * nm * 16 + t->sv_n_mu);
+      for (size_t e = 0; e < (size_t)t->sv.n_int * nm * 16; ++e) {
+        const int pw = (int)((e >> 2) & 3);                        // [i][j][p][q]: coefficient of (u - x_i)^p (mu - mu_j)^q
+        blk[e] = t->sv2d[e] * (pw == 0 ? 1.0 : pw == 1 ? h : pw == 2 ? h * h : h * h * h);
+      }
+      for (int k = 0; k < t->sv_n_mu; ++k) blk[(size_t)t->sv.n_int * nm * 16 + k] = t->sv_mu[k];
+      o_sva = up.add(blk.data(), blk.size());
+      ctx->sva_doubles = (int)blk.size();
+    }
   }
   size_t o_usv = 0, o_uxi = 0, o_uxc = 0, o_ulut = 0, o_uk = 0, o_uvb = 0, o_uv2 = 0, o_uda = 0, o_uge = 0, o_udab = 0, o_uempb = 0;
   const bool have_lut = t->uni_n > 0 && t->uni_lut_n > 0 && t->uni_lut && t->uni_knots;
@@ -1115,6 +1166,7 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
   if (t->sv_n_mu) {
     ctx->d_sv_mu = base + o_svmu;
     ctx->d_sv2d = base + o_sv2d;
+    if (ctx->sva_doubles) ctx->d_sva = base + o_sva;
   }
   {
     // batch-independent staging tables + bookkeeping of the split / fused launches

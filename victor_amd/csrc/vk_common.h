@@ -80,6 +80,9 @@ struct TheoryArgs {
   double sv_mu_inv_h;
   const double* sv_mu;
   const double* sv2d;
+  const double* sva;      // anisotropic sigma_v(r, mu) for the fast kernels: [sv.n_int][sv_n_mu-1][4][4] patches in powers of the
+                          // r-interval's local coordinate in [0, 1) and of (mu - mu_j), followed by the sv_n_mu mu knots (built in vk_create)
+  int sva_doubles;        // length of that block (0: not available)
   int uni_n;              // unified refined grid (vk_tables.uni_*): one interval index for sigma_v, V1, xi^r_l
   double uni_u0, uni_inv_h;
   const double* uni_sv_v;

@@ -22,14 +22,14 @@ namespace vk {
 //               64-point batch fill the chip.
 // --------------------------------------------------------------------------------------------------
 struct CellsPlan {
-  int mu, w, s, betar, da, v1, image_end, acc, like, total;
+  int mu, w, s, betar, da, v1, sva, image_end, acc, like, total;
 };
 
 // s bins a range of `cpi` cells can touch
 __host__ __device__ inline int cells_range_bins(int n_mu, int cpi) { return (cpi + n_mu - 2) / n_mu + 1; }
 
 __host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s, int uni_n, int nlr, int n_beta_r,
-                                                     int lut_n, int with_da, int cpi, int n_like) {
+                                                     int lut_n, int with_da, int cpi, int n_like, int n_sva = 0) {
   CellsPlan p;
   int o = fast_fixed_doubles(uni_n, nlr, lut_n);          // exp table + records first (fixed offsets)
   o = (o + 1) & ~1;
@@ -40,6 +40,7 @@ __host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s,
   p.da = o;    o += with_da ? uni_n * 4 : 0;      // Da table of the dispersion model
   p.v1 = o;    o += with_da ? 0 : uni_n * 4;      // unscaled V1 cubics (streaming modes, see scale_uni_v)
   o = (o + 1) & ~1;
+  p.sva = o;   o += (n_sva + 1) & ~1;             // anisotropic sigma_v patches + mu knots (SVA instantiations)
   p.image_end = o;                                 // batch-constant up to here (LDS image, see vk_kernel_fast.h)
   int bins = cells_range_bins(n_mu, cpi);
   if (bins > n_s) bins = n_s;
@@ -66,6 +67,8 @@ __device__ __forceinline__ void stage_cells(const TheoryArgs& a, const CellsPlan
   else for (int e = tid; e < a.uni_n * 4; e += kBlock) lds[pl.v1 + e] = a.uni_sv_v[(e >> 2) * 8 + 4 + (e & 3)];
   if (a.n_beta_r > 0)
     for (int i = tid; i < a.n_beta_r; i += kBlock) lds[pl.betar + i] = a.beta_r[i];
+  if (pl.image_end > pl.sva)
+    for (int e = tid; e < a.sva_doubles; e += kBlock) lds[pl.sva + e] = a.sva[e];
 }
 
 // The workgroup that completed a point whose cells were split into ranges: add every (l, s bin)'s partials in range order,
@@ -92,8 +95,8 @@ __device__ __forceinline__ void finish_point_ranges(const TheoryArgs& a, long lo
 
 // 5 workgroups per CU for the streaming mode (<= 96 VGPRs); the from_data and dispersion modes need more registers and
 // run 4 per CU without spills
-template <int NLR, int NL, int GRID, int MODE>
-__global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_theory_cells_kernel(TheoryArgs a) {
+template <int NLR, int NL, int GRID, int MODE, int SVA = 0>
+__global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 5 : 4) void vk_theory_cells_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
   vkm::clamp_keeps_nan();
   warm_kernarg_lines<sizeof(TheoryArgs)>();
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
   const int cpi = a.cells_per_item;
   const bool tail = a.fuse || R > 1;
   CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, mode_is_dispersion(MODE), cpi,
-                                 tail ? N : 0);
+                                 tail ? N : 0, SVA ? a.sva_doubles : 0);
   // the offset behind the accumulators depends on an integer division by n_mu, which the compiler evaluates on the vector ALU:
   // wave-uniform, but held - and once spilled - as a vector register unless it is made a scalar here
   pl.like = __builtin_amdgcn_readfirstlane(pl.like);
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
   if (a.image) copy_image(lds, a.image, pl.image_end);
   else stage_cells<NLR>(a, pl, lds, mode_is_dispersion(MODE));
   constexpr bool kHalf = !mode_is_dispersion(MODE);       // streaming modes: half units (vk_kernel_fast.h: FastPoint)
-  const FastConsts fc = make_fast_consts<NLR>(a, kHalf);
+  const FastConsts fc = make_fast_consts<NLR>(a, kHalf, SVA ? pl.sva : 0);
   __syncthreads();
   VK_STAMP(a, 1);
 
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
         for (int k = 0; k < a.n_x; ++k) {
           const vk_d2 xw = cxg[k];
           double inv_sv;
-          const double p = uni_point<NLR, GRID, MODE == kModeFromData, 1, 0>(lds, fc, 0.0, fma(-xw.x, fp.Bk, s_par), sperp2, xw.x, fp.fa,
+          const double p = uni_point<NLR, GRID, MODE == kModeFromData, 1, 0, 0, SVA>(lds, fc, 0.0, fma(-xw.x, fp.Bk, s_par), sperp2, xw.x, fp.fa,
                                                                             sperp2x, 0u, inv_sv);
           gs = fma(inv_sv, p, gs);
           if (__double2hiint(xw.y) != 0) {            // wave-uniform: a scalar branch, taken at the last node of a group
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 5 : 4) void vk_the
         for (int k = 0; k < a.n_x; ++k) {
           const vk_d2 xw = cxg[k];
           double inv_sv;
-          const double p = uni_point<NLR, GRID, MODE == kModeFromData, 1, 1>(lds, fc, 0.0, fma(-xw.x, fp.Bk, s_par), sperp2, xw.x, fp.fa,
+          const double p = uni_point<NLR, GRID, MODE == kModeFromData, 1, 1, 0, SVA>(lds, fc, 0.0, fma(-xw.x, fp.Bk, s_par), sperp2, xw.x, fp.fa,
                                                                             sperp2x, 0u, inv_sv);
           gs = fma(inv_sv, p, gs);
           if (__double2hiint(xw.y) != 0) {            // wave-uniform: a scalar branch, taken at the last node of a group

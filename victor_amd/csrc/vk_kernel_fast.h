@@ -50,6 +50,10 @@ struct FastConsts {
   double rlo2, rhi2;              // the clamped coordinate stays inside (t_lo, n_eps) while rlo2 <= X < rhi2 (cell_in_table),
                                   // X = r'^2 (full units) or r'^2 / 4 (half units, the streaming modes)
   int lut_off;                    // GRID 1: byte offset of the look-up table in LDS
+  // SVA (anisotropic sigma_v(r, mu) template, bicubic patches in LDS; lattice form only)
+  double sv_a, sv_b, sv_tmax;     // interval coordinate on the sigma_v r grid: ts = r' sv_a + sv_b, clamped to [0, sv_tmax]
+  double mu_lo, mu_hi, mu_inv_h;  // mu box of the template; mu_inv_h > 0: uniform mu knots
+  int sva_off, svmu_off, sv_nm;   // byte offsets of the patches and of the mu knots in LDS; mu intervals
 };
 
 // v_min_f64 / v_max_f64 without the canonicalising v_max hipcc puts in front of fmin()/fmax() for a bound it cannot
@@ -77,9 +81,23 @@ __device__ __forceinline__ double cubic_b128(const double* rec, double t) {
 
 // HALF: the caller works in half units (every length times k/2, see uni_point), so the squares it tests are r'^2 / 4
 template <int NLR, int EXPT = 0>
-__device__ __forceinline__ FastConsts make_fast_consts(const TheoryArgs& a, bool half) {
+__device__ __forceinline__ FastConsts make_fast_consts(const TheoryArgs& a, bool half, int sva_off_doubles = 0) {
   FastConsts fc;
   const double sq = half ? 0.25 : 1.0;
+  fc.sv_a = fc.sv_b = fc.sv_tmax = fc.mu_lo = fc.mu_hi = fc.mu_inv_h = 0.0;
+  fc.sva_off = fc.svmu_off = fc.sv_nm = 0;
+  if (a.sv_n_mu > 0 && a.sva_doubles > 0 && a.uni_lut_n == 0) {
+    // r' (index units of the unified lattice) -> interval coordinate of the template's own uniform r grid
+    fc.sv_a = a.sv.inv_h / a.uni_inv_h;
+    fc.sv_b = -a.sv.knots[0] * a.sv.inv_h;
+    fc.sv_tmax = (double)a.sv.n_int * (1.0 - 0x1p-52);
+    fc.sv_nm = a.sv_n_mu - 1;
+    fc.mu_lo = a.sv_mu[0];
+    fc.mu_hi = a.sv_mu[fc.sv_nm];
+    fc.mu_inv_h = a.sv_mu_inv_h;
+    fc.sva_off = sva_off_doubles * 8;
+    fc.svmu_off = (sva_off_doubles + a.sv.n_int * fc.sv_nm * 16) * 8;
+  }
   if (a.uni_lut_n > 0) {
     fc.inv_h = 1.0;
     fc.off = 0.0;
@@ -307,6 +325,30 @@ __device__ __forceinline__ const double* locate(const double* __restrict__ lds, 
   return rec;
 }
 
+// sigma_v(r, mu_r) / sigma_v of the 3-key anisotropic template (ccf_model.py:271-277, 654-655): the tensor-product
+// not-a-knot spline of RectBivariateSpline as bicubic patches in LDS, both arguments clamped to the template's box as FITPACK's
+// bispeu does (a negative mu_r reads mu = mu_0).  `rp` = r' in index units of the unified lattice, `mu2` = 2 mu_r.
+__device__ __forceinline__ double sv_aniso(const double* __restrict__ lds, const FastConsts& fc, double rp, double mu2) {
+  const double ts = vmin_f64(vmax_f64(fma(rp, fc.sv_a, fc.sv_b), 0.0), fc.sv_tmax);
+  const double du = __builtin_amdgcn_fract(ts);
+  const int i = (int)ts;
+  const double m = vmin_f64(vmax_f64(0.5 * mu2, fc.mu_lo), fc.mu_hi);
+  const double* muk = lds_at(lds, fc.svmu_off);
+  int j;
+  if (fc.mu_inv_h > 0.0) {
+    j = min((int)((m - fc.mu_lo) * fc.mu_inv_h), fc.sv_nm - 1);
+  } else {
+    j = 0;
+    for (int k = 1; k < fc.sv_nm; ++k) j += (m >= muk[k]) ? 1 : 0;
+  }
+  const double dm = m - muk[j];
+  const double* c = lds_at(lds, fc.sva_off + (i * fc.sv_nm + j) * 128);
+  double acc = cubic_b128(c + 12, dm);
+  acc = fma(acc, du, cubic_b128(c + 8, dm));
+  acc = fma(acc, du, cubic_b128(c + 4, dm));
+  return fma(acc, du, cubic_b128(c, dm));
+}
+
 // One integrand point of the streaming model (ccf_model.py:648-657, 681-690): returns p = (1 + xi^r) exp(-z^2/2) and
 // 1/SV in `inv_sv`; the caller accumulates inv_sv * p (times the velocity node's weight, taken per weight group where the
 // node loop is wave-uniform).  HALF units (see FastPoint): `num` = r_par'/2, `sperp2` = s_perp'^2/4, `AVh` = AVk/2 (or
@@ -321,7 +363,8 @@ __device__ __forceinline__ const double* locate(const double* __restrict__ lds, 
 // fa = c/apar, fp = c/aperp (`sperp2x` carries the second product), through a second interval look-up.
 // PV = 1: the V cubics in the records already carry the per-point factor AVh (the kernels that own a point per workgroup
 // rescale them once per work item, scale_uni_v) - one multiply less per integrand point.
-template <int NLR, int GRID, int FD, int PV = 0, int CL = 1, int EXPT = 0>
+// SVA = 1: sigma_v from the anisotropic template's bicubic patches (sv_aniso) instead of the record's cubic; lattice form only.
+template <int NLR, int GRID, int FD, int PV = 0, int CL = 1, int EXPT = 0, int SVA = 0>
 __device__ __forceinline__ double uni_point(const double* __restrict__ lds, const FastConsts& fc, double AVh,
                                             double num, double sperp2, double xk, double fa, double sperp2x,
                                             unsigned lane_off, double& inv_sv) {
@@ -331,8 +374,9 @@ __device__ __forceinline__ double uni_point(const double* __restrict__ lds, cons
   double mu_x = mu2;                            // (twice) the mu at which xi^r is read
   double tq;
   int qi;
-  const double* rec = locate<NLR, GRID, CL, EXPT>(lds, fc, GRID == 0 ? fma(X, yy, fc.off) : X * yy, tq, qi);
-  const double SV = cubic_b128(rec, tq);
+  const double rp = SVA ? X * yy : 0.0;
+  const double* rec = locate<NLR, GRID, CL, EXPT>(lds, fc, GRID == 0 ? (SVA ? rp + fc.off : fma(X, yy, fc.off)) : X * yy, tq, qi);
+  const double SV = SVA ? sv_aniso(lds, fc, rp, mu2) : cubic_b128(rec, tq);
   const double V = cubic_b128(rec + 4, tq);
   const double ynum = PV ? fma(V, mu2, xk) : fma(AVh * V, mu2, xk);
   if (FD) {
@@ -492,11 +536,12 @@ __device__ __forceinline__ void copy_image(double* lds, const double* __restrict
 }
 
 struct FastPlan {
-  int murec, xrec, betar, da, v1, image_end, red, like, total;
+  int murec, xrec, betar, da, v1, sva, image_end, red, like, total;
 };
 
+// n_sva: doubles of the anisotropic sigma_v block (TheoryArgs::sva_doubles) for the SVA instantiations, else 0
 __host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int uni_n, int nlr, int n_beta_r, int lut_n,
-                                                   int with_da, int n_like) {
+                                                   int with_da, int n_like, int n_sva = 0) {
   FastPlan p;
   int o = fast_fixed_doubles(uni_n, nlr, lut_n);   // exp table + records first (fixed offsets)
   o = (o + 1) & ~1;
@@ -506,6 +551,7 @@ __host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int uni_n,
   p.da = o;    o += with_da ? uni_n * 4 : 0;  // Da table of the dispersion model
   p.v1 = o;    o += with_da ? 0 : uni_n * 4;  // unscaled V1 cubics (streaming modes: the records hold AVk * V, see scale_uni_v)
   o = (o + 1) & ~1;
+  p.sva = o;   o += (n_sva + 1) & ~1;         // anisotropic sigma_v patches + mu knots
   p.image_end = o;                            // everything up to here is batch-constant (or rebuilt per point)
   p.red = o;   o += kWaves * kMaxEll;
   o = (o + 1) & ~1;
@@ -537,17 +583,20 @@ __device__ __forceinline__ void stage_fast(const TheoryArgs& a, const FastPlan& 
   else for (int e = tid; e < a.uni_n * 4; e += kBlock) lds[pl.v1 + e] = a.uni_sv_v[(e >> 2) * 8 + 4 + (e & 3)];
   if (a.n_beta_r > 0)
     for (int i = tid; i < a.n_beta_r; i += kBlock) lds[pl.betar + i] = a.beta_r[i];
+  if (pl.image_end > pl.sva)
+    for (int e = tid; e < a.sva_doubles; e += kBlock) lds[pl.sva + e] = a.sva[e];
 }
 
-template <int NLR, int NL, int GRID, int MODE>
-__global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 3 : 2) void vk_theory_fast_kernel(TheoryArgs a) {
+template <int NLR, int NL, int GRID, int MODE, int SVA = 0>
+__global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 3 : 2) void vk_theory_fast_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
   vkm::clamp_keeps_nan();
   warm_kernarg_lines<sizeof(TheoryArgs)>();
   const int N = a.n_ell * a.n_s;
   const int Q = a.parts;
   const bool tail = a.fuse || Q > 1;
-  const FastPlan pl = make_fast_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, mode_is_dispersion(MODE), tail ? N : 0);
+  const FastPlan pl = make_fast_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, mode_is_dispersion(MODE), tail ? N : 0,
+                                     SVA ? a.sva_doubles : 0);
   const int tid = threadIdx.x;
   VK_STAMP(a, 0);
   // The first work item's per-point scalars (parameter row from global memory, AP integral, reciprocals: a serial chain
@@ -561,7 +610,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 3 : 2) void vk_the
   if (a.image) copy_image(lds, a.image, pl.image_end);
   else stage_fast<NLR>(a, pl, lds, mode_is_dispersion(MODE));
   constexpr bool kHalf = !mode_is_dispersion(MODE);       // streaming modes: half units (FastPoint)
-  const FastConsts fc = make_fast_consts<NLR>(a, kHalf);
+  const FastConsts fc = make_fast_consts<NLR>(a, kHalf, SVA ? pl.sva : 0);
   __syncthreads();
   VK_STAMP(a, 1);
 
@@ -625,7 +674,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming ? 3 : 2) void vk_the
             f = xw.y * disp_value<NLR, GRID, MODE == kModeDispersionFromData>(lds, lds + pl.da, fc, fp, a.niter, num, s_par, sperp2, xw.x);
           } else {
             double inv_sv;
-            const double p = uni_point<NLR, GRID, MODE == kModeFromData, 1>(lds, fc, 0.0, num, sperp2, xw.x, fp.fa, sperp2 * fp.fp2, 0u, inv_sv);
+            const double p = uni_point<NLR, GRID, MODE == kModeFromData, 1, 1, 0, SVA>(lds, fc, 0.0, num, sperp2, xw.x, fp.fa, sperp2 * fp.fp2, 0u, inv_sv);
             f = (xw.y * inv_sv) * p;
           }
           const vk_d2 w01 = *reinterpret_cast<const vk_d2*>(mr + 2);

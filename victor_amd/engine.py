@@ -128,7 +128,9 @@ def build_tables(model, fit=None, matter_model=None, simpson_even=None):
     # r and r_sv grids: the lattice form (index arithmetic).  Anything else: the union-grid form (look-up table).
     t.uni_n = 0
     t.uni_lut_n = 0
-    if t.sv_n_mu == 0 and r[0] > r_ext[0] and model.r_for_sv[0] >= r_ext[0]:
+    # (an anisotropic sigma_v(r, mu) template keeps its bicubic patches in `sv2d`; the sigma_v half of the unified records then
+    # holds the mu = mu_0 row and is not read by the kernels that take the patches)
+    if r[0] > r_ext[0] and model.r_for_sv[0] >= r_ext[0]:
         grid = None
         if t.xi.inv_h > 0 and t.sv.inv_h > 0 and t.vr.inv_h > 0:
             cr = T.common_refinement(r, model.r_for_sv)
