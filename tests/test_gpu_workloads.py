@@ -496,6 +496,30 @@ def test_one_process_driving_several_contexts():
     multi.close()
 
 
+def test_grouped_rccl_gather_of_one_process_at_one_context():
+    """The RCCL calls of the one-process layout - ncclCommInitAll, ncclGroupStart / ncclAllGather / ncclGroupEnd on the context's
+    stream (vk_comm_init_all, vk_comm_allgather_group_async) - with the one context a one-GPU box allows: MultiGPUFit's gathered
+    evaluation (shard upload, launch, grouped all-gather, download from device 0) against the plain batch API, for sizes around
+    the padding and buffer-growth edges; a second device entry for the same GPU is refused without calling RCCL."""
+    import victor_amd
+    from victor_amd.sharding import MultiGPUFit
+    opts = cases.boss_options("config")
+    multi = MultiGPUFit(*opts, devices=[0])
+    assert multi.enable_rccl() is True, getattr(multi, "_rccl_error", "")
+    single = victor_amd.CCFFit(*opts)
+    for n in (1, 63, 64, 65, 3000):
+        hp = cases.halton_params(n, with_beta=True)
+        got = multi.log_likelihood_gathered(hp)
+        want = single.log_likelihood_batch(hp)[0]
+        assert got.shape == (n,) and np.array_equal(got, want), n
+    multi.close()
+    shared = MultiGPUFit(*opts, devices=[0, 0])
+    assert shared.enable_rccl() is False and "share device" in shared._rccl_error
+    hp = cases.halton_params(101, with_beta=True)
+    assert np.max(np.abs(shared.log_likelihood_gathered(hp) / single.log_likelihood_batch(hp)[0] - 1)) < 1e-11     # host fallback
+    shared.close()
+
+
 def test_c_abi_rejects_bad_calls_without_crashing():
     """Error conventions of the boundary: NULL handles and buffers, negative sizes, unknown option values and grids the
     kernels cannot take all come back as VK_E_ARG with a message - nothing is launched."""
