@@ -14,6 +14,8 @@ __global__ __launch_bounds__(1024) void rate(double* out, unsigned long long* cy
   int iv[CHAINS];
   for (int c = 0; c < CHAINS; ++c) { v[c] = seed + 0.001 * (threadIdx.x + c); iv[c] = threadIdx.x + c; }
   const double k1 = seed * 0.999, k2 = seed * 1e-3;
+  const int kinv = (int)(seed * 77) + threadIdx.x, kinv2 = kinv * 3;
+  const unsigned long long smask = __builtin_amdgcn_ballot_w64((threadIdx.x & 1) != 0);
   unsigned long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
@@ -38,6 +40,16 @@ __global__ __launch_bounds__(1024) void rate(double* out, unsigned long long* cy
       if (OP == 17) asm volatile("v_cmp_gt_f64 vcc, %0, %1" :: "v"(v[c]), "v"(k1) : "vcc");
       if (OP == 18) asm volatile("v_and_b32 %0, %1, %2" : "=v"(iv[c]) : "v"(iv[c]), "v"(iv[(c + 1) % CHAINS]));
       if (OP == 19) asm volatile("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(iv[c]) : "v"(iv[c]), "v"(iv[(c + 1) % CHAINS]));
+      if (OP == 20) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(iv[c]), "+v"(iv[(c + 1) % CHAINS]));
+      if (OP == 21) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(iv[c]), "+v"(iv[(c + 1) % CHAINS]));
+      if (OP == 22) asm volatile("s_nop 1\n v_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(iv[c]) : "v"(iv[(c + 1) % CHAINS]));
+      if (OP == 23) asm volatile("s_nop 1\n v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(iv[c]) : "v"(iv[(c + 1) % CHAINS]));
+      if (OP == 24) asm volatile("s_nop 1\n v_mov_b32_dpp %0, %1 row_bcast:31 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(iv[c]) : "v"(iv[(c + 1) % CHAINS]));
+      if (OP == 25) asm volatile("v_swap_b32 %0, %1" : "+v"(iv[c]), "+v"(iv[(c + 1) % CHAINS]));
+      if (OP == 26) asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(iv[c]) : "v"(iv[c]), "v"(iv[(c + 1) % CHAINS]), "s"(smask));
+      if (OP == 27) asm volatile("v_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(iv[c]) : "v"(kinv));
+      if (OP == 28) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(iv[c]) : "v"(kinv), "v"(kinv2));
+      if (OP == 29) asm volatile("s_nop 1\n v_add_u32 %0, %1, %2" : "=v"(iv[c]) : "v"(iv[c]), "v"(iv[(c + 1) % CHAINS]));
     }
   }
   unsigned long long t1 = __builtin_readcyclecounter();
@@ -58,7 +70,7 @@ double run(const char* name, double* d_out, unsigned long long* d_cyc, int block
   avg /= blocks;
   // one block = 16 waves = 4 per SIMD; each wave issues ITERS*CHAINS instructions
   double per = avg / (4.0 * ITERS * CHAINS);
-  printf("%-16s %7.2f cycles per wave-instruction per SIMD\n", name, per);
+  printf("%-32s %7.2f cycles per wave-instruction per SIMD\n", name, per);
   return per;
 }
 
@@ -88,6 +100,16 @@ int main() {
     run<17>("v_cmp_gt_f64", d_out, d_cyc, blocks);
     run<18>("v_and_b32", d_out, d_cyc, blocks);
     run<19>("v_lshl_add_u32", d_out, d_cyc, blocks);
+    run<20>("v_permlane32_swap", d_out, d_cyc, blocks);
+    run<21>("v_permlane16_swap", d_out, d_cyc, blocks);
+    run<22>("dpp row_ror:8 (+s_nop 1)", d_out, d_cyc, blocks);
+    run<23>("dpp quad_perm (+s_nop 1)", d_out, d_cyc, blocks);
+    run<24>("dpp row_bcast:31 (+s_nop 1)", d_out, d_cyc, blocks);
+    run<25>("v_swap_b32", d_out, d_cyc, blocks);
+    run<26>("v_cndmask_b32_e64 (sgpr mask)", d_out, d_cyc, blocks);
+    run<27>("dpp mov, no hazard", d_out, d_cyc, blocks);
+    run<28>("v_cndmask_b32 vcc, no dep", d_out, d_cyc, blocks);
+    run<29>("s_nop 1 + v_add_u32", d_out, d_cyc, blocks);
   }
   return 0;
 }

@@ -188,6 +188,21 @@ __device__ __forceinline__ double clampd(double u, double lo, double hi) { retur
 
 __device__ __forceinline__ double wave_sum(double v) { return vkm::wave_sum(v); }
 
+// One entry of TheoryArgs::xgw - {x'_k, weight of the group that ends with node k, else 0} - read through the scalar cache.
+// The four dwords are loaded as integers so that "is this the last node of its group" stays a 32-bit scalar compare on the
+// weight's high word (as a test on the double the compiler forms a 64-bit compare, which gfx950 only has on the vector ALU).
+struct VelocityNode { double x, w; int last; };
+__device__ __forceinline__ VelocityNode load_node(const double* xgw, int k) {
+  typedef int node_words __attribute__((ext_vector_type(4)));
+  typedef const node_words __attribute__((address_space(4))) * node_ptr;
+  const node_words q = ((node_ptr)(unsigned long long)xgw)[k];
+  VelocityNode n;
+  n.x = __hiloint2double(q.y, q.x);
+  n.w = __hiloint2double(q.w, q.z);
+  n.last = q.w;
+  return n;
+}
+
 // The kernel-argument struct spans ten 64-byte lines and the compiler fetches its fields where it first needs them (they
 // are rematerialised rather than kept in SGPRs), so a workgroup meets the lines one at a time: up to ten dependent
 // round trips from the scalar cache to L2 spread over its serial path.  Touch every line once at kernel entry - all loads in

@@ -41,6 +41,29 @@ __device__ __forceinline__ double wave_sum(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// Transposing reductions for several sums at once (the cells kernel's projection).  v_permlane32_swap / v_permlane16_swap
+// (new on gfx950) exchange half-waves / odd and even rows of two registers, so that one addition folds TWO values at once:
+//   fold32(x, y): lanes 0-31 hold x[L] + x[L + 32], lanes 32-63 hold y[L - 32] + y[L]
+//   fold16(x, y): rows 0 and 2 hold x's row pairs (0 + 1, 2 + 3), rows 1 and 3 hold y's
+// i.e. three instructions per stage for two values where the DPP chain spends three per value.
+__device__ __forceinline__ double fold32(double x, double y) {
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double fold16(double x, double y) {
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// sum over the eight lanes of an octet, in every lane of it
+__device__ __forceinline__ double octet_sum(double v) {
+  v += dpp_move<0x141, 0xF, true>(v);   // row_half_mirror
+  v += dpp_move<0xB1, 0xF, true>(v);    // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E, 0xF, true>(v);    // quad_perm [2,3,0,1]
+  return v;
+}
+
 // g ~ sqrt(x), returns also ir ~ 1/sqrt(x).  x must be a positive normal number (r^2 of a separation in
 // Mpc/h); x = 0 gives NaN, which is what the reference's r_par / r produces there too.
 // One third-order (Halley-type) step from the 2^-24 hardware seed: y' = y (1 + e/2 + 3e^2/8), e = 1 - x y^2,

@@ -93,6 +93,42 @@ __device__ __forceinline__ void finish_point_ranges(const TheoryArgs& a, long lo
   if (a.fuse) like_point_workgroup(a.like, point, beta, th, th + ((N + 1) & ~1));
 }
 
+// Projection of one trip: sum_lanes W_l[i] g over the lanes of the trip's first s bin and over those of its second, for every
+// l, added to the wave's accumulators (acc: this wave's entry of the first bin for l = 0; `lstride` doubles from one l to
+// the next, kWaves from a bin to the next).  The 2 NL sums are folded together (fold32, fold16: two values per addition) down
+// to rows of 16 lanes, the rows to octets with one exchange, the octets by DPP: 50 vector instructions for NL = 3 where six
+// full-wave DPP chains took 150.  Lane -> sum it ends up with (NL = 3): bits 5, 4, 3 of the lane = (second bin, l & 1, l == 2).
+template <int NL>
+__device__ __forceinline__ void project_trip(double g, bool first, bool second, const double* w_i, int n_mu, double* acc, int lstride, int lane) {
+  const double ga = first ? g : 0.0, gb = second ? g : 0.0;
+  double z[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    const double w = w_i[l * n_mu];
+    z[l] = vkm::fold32(w * ga, w * gb);               // lanes 0-31: first bin, 32-63: second bin
+  }
+  double x;
+  int l_mine;
+  bool mine;
+  const int row = lane >> 4;
+  if (NL == 3) {
+    const double u = vkm::fold16(z[0], z[1]);          // rows: (l 0, bin 0), (l 1, bin 0), (l 0, bin 1), (l 1, bin 1)
+    const double v = vkm::fold16(z[2], 0.0);           // rows 0 and 2: l = 2; rows 1 and 3: zero
+    const bool up = (lane & 8) != 0;                   // the upper octet of a row keeps v, the lower one u
+    const double keep = up ? v : u, send = up ? u : v;
+    x = keep + vkm::dpp_move<0x128, 0xF, true>(send);  // row_ror:8: from the lane eight away, which keeps the other one
+    l_mine = up ? 2 : (row & 1);
+    mine = (lane & 7) == 0 && !(up && (row & 1));
+  } else {
+    x = vkm::fold16(z[0], NL == 2 ? z[NL - 1] : 0.0);
+    x += vkm::dpp_move<0x128, 0xF, true>(x);
+    l_mine = row & 1;
+    mine = (lane & 15) == 0 && (NL == 2 || !(row & 1));
+  }
+  x = vkm::octet_sum(x);
+  if (mine) acc[l_mine * lstride + (lane >> 5) * kWaves] += x;
+}
+
 // 5 workgroups per CU for the streaming mode (<= 96 VGPRs); the from_data and dispersion modes need more registers and
 // run 4 per CU without spills
 template <int NLR, int NL, int GRID, int MODE, int SVA = 0>
@@ -122,8 +158,6 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 5 : 4) voi
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: a scalar register, not one VGPR per lane
   const double* l_mu = lds + pl.mu;
   const double* l_w = lds + pl.w;
-  typedef const vk_d2 __attribute__((address_space(4))) * cvec_ptr;
-  const cvec_ptr cxg = (cvec_ptr)(unsigned long long)a.xgw;    // velocity nodes in groups of equal weight (see the lanes kernel), scalar-cache reads
   const double* l_s = lds + pl.s;
   const int slots = min(cells_range_bins(a.n_mu, cpi), a.n_s) + 1;   // local bins of a range (+ one that only ever receives zeros)
   double* l_acc = lds + pl.acc;                              // [l][local bin][wave]: each entry touched by one wave only
@@ -166,56 +200,45 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 5 : 4) voi
       double gs = 0.0;
       if (mode_is_dispersion(MODE)) {
         for (int k = 0; k < a.n_x; ++k) {
-          const vk_d2 xw = cxg[k];
+          const VelocityNode xw = load_node(a.xgw, k);
           gs += disp_value<NLR, GRID, MODE == kModeDispersionFromData>(lds, lds + pl.da, fc, fp, a.niter, fma(-xw.x, fp.Bk, s_par), s_par,
                                                                      sperp2, xw.x);
-          if (__double2hiint(xw.y) != 0) {            // wave-uniform: a scalar branch, taken at the last node of a group
+          if (xw.last != 0) {            // wave-uniform: a scalar branch, taken at the last node of a group
             asm volatile("" ::: "memory");            // (keeps the compiler from turning it into per-lane selects)
-            g = fma(xw.y, gs, g);
+            g = fma(xw.w, gs, g);
             gs = 0.0;
           }
         }
       } else if (inside) {
         for (int k = 0; k < a.n_x; ++k) {
-          const vk_d2 xw = cxg[k];
+          const VelocityNode xw = load_node(a.xgw, k);
           double inv_sv;
           const double p = uni_point<NLR, GRID, MODE == kModeFromData, 1, 0, 0, SVA>(lds, fc, 0.0, fma(-xw.x, fp.Bk, s_par), sperp2, xw.x, fp.fa,
                                                                             sperp2x, 0u, inv_sv);
           gs = fma(inv_sv, p, gs);
-          if (__double2hiint(xw.y) != 0) {            // wave-uniform: a scalar branch, taken at the last node of a group
+          if (xw.last != 0) {            // wave-uniform: a scalar branch, taken at the last node of a group
             asm volatile("" ::: "memory");            // (keeps the compiler from turning it into per-lane selects)
-            g = fma(xw.y, gs, g);
+            g = fma(xw.w, gs, g);
             gs = 0.0;
           }
         }
       } else {
         for (int k = 0; k < a.n_x; ++k) {
-          const vk_d2 xw = cxg[k];
+          const VelocityNode xw = load_node(a.xgw, k);
           double inv_sv;
           const double p = uni_point<NLR, GRID, MODE == kModeFromData, 1, 1, 0, SVA>(lds, fc, 0.0, fma(-xw.x, fp.Bk, s_par), sperp2, xw.x, fp.fa,
                                                                             sperp2x, 0u, inv_sv);
           gs = fma(inv_sv, p, gs);
-          if (__double2hiint(xw.y) != 0) {            // wave-uniform: a scalar branch, taken at the last node of a group
+          if (xw.last != 0) {            // wave-uniform: a scalar branch, taken at the last node of a group
             asm volatile("" ::: "memory");            // (keeps the compiler from turning it into per-lane selects)
-            g = fma(xw.y, gs, g);
+            g = fma(xw.w, gs, g);
             gs = 0.0;
           }
         }
       }
-      if (!live) g = 0.0;
       // projection: this trip's cells belong to local bin jj0 or jj0 + 1 (the latter may be the spill bin)
       const int jj0 = __builtin_amdgcn_readfirstlane(jj);
-      const bool first = (jj == jj0);
-#pragma unroll
-      for (int l = 0; l < NL; ++l) {
-        const double v = l_w[l * a.n_mu + i] * g;
-        const double s0 = wave_sum(first ? v : 0.0);
-        const double s1 = wave_sum(first ? 0.0 : v);
-        if (lane == 0) {
-          l_acc[(l * slots + jj0) * kWaves + wave] += s0;
-          l_acc[(l * slots + jj0 + 1) * kWaves + wave] += s1;
-        }
-      }
+      project_trip<NL>(g, live && jj == jj0, live && jj != jj0, l_w + i, a.n_mu, l_acc + jj0 * kWaves + wave, slots * kWaves, lane);
     }
     // this range's share of the theory vector is complete in LDS once every wave has finished its trips
     __syncthreads();

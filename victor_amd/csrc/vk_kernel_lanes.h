@@ -110,8 +110,6 @@ __global__ __launch_bounds__(kBlock, VK_LANES_WG_PER_CU) void vk_theory_lanes_ke
   const double* l_smu = lds + pl.smu;
   // velocity nodes through the scalar cache: wave-uniform, read-only for the whole launch (constant address space
   // tells the compiler so), which keeps them out of the VALU and LDS pipes
-  typedef const vk_d2 __attribute__((address_space(4))) * cvec_ptr;
-  const cvec_ptr cxg = (cvec_ptr)(unsigned long long)a.xgw;
   const long long chunks = (a.n + 63) >> 6;
   const long long items = chunks * a.n_s;
   // XCD-aware block order: the n_s waves of a 64-point chunk read the same 6 KB of parameter rows; consecutive
@@ -158,14 +156,14 @@ __global__ __launch_bounds__(kBlock, VK_LANES_WG_PER_CU) void vk_theory_lanes_ke
       // (a wave-uniform test on a scalar register) - one multiply per group instead of one per integrand point
       double gs = 0.0;
 #define VK_GROUP_END(xw)                                                                                                  \
-  if (__double2hiint((xw).y) != 0) {            /* wave-uniform: a scalar branch, taken at the last node of a group */   \
+  if ((xw).last != 0) {            /* wave-uniform: a scalar branch, taken at the last node of a group */   \
     asm volatile("" ::: "memory");              /* (keeps the compiler from turning it into per-lane selects) */        \
-    g = fma((xw).y, gs, g);                                                                                               \
+    g = fma((xw).w, gs, g);                                                                                               \
     gs = 0.0;                                                                                                             \
   }
       if (inside) {
         for (int k = 0; k < a.n_x; ++k) {
-          const vk_d2 xw = cxg[k];
+          const VelocityNode xw = load_node(a.xgw, k);
           double inv_sv;
           const double p = uni_point<NLR, GRID, 0, 0, 0, EXPT>(lds, fc, fp.AVk, fma(-xw.x, fp.Bk, s_par), sperp2, xw.x, 0.0, 0.0, lane_off, inv_sv);
           gs = fma(inv_sv, p, gs);
@@ -173,7 +171,7 @@ __global__ __launch_bounds__(kBlock, VK_LANES_WG_PER_CU) void vk_theory_lanes_ke
         }
       } else {
         for (int k = 0; k < a.n_x; ++k) {
-          const vk_d2 xw = cxg[k];
+          const VelocityNode xw = load_node(a.xgw, k);
           double inv_sv;
           const double p = uni_point<NLR, GRID, 0, 0, 1, EXPT>(lds, fc, fp.AVk, fma(-xw.x, fp.Bk, s_par), sperp2, xw.x, 0.0, 0.0, lane_off, inv_sv);
           gs = fma(inv_sv, p, gs);
