@@ -210,8 +210,10 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 5 : 4) voi
           }
         }
       } else if (inside) {
+        VelocityNode nxt = load_node(a.xgw, 0);
         for (int k = 0; k < a.n_x; ++k) {
-          const VelocityNode xw = load_node(a.xgw, k);
+          const VelocityNode xw = nxt;
+          nxt = load_node(a.xgw, k + 1);            // one node ahead (the table has n_x + 1 entries)
           double inv_sv;
           const double p = uni_point<NLR, GRID, MODE == kModeFromData, 1, 0, 0, SVA>(lds, fc, 0.0, fma(-xw.x, fp.Bk, s_par), sperp2, xw.x, fp.fa,
                                                                             sperp2x, 0u, inv_sv);
@@ -223,8 +225,10 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 5 : 4) voi
           }
         }
       } else {
+        VelocityNode nxt = load_node(a.xgw, 0);
         for (int k = 0; k < a.n_x; ++k) {
-          const VelocityNode xw = load_node(a.xgw, k);
+          const VelocityNode xw = nxt;
+          nxt = load_node(a.xgw, k + 1);            // one node ahead (the table has n_x + 1 entries)
           double inv_sv;
           const double p = uni_point<NLR, GRID, MODE == kModeFromData, 1, 1, 0, SVA>(lds, fc, 0.0, fma(-xw.x, fp.Bk, s_par), sperp2, xw.x, fp.fa,
                                                                             sperp2x, 0u, inv_sv);
