@@ -20,7 +20,7 @@ opts = eng.make_opts(fit.model, fit.fit_options)
 bufs = [eng.alloc(rows.size), eng.alloc(batch), eng.alloc(batch), eng.alloc(batch * eng.n_data)]
 eng.upload(bufs[0], rows)
 lib = _native.load()
-stamps = np.zeros((4096, 8), dtype=np.int64)
+stamps = np.zeros((4096, 16), dtype=np.int64)
 acc = []
 for rep in range(60):
     eng.eval_device_async(opts, bufs[0], batch, bufs[1], bufs[2], bufs[3])
@@ -36,11 +36,15 @@ for rep in range(60):
     last = np.nanargmax(us[:, 5]) if np.any(~np.isnan(us[:, 5])) else None
     acc.append([live.sum(), np.nanmax(us[:, 0]), np.nanmedian(us[:, 1] - us[:, 0]), np.nanmedian(us[:, 2] - us[:, 1]),
                 np.nanmedian(us[:, 3] - us[:, 2]), np.nanmedian(us[:, 4] - us[:, 3]), np.nanmax(us[:, 4]),
-                np.nanmax(us[:, 5] - us[:, 4]), np.nanmax(us[:, 5])])
+                np.nanmax(us[:, 5] - us[:, 4]), np.nanmax(us[:, 5]), np.nanmax(us[:, 6] - us[:, 4]) if np.any(s[:, 6] > 0) else np.nan])
 # distribution over the workgroups of the last repetition: start, integrand phase, end of the integrand phase
 pc = lambda v: " / ".join(f"{x:.1f}" for x in np.nanpercentile(v, [0, 10, 50, 90, 100]))   # noqa: E731
 print(f"  workgroup start {pc(us[:, 0])}; integrand phase {pc(us[:, 3] - us[:, 2])}; integrand done at {pc(us[:, 3])}  (min / p10 / median / p90 / max, us)")
+fin = int(np.nanargmax(us[:, 5]))
+marks = us[fin, [4, 6, 8, 9, 10, 11, 12, 5]]
+print("  finishing workgroup, us after its counter mark: partial sums gathered %.2f | chi2 entry %.2f | beta searches done %.2f | residual in LDS %.2f | "
+      "quadratic form %.2f | block sum %.2f | results stored %.2f" % tuple(marks[1:] - marks[0]))
 a = np.median(np.array(acc), axis=0)
 print(f"{which} batch {batch}: workgroups {a[0]:.0f}; last workgroup starts at {a[1]:.2f} us; per workgroup (median): staging {a[2]:.2f}, "
       f"point set-up {a[3]:.2f}, integrand + projection {a[4]:.2f}, completion counter {a[5]:.2f}; all counters done at {a[6]:.2f}; "
-      f"tail (gather + chi2) {a[7]:.2f}; kernel end (last mark) at {a[8]:.2f} us")
+      f"tail (gather + chi2) {a[7]:.2f} (of which the gather of the partial sums {a[9]:.2f}); kernel end (last mark) at {a[8]:.2f} us")

@@ -144,7 +144,7 @@ struct vk_ctx {
   const double* d_xgw = nullptr;                  // velocity nodes grouped by quadrature weight (TheoryArgs::xgw)
   double xw_max = 0.0;                            // max |kExpScale x_k|
   const double *d_s = nullptr, *d_mu = nullptr, *d_w = nullptr, *d_x = nullptr, *d_wx = nullptr, *d_beta_r = nullptr,
-               *d_beta_d = nullptr, *d_data = nullptr, *d_beta_c = nullptr, *d_prec = nullptr, *d_logdet = nullptr,
+               *d_beta_d = nullptr, *d_data = nullptr, *d_beta_c = nullptr, *d_prec = nullptr, *d_tri = nullptr, *d_logdet = nullptr,
                *d_eig = nullptr;
   PPView xi{}, vr{}, sv{};
   bool fast_ok = false;      // tables qualify for vk_theory_fast_kernel
@@ -575,8 +575,8 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
 #ifdef VK_PHASES
   {
     static long long* d_stamps = nullptr;
-    if (!d_stamps) (void)hipMalloc((void**)&d_stamps, 4096 * 8 * sizeof(long long));
-    (void)hipMemsetAsync(d_stamps, 0, 4096 * 8 * sizeof(long long), ctx->stream);
+    if (!d_stamps) (void)hipMalloc((void**)&d_stamps, 4096 * 16 * sizeof(long long));
+    (void)hipMemsetAsync(d_stamps, 0, 4096 * 16 * sizeof(long long), ctx->stream);
     a.stamps = d_stamps;
     g_stamps = d_stamps;
   }
@@ -607,6 +607,9 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
                                                      : (a.n <= kFuseMaxDefault || (like && like->n_beta_c > 0 && a.n >= kFuseBlendedMin));
   const bool want_fuse = like && !ctx->knobs.no_fuse && fuse_by_size && like_lds_doubles(N) * sizeof(double) <= 32 * 1024;
   if (like) a.like = *like;
+#ifdef VK_PHASES
+  a.like.stamps = a.stamps;
+#endif
   const long long kDefaultCap = 256;                                // VICTOR_HIP_POINT_CAP: workgroups per CU in the launch
   const long long cap = (ctx->knobs.point_cap > 0 ? ctx->knobs.point_cap : kDefaultCap) * ctx->n_cu;
   // lanes-over-batch variant: batch-constant tables and enough points to fill the chip with n_s * n/64 waves
@@ -749,6 +752,7 @@ void fill_like_args(const vk_ctx* ctx, const vk_eval_opts* o, const double* d_pa
   a->n_beta_c = ctx->n_beta_c;
   a->beta_c = ctx->d_beta_c;
   a->prec = ctx->d_prec;
+  a->tri = ctx->d_tri;
   a->logdet = ctx->d_logdet;
   a->eig = ctx->d_eig;
   a->like_form = o->like_form;
@@ -860,10 +864,10 @@ extern "C" {
 int vk_abi_version(void) { return VK_ABI_VERSION; }
 
 #ifdef VK_PHASES
-// profiling build only: wall_clock64() marks (100 MHz) of the last point-major launch, [4096][8]
+// profiling build only: wall_clock64() marks (100 MHz) of the last point-major launch, [4096][16]
 int vk_debug_read_stamps(long long* out) {
   if (!g_stamps) return VK_E_ARG;
-  return hipMemcpy(out, g_stamps, 4096 * 8 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? VK_OK : VK_E_HIP;
+  return hipMemcpy(out, g_stamps, 4096 * 16 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? VK_OK : VK_E_HIP;
 }
 #endif
 
@@ -1122,6 +1126,30 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
       o_prec = up.add(t->prec, (size_t)N * N);
     }
   }
+  // the quadratic form of every precision slice folded onto its upper triangle, two triangle rows per "combined row" of
+  // M + 1 entries (+ 1 of padding), M = N rounded up to even (a zero row and column for an odd N): what the fused tail and
+  // the wide K2 read (vk_kernel_like.h: LikePrefetch), half the bytes of the slice
+  size_t o_tri = 0;
+  const bool have_tri = t->data != nullptr;
+  if (have_tri) {
+    const int slices = t->n_beta_c > 0 ? t->n_beta_c : 1;
+    const int M = (N + 1) & ~1, half = M / 2, W = M + 2;
+    std::vector<double> tri((size_t)slices * half * W, 0.0);
+    for (int sl = 0; sl < slices; ++sl) {
+      const double* P = t->prec + (size_t)sl * N * N;
+      auto fold = [&](int i, int j) {
+        if (i >= N || j >= N) return 0.0;
+        return i == j ? P[(size_t)i * N + i] : P[(size_t)i * N + j] + P[(size_t)j * N + i];
+      };
+      for (int c = 0; c < half; ++c) {
+        double* row = tri.data() + ((size_t)sl * half + c) * W;
+        for (int j = c; j < M; ++j) row[j - c] = fold(c, j);                        // triangle row c: entries [0, M - c)
+        const int i = M - 1 - c;
+        for (int j = i; j < M; ++j) row[(M - c) + (j - i)] = fold(i, j);            // triangle row M - 1 - c: the next c + 1 entries
+      }
+    }
+    o_tri = up.add(tri.data(), tri.size());
+  }
   const size_t bytes = up.host.size() * sizeof(double);
   if ((rc = hipMalloc((void**)&ctx->d_tables, bytes)) != hipSuccess) return hip_bail(rc, "hipMalloc(tables)");
   if ((rc = hipMemcpy(ctx->d_tables, up.host.data(), bytes, hipMemcpyHostToDevice)) != hipSuccess)
@@ -1200,6 +1228,7 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
     ctx->d_data = base + o_data;
     ctx->d_beta_c = t->n_beta_c > 0 ? base + o_bc : nullptr;
     ctx->d_prec = base + o_prec;
+    ctx->d_tri = have_tri ? base + o_tri : nullptr;
     ctx->d_logdet = t->n_beta_c > 0 ? base + o_ld : nullptr;
     ctx->d_eig = t->n_beta_c > 0 ? base + o_eig : nullptr;
   }

@@ -35,6 +35,7 @@ struct PPView {           // a vk_pp living in global memory (device pointers)
   const double* coef;
 };
 
+constexpr int kLikeRed = 4 * kWaves;     // doubles of reduction scratch behind the theory vector of a fused tail (4 sums x kWaves)
 struct LikeArgs {
   const double* params;
   const double* theory;   // [n][N]
@@ -46,12 +47,16 @@ struct LikeArgs {
   int n_beta_c;
   const double* beta_c;
   const double* prec;
+  const double* tri;      // [slices][M/2][M+2], M = N rounded up to even: every slice's quadratic form folded onto its upper triangle (vk_kernel_like.h)
   const double* logdet;
   const double* eig;
   int like_form;
   double nmocks, nparams;
   double* lnl;
   double* chi2;
+#ifdef VK_PHASES
+  long long* stamps;      // profiling build only: the theory kernel's marks (slots 8-12 belong to the fused tail)
+#endif
 };
 
 struct TheoryArgs {
@@ -127,12 +132,12 @@ struct TheoryArgs {
   double* partial;        // [n][n_s][parts][kMaxEll] partial projections (point-major, parts > 1)
   LikeArgs like;
 #ifdef VK_PHASES
-  long long* stamps;      // profiling build only (make phases): [workgroup][8] wall_clock64() marks of the point-major kernel
+  long long* stamps;      // profiling build only (make phases): [workgroup][16] wall_clock64() marks of the point-major kernel
 #endif
 };
 
 #ifdef VK_PHASES
-#define VK_STAMP(a, k) do { if ((a).stamps && threadIdx.x == 0 && blockIdx.x < 4096) (a).stamps[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#define VK_STAMP(a, k) do { if ((a).stamps && threadIdx.x == 0 && blockIdx.x < 4096) (a).stamps[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
 #else
 #define VK_STAMP(a, k) do { } while (0)
 #endif

@@ -73,11 +73,15 @@ __device__ __forceinline__ void stage_cells(const TheoryArgs& a, const CellsPlan
 
 // The workgroup that completed a point whose cells were split into ranges: add every (l, s bin)'s partials in range order,
 // publish the theory vector, take the chi-square.  `th`: LDS, see like_lds_doubles.
+// `gather` false: the point was this workgroup's alone and its theory vector is in `th` already (written, not yet synchronised).
 template <int NL>
-__device__ __forceinline__ void finish_point_ranges(const TheoryArgs& a, long long point, double beta, double poison, double* th) {
+__device__ __forceinline__ void finish_point_ranges(const TheoryArgs& a, long long point, double beta, double poison, double* th,
+                                                    bool gather) {
   const int N = a.n_ell * a.n_s;
   const double w0 = a.wsum[0], w1 = a.wsum[1], w2 = a.wsum[2];
-  for (int e = late_tid(); e < N; e += kBlock) {
+  LikePrefetch<kLikeRowsCells> pf;
+  if (a.fuse) pf.issue(a.like, beta, late_tid());      // travels with the gather (vk_kernel_like.h)
+  for (int e = late_tid(); gather && e < N; e += kBlock) {
     const int l = (e >= 2 * a.n_s) ? 2 : (e >= a.n_s ? 1 : 0), j = e - l * a.n_s;
     const int q_first = (j * a.n_mu) / a.cells_per_item, q_last = (j * a.n_mu + a.n_mu - 1) / a.cells_per_item;
     double part[8];
@@ -90,7 +94,7 @@ __device__ __forceinline__ void finish_point_ranges(const TheoryArgs& a, long lo
     th[e] = v;
   }
   __syncthreads();
-  if (a.fuse) like_point_workgroup(a.like, point, beta, th, th + ((N + 1) & ~1));
+  if (a.fuse) like_point_workgroup(a.like, point, beta, th, th + ((N + 1) & ~1), pf);
 }
 
 // Projection of one trip: sum_lanes W_l[i] g over the lanes of the trip's first s bin and over those of its second, for every
@@ -263,19 +267,15 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 5 : 4) voi
     VK_STAMP(a, 3);
     if (tail) {
       // fused / split launches run one item per workgroup and leave from here (see vk_kernel_fast.h)
-      if (R == 1) {
-        __syncthreads();
-        VK_STAMP(a, 4);
-        like_point_workgroup(a.like, point, row[VK_P_BETA], th, th + ((N + 1) & ~1));
+      bool last = true;
+      if (R > 1) {
+        int* flag = reinterpret_cast<int*>(th + ((N + 1) & ~1) + kLikeRed + 2);
+        last = point_completed(a.counters, point, (unsigned)R, flag);
+      }
+      VK_STAMP(a, 4);
+      if (last) {
+        finish_point_ranges<NL>(a, point, row[VK_P_BETA], ps.poison, th, R > 1);
         VK_STAMP(a, 5);
-      } else {
-        int* flag = reinterpret_cast<int*>(th + ((N + 1) & ~1) + kWaves + 2);
-        const bool last = point_completed(a.counters, point, (unsigned)R, flag);
-        VK_STAMP(a, 4);
-        if (last) {
-          finish_point_ranges<NL>(a, point, row[VK_P_BETA], ps.poison, th);
-          VK_STAMP(a, 5);
-        }
       }
       return;
     }

@@ -467,9 +467,9 @@ __device__ __forceinline__ void rebuild_da_emp(const TheoryArgs& a, double* da, 
 // is complete - in this workgroup's LDS, or in the global workspace after the last of the workgroups sharing the point
 // has finished (point_completed) - the same workgroup takes the chi-square and the log-likelihood
 // (like_point_workgroup), so a batch needs ONE launch and the theory vector makes no round trip through HBM before it
-// is used.  `th`: LDS, N doubles + kWaves + 4.
+// is used.  `th`: LDS, N doubles + kLikeRed + 4 (reduction scratch, completion flag).
 // --------------------------------------------------------------------------------------------------
-__host__ __device__ constexpr int like_lds_doubles(int N) { return ((N + 1) & ~1) + kWaves + 4; }
+__host__ __device__ constexpr int like_lds_doubles(int N) { return ((N + 1) & ~1) + kLikeRed + 4; }
 
 // partial projections of a split plane: [point][l][s bin][kMaxParts], the parts of one (l, s bin) adjacent (64 bytes)
 __device__ __forceinline__ double* partial_slot(double* partial, int n_s, long long point, int l, int j) {
@@ -485,6 +485,8 @@ __device__ __forceinline__ void finish_point(const TheoryArgs& a, long long poin
   const int N = a.n_ell * a.n_s;
   double* red = th + ((N + 1) & ~1);
   const double w0 = a.wsum[0], w1 = a.wsum[1], w2 = a.wsum[2];
+  LikePre pf;
+  if (a.fuse) pf.issue(a.like, beta, late_tid());      // everything the chi-square needs besides the theory vector travels with the gather
   for (int e = threadIdx.x; e < N; e += kBlock) {
     double v;
     if (gather_partials) {
@@ -502,7 +504,8 @@ __device__ __forceinline__ void finish_point(const TheoryArgs& a, long long poin
     th[e] = v;
   }
   __syncthreads();
-  if (a.fuse) like_point_workgroup(a.like, point, beta, th, red);
+  VK_STAMP(a, 6);
+  if (a.fuse) like_point_workgroup(a.like, point, beta, th, red, pf);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -726,7 +729,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 3 : 2) voi
       // Fused / split launches run ONE item per workgroup (the host sizes the grid so) and leave from here: nothing is
       // live after the tail, so its registers (the chi-square needs ~100) do not spill the state of the loop above.
       double* th = lds + pl.like;
-      int* flag = reinterpret_cast<int*>(th + ((N + 1) & ~1) + kWaves + 2);
+      int* flag = reinterpret_cast<int*>(th + ((N + 1) & ~1) + kLikeRed + 2);
       // a point owned by this workgroup alone needs no counter (and batches beyond the counter array have none): its theory
       // vector is re-read from L2 once this workgroup's own write-through stores have landed
       bool last = true;

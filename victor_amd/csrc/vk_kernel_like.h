@@ -9,13 +9,16 @@ namespace vk {
 // --------------------------------------------------------------------------------------------------
 // likelihood form (ccf_fit.py:455-473); `factor` = -1/2 log det of the covariance when it depends on beta, else 0
 __device__ __forceinline__ double like_form(const LikeArgs& a, double chisq, double factor) {
-  const double nm = a.nmocks;
+  double nm = a.nmocks, np = a.nparams, nd = (double)a.N;
+  // Everything below but chisq is the same for every point of a launch, and the compiler would evaluate it (four divisions) at
+  // the top of the kernel and carry the results through the theory loops - in registers those loops need.  One thread
+  // evaluates this once per point: keep it here.
+  asm volatile("" : "+v"(nm), "+v"(np), "+v"(nd));
   if (a.like_form == VK_LIKE_SELLENTIN) return -nm * log(1.0 + chisq / (nm - 1.0)) / 2.0 + factor;
-  if (a.like_form == VK_LIKE_HARTLAP) return -0.5 * chisq * ((nm - a.N - 2.0) / (nm - 1.0)) + factor;
+  if (a.like_form == VK_LIKE_HARTLAP) return -0.5 * chisq * ((nm - nd - 2.0) / (nm - 1.0)) + factor;
   if (a.like_form == VK_LIKE_PERCIVAL) {
-    const double nd = (double)a.N;
     const double B = (nm - nd - 2.0) / ((nm - nd - 1.0) * (nm - nd - 4.0));
-    const double m = a.nparams + 2.0 + (nm - 1.0 + B * (nd - a.nparams)) / (1.0 + B * (nd - a.nparams));
+    const double m = np + 2.0 + (nm - 1.0 + B * (nd - np)) / (1.0 + B * (nd - np));
     return -m * log(1.0 + chisq / (nm - 1.0)) / 2.0 + factor;
   }
   return -0.5 * chisq + factor;
@@ -84,149 +87,235 @@ __device__ __forceinline__ int block_count(bool pred, double* red) {
   return (int)s;
 }
 
-// sum_b (sum_{r in [r0, r1)} th[r] P[r][b]) th[b] over this lane's column pairs b = 2 lane, 2 lane + 128, ... (N even), with
-// P = (1-t) P0 + t P1 when BLEND.  The rows of a column pair are streamed through a rolling window of D 16-byte loads:
-// D in flight at any time, so the whole column costs one exposed round trip to L2 plus issue time, in 4 D registers.
-template <bool BLEND>
-__device__ __forceinline__ double like_quadratic(int N, const double* P0, const double* P1, double t, const double* th, int r0,
-                                                 int r1, int lane) {
-  typedef double d2 __attribute__((ext_vector_type(2)));
-  constexpr int D = BLEND ? 4 : 8;
-  const double omt = 1.0 - t;
-  const int rows = r1 - r0;
-  const unsigned stride = (unsigned)N * 8u;             // bytes; a slice is < 4 GB, so 32-bit byte offsets from its (uniform) base
-  const char* s0 = reinterpret_cast<const char*>(P0);
-  const char* s1 = reinterpret_cast<const char*>(P1);
-  double part = 0.0;
-  for (int b = 2 * lane; b < N; b += 128) {
-    unsigned next = ((unsigned)r0 * (unsigned)N + (unsigned)b) * 8u;   // byte offset of the next row to fetch
-    d2 p[D], q[D];
+// four sums over the workgroup in one pass (two barriers instead of eight); `red`: kLikeRed doubles
+__device__ __forceinline__ void block_sum4(double (&v)[4], double* red) {
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-      p[j] = d2{0.0, 0.0};
-      q[j] = d2{0.0, 0.0};
-      if (j < rows) {
-        p[j] = *reinterpret_cast<const d2*>(s0 + next);
-        if (BLEND) q[j] = *reinterpret_cast<const d2*>(s1 + next);
-        next += stride;
-      }
-    }
-    double y0 = 0.0, y1 = 0.0;
-    for (int base = 0; base < rows; base += D) {
+  for (int q = 0; q < 4; ++q) v[q] = wave_sum(v[q]);
+  __syncthreads();                       // `red` may still be read from a previous call
+  if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-      for (int j = 0; j < D; ++j) {
-        const int i = base + j;
-        const d2 cp = p[j], cq = q[j];
-        if (i + D < rows) {
-          p[j] = *reinterpret_cast<const d2*>(s0 + next);
-          if (BLEND) q[j] = *reinterpret_cast<const d2*>(s1 + next);
-          next += stride;
-        }
-        if (i < rows) {
-          const double w = th[r0 + i];
-          y0 = fma(w, BLEND ? omt * cp.x + t * cq.x : cp.x, y0);
-          y1 = fma(w, BLEND ? omt * cp.y + t * cq.y : cp.y, y1);
-        }
-      }
-    }
-    part = fma(y0, th[b], part);
-    part = fma(y1, th[b + 1], part);
+    for (int q = 0; q < 4; ++q) red[q * kWaves + (threadIdx.x >> 6)] = v[q];
   }
-  return part;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    double s = red[q * kWaves];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) s += red[q * kWaves + w];
+    v[q] = s;
+  }
 }
 
-// chi2 / lnL of ONE point by a whole workgroup (kBlock threads).  On entry `th` (LDS, N doubles) holds the point's theory
-// vector and the workgroup is synchronised; `th` is overwritten with the residual.  `red`: kWaves + 2 doubles of LDS.
-// Threads = (row slice, column pair): rows of the precision matrix split over the four waves, lanes over PAIRS of adjacent
-// columns (one 16-byte load serves two), rows streamed through a rolling window of loads (like_quadratic): one point's N^2
-// products cost about one round trip to L2, not the N / 64 * N of the wave-per-point kernel - this is what a batch of one
-// (the reference's calling convention, CCFLikelihood.py:32-39) needs.
-// ccf_fit.py:349-354 (chi2), :166-193 (data vector), :195-260 (bracket), :444-481 (log det, forms, guards).
-__device__ __forceinline__ void like_point_workgroup(const LikeArgs& a, long long point, double beta, double* th, double* red) {
-  typedef double d2 __attribute__((ext_vector_type(2)));
-  const int tid = late_tid();
-  const double inf = __longlong_as_double(0x7ff0000000000000LL);
-  // Interval searches on the (increasing) beta grids as counts over the threads - one grid value per thread, one
-  // barrier each - instead of loops whose loads the compiler keeps in program order (31 dependent round trips each for
-  // BOSS).  Grids longer than the workgroup fall back to the loops.
-  const bool by_count = a.n_beta_d <= kBlock && a.n_beta_c <= kBlock;
-  int k = 0;                              // PCHIP piece of the data vector: last i in [1, n-2] with beta >= beta_d[i], else 0
-  int lo = 0;
-  double t = 0.0;
-  if (by_count) {
-    if (a.n_beta_d > 0) k = block_count(tid >= 1 && tid < a.n_beta_d - 1 && beta >= a.beta_d[tid < a.n_beta_d ? tid : 0], red);
+// --------------------------------------------------------------------------------------------------
+// chi2 / lnL of ONE point by a whole workgroup (kBlock threads): the fused tail of the point-major and cells kernels and
+// the "wide" K2.  ccf_fit.py:349-354 (chi2), :166-193 (data vector), :195-260 (bracket), :444-481 (log det, forms, guards).
+//
+// A launch starts with cold L2s (each XCD's is invalidated at the kernel boundary), so every dependent load of the tail is
+// a trip to the memory side - ~0.9 us each on MI355X (tools/gpu_phases.py) - and a single-point launch, the reference's
+// calling convention (CCFLikelihood.py:32-39), is little else: partial sums, beta grids, data vector, precision slices and
+// log-det factors in sequence were 5-6 us of its 14.  The tail is therefore split in two:
+//   LikePrefetch::issue   everything that depends on beta alone - the interval searches, this thread's entry of the data
+//                         vector, the log-det factors of the blended covariance, the first rows of the quadratic form -
+//                         is requested BEFORE the theory vector is gathered, and travels with it;
+//   like_point_workgroup  residual, quadratic form, reductions, likelihood form, once the theory vector sits in LDS.
+//
+// The quadratic form on the folded triangle.  The host folds every precision slice onto its upper triangle, T_ii = P_ii,
+// T_ij = P_ij + P_ji (i < j), so that chi2 = sum_{i <= j} T_ij r_i r_j needs half the bytes, and stores row c of the triangle
+// (M - c entries) together with row M - 1 - c (c + 1 entries) as one "combined row" of M + 1 entries (+ one zero of padding):
+// M / 2 combined rows of EQUAL length, M = N rounded up to even (an odd N gets a zero row and column; vk_create).  Waves take
+// the combined rows round-robin, lanes the entry pairs (16-byte loads; more than 64 pairs - N > 126 - in chunks); RB rows
+// per lane are in flight (4 RB registers; blended slices: RB / 2 of each), the first RB from the prefetch: N = 120 costs one
+// exposed round trip more (the wave's last 7 rows), the full-matrix rolling window it replaces cost four.
+// --------------------------------------------------------------------------------------------------
+typedef double like_d2 __attribute__((ext_vector_type(2)));
+
+template <int RB>
+struct LikePrefetch {
+  int k, lo;              // PCHIP piece of the data vector; lower slice of the covariance bracket
+  double t;               // blend weight of the bracket (0: slice `lo` alone; NaN beta: NaN)
+  double db;              // beta - beta_d[k]
+  bool data_in_regs;      // N <= kBlock: this thread's data-vector entry is in c[]
+  double c[4];            // data-vector entry of element `tid`: PCHIP coefficients in db (fixed data vector: c[0] alone)
+  double ld, n_neg, n_bad;   // this thread's share of log|det| of the blended covariance, negative and zero / NaN factors
+  const double* T0;
+  const double* T1;
+  like_d2 rows[RB];       // t == 0: rows wave, wave + 4, ... of T0; else RB / 2 rows of T0, then the same rows of T1
+
+  // rows c0, c0 + kWaves, ... of this wave, entry pair e0 / 2 of this lane; M = N rounded up to even
+  template <bool BLEND>
+  __device__ __forceinline__ void load_rows(int M, int c0, int e0) {
+    constexpr int R = BLEND ? RB / 2 : RB;
+    const int half = M >> 1, W = M + 2;
+    const char* b0 = reinterpret_cast<const char*>(T0);   // a slice is far below 4 GB: 32-bit byte offsets from the uniform bases
+    const char* b1 = reinterpret_cast<const char*>(T1);
+    unsigned off = ((unsigned)c0 * (unsigned)W + (unsigned)e0) * 8u;
+    const unsigned stride = (unsigned)(kWaves * W) * 8u;
+#pragma unroll
+    for (int s = 0; s < R; ++s) {
+      const bool live = c0 + kWaves * s < half && e0 < W;
+      rows[s] = live ? *reinterpret_cast<const like_d2*>(b0 + off) : like_d2{0.0, 0.0};
+      if (BLEND) rows[R + s] = live ? *reinterpret_cast<const like_d2*>(b1 + off) : like_d2{0.0, 0.0};
+      off += stride;
+    }
+  }
+
+  // no barrier, no LDS traffic: may be called by every thread of the workgroup at any point before like_point_workgroup
+  __device__ __forceinline__ void issue(const LikeArgs& a, double beta, int tid) {
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    // Interval searches on the (increasing) beta grids as COUNTS: every wave counts the whole grid by itself, lanes over the
+    // grid values, a ballot per 64 of them - no barrier, the loads of both grids in flight together (loops over the grids
+    // cost 31 dependent round trips each for BOSS, counts over the workgroup six barriers).
+    const int lane = tid & 63;
+    k = 0;                                  // last i in [1, n-2] with beta >= beta_d[i], else 0
+    lo = 0;
+    t = 0.0;
+    int n_lt = 0, n_eq = 0;
+    const int n_max = max(a.n_beta_d, a.n_beta_c);
+    for (int base = 0; base < n_max; base += 64) {          // wave-uniform trip count (one trip for BOSS)
+      const int i = base + lane;
+      const double gd = (i < a.n_beta_d) ? a.beta_d[i] : inf;
+      const double gc = (i < a.n_beta_c) ? a.beta_c[i] : inf;
+      k += __popcll(__ballot(i >= 1 && i < a.n_beta_d - 1 && beta >= gd));
+      n_lt += __popcll(__ballot(i < a.n_beta_c && gc < beta));
+      n_eq += __popcll(__ballot(i < a.n_beta_c && gc == beta));
+    }
+    const int last = a.n_beta_c - 1;
     if (a.n_beta_c > 0) {
-      const double g = tid < a.n_beta_c ? a.beta_c[tid] : inf;
-      const int n_lt = block_count(tid < a.n_beta_c && g < beta, red);
-      const int n_eq = block_count(tid < a.n_beta_c && g == beta, red);
-      const int last = a.n_beta_c - 1;
       if (beta != beta) {
-        t = beta;                         // NaN beta: the blend weight of cov_bracket, i.e. the row reports (-inf, inf) in every K2 variant
+        t = beta;                           // NaN beta: the blend weight of cov_bracket, i.e. the row reports (-inf, inf) in every K2 variant
       } else if (n_lt == 0 && !n_eq) {
-        lo = 0;                           // below the grid: first slice
+        lo = 0;                             // below the grid: first slice
       } else if (n_lt == a.n_beta_c) {
-        lo = last;                        // above the grid: last slice
+        lo = last;                          // above the grid: last slice
       } else if (n_eq) {
-        lo = n_lt;                        // exact grid value (ccf_fit.py:221-222)
+        lo = n_lt;                          // exact grid value (ccf_fit.py:221-222)
       } else {
         lo = n_lt - 1;
         t = (beta - a.beta_c[lo]) / (a.beta_c[last] - a.beta_c[lo]);
       }
     }
-  } else {
-    for (int i = 1; i < a.n_beta_d - 1; ++i) k = (beta >= a.beta_d[i]) ? i : k;
-    if (a.n_beta_c > 0) cov_bracket(a, beta, &lo, &t);
+    // (first, while nothing else is held in registers: log() is register-hungry)
+    // log det of the blended covariance: det((1-t) C_lo + t C_last) = det(C_lo) prod_i (1 - t + t lambda_i), ccf_fit.py:445-451
+    ld = n_neg = n_bad = 0.0;
+    if (a.n_beta_c > 0 && t != 0.0) {
+      int neg = 0, bad = 0;
+      const double* ev = a.eig + (size_t)lo * a.N;
+      for (int e = tid; e < a.N; e += kBlock) ld += logdet_term(fma(t, ev[e], 1.0 - t), &neg, &bad);
+      n_neg = (double)neg;
+      n_bad = (double)bad;
+    }
+    // the first rows of the quadratic form
+    {
+      const int M = (a.N + 1) & ~1;
+      const size_t slice = (size_t)(M >> 1) * (M + 2);
+      T0 = a.tri + (a.n_beta_c > 0 ? (size_t)lo * slice : 0);
+      T1 = a.tri + (a.n_beta_c > 0 ? (size_t)last * slice : 0);
+      if (t != 0.0) load_rows<true>(M, tid >> 6, 2 * lane); else load_rows<false>(M, tid >> 6, 2 * lane);
+    }
+    // this thread's entry of the data vector (ccf_fit.py:166-193)
+    data_in_regs = a.N <= kBlock;
+    db = a.n_beta_d > 0 ? beta - a.beta_d[k] : 0.0;
+    c[0] = c[1] = c[2] = c[3] = 0.0;
+    if (data_in_regs && tid < a.N) {
+      if (a.n_beta_d > 0) {
+        const double* p = a.data + ((size_t)k * a.N + tid) * 4;
+        c[0] = p[0]; c[1] = p[1]; c[2] = p[2]; c[3] = p[3];
+      } else {
+        c[0] = a.data[tid];
+      }
+    }
   }
-  if (a.n_beta_d > 0) {
-    const double db = beta - a.beta_d[k];
-    const double* piece = a.data + (size_t)k * a.N * 4;
+
+  // sum_{i <= j} T_ij r_i r_j, this thread's share; `r` = residual in LDS, r[N] = 0 when N is odd.  The first batch of rows
+  // (of the first chunk of entry pairs) is in rows[] already (issue); further batches are loaded here, one exposed round trip
+  // each - N = 120: one more, 7 rows.  (Refilling a slot as soon as its row is consumed would hide that trip, but the
+  // loop-carried register array costs the cells kernel its 96-register budget: 141 registers measured.)
+  template <bool BLEND>
+  __device__ __forceinline__ double quadratic(const LikeArgs& a, const double* r, int tid) {
+    constexpr int R = BLEND ? RB / 2 : RB;
+    const int M = (a.N + 1) & ~1, half = M >> 1, W = M + 2;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double omt = 1.0 - t;
+    double part = 0.0;
+    for (int e0 = 2 * (tid & 63); e0 < W; e0 += 128) {     // one chunk of 64 entry pairs up to N = 126
+      // Entry e of combined row c is T[c][c + e] for e < M - c, else T[M-1-c][e - 1]: this lane's two entries are in the
+      // second triangle row from row c = M - e0 (resp. M - e0 - 1) on, where their column no longer depends on the row
+      const int first0 = M - e0, first1 = M - e0 - 1;
+      const double q0 = r[max(e0 - 1, 0)], q1 = r[min(e0, M - 1)];      // (entry 0 is never in a second row; entry M + 1 is the padding)
+      const double* rl = r + e0;
+      for (int base = wave; base < half; base += kWaves * R) {
+        if (e0 >= 128 || base != wave) load_rows<BLEND>(M, base, e0);
+#pragma unroll
+        for (int s = 0; s < R; ++s) {
+          const int c = base + kWaves * s;                   // wave-uniform
+          if (c < half) {
+            const double x = BLEND ? omt * rows[s].x + t * rows[R + s].x : rows[s].x;
+            const double y = BLEND ? omt * rows[s].y + t * rows[R + s].y : rows[s].y;
+            const double u1 = r[c], u2 = r[M - 1 - c];       // the factors of triangle rows c and M - 1 - c (broadcast reads)
+            const double v0 = rl[min(c, M - 1 - e0)], v1 = rl[min(c + 1, M - 1 - e0)];
+            part = fma(x, c < first0 ? u1 * v0 : u2 * q0, part);
+            part = fma(y, c < first1 ? u1 * v1 : u2 * q1, part);
+          }
+        }
+      }
+    }
+    return part;
+  }
+};
+
+constexpr int kLikeRows = 8;   // rows in flight in the point-major kernel and the wide K2, where the tail's latency is the launch's: N = 120
+                               // takes two batches per wave (8 + 7 rows); 16 would make it one, but the point-major kernel has 167
+                               // registers of 168 in use.  The cells kernel (96 registers, tail never latency-critical: it fuses
+                               // batches of 24-512 points) keeps 4 in flight.
+constexpr int kLikeRowsCells = 4;
+typedef LikePrefetch<kLikeRows> LikePre;
+
+#ifdef VK_PHASES
+#define VK_LIKE_STAMP(a, k) do { if ((a).stamps && threadIdx.x == 0 && blockIdx.x < 4096) (a).stamps[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define VK_LIKE_STAMP(a, k) do { } while (0)
+#endif
+
+// On entry `th` (LDS, N doubles) holds the point's theory vector, the workgroup is synchronised and `pf` was issued for
+// this point; `th` is overwritten with the residual.  `red`: kLikeRed doubles of LDS.
+template <int RB>
+__device__ __forceinline__ void like_point_workgroup(const LikeArgs& a, long long point, double beta, double* th, double* red,
+                                                     LikePrefetch<RB>& pf) {
+  const int tid = late_tid();
+  VK_LIKE_STAMP(a, 8);
+  const double inf = __longlong_as_double(0x7ff0000000000000LL);
+  const double t = pf.t;
+  const int lo = pf.lo;
+  // residual against the (beta-interpolated) data vector, ccf_fit.py:166-193, 323
+  if (pf.data_in_regs) {
+    if (tid < a.N) th[tid] -= fma(fma(fma(pf.c[3], pf.db, pf.c[2]), pf.db, pf.c[1]), pf.db, pf.c[0]);
+  } else if (a.n_beta_d > 0) {
+    const double* piece = a.data + (size_t)pf.k * a.N * 4;
     for (int e = tid; e < a.N; e += kBlock) {
       const double* c = piece + (size_t)e * 4;
-      th[e] -= fma(fma(fma(c[3], db, c[2]), db, c[1]), db, c[0]);
+      th[e] -= fma(fma(fma(c[3], pf.db, c[2]), pf.db, c[1]), pf.db, c[0]);
     }
   } else {
     for (int e = tid; e < a.N; e += kBlock) th[e] -= a.data[e];
   }
-  const double* P0 = a.prec;
-  const double* P1 = a.prec;
-  if (a.n_beta_c > 0) {
-    P0 = a.prec + (size_t)lo * a.N * a.N;
-    P1 = a.prec + (size_t)(a.n_beta_c - 1) * a.N * a.N;
-  }
+  if ((a.N & 1) && tid == 0) th[a.N] = 0.0;            // the zero row / column that makes an odd N even (the slot exists: like_lds_doubles)
   __syncthreads();
-  const int wave = tid >> 6, lane = tid & 63;
-  const int rows = (a.N + kWaves - 1) / kWaves;
-  const int r0 = wave * rows, r1 = min(a.N, r0 + rows);
-  const double omt = 1.0 - t;
-  double part = 0.0;
-  if ((a.N & 1) == 0) {
-    part = t != 0.0 ? like_quadratic<true>(a.N, P0, P1, t, th, r0, r1, lane) : like_quadratic<false>(a.N, P0, P1, t, th, r0, r1, lane);
-  } else {
-    for (int b = lane; b < a.N; b += 64) {
-      double y = 0.0;
-      for (int r = r0; r < r1; ++r) {
-        const double p = t != 0.0 ? omt * P0[(size_t)r * a.N + b] + t * P1[(size_t)r * a.N + b] : P0[(size_t)r * a.N + b];
-        y = fma(th[r], p, y);
-      }
-      part = fma(y, th[b], part);
-    }
-  }
-  const double chisq = block_sum(part, red);
-  double factor = 0.0;
+  VK_LIKE_STAMP(a, 10);
+  double sums[4] = {0.0, pf.ld, pf.n_neg, pf.n_bad};   // chi2 share, log |factors|, negative factors, zero / NaN factors
+  sums[0] = t != 0.0 ? pf.template quadratic<true>(a, th, tid) : pf.template quadratic<false>(a, th, tid);
+  VK_LIKE_STAMP(a, 11);
+  double chisq, factor = 0.0;
   bool singular = false;
   if (a.n_beta_c > 0) {
-    double ld = 0.0;
-    int n_neg = 0, n_bad = 0;
-    if (t != 0.0) {
-      const double* ev = a.eig + (size_t)lo * a.N;
-      for (int e = tid; e < a.N; e += kBlock) ld += logdet_term(fma(t, ev[e], omt), &n_neg, &n_bad);
-    }
-    ld = block_sum(ld, red);
-    const int neg = block_count(n_neg & 1, red);       // parity of the number of negative factors
-    const int bad = block_count(n_bad != 0, red);
+    block_sum4(sums, red);
+    chisq = sums[0];
+    const int neg = (int)sums[2], bad = (int)sums[3];   // np.linalg.slogdet's sign: parity of the negative factors (logdet_term)
     singular = (neg & 1) || bad || !(fabs(a.logdet[lo]) < inf);
-    factor = -0.5 * (a.logdet[lo] + ld);
+    factor = -0.5 * (a.logdet[lo] + sums[1]);
+  } else {
+    chisq = block_sum(sums[0], red);
   }
+  VK_LIKE_STAMP(a, 12);
   if (tid == 0) {
     double lnl = like_form(a, chisq, factor);
     double chi_out = chisq;
@@ -245,10 +334,13 @@ __global__ __launch_bounds__(kBlock, 4) void vk_like_wide_kernel(LikeArgs a) {
   double* th = lds;
   double* red = lds + ((a.N + 1) & ~1);
   for (long long point = blockIdx.x; point < a.n; point += gridDim.x) {
+    const double beta = a.params[point * VK_NPAR + VK_P_BETA];
+    LikePre pf;
+    pf.issue(a, beta, late_tid());
     __syncthreads();
     for (int e = threadIdx.x; e < a.N; e += kBlock) th[e] = a.theory[point * a.N + e];
     __syncthreads();
-    like_point_workgroup(a, point, a.params[point * VK_NPAR + VK_P_BETA], th, red);
+    like_point_workgroup(a, point, beta, th, red, pf);
   }
 }
 
