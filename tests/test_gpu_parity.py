@@ -718,3 +718,46 @@ def test_nan_beta_reports_a_failed_row_in_every_chi_square_kernel(synth_fit):
         assert np.all(np.isfinite(lnl[[0, 2, 3, 5]])), kn
     ref = synth_fit[3].log_likelihood_batch(rows)              # fixed covariance = slice 0: the row ON the first grid value
     assert abs(chi[3] / ref[1][3] - 1) < 1e-12
+
+
+@pytest.mark.gpu
+def test_quadratic_form_for_other_sizes_of_the_data_vector(tmp_path, oracle):
+    """The fused tail and the wide K2 take chi2 on the precision matrix folded onto its upper triangle, two triangle rows per
+    combined row (vk_kernel_like.h): N = 120 and 60 are the shipped sizes; here N = 135 (odd: a zero row and column make it
+    even; more than 64 entry pairs per row: two chunks of lanes), N = 150 (even, two chunks) and N = 21 (odd, fewer rows than
+    waves x rows in flight) against the oracle, through the single-point call, a fused small batch and a large batch (tiled K2)."""
+    import victor_amd
+    rng = np.random.default_rng(7)
+    for n_s, poles in ((45, 3), (50, 3), (7, 3)):
+        N = n_s * poles
+        s = np.linspace(3.0, 115.0, n_s)
+        data = {"s": s}
+        for l, name in zip(range(poles), ("monopole", "quadrupole", "hexadecapole")):
+            data[name] = 0.05 * rng.standard_normal(n_s) / (1 + l)
+        A = rng.standard_normal((N, N)) * 0.02
+        cov = (np.diag(rng.uniform(0.5, 2.0, N)) + A @ A.T) * 1e-4
+        cov[0, 1] += 3e-7                                   # a slightly unsymmetric precision matrix, as np.linalg.inv returns them
+        np.save(tmp_path / f"data_{N}.npy", data, allow_pickle=True)
+        np.save(tmp_path / f"cov_{N}.npy", {"covmat": cov}, allow_pickle=True)
+        model, dopt = cases.synth_options(3)
+        dopt = cases.clone(dopt)
+        dopt["dir"] = str(tmp_path)
+        dopt["redshift_space_ccf"]["data_file"] = f"data_{N}.npy"
+        dopt["covariance_matrix"]["data_file"] = f"cov_{N}.npy"
+        fit = victor_amd.CCFFit(model, dopt)
+        ofit = oracle.OracleFit(model, dopt)
+        hp = cases.halton_params(3000)
+        want = np.array([ofit.log_likelihood(cases.point(hp, i)) for i in range(6)])
+        for i in range(6):                                  # one point per call: point-major kernel, fused tail
+            lnl, chi2 = fit.log_likelihood(cases.point(hp, i))
+            assert abs(chi2 / want[i, 1] - 1) < RTOL and abs(lnl / want[i, 0] - 1) < RTOL, (N, i)
+        lnl40, chi40 = fit.log_likelihood_batch({k: v[:40] for k, v in hp.items()})      # cells kernel, fused tail
+        assert np.max(np.abs(chi40[:6] / want[:, 1] - 1)) < RTOL, N
+        _native.set_knob("VICTOR_HIP_NO_FUSE", "1")                                      # the same 40 points through the wide K2
+        try:
+            _, chi_w = fit.log_likelihood_batch({k: v[:40] for k, v in hp.items()})
+        finally:
+            _native.set_knob("VICTOR_HIP_NO_FUSE", None)
+        assert np.max(np.abs(chi_w / chi40 - 1)) < 1e-12, N
+        _, chi_big = fit.log_likelihood_batch(hp)                                         # 3000 points: K2 on the full matrix
+        assert np.max(np.abs(chi_big[:40] / chi40 - 1)) < 1e-11, N
