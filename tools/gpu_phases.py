@@ -1,5 +1,5 @@
 """Where a small-batch launch of the point-major kernel spends its time: wall_clock64() marks (100 MHz) per workgroup from the
-profiling build (make -C victor_amd/csrc phases).  Usage: VICTOR_HIP_LIB=victor_amd/csrc/libvictor_hip_phases.so gpu_phases.py {3|boss} BATCH"""
+profiling build (make -C victor_amd/csrc phases).  Usage: VICTOR_HIP_LIB=victor_amd/csrc/libvictor_hip_phases.so gpu_phases.py {3|boss} BATCH [api]"""
 import ctypes as C
 import os
 import sys
@@ -12,6 +12,7 @@ from tests import cases  # noqa: E402
 from victor_amd import _native  # noqa: E402
 
 which, batch = sys.argv[1], int(sys.argv[2])
+via_api = len(sys.argv) > 3 and sys.argv[3] == "api"      # one point through CCFFit.log_likelihood: parameters in host-mapped memory
 fit = victor_amd.CCFFit(*(cases.boss_options("config") if which == "boss" else cases.synth_options(int(which))))
 hp = cases.halton_params(max(batch, 2), with_beta=which == "boss")
 rows = fit._fit_rows(hp, fit.model)[:batch]
@@ -22,8 +23,12 @@ eng.upload(bufs[0], rows)
 lib = _native.load()
 stamps = np.zeros((4096, 16), dtype=np.int64)
 acc = []
+one = cases.point(hp, 0)
 for rep in range(60):
-    eng.eval_device_async(opts, bufs[0], batch, bufs[1], bufs[2], bufs[3])
+    if via_api:
+        fit.log_likelihood(one)
+    else:
+        eng.eval_device_async(opts, bufs[0], batch, bufs[1], bufs[2], bufs[3])
     eng.sync()
     if rep < 20:
         continue

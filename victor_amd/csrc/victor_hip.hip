@@ -114,6 +114,7 @@ struct Knobs {
   bool no_graph = false;               // VICTOR_HIP_NO_GRAPH
   bool lanes_by_chunk = false;         // VICTOR_HIP_LANES_BY_CHUNK: a workgroup takes all s bins of a 64-point chunk (A/B)
   bool no_fuse = false;                // VICTOR_HIP_NO_FUSE: keep chi2 in its own launch (A/B of the fused path)
+  bool no_inline_row = false;          // VICTOR_HIP_NO_INLINE_ROW: single-point host calls read their row from the pinned buffer (A/B)
   long long fuse_max = -1;             // VICTOR_HIP_FUSE_MAX: largest batch whose chi2 is taken inside the theory kernel (-1 = default)
   int split_q = 0;                     // third field of VICTOR_HIP_SPLIT "spi,team,parts": workgroups per (mu, v) plane
   int cells_parts = 0;                 // VICTOR_HIP_CELLS_PARTS: workgroups per point in the cells kernel (0 = choose)
@@ -163,6 +164,7 @@ struct vk_ctx {
   const double* d_exp_tab = nullptr;   // [ExpCfg<0>::kDoubles]
   const double* d_exp_tab_rep = nullptr;   // [ExpCfg<1>::kDoubles]
   const double* d_stage_mu = nullptr;  // [n_mu][kMuRec]
+  const double* inline_params = nullptr;   // set around a single-point host-buffer call: the row goes into the kernel arguments
   unsigned* d_counters = nullptr;      // [kCounterCap], zero between launches
   double* d_partial = nullptr;         // [partial_doubles]
   size_t partial_doubles = 0;
@@ -237,6 +239,7 @@ void load_knobs(vk_ctx* ctx) {
   k.like_untiled = getenv("VICTOR_HIP_LIKE_UNTILED") != nullptr;
   k.no_graph = getenv("VICTOR_HIP_NO_GRAPH") != nullptr;
   k.no_fuse = getenv("VICTOR_HIP_NO_FUSE") != nullptr;
+  k.no_inline_row = getenv("VICTOR_HIP_NO_INLINE_ROW") != nullptr;
   k.lanes_by_chunk = getenv("VICTOR_HIP_LANES_BY_CHUNK") != nullptr;
   ctx->knobs = k;
   ctx->knob_gen = g_knob_gen.load(std::memory_order_relaxed);
@@ -1331,6 +1334,10 @@ int vk_eval_batch_device_async(vk_ctx* ctx, const vk_eval_opts* opts, const doub
   if (rc) return rc;
   a.params = d_params;
   a.n = n;
+  if (ctx->inline_params && n == 1) {       // single point from host buffers: the row travels in the kernel arguments (TheoryArgs::row0)
+    memcpy(a.row0, ctx->inline_params, VK_NPAR * sizeof(double));
+    a.inline_row = 1;
+  }
   a.n_s = ctx->n_s; a.n_mu = ctx->n_mu; a.n_ell = ctx->n_ell;
   a.s = ctx->d_s; a.mu = ctx->d_mu; a.w_ell = ctx->d_w;
   a.stage_mu = ctx->d_stage_mu;
@@ -1528,7 +1535,9 @@ static int eval_batch_zero_copy(vk_ctx* ctx, const vk_eval_opts* opts, const dou
   volatile uint64_t* slots = reinterpret_cast<volatile uint64_t*>(h_out);
   if (spin)
     for (int64_t i = 0; i < 2 * n; ++i) slots[i] = kSpinSentinel;
+  ctx->inline_params = (n == 1 && !ctx->knobs.no_inline_row) ? ctx->h_zc : nullptr;
   int rc = vk_eval_batch_device_async(ctx, opts, ctx->d_zc, n, d_out, d_out + n, d_th);
+  ctx->inline_params = nullptr;
   if (rc) return rc;
   bool arrived = false;
   if (spin) {

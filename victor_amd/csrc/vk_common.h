@@ -131,6 +131,11 @@ struct TheoryArgs {
   unsigned* counters;     // [n] workgroups finished per point; zero on entry, reset to zero by the finishing workgroup
   double* partial;        // [n][n_s][parts][kMaxEll] partial projections (point-major, parts > 1)
   LikeArgs like;
+  // A single-point call through host buffers carries its parameter row HERE, in the kernel arguments: read from the pinned
+  // host buffer it is a PCIe round trip of ~2.7 us in front of every workgroup's loads (vector loads return in order, so
+  // even the table image waits for it), from the argument segment it is one more line of it (tools/gpu_phases.py ... api).
+  double row0[VK_NPAR];
+  int inline_row;
 #ifdef VK_PHASES
   long long* stamps;      // profiling build only (make phases): [workgroup][16] wall_clock64() marks of the point-major kernel
 #endif
@@ -208,14 +213,14 @@ __device__ __forceinline__ VelocityNode load_node(const double* xgw, int k) {
   return n;
 }
 
-// The kernel-argument struct spans ten 64-byte lines and the compiler fetches its fields where it first needs them (they
+// The kernel-argument struct spans thirteen 64-byte lines and the compiler fetches its fields where it first needs them (they
 // are rematerialised rather than kept in SGPRs), so a workgroup meets the lines one at a time: up to ten dependent
 // round trips from the scalar cache to L2 spread over its serial path.  Touch every line once at kernel entry - all loads in
 // flight together - and the later fetches hit the scalar cache.  Measured on a single-point launch (tools/gpu_phases.py):
 // see DESIGN.md section 5.
 template <int BYTES>
 __device__ __forceinline__ void warm_kernarg_lines() {
-  static_assert(BYTES <= 768, "extend the list of lines");
+  static_assert(BYTES <= 896, "extend the list of lines");
   const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
   unsigned d0, d1, d2, d3, d4, d5, d6, d7, d8, d9, d10, d11;
   asm volatile(
@@ -236,6 +241,13 @@ __device__ __forceinline__ void warm_kernarg_lines() {
         "=&s"(d10), "=&s"(d11)
       : "s"(kp)
       : "memory");
+  if constexpr (BYTES > 768) {          // lines 12 and 13 (the inline parameter row, the profiling build's pointer)
+    unsigned e0, e1;
+    if constexpr (BYTES > 832)
+      asm volatile("s_load_dword %0, %2, 0x300\n\ts_load_dword %1, %2, 0x340\n\ts_waitcnt lgkmcnt(0)" : "=&s"(e0), "=&s"(e1) : "s"(kp) : "memory");
+    else
+      asm volatile("s_load_dword %0, %1, 0x300\n\ts_waitcnt lgkmcnt(0)" : "=&s"(e0) : "s"(kp) : "memory");
+  }
 }
 
 // Data handed from one workgroup to another INSIDE a launch (partial projections, theory vectors awaiting their
@@ -282,6 +294,11 @@ __device__ __forceinline__ void drain_shared_stores() { asm volatile("s_waitcnt 
 #else   // A/B build of the round-2 form (tools/, never shipped): a workgroup-scope release fence, no vmcnt wait
 __device__ __forceinline__ void drain_shared_stores() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 #endif
+
+// parameter row of a point (see TheoryArgs::row0)
+__device__ __forceinline__ const double* param_row(const TheoryArgs& a, long long point) {
+  return a.inline_row ? a.row0 : a.params + point * VK_NPAR;
+}
 
 __device__ __forceinline__ bool point_completed(unsigned* counters, long long point, unsigned total, int* flag) {
   drain_shared_stores();

@@ -608,7 +608,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 3 : 2) voi
   const unsigned items = (unsigned)a.n * (unsigned)(groups * Q);     // the host keeps n * groups * parts below 2^31
   unsigned item = blockIdx.x;
   long long point = item < items ? (item / (unsigned)Q) / (unsigned)groups : 0;
-  PointScalars ps = point_scalars(a, a.params + point * VK_NPAR);
+  PointScalars ps = point_scalars(a, param_row(a, point));
   // ---- batch-constant tables: from the context's LDS image when there is one ------------------------
   if (a.image) copy_image(lds, a.image, pl.image_end);
   else stage_fast<NLR>(a, pl, lds, mode_is_dispersion(MODE));
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 3 : 2) voi
     const unsigned pg = item / (unsigned)Q;
     const int q = (int)(item - pg * (unsigned)Q);
     const int g = (int)(pg - (unsigned)point * (unsigned)groups);
-    const double* row = a.params + point * VK_NPAR;
+    const double* row = param_row(a, point);
     const FastPoint fp = make_fast_point(ps, fc, kHalf);
     constexpr int PV = mode_is_dispersion(MODE) ? 0 : 1;
     if (PV || a.n_beta_r > 0 || a.empirical) {
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 3 : 2) voi
       const long long next = (item / (unsigned)Q) / (unsigned)groups;
       if (next != point) {
         point = next;
-        ps = point_scalars(a, a.params + point * VK_NPAR);
+        ps = point_scalars(a, param_row(a, point));
       }
     }
   }

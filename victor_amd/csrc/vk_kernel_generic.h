@@ -296,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void vk_theory_kernel(TheoryArgs a) {
   for (long long item = blockIdx.x; item < items; item += gridDim.x) {
     const long long point = item / groups;
     const int g = (int)(item - point * groups);
-    const double* row = a.params + point * VK_NPAR;
+    const double* row = param_row(a, point);
     const PointScalars ps = point_scalars(a, row);
     if (a.n_beta_r > 0) {
       __syncthreads();  // previous item's readers are done with the per-point table
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(kBlock) void vk_xi_smu_kernel(TheoryArgs a) {
   const int cells = a.n_mu * a.n_s;
   const int rounds = (cells + kWaves - 1) / kWaves;
   for (long long point = blockIdx.x; point < a.n; point += gridDim.x) {
-    const double* row = a.params + point * VK_NPAR;
+    const double* row = param_row(a, point);
     const PointScalars ps = point_scalars(a, row);
     if (a.n_beta_r > 0) {
       __syncthreads();
