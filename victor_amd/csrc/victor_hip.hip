@@ -164,6 +164,7 @@ struct vk_ctx {
   const double* d_exp_tab = nullptr;   // [ExpCfg<0>::kDoubles]
   const double* d_exp_tab_rep = nullptr;   // [ExpCfg<1>::kDoubles]
   const double* d_stage_mu = nullptr;  // [n_mu][kMuRec]
+  int grids_in_lds = 0;                    // LikeArgs::grids_in_lds
   const double* inline_params = nullptr;   // set around a single-point host-buffer call: the row goes into the kernel arguments
   unsigned* d_counters = nullptr;      // [kCounterCap], zero between launches
   double* d_partial = nullptr;         // [partial_doubles]
@@ -755,6 +756,7 @@ void fill_like_args(const vk_ctx* ctx, const vk_eval_opts* o, const double* d_pa
   a->n_beta_c = ctx->n_beta_c;
   a->beta_c = ctx->d_beta_c;
   a->prec = ctx->d_prec;
+  a->grids_in_lds = ctx->grids_in_lds;
   a->tri = ctx->d_tri;
   a->logdet = ctx->d_logdet;
   a->eig = ctx->d_eig;
@@ -1232,6 +1234,8 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
     ctx->d_beta_c = t->n_beta_c > 0 ? base + o_bc : nullptr;
     ctx->d_prec = base + o_prec;
     ctx->d_tri = have_tri ? base + o_tri : nullptr;
+    auto same_grid = [&](const double* g, int n) { return n > 0 && n == t->n_beta_r && memcmp(g, t->beta_r, (size_t)n * sizeof(double)) == 0; };
+    ctx->grids_in_lds = (same_grid(t->beta_d, t->n_beta_d) ? 1 : 0) | (same_grid(t->beta_c, t->n_beta_c) ? 2 : 0);
     ctx->d_logdet = t->n_beta_c > 0 ? base + o_ld : nullptr;
     ctx->d_eig = t->n_beta_c > 0 ? base + o_eig : nullptr;
   }

@@ -76,11 +76,11 @@ __device__ __forceinline__ void stage_cells(const TheoryArgs& a, const CellsPlan
 // `gather` false: the point was this workgroup's alone and its theory vector is in `th` already (written, not yet synchronised).
 template <int NL>
 __device__ __forceinline__ void finish_point_ranges(const TheoryArgs& a, long long point, double beta, double poison, double* th,
-                                                    bool gather) {
+                                                    bool gather, const double* lds_beta_r) {
   const int N = a.n_ell * a.n_s;
   const double w0 = a.wsum[0], w1 = a.wsum[1], w2 = a.wsum[2];
   LikePrefetch<kLikeRowsCells> pf;
-  if (a.fuse) pf.issue(a.like, beta, late_tid());      // travels with the gather (vk_kernel_like.h)
+  if (a.fuse) pf.issue(a.like, beta, late_tid(), lds_beta_r);   // travels with the gather (vk_kernel_like.h)
   for (int e = late_tid(); gather && e < N; e += kBlock) {
     const int l = (e >= 2 * a.n_s) ? 2 : (e >= a.n_s ? 1 : 0), j = e - l * a.n_s;
     const int q_first = (j * a.n_mu) / a.cells_per_item, q_last = (j * a.n_mu + a.n_mu - 1) / a.cells_per_item;
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 5 : 4) voi
       }
       VK_STAMP(a, 4);
       if (last) {
-        finish_point_ranges<NL>(a, point, row[VK_P_BETA], ps.poison, th, R > 1);
+        finish_point_ranges<NL>(a, point, row[VK_P_BETA], ps.poison, th, R > 1, a.n_beta_r > 0 ? lds + pl.betar : nullptr);
         VK_STAMP(a, 5);
       }
       return;

@@ -481,12 +481,12 @@ __device__ __forceinline__ double* partial_slot(const TheoryArgs& a, long long p
 
 template <int NL>
 __device__ __forceinline__ void finish_point(const TheoryArgs& a, long long point, double beta, double poison, double* th,
-                                             bool gather_partials) {
+                                             bool gather_partials, const double* lds_beta_r) {
   const int N = a.n_ell * a.n_s;
   double* red = th + ((N + 1) & ~1);
   const double w0 = a.wsum[0], w1 = a.wsum[1], w2 = a.wsum[2];
   LikePre pf;
-  if (a.fuse) pf.issue(a.like, beta, late_tid());      // everything the chi-square needs besides the theory vector travels with the gather
+  if (a.fuse) pf.issue(a.like, beta, late_tid(), lds_beta_r);   // everything the chi-square needs besides the theory vector travels with the gather
   for (int e = threadIdx.x; e < N; e += kBlock) {
     double v;
     if (gather_partials) {
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 3 : 2) voi
       }
       VK_STAMP(a, 4);
       if (last) {
-        finish_point<NL>(a, point, row[VK_P_BETA], ps.poison, th, Q > 1);
+        finish_point<NL>(a, point, row[VK_P_BETA], ps.poison, th, Q > 1, a.n_beta_r > 0 ? lds + pl.betar : nullptr);
         VK_STAMP(a, 5);
       }
       return;

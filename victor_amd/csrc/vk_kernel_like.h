@@ -136,7 +136,7 @@ struct LikePrefetch {
   double db;              // beta - beta_d[k]
   bool data_in_regs;      // N <= kBlock: this thread's data-vector entry is in c[]
   double c[4];            // data-vector entry of element `tid`: PCHIP coefficients in db (fixed data vector: c[0] alone)
-  double ld, n_neg, n_bad;   // this thread's share of log|det| of the blended covariance, negative and zero / NaN factors
+  double ev_mine;         // eigenvalue `tid` of C_lo^-1 C_last (blended covariance), else 1
   const double* T0;
   const double* T1;
   like_d2 rows[RB];       // t == 0: rows wave, wave + 4, ... of T0; else RB / 2 rows of T0, then the same rows of T1
@@ -159,8 +159,11 @@ struct LikePrefetch {
     }
   }
 
-  // no barrier, no LDS traffic: may be called by every thread of the workgroup at any point before like_point_workgroup
-  __device__ __forceinline__ void issue(const LikeArgs& a, double beta, int tid) {
+  // no barrier, no LDS writes: may be called by every thread of the workgroup at any point before like_point_workgroup.
+  // `lds_beta_r`: the kernel's LDS copy of the real-space tables' beta grid, or null (see LikeArgs::grids_in_lds)
+  __device__ __forceinline__ void issue(const LikeArgs& a, double beta, int tid, const double* lds_beta_r = nullptr) {
+    const double* grid_d = (lds_beta_r && (a.grids_in_lds & 1)) ? lds_beta_r : a.beta_d;
+    const double* grid_c = (lds_beta_r && (a.grids_in_lds & 2)) ? lds_beta_r : a.beta_c;
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
     // Interval searches on the (increasing) beta grids as COUNTS: every wave counts the whole grid by itself, lanes over the
     // grid values, a ballot per 64 of them - no barrier, the loads of both grids in flight together (loops over the grids
@@ -173,8 +176,8 @@ struct LikePrefetch {
     const int n_max = max(a.n_beta_d, a.n_beta_c);
     for (int base = 0; base < n_max; base += 64) {          // wave-uniform trip count (one trip for BOSS)
       const int i = base + lane;
-      const double gd = (i < a.n_beta_d) ? a.beta_d[i] : inf;
-      const double gc = (i < a.n_beta_c) ? a.beta_c[i] : inf;
+      const double gd = (i < a.n_beta_d) ? grid_d[i] : inf;
+      const double gc = (i < a.n_beta_c) ? grid_c[i] : inf;
       k += __popcll(__ballot(i >= 1 && i < a.n_beta_d - 1 && beta >= gd));
       n_lt += __popcll(__ballot(i < a.n_beta_c && gc < beta));
       n_eq += __popcll(__ballot(i < a.n_beta_c && gc == beta));
@@ -191,19 +194,12 @@ struct LikePrefetch {
         lo = n_lt;                          // exact grid value (ccf_fit.py:221-222)
       } else {
         lo = n_lt - 1;
-        t = (beta - a.beta_c[lo]) / (a.beta_c[last] - a.beta_c[lo]);
+        t = (beta - grid_c[lo]) / (grid_c[last] - grid_c[lo]);
       }
     }
-    // (first, while nothing else is held in registers: log() is register-hungry)
-    // log det of the blended covariance: det((1-t) C_lo + t C_last) = det(C_lo) prod_i (1 - t + t lambda_i), ccf_fit.py:445-451
-    ld = n_neg = n_bad = 0.0;
-    if (a.n_beta_c > 0 && t != 0.0) {
-      int neg = 0, bad = 0;
-      const double* ev = a.eig + (size_t)lo * a.N;
-      for (int e = tid; e < a.N; e += kBlock) ld += logdet_term(fma(t, ev[e], 1.0 - t), &neg, &bad);
-      n_neg = (double)neg;
-      n_bad = (double)bad;
-    }
+    // log det of the blended covariance, det((1-t) C_lo + t C_last) = det(C_lo) prod_i (1 - t + t lambda_i) (ccf_fit.py:445-451):
+    // this thread's eigenvalue is requested here; the logarithm is taken in like_point_workgroup, after everything has arrived
+    ev_mine = (a.n_beta_c > 0 && t != 0.0 && tid < a.N) ? a.eig[(size_t)lo * a.N + tid] : 1.0;
     // the first rows of the quadratic form
     {
       const int M = (a.N + 1) & ~1;
@@ -214,7 +210,7 @@ struct LikePrefetch {
     }
     // this thread's entry of the data vector (ccf_fit.py:166-193)
     data_in_regs = a.N <= kBlock;
-    db = a.n_beta_d > 0 ? beta - a.beta_d[k] : 0.0;
+    db = a.n_beta_d > 0 ? beta - grid_d[k] : 0.0;
     c[0] = c[1] = c[2] = c[3] = 0.0;
     if (data_in_regs && tid < a.N) {
       if (a.n_beta_d > 0) {
@@ -301,7 +297,14 @@ __device__ __forceinline__ void like_point_workgroup(const LikeArgs& a, long lon
   if ((a.N & 1) && tid == 0) th[a.N] = 0.0;            // the zero row / column that makes an odd N even (the slot exists: like_lds_doubles)
   __syncthreads();
   VK_LIKE_STAMP(a, 10);
-  double sums[4] = {0.0, pf.ld, pf.n_neg, pf.n_bad};   // chi2 share, log |factors|, negative factors, zero / NaN factors
+  double sums[4] = {0.0, 0.0, 0.0, 0.0};               // chi2 share, log |factors|, negative factors, zero / NaN factors
+  if (a.n_beta_c > 0 && t != 0.0) {
+    int neg = 0, bad = 0;
+    if (tid < a.N) sums[1] = logdet_term(fma(t, pf.ev_mine, 1.0 - t), &neg, &bad);
+    for (int e = tid + kBlock; e < a.N; e += kBlock) sums[1] += logdet_term(fma(t, a.eig[(size_t)lo * a.N + e], 1.0 - t), &neg, &bad);
+    sums[2] = (double)neg;
+    sums[3] = (double)bad;
+  }
   sums[0] = t != 0.0 ? pf.template quadratic<true>(a, th, tid) : pf.template quadratic<false>(a, th, tid);
   VK_LIKE_STAMP(a, 11);
   double chisq, factor = 0.0;
