@@ -268,6 +268,11 @@ def test_general_grid_batches_through_every_work_split(synth_fit, boss_fit):
             for n in (1, 2, 7, 30, 200, 1500):
                 sub = fit.theory_multipoles_batch(s, {k: v[:n] for k, v in hp.items()}, poles)
                 assert np.max(np.abs(sub - big[:n])) <= 1e-12 * np.max(np.abs(big)), (beta, poles, n)
+    # a single multipole through the cells kernel (one sum per trip in its projection, not two or three)
+    hp = cases.halton_params(300)
+    mono = synth_fit[3].theory_multipoles_batch(s, hp, [0])
+    full = synth_fit[3].theory_multipoles_batch(s, hp, [0, 2, 4])
+    assert mono.shape == (300, 1, 13) and np.max(np.abs(mono[:, 0] - full[:, 0])) <= 1e-13 * np.max(np.abs(full[:, 0]))
     # and the reference-style scalar call
     one = synth_fit[3].theory_multipoles(s, cases.point(cases.halton_params(3), 2), poles=[0, 2, 4])
     assert set(one) == {"0", "2", "4"} and one["2"].shape == (13,)
