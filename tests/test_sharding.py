@@ -229,3 +229,52 @@ def test_socket_group_reports_ranks_that_are_out_of_step(tmp_path):
         t.join(60)
     assert set(errors) == {0, 1} and all("out of step" in e for e in errors.values()), errors
     assert "barrier" in errors[0] and "max" in errors[0]
+
+
+_EIGHT_RANK_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from victor_amd.sharding import Dist
+dist = Dist()
+assert dist.launched and dist.world == 8 and dist.rank == int(os.environ["RANK"]) and dist.local_rank == int(os.environ["LOCAL_RANK"])
+dist.connect(timeout=60)
+dist.barrier()
+uid = dist.broadcast_bytes(bytes(range(128)) if dist.rank == 0 else None, src=0, nbytes=128)      # bench.py: the RCCL unique id
+assert uid == bytes(range(128))
+assert dist.min_float(1.0 if dist.rank != 5 else 0.0) == 0.0                                        # one rank without a communicator
+B = 65536
+mine = np.arange(dist.rank * B, (dist.rank + 1) * B, dtype=float)                                   # the host-gather fallback's payload
+every = dist.allgather_host(mine, B)
+assert every.shape == (8 * B,) and np.array_equal(every, np.arange(8 * B, dtype=float))
+assert dist.max_float(10.0 + dist.rank) == 17.0
+dist.barrier()
+dist.close()
+print("ok", dist.rank)
+"""
+
+
+def test_eight_launched_ranks_meet_and_gather(tmp_path):
+    """The host side of `python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8`, without the GPUs: eight
+    processes with the launcher's environment (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT) find each other through
+    Dist().connect() - the Unix socket derived from MASTER_PORT - and run bench.py's sequence of host collectives, including
+    the 8 x 65536-double host gather of the degraded mode."""
+    import subprocess
+    import sys
+    port = _free_port()
+    script = tmp_path / "worker.py"
+    script.write_text(_EIGHT_RANK_WORKER)
+    procs = []
+    for r in range(8):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   TORCHELASTIC_RUN_ID=f"t{port}", TMPDIR=str(tmp_path))
+        env.pop("VICTOR_RDZV", None)
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    try:
+        outs = [p.communicate(timeout=120) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, (out, err)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and out.strip() == f"ok {r}", (r, err[-800:])
