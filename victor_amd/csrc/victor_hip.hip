@@ -114,6 +114,7 @@ struct Knobs {
   bool no_graph = false;               // VICTOR_HIP_NO_GRAPH
   bool lanes_by_chunk = false;         // VICTOR_HIP_LANES_BY_CHUNK: a workgroup takes all s bins of a 64-point chunk (A/B)
   bool no_fuse = false;                // VICTOR_HIP_NO_FUSE: keep chi2 in its own launch (A/B of the fused path)
+  bool no_alone = false;               // VICTOR_HIP_NO_ALONE: single-point launches through the ordinary point-major instantiation (A/B)
   bool no_inline_row = false;          // VICTOR_HIP_NO_INLINE_ROW: single-point host calls read their row from the pinned buffer (A/B)
   long long fuse_max = -1;             // VICTOR_HIP_FUSE_MAX: largest batch whose chi2 is taken inside the theory kernel (-1 = default)
   int split_q = 0;                     // third field of VICTOR_HIP_SPLIT "spi,team,parts": workgroups per (mu, v) plane
@@ -241,6 +242,7 @@ void load_knobs(vk_ctx* ctx) {
   k.no_graph = getenv("VICTOR_HIP_NO_GRAPH") != nullptr;
   k.no_fuse = getenv("VICTOR_HIP_NO_FUSE") != nullptr;
   k.no_inline_row = getenv("VICTOR_HIP_NO_INLINE_ROW") != nullptr;
+  k.no_alone = getenv("VICTOR_HIP_NO_ALONE") != nullptr;
   k.lanes_by_chunk = getenv("VICTOR_HIP_LANES_BY_CHUNK") != nullptr;
   ctx->knobs = k;
   ctx->knob_gen = g_knob_gen.load(std::memory_order_relaxed);
@@ -367,6 +369,16 @@ int launch_generic(vk_ctx* ctx, const TheoryArgs& a, int nlr, int grid, size_t l
 
 template <int NLR, int GRID, int MODE>
 int launch_fast_ngf(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
+  if constexpr (GRID == 0 && MODE == kModeStreaming) {
+    // every workgroup of the launch resident at once, one per CU (a single point: 160 workgroups): the ALONE instantiation
+    if (a.fuse && grid <= ctx->n_cu && !ctx->knobs.no_alone) {
+      switch (a.n_ell) {
+        case 1: if constexpr (VK_LITE_KEEP(NLR, 1, GRID, MODE)) return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 1, 0, kModeStreaming, 0, 1>, grid, lds, a); break;
+        case 2: if constexpr (VK_LITE_KEEP(NLR, 2, GRID, MODE)) return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 2, 0, kModeStreaming, 0, 1>, grid, lds, a); break;
+        case 3: if constexpr (VK_LITE_KEEP(NLR, 3, GRID, MODE)) return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 3, 0, kModeStreaming, 0, 1>, grid, lds, a); break;
+      }
+    }
+  }
   switch (a.n_ell) {
     case 1: if constexpr (VK_LITE_KEEP(NLR, 1, GRID, MODE)) return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 1, GRID, MODE>, grid, lds, a); break;
     case 2: if constexpr (VK_LITE_KEEP(NLR, 2, GRID, MODE)) return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 2, GRID, MODE>, grid, lds, a); break;

@@ -479,13 +479,13 @@ __device__ __forceinline__ double* partial_slot(const TheoryArgs& a, long long p
   return partial_slot(a.partial, a.n_s, point, l, j);
 }
 
-template <int NL>
+template <int NL, int RB = kLikeRows>
 __device__ __forceinline__ void finish_point(const TheoryArgs& a, long long point, double beta, double poison, double* th,
                                              bool gather_partials, const double* lds_beta_r) {
   const int N = a.n_ell * a.n_s;
   double* red = th + ((N + 1) & ~1);
   const double w0 = a.wsum[0], w1 = a.wsum[1], w2 = a.wsum[2];
-  LikePre pf;
+  LikePrefetch<RB> pf;
   if (a.fuse) pf.issue(a.like, beta, late_tid(), lds_beta_r);   // everything the chi-square needs besides the theory vector travels with the gather
   for (int e = threadIdx.x; e < N; e += kBlock) {
     double v;
@@ -590,8 +590,11 @@ __device__ __forceinline__ void stage_fast(const TheoryArgs& a, const FastPlan& 
     for (int e = tid; e < a.sva_doubles; e += kBlock) lds[pl.sva + e] = a.sva[e];
 }
 
-template <int NLR, int NL, int GRID, int MODE, int SVA = 0>
-__global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 3 : 2) void vk_theory_fast_kernel(TheoryArgs a) {
+// ALONE = 1: the instantiation for launches whose workgroups all fit on the chip at once, one per CU - a single point, the
+// reference's calling convention.  Occupancy is no concern there, so the kernel may use 256 registers and its fused tail keeps
+// 16 rows of the quadratic form in flight per lane: N = 120 in ONE batch, one memory round trip less in the serial tail.
+template <int NLR, int NL, int GRID, int MODE, int SVA = 0, int ALONE = 0>
+__global__ __launch_bounds__(kBlock, ALONE ? 1 : (MODE == kModeStreaming && !SVA ? 3 : 2)) void vk_theory_fast_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
   vkm::clamp_keeps_nan();
   warm_kernarg_lines<sizeof(TheoryArgs)>();
@@ -741,7 +744,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 3 : 2) voi
       }
       VK_STAMP(a, 4);
       if (last) {
-        finish_point<NL>(a, point, row[VK_P_BETA], ps.poison, th, Q > 1, a.n_beta_r > 0 ? lds + pl.betar : nullptr);
+        finish_point<NL, ALONE ? 16 : kLikeRows>(a, point, row[VK_P_BETA], ps.poison, th, Q > 1, a.n_beta_r > 0 ? lds + pl.betar : nullptr);
         VK_STAMP(a, 5);
       }
       return;
