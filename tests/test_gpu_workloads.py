@@ -579,3 +579,34 @@ def test_ten_million_point_batch_is_chunked_inside_the_library():
     probe = np.linspace(0, n - 1, 50).astype(int)
     l3, c3 = fit.log_likelihood_batch(rows[probe])
     assert np.max(np.abs(c3 / chi2[probe] - 1)) < 1e-11
+
+
+@pytest.mark.gpu
+def test_contexts_give_their_memory_back():
+    """Forty contexts created, used (single point, small batch, large batch: device tables, LDS images, scratch, pinned and
+    mapped host buffers, events, a stream) and closed: the device's free memory, read from the HIP runtime itself, ends where
+    it started (a chain that rebuilds its engine per option set must not creep)."""
+    import ctypes
+    import victor_amd
+    hip = ctypes.CDLL("libamdhip64.so")
+    free, total = ctypes.c_size_t(), ctypes.c_size_t()
+
+    def free_bytes():
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
+
+    hp = cases.halton_params(3000, with_beta=True)
+
+    def use_once():
+        fit = victor_amd.CCFFit(*cases.boss_options("config"))
+        fit.log_likelihood(cases.point(hp, 1))
+        fit.log_likelihood_batch({k: v[:50] for k, v in hp.items()})
+        fit.log_likelihood_batch(hp)
+        for eng in list(fit._engines.values()) if hasattr(fit, "_engines") else [fit._get_engine()]:
+            eng.close()
+
+    use_once()                                   # the runtime's own one-off allocations (code object, pools) happen here
+    start = free_bytes()
+    for _ in range(40):
+        use_once()
+    assert abs(free_bytes() - start) < 64 << 20, (start, free_bytes())
