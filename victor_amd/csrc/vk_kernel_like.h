@@ -73,19 +73,9 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return s;
 }
 
-// number of threads of the workgroup whose predicate holds, to every thread; `red` as for block_sum.  (Not __syncthreads_count:
-// HIP implements that through a static __shared__ word, which moves the base of dynamic LDS off zero for the whole kernel -
-// every LDS address of the theory loops then carries an addend the ds_read offset field could have held.)
-__device__ __forceinline__ int block_count(bool pred, double* red) {
-  const int c = __popcll(__ballot(pred));
-  __syncthreads();                       // `red` may still be read from a previous call
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = (double)c;
-  __syncthreads();
-  double s = red[0];
-#pragma unroll
-  for (int w = 1; w < kWaves; ++w) s += red[w];
-  return (int)s;
-}
+// (No __syncthreads_count anywhere in these kernels: HIP implements it through a static __shared__ word, which moves the
+// base of dynamic LDS off zero for the whole kernel - every LDS address of the theory loops then carries an addend the ds_read
+// offset field could have held.  The interval searches of the tail count per wave with ballots, see LikePrefetch::issue.)
 
 // four sums over the workgroup in one pass (two barriers instead of eight); `red`: kLikeRed doubles
 __device__ __forceinline__ void block_sum4(double (&v)[4], double* red) {
