@@ -267,6 +267,45 @@ def walker_rates(steps=150):
     return res
 
 
+def option_rates(batch=16384, steps=4):
+    """SURVEY.md 8(f) rows next to the headline: the other RSD models and model options of the reference on the BOSS CMASS
+    configuration (and the measured real-space ccf with the model + data covariance), resident, batch 16384 - evals/s and the
+    theory kernel that served them."""
+    import victor_amd
+    from tests import cases
+    res = {}
+
+    def run(fit, label, **kw):
+        model = fit._merged(kw)
+        eng = fit._get_engine(fit._engine_key(model))
+        o = eng.make_opts(model, fit.fit_options)
+        rows = fit._fit_rows(cases.halton_params(batch, with_beta=True), model)
+        bufs = [eng.alloc(rows.size), eng.alloc(batch), eng.alloc(batch), eng.alloc(batch * eng.n_data)]
+        eng.upload(bufs[0], rows)
+        warm_up(eng, lambda: eng.eval_device_async(o, bufs[0], batch, bufs[1], bufs[2], bufs[3]), 0.15)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.eval_device_async(o, bufs[0], batch, bufs[1], bufs[2], bufs[3])
+        eng.sync()
+        dt = (time.perf_counter() - t0) / steps
+        res[label] = {"evals_per_s": batch / dt, "ms_per_batch": dt * 1e3, "kernel": eng.last_kernel()}
+        for b in bufs:
+            eng.free(b)
+
+    boss = victor_amd.CCFFit(*cases.boss_options("config"))
+    for label, kw in (("dispersion", {"rsd_model": "dispersion"}), ("kaiser", {"rsd_model": "kaiser"}),
+                      ("euclid_special", {"rsd_model": "euclid_special"}), ("empirical_corr", {"empirical_corr": True}),
+                      ("linear_bias", {"matter_model": "linear_bias"}),
+                      ("linear_bias+empirical_corr+dispersion", {"matter_model": "linear_bias", "empirical_corr": True, "rsd_model": "dispersion"})):
+        run(boss, label, **kw)
+    m, d = cases.boss_options("config")
+    m["input_model_data_file"] = "boss/measured_model.npy"
+    m["realspace_ccf"]["from_data"] = True
+    d["covariance_matrix"]["data_file"] = "boss/cov_md_iso.npy"
+    run(victor_amd.CCFFit(m, d), "from_data (measured model, M+D covariance)")
+    return {"batch": batch, "config": "BOSS DR12 CMASS", "rates": res}
+
+
 def dsplit_measurement(batch=16384, steps=10):
     """BASELINE config 5 on one GPU: five table sets sharing one parameter batch (block-diagonal covariance, N = 5 x 120),
     one upload, the blocks on their own streams, sums on the device (vk_joint_eval_device_async)."""
@@ -579,6 +618,7 @@ def main():
             out["dsplit5"] = dsplit_measurement()
             out["host_api"] = api_latency()
             out["walker_ensembles"] = walker_rates()
+            out["model_options"] = option_rates()
         if base is not None:
             chi_o = np.array([v[1] for v in vals])
             lnl_o = np.array([v[0] for v in vals])
