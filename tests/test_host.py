@@ -479,8 +479,9 @@ def test_dispersion_filter_options(tmp_path):
     assert not np.allclose(seen[0], seen[2], rtol=1e-6) and not np.allclose(seen[0], seen[4], rtol=1e-6)
 
 
-def _gfx950_code_object(tmp_dir):
-    """Extract the gfx950 code object from libvictor_hip.so (clang offload bundle in .hip_fatbin) into a file."""
+def _gfx950_code_objects(tmp_dir):
+    """Extract the gfx950 code objects from libvictor_hip.so - one clang offload bundle per translation unit in .hip_fatbin
+    (victor_hip.hip, vk_cells_aniso.hip) - into files."""
     import re
     import struct
     import subprocess
@@ -494,33 +495,85 @@ def _gfx950_code_object(tmp_dir):
     with open(OUT, "rb") as fh:
         fh.seek(int(m.group(1), 16))
         blob = fh.read(int(m.group(2), 16))
-    assert blob[:24] == b"__CLANG_OFFLOAD_BUNDLE__"
-    n, pos, code = struct.unpack_from("<Q", blob, 24)[0], 32, None
-    for _ in range(n):
-        off, size, idlen = struct.unpack_from("<QQQ", blob, pos)
-        ident = blob[pos + 24:pos + 24 + idlen].decode()
-        pos += 24 + idlen
-        if "gfx950" in ident:
-            code = blob[off:off + size]
-    assert code, "no gfx950 code object in the bundle"
-    path = os.path.join(str(tmp_dir), "victor_gfx950.co")
-    with open(path, "wb") as fh:
-        fh.write(code)
-    return path
+    magic, paths, start = b"__CLANG_OFFLOAD_BUNDLE__", [], 0
+    assert blob[:24] == magic
+    while True:
+        at = blob.find(magic, start)
+        if at < 0:
+            break
+        n, pos = struct.unpack_from("<Q", blob, at + 24)[0], at + 32
+        for _ in range(n):
+            off, size, idlen = struct.unpack_from("<QQQ", blob, pos)
+            ident = blob[pos + 24:pos + 24 + idlen].decode()
+            pos += 24 + idlen
+            if "gfx950" in ident:
+                path = os.path.join(str(tmp_dir), f"victor_gfx950_{len(paths)}.co")
+                with open(path, "wb") as fh:
+                    fh.write(blob[at + off:at + off + size])
+                paths.append(path)
+        start = at + len(magic)
+    assert paths, "no gfx950 code object in the library"
+    return paths
+
+
+def _disassemble(paths):
+    """{kernel name: [instructions]} over the code objects."""
+    import re
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.isfile(objdump):
+        pytest.skip("llvm-objdump not found")
+    funcs, cur = {}, None
+    for co in paths:
+        asm = subprocess.run([objdump, "-d", "--mcpu=gfx950", co], capture_output=True, text=True).stdout
+        for ln in asm.split("\n"):
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", ln)
+            if m:
+                cur = funcs.setdefault(m.group(1), [])
+            elif cur is not None and ln.strip():
+                cur.append(ln.split("//")[0].strip())
+    return funcs
 
 
 def test_no_kernel_of_the_library_spills(lib, tmp_path):
-    """The gfx950 code object inside libvictor_hip.so, read with llvm-readelf: every kernel's private segment is 0 bytes -
-    no register spills, no scratch traffic (8 bytes per thread in the BOSS cells kernel once were 134 MB of HBM writes per
-    65536-point launch) - and the large-batch theory kernels keep the registers of five workgroups per CU."""
+    """The gfx950 code objects inside libvictor_hip.so, read with llvm-readelf: every kernel's private segment is 0 bytes - no
+    register spills, no scratch traffic (8 bytes per thread in the BOSS cells kernel once were 134 MB of HBM writes per
+    65536-point launch) - and the large-batch theory kernels keep the registers of five workgroups per CU.
+    The one exception is by choice: the cells kernel's six instantiations for the anisotropic real-space sum are compiled
+    with the iterative-ilp machine scheduler (vk_cells_aniso.hip), whose denser node loop costs a few values that live ACROSS
+    the loops their registers - at most 32 bytes per thread, written once per work item in the per-point set-up and read back
+    there and in the tail.  The disassembly is checked for it: no scratch instruction inside any loop of those kernels that
+    evaluates integrand points."""
     import re
     import subprocess
-    co = _gfx950_code_object(tmp_path)
-    notes = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
+    paths = _gfx950_code_objects(tmp_path)
+    assert len(paths) == 2
+    notes = "".join(subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
+                    for co in paths)
     kernels = re.findall(r"\.name:\s+(\S+)[\s\S]*?\.private_segment_fixed_size:\s+(\d+)[\s\S]*?\.vgpr_count:\s+(\d+)", notes)
     assert len(kernels) > 150
-    spilling = [k for k, priv, _ in kernels if int(priv) > 0]
+    aniso = re.compile(r"vk_theory_cells_kernelILi3ELi[123]ELi[01]ELi0ELi0EEEv")
+    spilling = [k for k, priv, _ in kernels if int(priv) > 0 and not aniso.search(k)]
     assert not spilling, spilling
+    exempt = [(k, int(priv)) for k, priv, _ in kernels if aniso.search(k)]
+    assert len(exempt) == 6 and all(priv <= 32 for _, priv in exempt), exempt
+    funcs = _disassemble(paths)
+    for k, _ in exempt:
+        body = funcs[k]
+        loops = 0
+        for i in [i for i, ins in enumerate(body) if ins.startswith("v_rcp_f64")]:    # every integrand point takes 1 / sigma_v ...
+            lo = i
+            while lo > 0 and not re.match(r"s_c?branch", body[lo - 1]):
+                lo -= 1
+            hi = i
+            while not re.match(r"s_c?branch", body[hi]):
+                hi += 1
+            block = body[lo:hi + 1]
+            if sum(ins.startswith("ds_read_b128") for ins in block) < 6:             # ... and reads its records: a node loop's body
+                continue
+            loops += 1
+            assert not any(ins.startswith("scratch_") for ins in block), (k, i)
+        assert loops >= 2, (k, loops)                                                 # in-table and clamped form
     for k, _, vgpr in kernels:
         if "vk_theory_lanes_kernel" in k or ("vk_theory_cells_kernel" in k and k.endswith("Li0ELi0EEEvNS_10TheoryArgsE")):   # MODE = streaming, SVA = 0
             assert int(vgpr) <= 96, (k, vgpr)          # 512 / 5 workgroups of four waves, in granules of 8
@@ -540,19 +593,7 @@ def test_cross_workgroup_handoff_is_ordered_in_the_code_object(lib, tmp_path):
     walking back from that barrier an `s_waitcnt vmcnt(0)` comes before any global store; the finishing workgroup's reads
     of the handed-over data are sc1 loads."""
     import re
-    import subprocess
-    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-    if not os.path.isfile(objdump):
-        pytest.skip("llvm-objdump not found")
-    co = _gfx950_code_object(tmp_path)
-    asm = subprocess.run([objdump, "-d", "--mcpu=gfx950", co], capture_output=True, text=True).stdout
-    funcs, cur = {}, None
-    for ln in asm.split("\n"):
-        m = re.match(r"^[0-9a-f]+ <(\S+)>:", ln)
-        if m:
-            cur = funcs.setdefault(m.group(1), [])
-        elif cur is not None and ln.strip():
-            cur.append(ln.strip())
+    funcs = _disassemble(_gfx950_code_objects(tmp_path))
     checked = 0
     for name, body in funcs.items():
         atomics = [i for i, ins in enumerate(body) if ins.startswith("global_atomic_add")]

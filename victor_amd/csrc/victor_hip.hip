@@ -41,6 +41,17 @@
 #include "vk_kernel_lanes.h"
 #include "vk_kernel_like.h"
 
+// The cells kernel's instantiations for the anisotropic real-space sum live in vk_cells_aniso.hip (another machine scheduler
+// for that translation unit, see build.py); VK_SINGLE_TU builds everything here.
+#ifndef VK_SINGLE_TU
+namespace vk {
+#define VK_CELLS_ANISO(NL, GRID) extern template __global__ void vk_theory_cells_kernel<3, NL, GRID, kModeStreaming, 0>(TheoryArgs);
+VK_CELLS_ANISO(1, 0) VK_CELLS_ANISO(2, 0) VK_CELLS_ANISO(3, 0)
+VK_CELLS_ANISO(1, 1) VK_CELLS_ANISO(2, 1) VK_CELLS_ANISO(3, 1)
+#undef VK_CELLS_ANISO
+}  // namespace vk
+#endif
+
 using namespace vk;
 
 // LDS image of a kernel variant's batch-constant tables (vk_kernel_fast.h: copy_image): run that variant's own staging

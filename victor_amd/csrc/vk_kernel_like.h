@@ -322,6 +322,7 @@ __device__ __forceinline__ void like_point_workgroup(const LikeArgs& a, long lon
   }
 }
 
+#ifndef VK_KERNEL_TEMPLATES_ONLY   // (the kernels that are not templates are defined in one translation unit only)
 // K2 "wide": one workgroup per point (small batches, and the theory kernels that do not carry the fused tail)
 __global__ __launch_bounds__(kBlock, 4) void vk_like_wide_kernel(LikeArgs a) {
   extern __shared__ double lds[];
@@ -420,6 +421,8 @@ __global__ __launch_bounds__(kBlock) void vk_like_kernel(LikeArgs a) {
   }
 }
 
+
+#endif  // VK_KERNEL_TEMPLATES_ONLY
 
 // --------------------------------------------------------------------------------------------------
 // K2 for a fixed covariance: T points per wave share every load of the precision matrix.
