@@ -720,7 +720,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
     if (lds_c > 160 * 1024) return fail(ctx, VK_E_ARG, "tables need %zu bytes of LDS (> 160 KiB)", lds_c);
     a.image = get_image(ctx, a, 1, nlr, disp, plc.image_end, sva);
     const long long items_c = a.n * R;
-    const int grid_c = (int)((tail || items_c < cap) ? items_c : cap);     // fused / split launches: one item per workgroup
+    const int grid_c = (int)items_c;                                       // one item per workgroup, always (vk_kernel_cells.h)
     if (fused) *fused = a.fuse != 0;
     switch (nlr) {
       case 1: return launch_cells_nl<1>(ctx, a, grid_c, lds_c);

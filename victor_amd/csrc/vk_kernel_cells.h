@@ -168,7 +168,12 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 5 : 4) voi
   const unsigned items = (unsigned)a.n * (unsigned)R;                // the host keeps n * parts below 2^31
   const int all_cells = a.n_s * a.n_mu;
 
-  for (unsigned item = blockIdx.x; item < items; item += gridDim.x) {
+  // ONE work item per workgroup, no grid-stride loop (the host launches `items` workgroups): around a loop the compiler hoists
+  // what the per-point set-up and the tail derive from the thread index and the kernel arguments to the top of the kernel and
+  // carries it through the node loops - seven values that cost the denser schedule of vk_cells_aniso.hip 32 bytes of scratch.
+  {
+    const unsigned item = blockIdx.x;
+    if (item >= items) return;
     const long long point = item / (unsigned)R;
     const int q = (int)(item - (unsigned)point * (unsigned)R);
     const int c0 = q * cpi, c1 = min(c0 + cpi, all_cells);           // this item's cells
