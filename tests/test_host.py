@@ -481,7 +481,7 @@ def test_dispersion_filter_options(tmp_path):
 
 def _gfx950_code_objects(tmp_dir):
     """Extract the gfx950 code objects from libvictor_hip.so - one clang offload bundle per translation unit in .hip_fatbin
-    (victor_hip.hip, vk_cells_aniso.hip) - into files."""
+    (victor_hip.hip, vk_cells_streaming.hip) - into files."""
     import re
     import struct
     import subprocess
@@ -538,7 +538,7 @@ def _disassemble(paths):
 def test_no_kernel_of_the_library_spills(lib, tmp_path):
     """The gfx950 code objects inside libvictor_hip.so (one per translation unit), read with llvm-readelf: every kernel's
     private segment is 0 bytes - no register spills, no scratch traffic (8 bytes per thread in the BOSS cells kernel once were
-    134 MB of HBM writes per 65536-point launch; the iterative-ilp scheduler of vk_cells_aniso.hip cost 24-32 bytes until the
+    134 MB of HBM writes per 65536-point launch; the iterative-ilp scheduler of vk_cells_streaming.hip cost 24-32 bytes until the
     cells kernel lost its grid-stride loop) - and the large-batch theory kernels keep the registers of five workgroups per CU."""
     import re
     import subprocess
@@ -550,8 +550,8 @@ def test_no_kernel_of_the_library_spills(lib, tmp_path):
     assert len(kernels) > 150
     spilling = [k for k, priv, _ in kernels if int(priv) > 0]
     assert not spilling, spilling
-    aniso = [k for k, _, _ in kernels if re.search(r"vk_theory_cells_kernelILi3ELi[123]ELi[01]ELi0ELi0EEEv", k)]
-    assert len(aniso) == 6                                  # the six instantiations of vk_cells_aniso.hip are in the library
+    aniso = [k for k, _, _ in kernels if re.search(r"vk_theory_cells_kernelILi[123]ELi[123]ELi[01]ELi0ELi0EEEv", k)]
+    assert len(aniso) == 18                                 # the instantiations of vk_cells_streaming.hip are in the library
     funcs = _disassemble(paths)
     assert not any(ins.startswith("scratch_") for k in aniso for ins in funcs[k])
     for k, _, vgpr in kernels:

@@ -2,12 +2,12 @@
 
 Two translation units, compiled side by side and linked into one library:
 
-``victor_hip.hip``       the C ABI, the host side and every kernel but six;
-``vk_cells_aniso.hip``   the cells kernel's instantiations for the anisotropic real-space sum (the kernel of the headline
-                         metric), compiled with LLVM's ``iterative-ilp`` machine scheduler: it interleaves the independent
-                         chains of the node loop and fills the hazard slots the default (occupancy-driven) scheduler leaves
-                         as ``s_nop`` - 1.3 % per launch, same bits.  The flag is per translation
-                         unit, hence the unit.
+``victor_hip.hip``           the C ABI, the host side and every other kernel;
+``vk_cells_streaming.hip``   the cells kernel's instantiations for the streaming model (the kernels of the headline
+                         metric and of the BOSS configuration), compiled with LLVM's ``iterative-ilp`` machine scheduler: it
+                         interleaves the independent chains of the node loop and fills the hazard slots the default
+                         (occupancy-driven) scheduler leaves as ``s_nop`` - about 1 % per launch, same bits (DESIGN.md
+                         section 5).  The flag is per translation unit, hence the unit.
 """
 
 import os
@@ -17,7 +17,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SRC = os.path.join(CSRC, "victor_hip.hip")
-UNITS = (("victor_hip.hip", ()), ("vk_cells_aniso.hip", ("-mllvm", "-amdgpu-sched-strategy=iterative-ilp")))
+UNITS = (("victor_hip.hip", ()), ("vk_cells_streaming.hip", ("-mllvm", "-amdgpu-sched-strategy=iterative-ilp")))
 OUT = os.path.join(CSRC, "libvictor_hip.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 COMMON = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC")

@@ -41,14 +41,17 @@
 #include "vk_kernel_lanes.h"
 #include "vk_kernel_like.h"
 
-// The cells kernel's instantiations for the anisotropic real-space sum live in vk_cells_aniso.hip (another machine scheduler
-// for that translation unit, see build.py); VK_SINGLE_TU builds everything here.
+// The cells kernel's instantiations for the streaming model live in vk_cells_streaming.hip (another machine scheduler for that
+// translation unit, see build.py); VK_SINGLE_TU builds everything here.
 #ifndef VK_SINGLE_TU
 namespace vk {
-#define VK_CELLS_ANISO(NL, GRID) extern template __global__ void vk_theory_cells_kernel<3, NL, GRID, kModeStreaming, 0>(TheoryArgs);
-VK_CELLS_ANISO(1, 0) VK_CELLS_ANISO(2, 0) VK_CELLS_ANISO(3, 0)
-VK_CELLS_ANISO(1, 1) VK_CELLS_ANISO(2, 1) VK_CELLS_ANISO(3, 1)
-#undef VK_CELLS_ANISO
+#define VK_CELLS_STREAMING(NLR, NL) \
+  extern template __global__ void vk_theory_cells_kernel<NLR, NL, 0, kModeStreaming, 0>(TheoryArgs); \
+  extern template __global__ void vk_theory_cells_kernel<NLR, NL, 1, kModeStreaming, 0>(TheoryArgs);
+VK_CELLS_STREAMING(1, 1) VK_CELLS_STREAMING(1, 2) VK_CELLS_STREAMING(1, 3)
+VK_CELLS_STREAMING(2, 1) VK_CELLS_STREAMING(2, 2) VK_CELLS_STREAMING(2, 3)
+VK_CELLS_STREAMING(3, 1) VK_CELLS_STREAMING(3, 2) VK_CELLS_STREAMING(3, 3)
+#undef VK_CELLS_STREAMING
 }  // namespace vk
 #endif
 

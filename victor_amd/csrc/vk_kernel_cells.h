@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 5 : 4) voi
 
   // ONE work item per workgroup, no grid-stride loop (the host launches `items` workgroups): around a loop the compiler hoists
   // what the per-point set-up and the tail derive from the thread index and the kernel arguments to the top of the kernel and
-  // carries it through the node loops - seven values that cost the denser schedule of vk_cells_aniso.hip 32 bytes of scratch.
+  // carries it through the node loops - seven values that cost the denser schedule of vk_cells_streaming.hip 32 bytes of scratch.
   {
     const unsigned item = blockIdx.x;
     if (item >= items) return;
