@@ -128,7 +128,6 @@ struct Knobs {
   bool no_graph = false;               // VICTOR_HIP_NO_GRAPH
   bool lanes_by_chunk = false;         // VICTOR_HIP_LANES_BY_CHUNK: a workgroup takes all s bins of a 64-point chunk (A/B)
   bool no_fuse = false;                // VICTOR_HIP_NO_FUSE: keep chi2 in its own launch (A/B of the fused path)
-  bool no_alone = false;               // VICTOR_HIP_NO_ALONE: single-point launches through the ordinary point-major instantiation (A/B)
   bool no_inline_row = false;          // VICTOR_HIP_NO_INLINE_ROW: single-point host calls read their row from the pinned buffer (A/B)
   long long fuse_max = -1;             // VICTOR_HIP_FUSE_MAX: largest batch whose chi2 is taken inside the theory kernel (-1 = default)
   int split_q = 0;                     // third field of VICTOR_HIP_SPLIT "spi,team,parts": workgroups per (mu, v) plane
@@ -256,7 +255,6 @@ void load_knobs(vk_ctx* ctx) {
   k.no_graph = getenv("VICTOR_HIP_NO_GRAPH") != nullptr;
   k.no_fuse = getenv("VICTOR_HIP_NO_FUSE") != nullptr;
   k.no_inline_row = getenv("VICTOR_HIP_NO_INLINE_ROW") != nullptr;
-  k.no_alone = getenv("VICTOR_HIP_NO_ALONE") != nullptr;
   k.lanes_by_chunk = getenv("VICTOR_HIP_LANES_BY_CHUNK") != nullptr;
   ctx->knobs = k;
   ctx->knob_gen = g_knob_gen.load(std::memory_order_relaxed);
@@ -383,16 +381,6 @@ int launch_generic(vk_ctx* ctx, const TheoryArgs& a, int nlr, int grid, size_t l
 
 template <int NLR, int GRID, int MODE>
 int launch_fast_ngf(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
-  if constexpr (GRID == 0 && MODE == kModeStreaming) {
-    // every workgroup of the launch resident at once, one per CU (a single point: 160 workgroups): the ALONE instantiation
-    if (a.fuse && grid <= ctx->n_cu && !ctx->knobs.no_alone) {
-      switch (a.n_ell) {
-        case 1: if constexpr (VK_LITE_KEEP(NLR, 1, GRID, MODE)) return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 1, 0, kModeStreaming, 0, 1>, grid, lds, a); break;
-        case 2: if constexpr (VK_LITE_KEEP(NLR, 2, GRID, MODE)) return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 2, 0, kModeStreaming, 0, 1>, grid, lds, a); break;
-        case 3: if constexpr (VK_LITE_KEEP(NLR, 3, GRID, MODE)) return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 3, 0, kModeStreaming, 0, 1>, grid, lds, a); break;
-      }
-    }
-  }
   switch (a.n_ell) {
     case 1: if constexpr (VK_LITE_KEEP(NLR, 1, GRID, MODE)) return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 1, GRID, MODE>, grid, lds, a); break;
     case 2: if constexpr (VK_LITE_KEEP(NLR, 2, GRID, MODE)) return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 2, GRID, MODE>, grid, lds, a); break;
@@ -686,7 +674,9 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
   // tools/gpu_small_batch_ab.py: one workgroup per point needs ~2.5 workgroups per CU to keep the SIMDs fed
   // crossover against the point-major kernel (whose finer split wins for a handful of points): config 3 / BOSS 8 points
   // 21.1 / 20.3 us point-major vs 25.9 / 24.2 cells, 16: 25.7 / 24.5 vs 27.2 / 25.1, 32: 41.3 / 36.7 vs 30.6 / 28.0
-  const long long cells_min = ctx->knobs.cells_min >= 0 ? ctx->knobs.cells_min : 24;
+  // (re-measured after both kernels lost their grid-stride loops, tools/gpu_cells_min_sweep.py, profiles/r03/z_*: point-major
+  // ahead up to 12 / 16 points, level at 20, the cells kernel ahead from 24 / 28 on)
+  const long long cells_min = ctx->knobs.cells_min >= 0 ? ctx->knobs.cells_min : 20;
   const bool cells = cells_ok && (mapping ? mapping == 2 : a.n >= cells_min);
   if (cells) {
     ctx->last_kernel = "vk_theory_cells_kernel";
@@ -744,7 +734,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
     if (lds > 160 * 1024) return fail(ctx, VK_E_ARG, "tables need %zu bytes of LDS (> 160 KiB)", lds);
     a.image = get_image(ctx, a, 0, nlr, disp, plf.image_end, sva);
     const long long items = a.n * groups * a.parts;
-    const int grid = (int)((tail || items < cap) ? items : cap);            // fused / split launches: one item per workgroup
+    const int grid = (int)items;                                            // one item per workgroup, always (vk_kernel_fast.h)
     if (fused) *fused = a.fuse != 0;
     switch (nlr) {
       case 1: return launch_fast_nl<1>(ctx, a, grid, lds);
@@ -802,8 +792,7 @@ int launch_like(vk_ctx* ctx, const LikeArgs& a) {
   const size_t lds_wide = (size_t)like_lds_doubles(ctx->N) * sizeof(double);
   const bool wide = ctx->knobs.like_wide >= 0 ? ctx->knobs.like_wide == 1 : n <= 2048;
   if (wide && lds_wide <= 160 * 1024) {
-    const long long capw = 64LL * ctx->n_cu;
-    return launch_on_stream(ctx, vk_like_wide_kernel, (int)(n < capw ? n : capw), lds_wide, a);
+    return launch_on_stream(ctx, vk_like_wide_kernel, (int)n, lds_wide, a);      // one point per workgroup
   }
   // fixed covariance: 8 points per wave share the loads of the precision matrix (LDS: 4 waves x 8 x N doubles)
   constexpr int kTile = 8;

@@ -250,10 +250,10 @@ struct LikePrefetch {
   }
 };
 
-constexpr int kLikeRows = 8;   // rows in flight in the point-major kernel and the wide K2, where the tail's latency is the launch's: N = 120
-                               // takes two batches per wave (8 + 7 rows); 16 would make it one, but the point-major kernel has 167
-                               // registers of 168 in use.  The cells kernel (96 registers, tail never latency-critical: it fuses
-                               // batches of 24-512 points) keeps 4 in flight.
+constexpr int kLikeRows = 16;  // rows in flight in the point-major kernel and the wide K2, where the tail's latency is the launch's: N = 120
+                               // (15 rows per wave) in ONE batch.  64 registers: affordable since those kernels lost their
+                               // grid-stride loops (128 in all).  The cells kernel (96 registers, tail never latency-critical:
+                               // it fuses batches of 24-512 points) keeps 4 in flight.
 constexpr int kLikeRowsCells = 4;
 typedef LikePrefetch<kLikeRows> LikePre;
 
@@ -324,11 +324,13 @@ __device__ __forceinline__ void like_point_workgroup(const LikeArgs& a, long lon
 
 #ifndef VK_KERNEL_TEMPLATES_ONLY   // (the kernels that are not templates are defined in one translation unit only)
 // K2 "wide": one workgroup per point (small batches, and the theory kernels that do not carry the fused tail)
-__global__ __launch_bounds__(kBlock, 4) void vk_like_wide_kernel(LikeArgs a) {
+__global__ __launch_bounds__(kBlock, 2) void vk_like_wide_kernel(LikeArgs a) {
   extern __shared__ double lds[];
   double* th = lds;
   double* red = lds + ((a.N + 1) & ~1);
-  for (long long point = blockIdx.x; point < a.n; point += gridDim.x) {
+  {
+    const long long point = blockIdx.x;               // one point per workgroup (the host launches n of them)
+    if (point >= a.n) return;
     const double beta = a.params[point * VK_NPAR + VK_P_BETA];
     LikePre pf;
     pf.issue(a, beta, late_tid());
