@@ -234,7 +234,7 @@ struct LikePrefetch {
 #pragma unroll
         for (int s = 0; s < R; ++s) {
           // no branch per row: a row beyond the last one holds zeros (load_rows) and reads the last row's residuals, so the
-          // LDS reads of several rows can be in flight together - four at a time (registers)
+          // LDS reads of several rows can be in flight together - eight at a time (registers)
           const int c = min(base + kWaves * s, half - 1);    // wave-uniform
           const double x = BLEND ? omt * rows[s].x + t * rows[R + s].x : rows[s].x;
           const double y = BLEND ? omt * rows[s].y + t * rows[R + s].y : rows[s].y;
@@ -242,7 +242,7 @@ struct LikePrefetch {
           const double v0 = rl[min(c, M - 1 - e0)], v1 = rl[min(c + 1, M - 1 - e0)];
           part = fma(x, c < first0 ? u1 * v0 : u2 * q0, part);
           part = fma(y, c < first1 ? u1 * v1 : u2 * q1, part);
-          if ((s & 3) == 3) asm volatile("" ::: "memory");
+          if ((s & 7) == 7) asm volatile("" ::: "memory");
         }
       }
     }
