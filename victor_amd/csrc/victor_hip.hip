@@ -121,7 +121,7 @@ __global__ void vk_init_stage_kernel(const double* mu, const double* w_ell, int 
 struct Knobs {
   int split_s = 0, split_t = 0;        // VICTOR_HIP_SPLIT "spi,team"
   bool force_generic = false;          // VICTOR_HIP_FORCE_GENERIC
-  long long point_cap = 0;             // VICTOR_HIP_POINT_CAP   (workgroups per CU; 0 = default)
+  long long point_cap = 0;             // VICTOR_HIP_POINT_CAP   (workgroups per CU, generic theory kernel; 0 = default)
   long long lanes_cap = 0;             // VICTOR_HIP_LANES_CAP   (0 = uncapped)
   int mapping = 0;                     // VICTOR_HIP_MAPPING: 0 auto, 1 point, 2 cells, 3 lanes, -1 unknown name
   bool like_untiled = false;           // VICTOR_HIP_LIKE_UNTILED
@@ -628,7 +628,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
 #ifdef VK_PHASES
   a.like.stamps = a.stamps;
 #endif
-  const long long kDefaultCap = 256;                                // VICTOR_HIP_POINT_CAP: workgroups per CU in the launch
+  const long long kDefaultCap = 256;                                // VICTOR_HIP_POINT_CAP: workgroups per CU in a launch of the generic kernel (the fast kernels take one item per workgroup)
   const long long cap = (ctx->knobs.point_cap > 0 ? ctx->knobs.point_cap : kDefaultCap) * ctx->n_cu;
   // lanes-over-batch variant: batch-constant tables and enough points to fill the chip with n_s * n/64 waves
   const int mapping = ctx->knobs.mapping;                           // VICTOR_HIP_MAPPING: 0 = choose by batch size
