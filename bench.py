@@ -63,6 +63,125 @@ def cpu_worker(args):
     return idx, busy, out, theory
 
 
+def chain_worker(idx, n_chains, seconds, broker, barrier, queue):
+    """One cobaya-style chain (runs in a child process): a CCFLikelihood built from config/boss_cobaya_config.yaml whose
+    ``calculate(state, **one_point)`` is called in a loop, as ``mpirun -n P cobaya-run`` does it (reference README.md:30,
+    CCFLikelihood.py:32-39).  ``broker``: value of VICTOR_HIP_BROKER for this chain, or None for a GPU context of its own."""
+    try:
+        os.chdir(ROOT)                      # the data paths in the config are relative to the repository root
+        if broker:
+            os.environ["VICTOR_HIP_BROKER"] = broker
+        else:
+            os.environ.pop("VICTOR_HIP_BROKER", None)
+        sys.path.insert(0, os.path.join(ROOT, "victor", "likelihoods"))
+        from CCFLikelihood import CCFLikelihood
+        from tests import cases
+        info = cases.cobaya_info()["likelihood"]["CCFLikelihood"]
+        lk = CCFLikelihood({"model": info["model"], "data": info["data"]})
+        h = cases.halton(4096 + 64 * idx, bases=(2, 3, 5, 7))[64 * idx:]         # every chain its own points of the prior box
+        pts = [{"fsigma8": 0.05 + 1.45 * a, "beta": 0.2 + 0.4 * b, "sigma_v": 100 + 400 * c, "epsilon": 0.8 + 0.4 * d}
+               for a, b, c, d in h.tolist()]
+        state = {}
+        for p in pts[:64]:
+            lk.calculate(state, want_derived=True, **p)
+        first = []
+        for p in pts[:4]:
+            lk.calculate(state, want_derived=True, **p)
+            first.append(state["logp"])
+        barrier.wait(timeout=600)
+        n, k = 0, 0
+        t0 = time.perf_counter()
+        t_end = t0 + seconds
+        while time.perf_counter() < t_end:
+            for p in pts[k:k + 32]:
+                lk.calculate(state, want_derived=True, **p)
+            n += 32
+            k = (k + 32) % 4096
+        dt = time.perf_counter() - t0
+        barrier.wait(timeout=600)
+        queue.put((idx, n, dt, first, None))
+    except Exception as exc:       # noqa: BLE001 - reported to the parent, which must not wait for ever
+        try:
+            barrier.abort()
+        except Exception:
+            pass
+        queue.put((idx, 0, 0.0, [], repr(exc)))
+
+
+def chains_sharing_one_gpu(seconds=1.0):
+    """P independent chains - processes, one point per ``calculate`` call - sharing ONE GPU: `direct`, each with a context of
+    its own (a GPU box admits a handful of GPU processes: P <= 4 here), and `brokered`, all of them attached to one owner
+    process that batches whatever is pending (victor_amd/broker.py; the chains never touch the GPU).  Aggregate evaluations
+    per second and microseconds per call per P.  Must run before this process initialises the GPU: it starts processes."""
+    import multiprocessing as mp
+    import subprocess
+    ctx = mp.get_context("spawn")
+    cores = host_cores()
+
+    def run(P, broker):
+        barrier = ctx.Barrier(P)
+        queue = ctx.Queue()
+        procs = [ctx.Process(target=chain_worker, args=(i, P, seconds, broker, barrier, queue)) for i in range(P)]
+        for p in procs:
+            p.start()
+        res = []
+        try:
+            for _ in procs:
+                res.append(queue.get(timeout=900))
+        finally:
+            for p in procs:
+                p.join(timeout=30)
+                if p.is_alive():
+                    p.kill()
+        errs = [r[4] for r in res if r[4]]
+        if errs:
+            return {"error": errs[0]}
+        calls = sum(r[1] for r in res)
+        wall = max(r[2] for r in res)
+        first = sorted(res)[0][3]
+        return {"chains": P, "evals_per_s": calls / wall, "us_per_call": 1e6 * wall * P / calls, "first_logp": first}
+
+    out = {"config": "config/boss_cobaya_config.yaml (BOSS DR12 CMASS), CCFLikelihood.calculate(state, **one_point) in a loop",
+           "seconds_per_run": seconds, "host_cores": cores, "direct": {}, "brokered": {}}
+    for P in (1, 2, 4):
+        out["direct"][str(P)] = run(P, None)
+    name = f"victor_bench_{os.getpid()}"
+    log = os.path.join(ROOT, "gpurun_out", "broker_bench.log") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else os.devnull
+    env = dict(os.environ, PYTHONPATH=ROOT + (os.pathsep + os.environ["PYTHONPATH"] if os.environ.get("PYTHONPATH") else ""))
+    env.pop("VICTOR_HIP_BROKER", None)
+    with open(log, "ab") as lf:
+        srv = subprocess.Popen([sys.executable, "-m", "victor_amd.broker", "--config", "config/boss_cobaya_config.yaml", "--name", name,
+                                "--slots", "32"], cwd=ROOT, env=env, stdin=subprocess.DEVNULL, stdout=lf, stderr=lf)
+        try:
+            for P in (1, 2, 4, 8, 16):
+                r = run(P, name)
+                if P >= cores:
+                    r["note"] = f"{P} spinning chains + the broker on {cores} cores: oversubscribed"
+                out["brokered"][str(P)] = r
+                if "error" in r:
+                    break
+            from victor_amd import broker as B
+            try:
+                seg = B._Segment(B.shm_path(name))
+                st = seg.header.stats
+                out["broker_stats"] = {"batches": int(st.batches), "evals": int(st.evals), "max_batch": int(st.max_batch),
+                                       "mean_batch": st.evals / max(st.batches, 1), "windows_timed_out": int(st.windows_timed_out),
+                                       "busy_seconds": st.busy_seconds, "gather_window_us": seg.header.gather_window_us}
+                seg.header.stop = 1
+                seg.close()
+            except Exception as exc:       # noqa: BLE001
+                out["broker_stats"] = {"error": repr(exc)}
+        finally:
+            try:
+                srv.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                srv.kill()
+    d1 = out["direct"].get("1", {}).get("first_logp")
+    b = [v.get("first_logp") for v in out["brokered"].values() if "first_logp" in v]
+    out["brokered_logp_identical_to_direct"] = bool(d1) and all(x == d1 for x in b) if b else None
+    return out
+
+
 class stdout_to_stderr:
     """Route file descriptor 1 to stderr while native libraries (gloo, RCCL) print their banners, so that the only thing
     this program ever writes to stdout is rank 0's JSON line."""
@@ -370,6 +489,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="points per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-boss", action="store_true", help="skip the secondary BOSS CMASS measurement")
+    ap.add_argument("--no-chains", action="store_true", help="skip the chains-sharing-one-GPU measurement (child processes)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="oracle evaluations (default: about 10 per core)")
     ap.add_argument("--simpson-even", default="simpson",
                     help="even-N Simpson convention of the velocity integral: 'simpson' (SciPy >= 1.11, default) or "
@@ -385,7 +505,10 @@ def main():
     dist = Dist()
     launched = dist.launched
     if launched:
-        dist.connect()
+        if dist.rank == 0:
+            from victor_amd.build import build_native as _build     # (a no-op when the library is current) before the others
+            _build()                                                # are kept waiting in a collective
+        dist.connect(timeout=600.0)
     rank, world = dist.rank, dist.world
     if launched and world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
@@ -415,6 +538,10 @@ def main():
         sample = [cases.point(hp_all, int(i)) for i in sel]
         base, vals, theory_o = cpu_baseline(sample, args.simpson_even)
         base["single_thread"] = cpu_single_thread(sample[:: max(1, len(sample) // 64)][:64], args.simpson_even)
+    # the reference's own calling convention under load (P chains, one point per call): child processes again, so before the GPU
+    chains = None
+    if rank == 0 and total == 1 and not args.no_boss and not args.no_chains:
+        chains = chains_sharing_one_gpu()
 
     # one context per GPU; on a box with fewer GPUs than contexts (rehearsals) contexts share devices and no RCCL
     # communicator can be built, which exercises the host-gather fallback below
@@ -449,6 +576,10 @@ def main():
                     if rccl_ok:
                         try:
                             eng.comm_init(uid, rank, world)
+                        except _native.CommInitTimeout as exc:   # a thread is stuck inside RCCL on this context: fatal, no fallback
+                            print(f"rank {rank}: {exc}", file=sys.stderr)
+                            sys.stderr.flush()
+                            os._exit(4)
                         except Exception as exc:
                             print(f"rank {rank}: ncclCommInitRank failed ({exc})", file=sys.stderr)
                             rccl_ok = 0.0
@@ -617,6 +748,8 @@ def main():
             out["batch_sweep"] = batch_sweep()
             out["dsplit5"] = dsplit_measurement()
             out["host_api"] = api_latency()
+            if chains is not None:
+                out["chains_sharing_one_gpu"] = chains
             out["walker_ensembles"] = walker_rates()
             out["model_options"] = option_rates()
         if base is not None:

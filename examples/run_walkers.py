@@ -77,6 +77,10 @@ def main():
             ok = 1.0
             try:
                 gather = RcclGather(engine, dist, args.walkers)
+            except _native.CommInitTimeout as exc:                     # a thread is stuck inside RCCL on this context: fatal
+                print(f"rank {dist.rank}: {exc}", file=sys.stderr)
+                sys.stderr.flush()
+                os._exit(4)
             except Exception as exc:                                   # every rank must take the same branch
                 print(f"rank {dist.rank}: RCCL gather unavailable ({exc}); using the socket group", file=sys.stderr)
                 ok = 0.0

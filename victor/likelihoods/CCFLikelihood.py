@@ -59,8 +59,16 @@ class CCFLikelihood(Likelihood):
                 info = yaml.full_load(fh)
             self.model = info["model"]
             self.data = info["data"]
-        from victor_amd.sharding import default_device
-        self.ccf = CCFFit(self.model, self.data, device=default_device())   # one chain per GPU under mpirun / torchrun
+        # One chain per GPU under mpirun / torchrun - or, with VICTOR_HIP_BROKER set in the job's environment, every chain's
+        # calculate() goes to the mailbox of one GPU owner process that batches them (victor_amd/broker.py): this file, the
+        # YAML and the mpirun line stay as they are.
+        if os.environ.get("VICTOR_HIP_BROKER"):
+            from victor_amd.broker import broker_device
+            device = broker_device()            # without asking the HIP runtime: a brokered chain never initialises the GPU
+        else:
+            from victor_amd.sharding import default_device
+            device = default_device()
+        self.ccf = CCFFit(self.model, self.data, device=device)
 
     def get_can_provide_params(self):
         return ["fsigma8"]

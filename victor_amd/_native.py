@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-VK_ABI_VERSION = 14
+VK_ABI_VERSION = 15
 VK_NPAR = 12
 (P_FSIGMA8, P_SIGMAV, P_APERP, P_APAR, P_EPSILON, P_BETA, P_ASTAR, P_M, P_Q, P_BIAS, P_AV, P_SPARE) = range(12)
 MATTER = {"template": 0, "linear_bias": 1, "velocity_template": 2}
@@ -52,8 +52,34 @@ class vk_eval_opts(C.Structure):
     ]
 
 
+class vk_mailbox(C.Structure):
+    """One caller's slot in the shared-memory array ``vk_serve_mailboxes`` serves (include/victor_hip.h; 256 bytes)."""
+    _fields_ = [
+        ("req_seq", C.c_uint64), ("state", C.c_uint32), ("reserved0", C.c_uint32), ("client_pid", C.c_int64),
+        ("reserved1", C.c_uint64 * 5),
+        ("row", C.c_double * VK_NPAR),
+        ("reserved2", C.c_uint64 * 4),
+        ("resp_seq", C.c_uint64), ("lnl", C.c_double), ("chi2", C.c_double), ("status", C.c_int32), ("reserved3", C.c_uint32),
+        ("reserved4", C.c_uint64 * 4),
+    ]
+
+
+class vk_serve_stats(C.Structure):
+    _fields_ = [("batches", C.c_uint64), ("evals", C.c_uint64), ("max_batch", C.c_uint64), ("windows_timed_out", C.c_uint64),
+                ("busy_seconds", C.c_double)]
+
+
+assert C.sizeof(vk_mailbox) == 256 and vk_mailbox.row.offset == 64 and vk_mailbox.resp_seq.offset == 192
+
+
 class NativeError(RuntimeError):
     """The HIP library is missing or a device call failed."""
+
+
+class CommInitTimeout(NativeError):
+    """``ncclCommInitRank`` did not return: a helper thread is still inside RCCL on this context, so the context (and with it
+    the process's GPU state) must not be used again.  Fatal for the process - report it and exit non-zero so that the job is
+    restarted as fresh processes; do not fall back to another gather on the same context."""
 
 
 def library_path():
@@ -87,6 +113,7 @@ SYMBOLS = {
     "vk_sync": (C.c_int, [_vp]),
     "vk_joint_workspace_doubles": (C.c_size_t, [C.POINTER(C.c_void_p), C.c_int32, C.c_int64]),
     "vk_joint_eval_device_async": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, _optp, _vp, C.c_int64, _vp, _vp, _vp]),
+    "vk_serve_mailboxes": (C.c_int, [_vp, _optp, _vp, C.c_int32, _vp, C.c_double, C.c_double, C.POINTER(vk_serve_stats)]),
     "vk_timing_enable": (C.c_int, [_vp, C.c_int]),
     "vk_timing_read": (C.c_int, [_vp, _dp, _dp, C.POINTER(C.c_int64), C.c_int]),
     "vk_comm_unique_id": (C.c_int, [C.c_char_p]),
@@ -128,7 +155,10 @@ def load():
 
 def set_knob(name, value):
     """Set (``value`` a string) or clear (``None``) a ``VICTOR_HIP_*`` tuning / A-B knob in this process and make every
-    context re-read the knobs at its next call (they are cached per context, not read per launch)."""
+    context re-read the knobs at its next call (they are cached per context, not read per launch).  Development only: the
+    library ignores every knob unless ``VICTOR_HIP_DEV=1`` is set, which this function does (tests/ and tools/ go through
+    it); a production process that merely inherits a ``VICTOR_HIP_*`` variable runs the default kernels."""
+    os.environ["VICTOR_HIP_DEV"] = "1"
     if value is None:
         os.environ.pop(name, None)
     else:

@@ -45,9 +45,12 @@ def build_native(force=False, verbose=False, defines=(), out=None):
         if verbose:
             print(" ".join(cmd))
         jobs.append((cmd, obj, subprocess.Popen(cmd)))
-    for cmd, _, proc in jobs:
-        if proc.wait() != 0:
-            raise subprocess.CalledProcessError(proc.returncode, cmd)
+    failed = [(cmd, proc.returncode) for cmd, _, proc in jobs if proc.wait() != 0]      # every compile is waited for
+    if failed:
+        for _, obj, _ in jobs:             # no object of a failed build stays behind for a later link to pick up
+            if os.path.exists(obj):
+                os.remove(obj)
+        raise subprocess.CalledProcessError(failed[0][1], failed[0][0])
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *[obj for _, obj, _ in jobs], "-ldl"]
     if verbose:
         print(" ".join(link))

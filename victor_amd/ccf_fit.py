@@ -24,8 +24,19 @@ _SCALARS = (float, int, np.float64)     # the common types of a sampler's parame
 class CCFFit(CCFModel):
     """Fits of the CCF model to measured redshift-space multipoles."""
 
-    def __init__(self, model, data, device=0):
+    def __init__(self, model, data, device=0, broker=None):
+        """``broker``: name of a GPU owner process to send plain single-point ``log_likelihood`` calls to
+        (:mod:`victor_amd.broker`), ``"auto"`` to start / share one per job, ``False`` for never; ``None`` (default) reads the
+        environment variable ``VICTOR_HIP_BROKER``.  The reference's constructor has the first two arguments
+        (``ccf_fit.py:15``)."""
         super().__init__(model, device=device)
+        if broker is None:
+            broker = os.environ.get("VICTOR_HIP_BROKER", "") or False
+        self._broker_spec = broker
+        self._broker_client = None
+        if broker:
+            import copy
+            self._broker_blocks = (copy.deepcopy(model), copy.deepcopy(data))
         base_dir = data.get("dir", "")
         data_fn = os.path.join(base_dir, data["redshift_space_ccf"].get("data_file"))
         cov_fn = os.path.join(base_dir, data["covariance_matrix"].get("data_file"))
@@ -36,6 +47,9 @@ class CCFFit(CCFModel):
         self._load_covariance_matrix(data["covariance_matrix"], cov_fn)
         self.fit_options = {"beta_interpolation": data.get("beta_interpolation", "datavector"),
                             "likelihood": data.get("likelihood", {"form": "Gaussian"})}
+        if broker:
+            import copy
+            self._broker_pristine = (copy.deepcopy(self.model), copy.deepcopy(self.fit_options))
 
     # ------------------------------------------------------------------ set-up (host) -----
     def _load_redshiftspace_ccf(self, ccf, input_fn):
@@ -232,6 +246,13 @@ class CCFFit(CCFModel):
         fit_options = self._merged_fit({})
         if fit_options["beta_interpolation"] == "likelihood" and not self.fixed_data:
             made = None                                         # two evaluations per point: the general path
+        elif self._broker_spec and (self.model, self.fit_options) == self._broker_pristine:
+            # the options are the ones the configuration blocks gave - what the job's broker evaluates: the point goes to its
+            # mailbox and this process never creates a GPU context for it (victor_amd/broker.py)
+            if self._broker_client is None:
+                from . import broker as B
+                self._broker_client = B.connect(*self._broker_blocks, self._broker_spec)
+            made = (None, None, self._needs_beta(model) or not self.fixed_data, self._needs_fsigma8(model), None)
         else:
             eng = self._get_engine(self._engine_key(model), model["simpson_even"])
             opts = eng.make_opts(model, fit_options)
@@ -247,7 +268,8 @@ class CCFFit(CCFModel):
             eng, opts, need_beta, need_fs8 = plan[:4]
             if not self.fixed_data and params.get("beta", None) is None:
                 raise InputError("Need to supply a valid value of beta for interpolation")   # ccf_fit.py:188-189
-            lnl, chi2 = eng.eval_point(opts, self._scalar_row(params, need_beta, need_fs8))
+            row = self._scalar_row(params, need_beta, need_fs8)
+            lnl, chi2 = eng.eval_point(opts, row) if eng is not None else self._broker_client.eval_point(row)
         else:
             lnl, chi2, _ = self._run(params, kwargs)
             lnl, chi2 = float(lnl[0]), float(chi2[0])
@@ -259,7 +281,7 @@ class CCFFit(CCFModel):
         """(lnL[n], chi2[n]) for a batch: ``params`` is a dict of equal-length arrays (scalars broadcast) or an
         ``(n, VK_NPAR)`` array of rows in the column order of ``include/victor_hip.h``."""
         plan = self._single_point_plan() if not kwargs else None
-        if plan is not None:
+        if plan is not None and plan[0] is not None:
             # plain call (a sampler's step): the cached (engine, option block) pair of log_likelihood, no option merging
             eng, _, need_beta, need_fs8, opts = plan
             if not isinstance(params, np.ndarray) and not self.fixed_data and params.get("beta", None) is None:

@@ -18,6 +18,8 @@
 
 #include <hip/hip_runtime.h>
 #include <chrono>
+#include <time.h>
+#include <cstddef>
 
 #include <dlfcn.h>
 
@@ -116,8 +118,10 @@ __global__ void vk_init_stage_kernel(const double* mu, const double* w_ell, int 
 // ==================================================================================================
 // host side
 // ==================================================================================================
-// Tuning / A-B knobs from the environment (VICTOR_HIP_*), read once per context - not once per launch - and again
-// after vk_knobs_refresh() (tests and tools/ change them between calls).
+// Development-only tuning / A-B knobs from the environment (VICTOR_HIP_*).  They are honoured ONLY when VICTOR_HIP_DEV=1 is set
+// as well (tests/ and tools/ set it, victor_amd._native.set_knob does): a variable inherited from somebody's shell must never
+// change the kernel mapping or switch the fused path off in a production run.  Read once per context - not once per launch -
+// and again after vk_knobs_refresh().
 struct Knobs {
   int split_s = 0, split_t = 0;        // VICTOR_HIP_SPLIT "spi,team"
   bool force_generic = false;          // VICTOR_HIP_FORCE_GENERIC
@@ -157,6 +161,7 @@ struct vk_ctx {
   const double* d_sva = nullptr;                  // anisotropic sigma_v block for the fast kernels (TheoryArgs::sva)
   int sva_doubles = 0;
   const double* d_xgw = nullptr;                  // velocity nodes grouped by quadrature weight (TheoryArgs::xgw)
+  int n_xg = 0;                                   // ... how many of them (nodes of weight zero are left out)
   double xw_max = 0.0;                            // max |kExpScale x_k|
   const double *d_s = nullptr, *d_mu = nullptr, *d_w = nullptr, *d_x = nullptr, *d_wx = nullptr, *d_beta_r = nullptr,
                *d_beta_d = nullptr, *d_data = nullptr, *d_beta_c = nullptr, *d_prec = nullptr, *d_tri = nullptr, *d_logdet = nullptr,
@@ -180,6 +185,7 @@ struct vk_ctx {
   const double* d_stage_mu = nullptr;  // [n_mu][kMuRec]
   int grids_in_lds = 0;                    // LikeArgs::grids_in_lds
   const double* inline_params = nullptr;   // set around a single-point host-buffer call: the row goes into the kernel arguments
+  bool theory_wanted = false;              // set around a host-buffer call that returns the theory vectors (TheoryArgs::want_theory)
   unsigned* d_counters = nullptr;      // [kCounterCap], zero between launches
   double* d_partial = nullptr;         // [partial_doubles]
   size_t partial_doubles = 0;
@@ -230,6 +236,12 @@ std::atomic<unsigned> g_knob_gen{1};
 
 void load_knobs(vk_ctx* ctx) {
   Knobs k;
+  ctx->knob_gen = g_knob_gen.load(std::memory_order_relaxed);
+  const char* dev = getenv("VICTOR_HIP_DEV");
+  if (!dev || strcmp(dev, "1") != 0) {       // not a development run: every knob at its default, whatever the environment holds
+    ctx->knobs = k;
+    return;
+  }
   if (const char* env = getenv("VICTOR_HIP_SPLIT")) {
     int sp = 0, t = 0, q = 1;
     const int got = sscanf(env, "%d,%d,%d", &sp, &t, &q);
@@ -257,7 +269,6 @@ void load_knobs(vk_ctx* ctx) {
   k.no_inline_row = getenv("VICTOR_HIP_NO_INLINE_ROW") != nullptr;
   k.lanes_by_chunk = getenv("VICTOR_HIP_LANES_BY_CHUNK") != nullptr;
   ctx->knobs = k;
-  ctx->knob_gen = g_knob_gen.load(std::memory_order_relaxed);
 }
 
 inline void sync_knobs(vk_ctx* ctx) {
@@ -532,6 +543,7 @@ int theory_args(vk_ctx* ctx, const vk_eval_opts* o, TheoryArgs* a, int* nlr) {
   a->xw_scaled = ctx->d_xws;
   a->xw_max = ctx->xw_max;
   a->xgw = ctx->d_xgw;
+  a->n_xg = ctx->n_xg;
   *nlr = o->assume_isotropic ? 1 : ctx->n_ell_r;
   return VK_OK;
 }
@@ -951,6 +963,12 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
       t->n_ell_r > kMaxEll)
     return bail("bad grid sizes (need n_s>=1, n_mu>=2, n_x>=3, 1<=n_ell<=3, 1<=n_ell_r<=3)");
   if (!t->s || !t->mu || !t->w_ell || !t->x || !t->w_x) return bail("grid arrays missing");
+  for (int k = 0; k < t->n_x; ++k) {
+    // a group of equal weights is closed by the non-zero high word of its weight (vk_common.h: load_node): zero weights are
+    // dropped below, anything else must be a normal number
+    if (!std::isfinite(t->x[k]) || !std::isfinite(t->w_x[k]) || (t->w_x[k] != 0.0 && std::fabs(t->w_x[k]) < std::numeric_limits<double>::min()))
+      return bail("velocity nodes x and quadrature weights w_x must be finite (weights: zero or normal numbers)");
+  }
   if (!(t->template_sigma8 > 0) || !(t->iaH > 0)) return bail("iaH and template_sigma8 must be positive");
   std::string e;
   if (check_pp(&t->xi, "xi", &e) || check_pp(&t->vr, "vr", &e) || check_pp(&t->sv, "sv", &e)) return bail(e);
@@ -1051,7 +1069,7 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
   {
     std::vector<char> taken(t->n_x, 0);
     for (int k0 = 0; k0 < t->n_x; ++k0) {
-      if (taken[k0]) continue;
+      if (taken[k0] || t->w_x[k0] == 0.0) continue;       // a node of weight zero adds nothing to the integral
       for (int k = k0; k < t->n_x; ++k)
         if (!taken[k] && t->w_x[k] == t->w_x[k0]) {
           taken[k] = 1;
@@ -1060,6 +1078,7 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
         }
       xgw.back() = t->w_x[k0];
     }
+    ctx->n_xg = (int)(xgw.size() / 2);
     xgw.resize(xgw.size() + 2, 0.0);      // pad pair
   }
   const size_t o_xgw = up.add(xgw.data(), xgw.size());
@@ -1353,6 +1372,7 @@ int vk_eval_batch_device_async(vk_ctx* ctx, const vk_eval_opts* opts, const doub
   if (rc) return rc;
   a.params = d_params;
   a.n = n;
+  a.want_theory = (!want_like || ctx->theory_wanted) ? 1 : 0;   // with lnL / chi2 requested the workspace is scratch (victor_hip.h)
   if (ctx->inline_params && n == 1) {       // single point from host buffers: the row travels in the kernel arguments (TheoryArgs::row0)
     memcpy(a.row0, ctx->inline_params, VK_NPAR * sizeof(double));
     a.inline_row = 1;
@@ -1613,12 +1633,104 @@ int vk_eval_batch(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, i
     if (rc == 1) return VK_OK;
   }
   VK_HIP(ctx, hipMemcpyAsync(d_par, params, nb_par, hipMemcpyHostToDevice, ctx->stream));
+  ctx->theory_wanted = theory != nullptr;
   rc = vk_eval_batch_device_async(ctx, opts, d_par, n, lnl ? d_lnl : nullptr, chi2 ? d_chi : nullptr, d_th);
+  ctx->theory_wanted = false;
   if (rc) return rc;
   if (lnl) VK_HIP(ctx, hipMemcpyAsync(lnl, d_lnl, nb_out, hipMemcpyDeviceToHost, ctx->stream));
   if (chi2) VK_HIP(ctx, hipMemcpyAsync(chi2, d_chi, nb_out, hipMemcpyDeviceToHost, ctx->stream));
   if (theory) VK_HIP(ctx, hipMemcpyAsync(theory, d_th, nb_th, hipMemcpyDeviceToHost, ctx->stream));
   return vk_sync(ctx);
+}
+
+// ---- mailboxes: many one-point callers, one launch (include/victor_hip.h) ---------------------------------------------
+static_assert(sizeof(vk_mailbox) == 256, "vk_mailbox is mirrored field by field in victor_amd/broker.py");
+static_assert(offsetof(vk_mailbox, row) == 64 && offsetof(vk_mailbox, resp_seq) == 192, "vk_mailbox layout");
+
+int vk_serve_mailboxes(vk_ctx* ctx, const vk_eval_opts* opts, vk_mailbox* boxes, int32_t n_boxes, const volatile uint32_t* stop,
+                       double gather_window_us, double max_seconds, vk_serve_stats* stats) {
+  if (!ctx) return VK_E_ARG;
+  int rc = check_opts(ctx, opts);
+  if (rc) return rc;
+  if (!boxes || n_boxes < 1 || n_boxes > 1024 || !stop || !(max_seconds > 0)) return fail(ctx, VK_E_ARG, "vk_serve_mailboxes: bad arguments");
+  if (!ctx->d_data) return fail(ctx, VK_E_ARG, "context was created without a data vector");
+  using clock = std::chrono::steady_clock;
+  const auto t_start = clock::now();
+  const auto window = std::chrono::nanoseconds((long long)(std::max(gather_window_us, 0.0) * 1e3));
+  std::vector<double> rows((size_t)n_boxes * VK_NPAR), lnl(n_boxes), chi2(n_boxes);
+  std::vector<int> idx(n_boxes);
+  std::vector<uint64_t> seq(n_boxes);
+  auto t_last_work = t_start;
+  auto t_first_pending = t_start;
+  bool waiting = false;
+  int last_batch = 0;
+  for (unsigned it = 0;; ++it) {
+    // one scan: who is attached, who has a request pending
+    int n = 0, attached = 0;
+    for (int b = 0; b < n_boxes; ++b) {
+      vk_mailbox& box = boxes[b];
+      if (box.state != VK_BOX_ATTACHED) continue;
+      ++attached;
+      const uint64_t r = __atomic_load_n(&box.req_seq, __ATOMIC_ACQUIRE);
+      if (r != box.resp_seq) {
+        idx[n] = b;
+        seq[n] = r;
+        ++n;
+      }
+    }
+    const auto now = clock::now();
+    if (n == 0) {
+      waiting = false;
+      if (*stop || std::chrono::duration<double>(now - t_start).count() >= max_seconds) return VK_OK;
+      const auto idle = now - t_last_work;
+      if (idle > std::chrono::milliseconds(50)) {
+        struct timespec ts = {0, 1000000};
+        nanosleep(&ts, nullptr);
+      } else if (idle > std::chrono::microseconds(200)) {
+        struct timespec ts = {0, 50000};
+        nanosleep(&ts, nullptr);
+      } else {
+        cpu_relax();
+      }
+      continue;
+    }
+    // chains in lock-step post within a few microseconds of each other: give the ones that were part of the previous round
+    // (and one more) the window to arrive, so that they share a launch instead of splitting into ever smaller batches
+    const int expect = std::min(attached, last_batch + 1);
+    if (n < expect && window.count() > 0) {
+      if (!waiting) {
+        waiting = true;
+        t_first_pending = now;
+      }
+      if (now - t_first_pending < window) {
+        cpu_relax();
+        continue;
+      }
+      if (stats) stats->windows_timed_out += 1;
+    }
+    waiting = false;
+    for (int k = 0; k < n; ++k) memcpy(&rows[(size_t)k * VK_NPAR], boxes[idx[k]].row, VK_NPAR * sizeof(double));
+    const auto t0 = clock::now();
+    rc = vk_eval_batch(ctx, opts, rows.data(), n, lnl.data(), chi2.data(), nullptr);
+    const auto t1 = clock::now();
+    for (int k = 0; k < n; ++k) {
+      vk_mailbox& box = boxes[idx[k]];
+      box.lnl = rc == VK_OK ? lnl[k] : -std::numeric_limits<double>::infinity();
+      box.chi2 = rc == VK_OK ? chi2[k] : std::numeric_limits<double>::infinity();
+      box.status = rc;
+      __atomic_store_n(&box.resp_seq, seq[k], __ATOMIC_RELEASE);
+    }
+    if (stats) {
+      stats->batches += 1;
+      stats->evals += (uint64_t)n;
+      if ((uint64_t)n > stats->max_batch) stats->max_batch = (uint64_t)n;
+      stats->busy_seconds += std::chrono::duration<double>(t1 - t0).count();
+    }
+    last_batch = n;
+    t_last_work = t1;
+    if (*stop) return VK_OK;
+    if ((it & 63u) == 0 && std::chrono::duration<double>(t1 - t_start).count() >= max_seconds) return VK_OK;
+  }
 }
 
 static int general_grid(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, int64_t n, const double* s,
@@ -1660,6 +1772,7 @@ static int general_grid(vk_ctx* ctx, const vk_eval_opts* opts, const double* par
   a.n_s = n_s; a.n_mu = n_mu; a.n_ell = ne;
   a.s = d_s; a.mu = d_mu; a.w_ell = d_w;
   a.out = d_out;
+  a.want_theory = 1;
   a.stage_mu = nullptr;                          // the caller's own (mu, W) grid: staged inside the kernel
   for (int l = 0; l < 3; ++l) {
     a.wsum[l] = 0.0;

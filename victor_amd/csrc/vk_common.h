@@ -74,7 +74,8 @@ struct TheoryArgs {
   double xw_max;            // max |kExpScale x_k| (cell_in_table)
   // velocity nodes in groups of equal quadrature weight (Simpson: a handful of distinct values) for the kernels whose node
   // loop is wave-uniform (lanes, cells): the weight multiplies the group's sum once instead of every integrand point
-  const double* xgw;        // [n_x + 1][2]: {kExpScale x_k in group order, the group's weight at its LAST node else 0} (scalar-cache reads)
+  const double* xgw;        // [n_xg + 1][2]: {kExpScale x_k in group order, the group's weight at its LAST node else 0} (scalar-cache reads)
+  int n_xg;                 // nodes in xgw: the n_x nodes without those of weight zero (which contribute nothing and could not end a group)
   int n_beta_r;           // 0 = fixed xi tables
   const double* beta_r;
   PPView xi, vr, sv;
@@ -138,6 +139,10 @@ struct TheoryArgs {
   // even the table image waits for it), from the argument segment it is one more line of it (tools/gpu_phases.py ... api).
   double row0[VK_NPAR];
   int inline_row;
+  // 1: the theory vectors in `out` are a result of this call (the caller reads them back, or a separate chi-square launch does).
+  // 0 with `fuse`: nobody reads `out` - the chi-square is taken from LDS in the same workgroup - and the kernels that hold a
+  // point's whole vector in LDS (cells) do not write it to HBM at all (BOSS, 65536 points: 31.5 MB per launch that nobody read).
+  int want_theory;
 #ifdef VK_PHASES
   long long* stamps;      // profiling build only (make phases): [workgroup][16] wall_clock64() marks of the point-major kernel
 #endif
@@ -291,11 +296,9 @@ __device__ __forceinline__ void load_shared_x8(const double* p, double (&v)[8]) 
 // second barrier (MI355X_MICROARCH.md, "Valid forms": sc1 stores, every storing wave drained, one lane signalling behind a
 // workgroup barrier, sc1 loads after the returned add).  tests/test_host.py checks the wait in the shipped code object.
 // The finishing workgroup resets counters[point] for the next launch.  `flag`: one int of LDS.
-#ifndef VK_AB_NO_DRAIN
+// (The round-2 form - a workgroup-scope release fence without the vmcnt wait - measured the same speed and is not ordered:
+// profiles/r03/a_handoff_drain_ab.txt.  It is gone from the source; there is no build switch that removes the wait.)
 __device__ __forceinline__ void drain_shared_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-#else   // A/B build of the round-2 form (tools/, never shipped): a workgroup-scope release fence, no vmcnt wait
-__device__ __forceinline__ void drain_shared_stores() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
-#endif
 
 // parameter row of a point (see TheoryArgs::row0)
 __device__ __forceinline__ const double* param_row(const TheoryArgs& a, long long point) {

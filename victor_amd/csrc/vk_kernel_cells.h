@@ -79,6 +79,7 @@ __device__ __forceinline__ void finish_point_ranges(const TheoryArgs& a, long lo
                                                     bool gather, const double* lds_beta_r) {
   const int N = a.n_ell * a.n_s;
   const double w0 = a.wsum[0], w1 = a.wsum[1], w2 = a.wsum[2];
+  const bool keep_out = !a.fuse || a.want_theory;       // see TheoryArgs::want_theory
   LikePrefetch<kLikeRowsCells> pf;
   if (a.fuse) pf.issue(a.like, beta, late_tid(), lds_beta_r);   // travels with the gather (vk_kernel_like.h)
   for (int e = late_tid(); gather && e < N; e += kBlock) {
@@ -90,7 +91,7 @@ __device__ __forceinline__ void finish_point_ranges(const TheoryArgs& a, long lo
 #pragma unroll
     for (int c = 0; c < kMaxParts; ++c) v += (c <= q_last - q_first) ? part[c] : 0.0;
     v = v - (l == 0 ? w0 : (l == 1 ? w1 : w2)) + poison;
-    a.out[point * (long long)N + e] = v;
+    if (keep_out) a.out[point * (long long)N + e] = v;
     th[e] = v;
   }
   __syncthreads();
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 5 : 4) voi
       const bool inside = !mode_is_dispersion(MODE) && !__any(!cell_in_table(fc, s_par, sperp2, a.xw_max * fabs(fp.Bk)));
       double gs = 0.0;
       if (mode_is_dispersion(MODE)) {
-        for (int k = 0; k < a.n_x; ++k) {
+        for (int k = 0; k < a.n_xg; ++k) {
           const VelocityNode xw = load_node(a.xgw, k);
           gs += disp_value<NLR, GRID, MODE == kModeDispersionFromData>(lds, lds + pl.da, fc, fp, a.niter, fma(-xw.x, fp.Bk, s_par), s_par,
                                                                      sperp2, xw.x);
@@ -220,9 +221,9 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 5 : 4) voi
         }
       } else if (inside) {
         VelocityNode nxt = load_node(a.xgw, 0);
-        for (int k = 0; k < a.n_x; ++k) {
+        for (int k = 0; k < a.n_xg; ++k) {
           const VelocityNode xw = nxt;
-          nxt = load_node(a.xgw, k + 1);            // one node ahead (the table has n_x + 1 entries)
+          nxt = load_node(a.xgw, k + 1);            // one node ahead (the table has n_xg + 1 entries)
           double inv_sv;
           const double p = uni_point<NLR, GRID, MODE == kModeFromData, 1, 0, 0, SVA>(lds, fc, 0.0, fma(-xw.x, fp.Bk, s_par), sperp2, xw.x, fp.fa,
                                                                             sperp2x, 0u, inv_sv);
@@ -235,9 +236,9 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 5 : 4) voi
         }
       } else {
         VelocityNode nxt = load_node(a.xgw, 0);
-        for (int k = 0; k < a.n_x; ++k) {
+        for (int k = 0; k < a.n_xg; ++k) {
           const VelocityNode xw = nxt;
-          nxt = load_node(a.xgw, k + 1);            // one node ahead (the table has n_x + 1 entries)
+          nxt = load_node(a.xgw, k + 1);            // one node ahead (the table has n_xg + 1 entries)
           double inv_sv;
           const double p = uni_point<NLR, GRID, MODE == kModeFromData, 1, 1, 0, SVA>(lds, fc, 0.0, fma(-xw.x, fp.Bk, s_par), sperp2, xw.x, fp.fa,
                                                                             sperp2x, 0u, inv_sv);
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 5 : 4) voi
         store_shared(partial_slot(a, point, l, j) + (q - (j * a.n_mu) / cpi), sum);
       } else {
         const double v = sum - (l == 0 ? a.wsum[0] : (l == 1 ? a.wsum[1] : a.wsum[2])) + ps.poison;
-        a.out[point * (long long)N + l * a.n_s + j] = v;
+        if (!a.fuse || a.want_theory) a.out[point * (long long)N + l * a.n_s + j] = v;   // see TheoryArgs::want_theory
         if (tail) th[l * a.n_s + j] = v;
       }
     }

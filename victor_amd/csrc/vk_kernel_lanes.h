@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kBlock, VK_LANES_WG_PER_CU) void vk_theory_lanes_ke
     gs = 0.0;                                                                                                             \
   }
       if (inside) {
-        for (int k = 0; k < a.n_x; ++k) {
+        for (int k = 0; k < a.n_xg; ++k) {
           const VelocityNode xw = load_node(a.xgw, k);
           double inv_sv;
           const double p = uni_point<NLR, GRID, 0, 0, 0, EXPT>(lds, fc, fp.AVk, fma(-xw.x, fp.Bk, s_par), sperp2, xw.x, 0.0, 0.0, lane_off, inv_sv);
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kBlock, VK_LANES_WG_PER_CU) void vk_theory_lanes_ke
           VK_GROUP_END(xw)
         }
       } else {
-        for (int k = 0; k < a.n_x; ++k) {
+        for (int k = 0; k < a.n_xg; ++k) {
           const VelocityNode xw = load_node(a.xgw, k);
           double inv_sv;
           const double p = uni_point<NLR, GRID, 0, 0, 1, EXPT>(lds, fc, fp.AVk, fma(-xw.x, fp.Bk, s_par), sperp2, xw.x, 0.0, 0.0, lane_off, inv_sv);

@@ -354,6 +354,8 @@ class Engine:
             pass
 
     def _check(self, rc):
+        if getattr(self, "_dead", None):
+            raise N.CommInitTimeout(self._dead)
         if rc != 0:
             msg = self._lib.vk_last_error(self._ctx)
             msg = msg.decode() if msg else "unknown error"
@@ -496,8 +498,10 @@ class Engine:
 
     def comm_init(self, uid, rank, nranks, timeout=120.0):
         """ncclCommInitRank for this context.  The call blocks until every rank has joined; it runs on a helper thread so that a
-        rendezvous that never completes (a rank that died, a fabric problem) surfaces as an error after ``timeout`` seconds
-        instead of a silent hang - the caller then gathers through the host."""
+        rendezvous that never completes (a rank that died, a fabric problem) surfaces as :class:`CommInitTimeout` after
+        ``timeout`` seconds instead of a silent hang.  That error is FATAL for the process: the helper thread is still inside
+        RCCL with this context (its stream, a half-built communicator), so the engine refuses every later call and the caller
+        must exit - not fall back to the host gather on the same context (bench.py, examples/run_walkers.py exit non-zero)."""
         import threading
         box = {}
 
@@ -508,7 +512,9 @@ class Engine:
         t.start()
         t.join(timeout)
         if t.is_alive():
-            raise N.NativeError(f"ncclCommInitRank did not complete within {timeout:.0f} s")
+            self._dead = (f"ncclCommInitRank did not complete within {timeout:.0f} s; this context is still inside RCCL and "
+                          "is unusable - restart the job")
+            raise N.CommInitTimeout(self._dead)
         self._check(box["rc"])
 
     def comm_allgather_async(self, d_send, d_recv, count):

@@ -15,14 +15,18 @@ Where the ranks meet (first match):
     explicit TCP endpoint (multi-node runs, e.g. cobaya under ``mpirun``: export it in the job script).
 ``VICTOR_RDZV=unix:/path``
     explicit Unix-domain socket.
-launcher environment with a local ``MASTER_ADDR`` (``torch.distributed.run --master-addr 127.0.0.1``, the bench driver)
+launcher environment of a single-node job - ``MASTER_ADDR`` a literal loopback address (``torch.distributed.run --master-addr
+127.0.0.1``, the bench driver), or the launcher's local world size equal to the world size
     a Unix-domain socket in the temp directory named after ``MASTER_PORT`` (and ``TORCHELASTIC_RUN_ID``): the launcher's own
     store already listens on ``MASTER_PORT`` itself, so that port is not ours to bind.
-launcher environment with a remote ``MASTER_ADDR``
-    TCP on ``MASTER_PORT + 1``.
+any other launcher environment (several nodes)
+    TCP on ``MASTER_PORT + 1`` of ``MASTER_ADDR``; rank 0 binds every interface.
+The choice depends on nothing but the job's environment - never on the name of the host a rank runs on - so every rank of
+a job makes the same one.
 
 Rank and world size come from ``RANK`` / ``WORLD_SIZE`` (torchrun), ``OMPI_COMM_WORLD_RANK`` / ``_SIZE`` (Open MPI),
-``PMI_RANK`` / ``PMI_SIZE`` (MPICH, Intel MPI) or ``SLURM_PROCID`` / ``SLURM_NTASKS``.
+``PMI_RANK`` / ``PMI_SIZE`` (MPICH, Intel MPI) or - inside an ``srun`` step only: ``sbatch`` exports the same variables into
+the batch shell, where a plain ``python bench.py`` is one process, not rank 0 of many - ``SLURM_PROCID`` / ``SLURM_NTASKS``.
 
 The reference has no counterpart: its chains are independent processes under ``mpirun`` (README.md:30).
 """
@@ -42,7 +46,10 @@ _LOCAL_KEYS = ("LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "M
 def launcher_ranks(environ=None):
     """(rank, world, local_rank) from the launcher's environment, or ``None`` when the process was started on its own."""
     env = os.environ if environ is None else environ
+    in_srun_step = env.get("SLURM_STEP_ID", "") != "" or env.get("SLURM_SRUN_COMM_HOST", "") != ""
     for rk, wk in _RANK_KEYS:
+        if rk.startswith("SLURM_") and not in_srun_step:
+            continue                                   # the batch shell of an sbatch job, not a launched task
         if env.get(rk, "") != "" and env.get(wk, "") != "":
             rank, world = int(env[rk]), int(env[wk])
             local = rank
@@ -65,7 +72,15 @@ def endpoint(environ=None):
         return "tcp", (host or "127.0.0.1", int(port))
     addr = env.get("MASTER_ADDR", "127.0.0.1")
     port = int(env.get("MASTER_PORT", "29400"))
-    if addr in ("127.0.0.1", "localhost", "::1", socket.gethostname()):
+    found = launcher_ranks(env)
+    world = found[1] if found else 1
+    local_world = 0
+    for key in ("LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS", "MV2_COMM_WORLD_LOCAL_SIZE"):
+        if env.get(key, "") != "":
+            local_world = int(env[key])
+            break
+    single_node = addr in ("127.0.0.1", "localhost", "::1") or (local_world > 0 and local_world == world)
+    if single_node:
         run = "".join(c for c in env.get("TORCHELASTIC_RUN_ID", "") if c.isalnum())[:24]
         name = f"victor_rdzv_{os.getuid()}_{port}{'_' + run if run else ''}.sock"
         return "unix", os.path.join(tempfile.gettempdir(), name)
@@ -94,7 +109,10 @@ def _recv(sock):
 class SocketGroup:
     """The ranks of one job.  Every method is a collective: all ranks must call it, in the same order."""
 
-    def __init__(self, rank, world, where=None, timeout=120.0):
+    def __init__(self, rank, world, where=None, timeout=120.0, collective_timeout=None):
+        """``timeout`` bounds the handshake (rank 0 waiting for its peers, a peer waiting for rank 0).  The collectives after
+        it wait ``collective_timeout`` seconds for a message (default ``None``: as long as it takes - ranks may be minutes
+        apart, e.g. while one of them compiles the library)."""
         self.rank, self.world = int(rank), int(world)
         if not (0 <= self.rank < self.world):
             raise ValueError("bad rank/world")
@@ -116,7 +134,7 @@ class SocketGroup:
             srv = socket.socket(family, socket.SOCK_STREAM)
             if kind == "tcp":
                 srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind(addr)
+            srv.bind(("", addr[1]) if kind == "tcp" else addr)        # TCP: every interface (MASTER_ADDR names this node somehow)
             srv.listen(self.world)
             srv.settimeout(timeout)
             by_rank = {}
@@ -138,6 +156,7 @@ class SocketGroup:
             self._peers = [by_rank[r] for r in range(1, self.world)]
             for conn in self._peers:
                 _send(conn, _MAGIC)                       # everyone is here
+                conn.settimeout(collective_timeout)
         else:
             while True:
                 sock = socket.socket(family, socket.SOCK_STREAM)
@@ -155,6 +174,7 @@ class SocketGroup:
             _send(sock, _MAGIC + struct.pack("<ii", self.rank, self.world))
             if _recv(sock) != _MAGIC:
                 raise RuntimeError("rendezvous: bad reply from rank 0")
+            sock.settimeout(collective_timeout)
             self._root = sock
 
     # ---- the one primitive: everybody's bytes to everybody --------------------------------------------------------
