@@ -280,7 +280,7 @@ int vk_joint_eval_device_async(vk_ctx* const* ctxs, int32_t n_ctx, const vk_eval
  * throughput comes from several chains, one process each, under mpirun (README.md:30).  P processes with a context each
  * serialise P small launches on the GPU.  Instead ONE owner process holds the context and serves an array of mailboxes that
  * lives in memory shared with the chains (a file in /dev/shm, victor_amd/broker.py): a chain writes its parameter row and
- * bumps `req_seq`; the owner evaluates everything that is pending as ONE vk_eval_batch and answers each mailbox by
+ * bumps `req_seq`; the owner evaluates everything that is pending as ONE launch and answers each mailbox by
  * writing lnl / chi2 / status and then `resp_seq = req_seq`.  The chains never touch the GPU (or this library).
  *
  * Protocol of one mailbox (all fields naturally aligned; x86-64 / aarch64 release-acquire on the two sequence words):
@@ -312,14 +312,22 @@ typedef struct vk_serve_stats {      /* accumulated over calls until the caller 
   double busy_seconds;               /* inside vk_eval_batch */
 } vk_serve_stats;
 
-/* Serve `n_boxes` mailboxes with the context until *stop != 0 or `max_seconds` have passed (then returns VK_OK; call it
- * again - the owner looks after its clients between calls).  `gather_window_us`: after the first pending request of a
- * round the server waits up to this long for the other attached clients' requests so that lock-step chains share one
- * launch (0: launch at once).  When nothing is pending it polls for ~0.2 ms, then naps in steps of 50 us (1 ms after
- * 50 ms of silence).  n_boxes <= 1024.  Returns a VK_E_* code only for bad arguments: an evaluation error is reported to the
- * requesting mailboxes (status) and the loop goes on. */
-int vk_serve_mailboxes(vk_ctx* ctx, const vk_eval_opts* opts, vk_mailbox* boxes, int32_t n_boxes,
-                       const volatile uint32_t* stop, double gather_window_us, double max_seconds, vk_serve_stats* stats);
+/* Serve `n_boxes` mailboxes until *stop != 0 or `max_seconds` have passed (then returns VK_OK once nothing is in flight; call
+ * it again - the owner looks after its clients between calls).  `ctxs`: 1..8 contexts holding the SAME tables on one device
+ * (the owner creates them from one vk_tables): one launch per context may be in flight, so a round's requests start at once
+ * on a free context while earlier rounds are still on the GPU - the launches overlap there like those of separate processes -
+ * and requests that arrive together share a launch.  `gather_window_us`: after the first pending request of a round the
+ * server waits up to this long for the requests of the other attached clients that are not being served already (chains in
+ * lock-step then share one launch instead of splitting into ever smaller ones; 0: launch at once).  When nothing is pending
+ * or in flight it polls for ~0.2 ms, then naps in steps of 50 us (1 ms after 50 ms of silence).  n_boxes <= 1024.  Returns a
+ * VK_E_* code only for bad arguments: an evaluation error is reported to the requesting mailboxes (status) and the loop goes
+ * on.  A launch carries at most `max_batch` requests (1..32; 0 = 32: smaller launches finish sooner and leave the other contexts
+ * something to overlap with), and every request is evaluated with the work split of a single-point
+ * vk_eval_batch call whatever shares its launch: lnl / chi2 of a row are bit-identical to vk_eval_batch(ctx, opts, row, 1, ...)
+ * and do not depend on what the other clients were doing. */
+int vk_serve_mailboxes(vk_ctx* const* ctxs, int32_t n_ctx, const vk_eval_opts* opts, vk_mailbox* boxes, int32_t n_boxes,
+                       const volatile uint32_t* stop, double gather_window_us, int32_t max_batch, double max_seconds,
+                       vk_serve_stats* stats);
 
 /* ---- timing on the context's stream (HIP events) ------------------------------------ */
 /* Marks: 0 = before theory kernel, 1 = between kernels, 2 = after likelihood kernel, recorded by

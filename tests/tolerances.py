@@ -83,7 +83,7 @@ def assert_same_chi2(got, want, bound=None, n_data=None, what="", ulps=64):
     """chi-squares of two evaluation orders agree to ``bound`` (per point, from :func:`chi2_bound`; sliced by the caller for a
     sub-batch) or, without it, to :func:`generic_chi2_bound`.  Rows that failed in both (+inf) count as equal.  Returns the
     bound it used."""
-    got, want = np.asarray(got, float), np.asarray(want, float)
+    got, want = np.atleast_1d(np.asarray(got, float)), np.atleast_1d(np.asarray(want, float))
     assert got.shape == want.shape, (what, got.shape, want.shape)
     both_inf = np.isinf(got) & np.isinf(want) & (got == want)
     with np.errstate(invalid="ignore"):
@@ -106,11 +106,11 @@ def assert_same_lnl(got, want, chi2_bounds, what="", offset_scale=1000.0):
     (gaussian -1/2; hartlap / percival rescale by a factor below one; sellentin -n/2(n-1) / (1 + chi2/(n-1))), plus a
     beta-dependent log-determinant of magnitude <= ``offset_scale`` that carries a few roundings of its own.  ABSOLUTE bound:
     lnL passes through zero where the log-determinant term cancels the chi-square term."""
-    got, want = np.asarray(got, float), np.asarray(want, float)
+    got, want = np.atleast_1d(np.asarray(got, float)), np.atleast_1d(np.asarray(want, float))
     both_inf = np.isinf(got) & np.isinf(want) & (got == want)
     with np.errstate(invalid="ignore"):
         diff = np.where(both_inf, 0.0, np.abs(got - want))
-    bound = 0.51 * np.asarray(chi2_bounds, float) + 16 * U * (np.abs(want) + offset_scale)
+    bound = 0.51 * np.atleast_1d(np.asarray(chi2_bounds, float)) + 16 * U * (np.abs(want) + offset_scale)
     bound = np.where(np.isfinite(bound), bound, 0.0)
     margin = float(np.max(diff / np.where(bound > 0, bound, 1.0))) if diff.size else 0.0
     _record(f"lnl  {what}", margin)

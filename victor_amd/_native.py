@@ -113,7 +113,8 @@ SYMBOLS = {
     "vk_sync": (C.c_int, [_vp]),
     "vk_joint_workspace_doubles": (C.c_size_t, [C.POINTER(C.c_void_p), C.c_int32, C.c_int64]),
     "vk_joint_eval_device_async": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, _optp, _vp, C.c_int64, _vp, _vp, _vp]),
-    "vk_serve_mailboxes": (C.c_int, [_vp, _optp, _vp, C.c_int32, _vp, C.c_double, C.c_double, C.POINTER(vk_serve_stats)]),
+    "vk_serve_mailboxes": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, _optp, _vp, C.c_int32, _vp, C.c_double, C.c_int32,
+                           C.c_double, C.POINTER(vk_serve_stats)]),
     "vk_timing_enable": (C.c_int, [_vp, C.c_int]),
     "vk_timing_read": (C.c_int, [_vp, _dp, _dp, C.POINTER(C.c_int64), C.c_int]),
     "vk_comm_unique_id": (C.c_int, [C.c_char_p]),

@@ -9,6 +9,8 @@ GPU box lets only a handful of processes open the device at all.  Here ONE proce
   ``include/victor_hip.h``), write their parameter row and bump a sequence word;
 * the broker sits in ``vk_serve_mailboxes`` (native loop, ``victor_amd/csrc/victor_hip.hip``): whatever is pending becomes ONE
   ``vk_eval_batch`` - chains that run in lock-step share a launch - and every mailbox gets its ``(lnL, chi2)`` back;
+  it holds a few contexts (streams) and keeps one launch in flight on each, so a round's requests start at once while earlier
+  rounds are still on the GPU - the launches overlap there the way the launches of separate processes do;
 * the chains never load the HIP library or touch the GPU: 16 chains are one GPU process.
 
 Nothing changes for the user's YAML or the plug-in: the route is chosen by the environment,
@@ -60,6 +62,7 @@ class _Header(C.Structure):
         ("digest", C.c_char * 64),
         ("stats", N.vk_serve_stats),
         ("gather_window_us", C.c_double),
+        ("depth", C.c_uint32), ("max_batch", C.c_uint32),
         ("error", C.c_char * 512),
     ]
 
@@ -163,8 +166,11 @@ class Broker:
     ``attach_existing``: the segment was created (state STARTING) by the chain that elected itself to start this process.
     """
 
-    def __init__(self, model, data, name, n_slots=64, device=0, gather_window_us=6.0, attach_existing=False):
+    def __init__(self, model, data, name, n_slots=64, device=0, gather_window_us=3.0, attach_existing=False, depth=4, max_batch=4):
+        """``depth``: contexts (streams) of the owner = launches that may be in flight at once (1..8); ``max_batch``: requests per
+        launch (0: the library's limit, 32).  Defaults from tools/gpu_broker_sweep.py (profiles/r04/broker_sweep.txt)."""
         self.name = name
+        depth = max(1, min(int(depth), 8))
         path = shm_path(name)
         self.seg = _Segment(path, create=not attach_existing, n_slots=n_slots)
         h = self.seg.header
@@ -182,8 +188,16 @@ class Broker:
             if plan is None:
                 raise InputError("beta_interpolation 'likelihood' evaluates two rows per point: not served by the broker")
             self.engine, self.opts = plan[0], plan[4]
+            # one context (stream, device tables, pinned buffers) per launch in flight
+            from .engine import Engine
+            key = self.fit._engine_key(self.fit._merged({}))
+            self.engines = [self.engine] + [Engine(self.fit, self.fit, device=device, matter_model=key,
+                                                   simpson_even=self.engine.simpson_even) for _ in range(depth - 1)]
             # first evaluation here, not under the first client's clock (runtime, code object, LDS image)
-            self.engine.eval_point(plan[1], [0.5, 380.0, 1.0, 1.0, 1.0, 0.4, 1.0, 1.0, 1.0, float(self.fit.model["bias"]), 0.0, 0.0])
+            for eng in self.engines:
+                eng.eval_point(plan[1], [0.5, 380.0, 1.0, 1.0, 1.0, 0.4, 1.0, 1.0, 1.0, float(self.fit.model["bias"]), 0.0, 0.0])
+            h.depth = depth
+            h.max_batch = max(0, int(max_batch))
         except Exception as exc:
             h.error = str(exc).encode()[:500]
             h.state = FAILED
@@ -199,11 +213,12 @@ class Broker:
         stats = N.vk_serve_stats()
         boxes_addr = C.addressof(seg.boxes)
         stop_addr = C.addressof(h) + _Header.stop.offset
+        ctxs = (C.c_void_p * len(self.engines))(*[e._ctx for e in self.engines])
         ever, empty_since = False, time.time()
         try:
             while True:
-                rc = lib.vk_serve_mailboxes(self.engine._ctx, C.byref(self.opts), boxes_addr, seg.n_slots, stop_addr,
-                                            float(h.gather_window_us), float(slice_s), C.byref(stats))
+                rc = lib.vk_serve_mailboxes(ctxs, len(self.engines), C.byref(self.opts), boxes_addr, seg.n_slots, stop_addr,
+                                            float(h.gather_window_us), int(h.max_batch), float(slice_s), C.byref(stats))
                 if rc != 0:
                     self.engine._check(rc)
                 h.stats = stats
@@ -338,7 +353,7 @@ class BrokerClient:
             pass
 
 
-def spawn_broker(model, data, name, device=0, n_slots=64, linger=5.0, gather_window_us=6.0, log=None):
+def spawn_broker(model, data, name, device=0, n_slots=64, linger=5.0, gather_window_us=3.0, log=None, depth=4, max_batch=4):
     """Start ``python -m victor_amd.broker`` for a segment this process has just created (election winner) or will create.
     The child is a fresh interpreter: it is the only process that initialises the GPU."""
     import subprocess
@@ -347,7 +362,8 @@ def spawn_broker(model, data, name, device=0, n_slots=64, linger=5.0, gather_win
     json.dump({"model": model, "data": data}, cfg, default=str)
     cfg.close()
     cmd = [sys.executable, "-m", "victor_amd.broker", "--config-json", cfg.name, "--name", name, "--device", str(device),
-           "--slots", str(n_slots), "--linger", str(linger), "--window-us", str(gather_window_us), "--attach-existing",
+           "--slots", str(n_slots), "--linger", str(linger), "--window-us", str(gather_window_us), "--depth", str(depth), "--max-batch", str(max_batch),
+           "--attach-existing",
            "--parent-pid", str(os.getpid()), "--delete-config"]
     env = dict(os.environ)
     env.pop("VICTOR_HIP_BROKER", None)
@@ -391,7 +407,8 @@ def connect(model, data, spec, timeout=300.0):
             continue
         seg.close()
         spawn_broker(model, data, name, device=device, n_slots=int(os.environ.get("VICTOR_HIP_BROKER_SLOTS", "64")),
-                     log=os.environ.get("VICTOR_HIP_BROKER_LOG"))
+                     log=os.environ.get("VICTOR_HIP_BROKER_LOG"), depth=int(os.environ.get("VICTOR_HIP_BROKER_DEPTH", "4")),
+                     max_batch=int(os.environ.get("VICTOR_HIP_BROKER_MAX_BATCH", "4")))
         return BrokerClient(name, digest, timeout=timeout)
     raise N.NativeError(f"could not start or reach broker {name}")
 
@@ -406,7 +423,10 @@ def main(argv=None):
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--slots", type=int, default=64)
     ap.add_argument("--linger", type=float, default=None, help="exit this many seconds after the last client has gone")
-    ap.add_argument("--window-us", type=float, default=6.0, help="how long a round waits for the other chains' requests")
+    ap.add_argument("--window-us", type=float, default=3.0, help="how long a round waits for the other chains' requests")
+    ap.add_argument("--depth", type=int, default=4, help="contexts (streams) of the owner = launches in flight at once")
+    ap.add_argument("--max-batch", type=int, default=4, help="requests per launch (0: the library's limit of 32); measured "
+                                                             "best at 4 for 8 and 16 chains (tools/gpu_broker_sweep.py)")
     ap.add_argument("--attach-existing", action="store_true")
     ap.add_argument("--parent-pid", type=int, default=0)
     ap.add_argument("--delete-config", action="store_true")
@@ -428,7 +448,7 @@ def main(argv=None):
     name = args.name or auto_name(config_digest(model, data), args.device)
     try:
         broker = Broker(model, data, name, n_slots=args.slots, device=args.device, gather_window_us=args.window_us,
-                        attach_existing=args.attach_existing)
+                        attach_existing=args.attach_existing, depth=args.depth, max_batch=args.max_batch)
     except Exception as exc:
         if args.attach_existing:            # tell the chains that are waiting for READY
             try:
@@ -439,7 +459,8 @@ def main(argv=None):
             except Exception:
                 pass
         raise
-    print(f"victor broker '{name}' ready: pid {os.getpid()}, device {args.device}, {args.slots} mailboxes", file=sys.stderr, flush=True)
+    print(f"victor broker '{name}' ready: pid {os.getpid()}, device {args.device}, {broker.seg.n_slots} mailboxes, "
+          f"{len(broker.engines)} launches in flight", file=sys.stderr, flush=True)
     broker.serve(linger=args.linger, parent_pid=args.parent_pid or None)
 
 

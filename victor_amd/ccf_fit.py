@@ -264,12 +264,19 @@ class CCFFit(CCFModel):
     def log_likelihood(self, params, **kwargs):
         """(lnL, chi2) at one parameter point (reference: ccf_fit.py:356-483)."""
         plan = self._single_point_plan() if (not kwargs and type(params) is dict) else None
-        if plan is not None and all(type(v) in _SCALARS or not np.ndim(v) for v in params.values()):
-            eng, opts, need_beta, need_fs8 = plan[:4]
+        row = None
+        if plan is not None:
             if not self.fixed_data and params.get("beta", None) is None:
                 raise InputError("Need to supply a valid value of beta for interpolation")   # ccf_fit.py:188-189
-            row = self._scalar_row(params, need_beta, need_fs8)
-            lnl, chi2 = eng.eval_point(opts, row) if eng is not None else self._broker_client.eval_point(row)
+            try:
+                # one point given as scalars (cobaya hands over all ~25 declared inputs per call: only the ones that enter the row
+                # are looked at); an array-valued entry fails the float() inside and takes the general path
+                row = self._scalar_row(params, plan[2], plan[3])
+            except TypeError:
+                row = None
+        if row is not None:
+            eng = plan[0]
+            lnl, chi2 = eng.eval_point(plan[1], row) if eng is not None else self._broker_client.eval_point(row)
         else:
             lnl, chi2, _ = self._run(params, kwargs)
             lnl, chi2 = float(lnl[0]), float(chi2[0])
