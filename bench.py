@@ -261,6 +261,25 @@ def warm_up(eng, launch, seconds=0.3):
         eng.sync()
 
 
+def profiled_traffic(which, batch):
+    """HBM bytes per launch of the dominant kernel from the last rocprofv3 --pmc passes (separate FETCH_SIZE / WRITE_SIZE runs,
+    tools/update_traffic.py -> profiles/traffic_latest.json): this run makes no counter passes, so the figure is quoted with
+    its source and the commit it was taken at, scaled from the profiled batch to this run's (traffic is per point)."""
+    tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if not os.path.isfile(tfile):
+        return None
+    with open(tfile) as fh:
+        tj = json.load(fh)
+    rec = tj.get(which)
+    if not rec:
+        return None
+    scale = batch / rec["batch"]
+    return {"bytes_per_launch": rec["theory_kernel_hbm_bytes_per_launch"] * scale, "batch": batch,
+            "profiled_batch": rec["batch"], "algorithmic_bytes_per_launch": rec["algorithmic_bytes_per_launch"] * scale,
+            "ratio_to_algorithmic": rec["theory_kernel_hbm_bytes_per_launch"] / rec["algorithmic_bytes_per_launch"],
+            "kernel": rec["kernel"], "commit": tj.get("commit"), "source": tj.get("source")}
+
+
 def boss_measurement(args, batch=16384, steps=20):
     """Secondary figure: the BOSS DR12 CMASS configuration the north star's 1e5 evals/s target is quoted on
     (config/boss_config.yaml: 30 s bins x 100 mu x 50 v, l = 0,2, reconstruction-beta dependent tables, data and
@@ -283,6 +302,7 @@ def boss_measurement(args, batch=16384, steps=20):
     dt = time.perf_counter() - t0
     k1, k2, launches = eng.read_timing(reset=True)
     eng.timing(False)
+    fused = eng.last_fused()
     import numpy as np
     lnl = eng.download(d_lnl, batch)
     for p in (d_rows, d_lnl, d_chi, d_ws):
@@ -292,7 +312,8 @@ def boss_measurement(args, batch=16384, steps=20):
     return {"evals_per_s": batch * steps / dt, "batch": batch, "steps": steps, "kernel": eng.last_kernel() + "<1,2>",
             "kernels_ms": {"theory": k1, "likelihood": k2 / max(launches, 1)},
             "fp64_valu_frac": F * batch / (k1 * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if k1 > 0 else None,
-            "flops_per_eval": F, "all_finite": bool(np.all(np.isfinite(lnl)))}
+            "flops_per_eval": F, "all_finite": bool(np.all(np.isfinite(lnl))), "fused": fused,
+            "traffic_profiled": profiled_traffic("boss_cmass", batch)}
 
 
 def batch_sweep():
@@ -372,7 +393,7 @@ def walker_rates(steps=150):
     specs, fixed = parse_cobaya_params(info["params"])
     res = {}
     for walkers in (8, 64, 512):
-        ens = EnsembleMetropolis(lambda batch: fit.log_likelihood_batch(batch)[0], specs, walkers, seed=1, fixed=fixed)
+        ens = EnsembleMetropolis(None, specs, walkers, seed=1, fixed=fixed, fit=fit)      # rows written in place, straight to the engine
         ens.initialise()
         t_end = time.perf_counter() + 0.4    # past the first call's one-off costs and the runtime's stall after fresh allocations (see warm_up)
         while time.perf_counter() < t_end:
@@ -698,15 +719,8 @@ def main():
         achieved_tf = F * B / (k1_ms * 1e-3) / 1e12 if k1_ms > 0 else None
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (MI355X_MICROARCH.md), which this run
         # does not make: `traffic` is null here and the last profiled figure is reported beside it with its source
-        traffic_profiled = None
-        tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.isfile(tfile):
-            with open(tfile) as fh:
-                tj = json.load(fh)
-            if tj.get("batch") == B:
-                traffic_profiled = {"bytes_per_launch": tj.get("theory_kernel_hbm_bytes_per_launch"),
-                                    "source": tj.get("source", "profiles/traffic_latest.json"), "kernel": tj.get("kernel")}
-        alg_bytes = (8 * 10 + 16) * B     # 80 B of parameters in, lnL + chi2 out, per evaluation
+        traffic_profiled = profiled_traffic("config3", B)
+        alg_bytes = (8 * 12 + 16) * B     # a parameter row of VK_NPAR = 12 doubles in, lnL + chi2 out, per evaluation
         out = {
             "metric": "likelihood evals/sec (40 s-bins, 100 mu, l=0,2,4)",
             "value": value, "unit": "evals/s", "n_gpus": total, "steps": args.steps, "warmup": args.warmup,
@@ -732,7 +746,7 @@ def main():
             "roofline_hbm": {"bound": "hbm", "achieved": alg_bytes / ((k1_ms + k2_ms) * 1e-3) / 1e9 if k1_ms else None,
                              "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": alg_bytes / ((k1_ms + k2_ms) * 1e-3) / 1e9 / PEAK_HBM_GBS if k1_ms else None,
-                             "bytes_per_eval": 96},
+                             "bytes_per_eval": 112},
             "kernels_ms": {"theory": k1_ms, "likelihood": k2_ms},
             "outputs_finite": ok,
         }

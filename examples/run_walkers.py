@@ -89,7 +89,7 @@ def main():
                     gather.close()
                 gather = None
         ens = DistributedEnsemble(lambda batch: fit.log_likelihood_batch(batch)[0], specs, args.walkers, dist,
-                                  seed=args.seed, fixed=fixed, gather=gather, sampler=sampler)
+                                  seed=args.seed, fixed=fixed, gather=gather, sampler=sampler, fit=fit)
         gather_name = "rccl" if gather is not None else "host"
     # the first evaluation of a process pays for the HIP runtime, the code object and the device tables (~0.25 s): timed apart
     t0 = time.perf_counter()

@@ -680,3 +680,64 @@ def test_shipped_file_combinations_on_gpu(case, tmp_path):
                     _native.set_knob(k, None)
             assert np.max(np.abs(cb.reshape(700, -1) / want_c - 1)) < RTOL, (form, knob)
             assert np.max(np.abs(lb.reshape(700, -1) / want_l - 1)) < RTOL, (form, knob)
+
+
+def test_kaiser_and_euclid_special_run_on_the_cells_kernel(tmp_path):
+    """The models without a velocity integral (ccf_model.py:692-784) take the cells kernel on the unified-grid records (one lane
+    per (s, mu) cell, chi-square fused) for every grid form and option the tables allow; FORCE_GENERIC keeps the generic kernel
+    (library sqrt / division, knot search) as the yardstick.  Every option combination against the live oracle on a few rows
+    and against the generic kernel on the whole batch."""
+    import os
+    import sys
+    import victor_amd
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import victor_oracle as vo
+
+    def run(fit, ora, hp, tag, probe, **kw):
+        got = fit.log_likelihood_batch(hp, **kw)
+        key = fit._engine_key(fit._merged(kw))
+        assert fit._get_engine(key).last_kernel() == "vk_theory_cells_kernel" and fit._get_engine(key).last_fused(), (tag, kw)
+        _native.set_knob("VICTOR_HIP_FORCE_GENERIC", "1")
+        try:
+            ref = fit.log_likelihood_batch(hp, **kw)
+            assert fit._get_engine(key).last_kernel() == "vk_theory_kernel"
+        finally:
+            _native.set_knob("VICTOR_HIP_FORCE_GENERIC", None)
+        assert_same_chi2(got[1], ref[1], chi2_bound(fit, hp, ulps=1024, **kw), what=f"kaiser cells vs generic: {tag} {kw}")
+        for i in probe:
+            want = ora.log_likelihood(cases.point(hp, i), **kw)
+            assert abs(got[1][i] / want[1] - 1) < RTOL and abs(got[0][i] - want[0]) < RTOL * (abs(want[0]) + want[1]), (tag, kw, i)
+        # one point per call and a handful of points (cell ranges, partial sums) agree with the rows of the batch
+        one = fit.log_likelihood(cases.point(hp, probe[0]), **kw)
+        assert abs(one[1] / got[1][probe[0]] - 1) < 1e-11, (tag, kw)
+        few = fit.log_likelihood_batch({k: (v[:5] if np.ndim(v) else v) for k, v in hp.items()}, **kw)
+        assert np.max(np.abs(few[1] / got[1][:5] - 1)) < 1e-11, (tag, kw)
+
+    # BOSS: beta-dependent tables, isotropic xi^r, sellentin form, blended covariance
+    opts = cases.boss_options("config")
+    fit, ora = victor_amd.CCFFit(*opts), vo.OracleFit(*opts)
+    hp = dict(cases.halton_params(700, with_beta=True), M=1.07, Q=0.93, bias=2.0, Av=0.6)
+    for kw in ({"rsd_model": "kaiser"}, {"rsd_model": "euclid_special"}, {"rsd_model": "kaiser", "kaiser_coord_shift": False},
+               {"rsd_model": "kaiser", "kaiser_approximation": True}, {"rsd_model": "kaiser", "niter": 2},
+               {"rsd_model": "kaiser", "matter_model": "linear_bias"}, {"rsd_model": "euclid_special", "empirical_corr": True},
+               {"rsd_model": "kaiser", "matter_model": "linear_bias", "empirical_corr": True}):
+        run(fit, ora, hp, "boss", (0, 350, 699), **kw)
+    # config 3: fixed tables, three real-space multipoles, l = 0, 2, 4 (lattice grid)
+    opts = cases.synth_options(3)
+    fit, ora = victor_amd.CCFFit(*opts), vo.OracleFit(*opts)
+    hp = dict(cases.halton_params(9000), M=0.95, Q=1.1)
+    for kw in ({"rsd_model": "kaiser"}, {"rsd_model": "euclid_special"}, {"rsd_model": "kaiser", "assume_isotropic": True}):
+        run(fit, ora, hp, "config3", (0, 4500, 8999), **kw)
+    # the union-grid form (r grid and sigma_v grid not commensurate)
+    src = np.load(os.path.join(cases.GOLDEN, "synth", "model.npy"), allow_pickle=True).item()
+    tab = dict(src)
+    tab["rsv"] = np.asarray(src["rsv"]) * 1.037 + 0.21
+    np.save(tmp_path / "model_union.npy", tab, allow_pickle=True)
+    model, data = cases.synth_options(3)
+    model = dict(model, dir=str(tmp_path), input_model_data_file="model_union.npy")
+    fit, ora = victor_amd.CCFFit(model, data), vo.OracleFit(model, data)
+    from victor_amd.engine import build_tables
+    tabs, _keep = build_tables(fit, fit)
+    assert tabs.uni_n > 0 and tabs.uni_lut_n > 0
+    hp = dict(cases.halton_params(300), M=1.0, Q=1.0)
+    run(fit, ora, hp, "union grid", (0, 299), rsd_model="kaiser")

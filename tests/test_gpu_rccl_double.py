@@ -1,0 +1,121 @@
+"""The N > 1 branch of the RCCL gather on a one-GPU box: two and three launched ranks SHARING device 0 build a communicator of
+tests/rccl_double (a gcc-built stand-in for the RCCL entry points the library dlsym()s, moving the bytes with hipMemcpy and a
+Unix socket) through the product's unchanged code path - vk_comm_unique_id on rank 0, the 128-byte id broadcast over the ranks'
+socket group, vk_comm_init(id, rank, n) on every rank, vk_comm_allgather_async on the context's stream.  What a real multi-GPU
+node would add is xGMI instead of the socket; what runs here for the first time is everything of OURS around it: the id crossing
+processes by value, the rank-major receive layout, the padded last shard, bench.py's and run_walkers.py's multi-rank legs."""
+
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "rccl_double", "rccl_double.c")
+
+
+def build_double(out_dir):
+    out = os.path.join(str(out_dir), "librccl_double.so")
+    cmd = ["gcc", "-shared", "-fPIC", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", SRC, "-L/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath,/opt/rocm/lib", "-o", out]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    return out
+
+
+def test_double_provides_every_entry_point_the_library_looks_up(tmp_path):
+    """(CPU) the stand-in exports exactly the nccl* names victor_hip.hip passes to dlsym - a new call in the product without a
+    counterpart here would make these tests fall back to the host gather silently."""
+    lib = build_double(tmp_path)
+    exported = set(re.findall(r" T (nccl\w+)", subprocess.run(["nm", "-D", lib], capture_output=True, text=True).stdout))
+    with open(os.path.join(ROOT, "victor_amd", "csrc", "victor_hip.hip")) as fh:
+        wanted = set(re.findall(r'dlsym\([^,]+,\s*"(nccl\w+)"\)', fh.read()))
+    assert wanted and wanted <= exported, (wanted - exported)
+
+
+def _env(double, tmp_path):
+    return {"VICTOR_HIP_RCCL_LIB": double, "VICTOR_HIP_RCCL_SHARED_DEVICE_OK": "1", "RCCL_DOUBLE_DIR": str(tmp_path)}
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_gather_through_the_communicator(tmp_path):
+    from tests.test_gpu_workloads import _launch_ranks
+    double = build_double(tmp_path)
+    res = _launch_ranks([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4096",
+                         "--no-cpu-baseline", "--no-boss"], 2, extra_env=_env(double, tmp_path))
+    for rc, out, err in res:
+        assert rc == 0, err[-3000:]
+    lines = [ln for ln in res[0][1].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res[0][1][-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["processes"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["gather"].startswith("rccl allgather of lnL (ncclCommInitRank"), out["config"]["gather"]      # not "host ..."
+    assert out["config"]["rccl"]["rccl"].endswith("librccl_double.so") and out["config"]["rccl"]["rccl_version"] == 1
+    # every rank checked EVERY slot of its gathered vector: its own shard bit for bit, the other rank's against its own
+    # recomputation of that rank's rows - the rank-major layout of the receive buffer
+    assert out["gather_matches_local"] is True and out["outputs_finite"] is True
+    strong = out["strong_scaling"]
+    assert strong["global_batch"] == 4096 and strong["batch_per_gpu"] == 2048 and len(strong["theory_kernel_ms_per_rank"]) == 2
+    assert not list(tmp_path.glob("rccl_double_*.sock"))          # communicators were destroyed
+
+
+@pytest.mark.gpu
+def test_walker_example_two_ranks_gather_through_the_communicator(tmp_path):
+    from tests.test_gpu_workloads import _launch_ranks
+    double = build_double(tmp_path)
+    res = _launch_ranks([os.path.join(ROOT, "examples", "run_walkers.py"), "--steps", "20"], 2, extra_env=_env(double, tmp_path))
+    for rc, out, err in res:
+        assert rc == 0, err[-3000:]
+    r0 = json.loads(res[0][1].strip().splitlines()[-1])
+    assert r0["gather"] == "rccl" and r0["walkers_total"] == 16 and r0["gathered_shape"] == [20, 16]
+    assert r0["best_lnl_over_all_ranks"] > 200
+
+
+_SHARDED = r'''
+import json, os, sys
+import numpy as np
+root = sys.argv[1]
+sys.path.insert(0, root)
+import victor_amd
+from victor_amd.sharding import Dist, ShardedLikelihood, one_device_per_rank
+from tests import cases
+dist = Dist().connect()
+fit = victor_amd.CCFFit(*cases.boss_options("config"))
+eng = fit._get_engine()
+assert one_device_per_rank(dist, eng)
+uid = eng.comm_unique_id() if dist.rank == 0 else None
+uid = dist.broadcast_bytes(uid, src=0, nbytes=128)
+eng.comm_init(uid, dist.rank, dist.world)
+n = int(sys.argv[2])
+rows = fit._fit_rows(cases.halton_params(n, with_beta=True), fit.model)
+sharded = ShardedLikelihood(fit.log_likelihood_batch, dist, gather="rccl", engine=eng)
+lnl, chi2 = sharded(rows)
+own_l, own_c = fit.log_likelihood_batch(rows)             # every rank: the whole batch on its own
+worst = float(np.max(np.abs(chi2 / own_c - 1)))
+worst = dist.max_float(worst)
+eng.comm_destroy()
+if dist.rank == 0:
+    print(json.dumps({"n": n, "world": dist.world, "shape": list(lnl.shape), "worst_rel_dchi2": worst,
+                      "finite": bool(np.all(np.isfinite(lnl)))}))
+dist.close()
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n", [(2, 1001), (3, 1000), (3, 2)])
+def test_sharded_batch_with_a_padded_last_shard(tmp_path, world, n):
+    """ShardedLikelihood over the communicator with batch sizes the ranks do not divide: the short last shard is padded to the
+    common count for the all-gather and un-padded afterwards; with 2 rows on 3 ranks one rank contributes padding only.  Every
+    rank compares the gathered batch with its own evaluation of all rows (another batch size, hence another work split:
+    agreement to rounding)."""
+    from tests.test_gpu_workloads import _launch_ranks
+    double = build_double(tmp_path)
+    res = _launch_ranks(["-c", _SHARDED, ROOT, str(n)], world, extra_env=_env(double, tmp_path))
+    for rc, out, err in res:
+        assert rc == 0, err[-3000:]
+    r0 = json.loads(res[0][1].strip().splitlines()[-1])
+    assert r0 == {"n": n, "world": world, "shape": [n], "worst_rel_dchi2": r0["worst_rel_dchi2"], "finite": True}
+    assert r0["worst_rel_dchi2"] < 1e-9

@@ -43,6 +43,16 @@ def test_walker_ensemble_matches_oracle_driven_chain():
     assert np.array_equal(cg, cc)
     assert np.max(np.abs(lg / lc - 1)) < 1e-9
     assert g.n_accept == c.n_accept and g.n_evals == c.n_evals
+    # the direct route (rows written in place, straight to the engine - what bench.py and run_walkers.py use): the same chain,
+    # bit for bit the values of the dictionary route (same rows, same kernel), over enough steps to cross a block of
+    # pre-drawn random numbers and to meet proposals outside the prior
+    d = EnsembleMetropolis(None, specs, 8, seed=2024, fixed=fixed, fit=fit).initialise()
+    assert d._direct is not None
+    g2 = EnsembleMetropolis(gpu_eval, specs, 8, seed=2024, fixed=fixed).initialise()
+    cd, ld = d.run(150)
+    cg2, lg2 = g2.run(150)
+    assert np.array_equal(cd[:5], cg) and np.array_equal(cd, cg2) and np.array_equal(ld, lg2)
+    assert d.n_accept == g2.n_accept and d.n_evals == g2.n_evals and 0 < d.n_accept < 150 * 8
 
 
 def test_cobaya_plugin_calculate_on_gpu():

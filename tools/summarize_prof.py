@@ -8,6 +8,17 @@ from collections import defaultdict
 
 out_dir = sys.argv[1]
 summary = {}
+# --points N: integrand points (or cells) one launch of the theory kernel processes -> instructions per point; --label TEXT
+points = None
+label = None
+for i, a in enumerate(sys.argv):
+    if a == "--points":
+        points = float(sys.argv[i + 1])
+    if a == "--label":
+        label = sys.argv[i + 1]
+if label:
+    print("==", label)
+    summary["label"] = label
 for f in glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_stats.csv"), recursive=True):
     print("== kernel stats:", os.path.relpath(f, out_dir))
     with open(f) as fh:
@@ -51,5 +62,19 @@ for k, cs in summary["pmc"].items():
         summary["theory_kernel_hbm_bytes_per_launch"] = traffic
         print(f"== theory kernel HBM traffic per launch: {traffic/1e6:.2f} MB "
               f"(fetch 2 x {cs['FETCH_SIZE']['avg']*1024/1e6:.2f} MB, write {cs['WRITE_SIZE']['avg']*1024/1e6:.2f} MB)")
+# instruction counts per integrand point (per lane): SQ_INSTS_* count wave-level instructions, one per 64 lanes
+if points:
+    for k, cs in summary["pmc"].items():
+        if "vk_theory" not in k:
+            continue
+        per = {c: cs[c]["avg"] * 64.0 / points for c in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD") if c in cs}
+        busy = {}
+        if "SQ_ACTIVE_INST_VALU" in cs and "SQ_BUSY_CYCLES" in cs:
+            busy["valu_busy_of_sq_busy_x4"] = 4.0 * cs["SQ_ACTIVE_INST_VALU"]["avg"] / cs["SQ_BUSY_CYCLES"]["avg"]
+        if "SQ_LDS_BANK_CONFLICT" in cs and "SQ_LDS_IDX_ACTIVE" in cs and cs["SQ_LDS_IDX_ACTIVE"]["avg"] > 0:
+            busy["lds_bank_conflict_frac"] = cs["SQ_LDS_BANK_CONFLICT"]["avg"] / cs["SQ_LDS_IDX_ACTIVE"]["avg"]
+        summary.setdefault("per_point", {})[k] = {"points_per_launch": points, **per, **busy}
+        print(f"== {k[:70]}: per point of {points:.4g} per launch: " + ", ".join(f"{c[8:]} {v:.1f}" for c, v in per.items())
+              + ("; " + ", ".join(f"{c} {v:.3f}" for c, v in busy.items()) if busy else ""))
 with open(os.path.join(out_dir, "summary.json"), "w") as fh:
     json.dump(summary, fh, indent=1)

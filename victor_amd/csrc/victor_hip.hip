@@ -468,6 +468,7 @@ int launch_cells_ngf(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
 
 template <int NLR, int GRID>
 int launch_cells_ng(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
+  if (a.rsd == VK_RSD_KAISER || a.rsd == VK_RSD_EUCLID) return launch_cells_ngf<NLR, GRID, kModeKaiser>(ctx, a, grid, lds);
   if (a.sv_n_mu > 0) return launch_cells_sva<NLR>(ctx, a, grid, lds);
   if (a.rsd == VK_RSD_DISPERSION)
     return a.from_data ? launch_cells_ngf<NLR, GRID, kModeDispersionFromData>(ctx, a, grid, lds)
@@ -624,15 +625,17 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
   // fast kernels: the streaming model, and the dispersion model on fixed velocity tables (cells / point-major only)
   // (fixed velocity tables: Da / Ge staged once; beta-dependent ones - linear_bias on a reconstructed real-space ccf - rebuilt
   // per point from their beta polynomials, uni_dab / uni_empb)
-  const bool disp = a.rsd == VK_RSD_DISPERSION &&
-                    (a.vr_beta_dep ? (a.uni_dab && (!a.empirical || a.uni_empb)) : (a.uni_da && (!a.empirical || a.uni_ge)));
+  const bool da_tabs = a.vr_beta_dep ? (a.uni_dab && (!a.empirical || a.uni_empb)) : (a.uni_da && (!a.empirical || a.uni_ge));
+  const bool disp = a.rsd == VK_RSD_DISPERSION && da_tabs;
+  // kaiser / euclid_special (no velocity integral, no sigma_v): one evaluation per (s, mu) cell in the cells kernel
+  const bool kais = (a.rsd == VK_RSD_KAISER || a.rsd == VK_RSD_EUCLID) && da_tabs;
   const bool emp_ok = !a.empirical || (a.vr_beta_dep ? a.uni_empb != nullptr : a.uni_v2 != nullptr);
   // anisotropic sigma_v(r, mu): its bicubic patches ride in LDS for the streaming model on the lattice form (SVA instantiations)
-  const bool sva = a.sv_n_mu > 0;
+  const bool sva = a.sv_n_mu > 0 && !kais;
   const bool sva_ok = !sva || (a.sva_doubles > 0 && a.rsd == VK_RSD_STREAMING && !a.from_data && a.uni_lut_n == 0);
   const int n_sva = sva ? a.sva_doubles : 0;
-  const bool fast = (a.rsd == VK_RSD_STREAMING || disp) && ctx->fast_ok && emp_ok && sva_ok &&
-                    a.n_mu <= 1024 && a.n_x <= 2048 && !ctx->knobs.force_generic;
+  bool fast = (a.rsd == VK_RSD_STREAMING || disp || kais) && ctx->fast_ok && emp_ok && sva_ok &&
+              a.n_mu <= 1024 && a.n_x <= 2048 && !ctx->knobs.force_generic;
   // chi-square inside the theory kernel: point-major and cells kernels only, up to fuse_max points (A/B: DESIGN.md section 5)
   // A/B (tools/gpu_small_batch_ab.py, config 3 / BOSS, resident): the fused launch wins up to ~256 points (64 points: 41.2 vs
   // 43.7 us, 33.0 vs 34.9), ties at 512 and is 1 % behind the two-launch path from 1024 on (461.5 vs 455.4 us), where the
@@ -644,7 +647,8 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
   const long long kFuseMaxDefault = 512, kFuseBlendedMin = 8192;
   const bool fuse_by_size = ctx->knobs.fuse_max >= 0 ? a.n <= ctx->knobs.fuse_max
                                                      : (a.n <= kFuseMaxDefault || (like && like->n_beta_c > 0 && a.n >= kFuseBlendedMin));
-  const bool want_fuse = like && !ctx->knobs.no_fuse && fuse_by_size && like_lds_doubles(N) * sizeof(double) <= 32 * 1024;
+  // (kaiser / euclid_special: the theory kernel is ~50 times shorter, a chi-square launch of its own would be a tenth of the step)
+  const bool want_fuse = like && !ctx->knobs.no_fuse && (fuse_by_size || kais) && like_lds_doubles(N) * sizeof(double) <= 32 * 1024;
   if (like) a.like = *like;
 #ifdef VK_PHASES
   a.like.stamps = a.stamps;
@@ -653,7 +657,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
   const long long cap = (ctx->knobs.point_cap > 0 ? ctx->knobs.point_cap : kDefaultCap) * ctx->n_cu;
   // lanes-over-batch variant: batch-constant tables and enough points to fill the chip with n_s * n/64 waves
   const int mapping = ctx->knobs.mapping;                           // VICTOR_HIP_MAPPING: 0 = choose by batch size
-  const bool lanes_ok = fast && a.n_beta_r == 0 && !a.empirical && !a.from_data && !disp && !sva;   // per-point tables need a workgroup per point
+  const bool lanes_ok = fast && a.n_beta_r == 0 && !a.empirical && !a.from_data && !disp && !kais && !sva;   // per-point tables need a workgroup per point
   // One wave per (s bin, 64-point chunk), one workgroup per four of them; 5 workgroups are resident per CU.  Every item
   // runs for ~0.6 ms, so the launch ends with a ragged tail about one residency round long, while the cells kernel
   // (one workgroup per point, 2.20-2.25 M evals/s on config 3 from 2000 points on) has none: measured, the lanes kernel
@@ -698,7 +702,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
   // (re-measured after both kernels lost their grid-stride loops, tools/gpu_cells_min_sweep.py, profiles/r03/z_*: point-major
   // ahead up to 12 / 16 points, level at 20, the cells kernel ahead from 24 / 28 on)
   const long long cells_min = ctx->knobs.cells_min >= 0 ? ctx->knobs.cells_min : 20;
-  const bool cells = cells_ok && (mapping ? mapping == 2 : n_dec >= cells_min);
+  const bool cells = cells_ok && (kais || (mapping ? mapping == 2 : n_dec >= cells_min));   // kaiser: this kernel only
   if (cells) {
     ctx->last_kernel = "vk_theory_cells_kernel";
     // A point's n_s * n_mu cells may be cut into `parts` ranges, one workgroup each (vk_kernel_cells.h): enough ranges to give
@@ -714,7 +718,8 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
       // measured (tools/gpu_small_batch_ab.py, config 3 / BOSS): ranges of one trip per wave (256 cells) below 128 points, two
       // below 256, four from there on - 64 points: 56.6 -> 41.7 us against the point-major kernel, 1024 points: 496 -> 462 us
       // against one workgroup per point; whole trips per wave only (a multiple of 256 cells)
-      const int cpi_want = a.n < 128 ? 256 : (a.n < 256 ? 512 : 1024);
+      // (kaiser: a cell is one evaluation, not 50 - ranges only for a handful of points)
+      const int cpi_want = kais ? (a.n < 8 ? 256 : (a.n < 32 ? 1024 : all_cells)) : (a.n < 128 ? 256 : (a.n < 256 ? 512 : 1024));
       R = (all_cells + cpi_want - 1) / cpi_want;
       R = std::max(1, std::min(R, (all_cells + min_cpi - 1) / min_cpi));
     }
@@ -729,10 +734,10 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
     a.cells_per_item = cpi;
     a.fuse = want_fuse ? 1 : 0;
     const bool tail = a.fuse || R > 1;
-    const CellsPlan plc = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, disp, cpi, tail ? N : 0, n_sva);
+    const CellsPlan plc = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, disp || kais, cpi, tail ? N : 0, n_sva);
     const size_t lds_c = (size_t)plc.total * sizeof(double);
     if (lds_c > 160 * 1024) return fail(ctx, VK_E_ARG, "tables need %zu bytes of LDS (> 160 KiB)", lds_c);
-    a.image = get_image(ctx, a, 1, nlr, disp, plc.image_end, sva);
+    a.image = get_image(ctx, a, 1, nlr, disp || kais, plc.image_end, sva);
     const long long items_c = a.n * R;
     const int grid_c = (int)items_c;                                       // one item per workgroup, always (vk_kernel_cells.h)
     if (fused) *fused = a.fuse != 0;
@@ -742,6 +747,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
       case 3: return launch_cells_nl<3>(ctx, a, grid_c, lds_c);
     }
   }
+  if (kais) fast = false;               // grids the cells kernel cannot take (n_mu < 64): the generic kernel
   ctx->last_kernel = fast ? "vk_theory_fast_kernel" : "vk_theory_kernel";
   if (fast) {
     const long long groups = (a.n_s + a.sbins_per_item - 1) / a.sbins_per_item;

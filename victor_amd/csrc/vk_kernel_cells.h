@@ -137,7 +137,7 @@ __device__ __forceinline__ void project_trip(double g, bool first, bool second, 
 // 5 workgroups per CU for the streaming mode (<= 96 VGPRs); the from_data and dispersion modes need more registers and
 // run 4 per CU without spills
 template <int NLR, int NL, int GRID, int MODE, int SVA = 0>
-__global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 5 : 4) void vk_theory_cells_kernel(TheoryArgs a) {
+__global__ __launch_bounds__(kBlock, (MODE == kModeStreaming && !SVA) || MODE == kModeKaiser ? 5 : 4) void vk_theory_cells_kernel(TheoryArgs a) {
   extern __shared__ double lds[];
   vkm::clamp_keeps_nan();
   warm_kernarg_lines<sizeof(TheoryArgs)>();
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 5 : 4) voi
   const int R = a.parts;
   const int cpi = a.cells_per_item;
   const bool tail = a.fuse || R > 1;
-  CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, mode_is_dispersion(MODE), cpi,
+  CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, mode_has_da(MODE), cpi,
                                  tail ? N : 0, SVA ? a.sva_doubles : 0);
   // the offset behind the accumulators depends on an integer division by n_mu, which the compiler evaluates on the vector ALU:
   // wave-uniform, but held - and once spilled - as a vector register unless it is made a scalar here
@@ -153,8 +153,8 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 5 : 4) voi
   const int tid = threadIdx.x;
   VK_STAMP(a, 0);
   if (a.image) copy_image(lds, a.image, pl.image_end);
-  else stage_cells<NLR>(a, pl, lds, mode_is_dispersion(MODE));
-  constexpr bool kHalf = !mode_is_dispersion(MODE);       // streaming modes: half units (vk_kernel_fast.h: FastPoint)
+  else stage_cells<NLR>(a, pl, lds, mode_has_da(MODE));
+  constexpr bool kHalf = !mode_has_da(MODE);              // streaming modes: half units (vk_kernel_fast.h: FastPoint)
   const FastConsts fc = make_fast_consts<NLR>(a, kHalf, SVA ? pl.sva : 0);
   __syncthreads();
   VK_STAMP(a, 1);
@@ -183,10 +183,10 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 5 : 4) voi
     const double* row = a.params + point * VK_NPAR;
     const PointScalars ps = point_scalars(a, row);
     const FastPoint fp = make_fast_point(ps, fc, kHalf);
-    constexpr int PV = mode_is_dispersion(MODE) ? 0 : 1;
+    constexpr int PV = mode_has_da(MODE) ? 0 : 1;
     __syncthreads();      // every wave is done with the previous item's records and accumulators
-    rebuild_point_tables<NLR, PV>(a, lds, pl.betar, pl.v1, row[VK_P_BETA], ps.av, fp.AVk, mode_is_dispersion(MODE) ? lds + pl.da : nullptr);
-    if (mode_is_dispersion(MODE) && a.empirical && !a.vr_beta_dep) rebuild_da_emp(a, lds + pl.da, ps.av);
+    rebuild_point_tables<NLR, PV>(a, lds, pl.betar, pl.v1, row[VK_P_BETA], ps.av, fp.AVk, mode_has_da(MODE) ? lds + pl.da : nullptr);
+    if (mode_has_da(MODE) && a.empirical && !a.vr_beta_dep) rebuild_da_emp(a, lds + pl.da, ps.av);
     for (int e = lane; e < kMaxEll * slots; e += 64) l_acc[e * kWaves + wave] = 0.0;
     __syncthreads();
     VK_STAMP(a, 2);
@@ -206,9 +206,12 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 5 : 4) voi
       double g = 0.0;
       // trips whose 64 x 50 radii all fall inside the table skip the clamp pair of the interval coordinate (see the lanes
       // kernel; a trip that holds a mu = 1 cell reaches r < 0.01 and keeps it)
-      const bool inside = !mode_is_dispersion(MODE) && !__any(!cell_in_table(fc, s_par, sperp2, a.xw_max * fabs(fp.Bk)));
+      const bool inside = !mode_has_da(MODE) && !__any(!cell_in_table(fc, s_par, sperp2, a.xw_max * fabs(fp.Bk)));
       double gs = 0.0;
-      if (mode_is_dispersion(MODE)) {
+      if (MODE == kModeKaiser) {
+        g = kaiser_value<NLR, GRID>(lds, lds + pl.da, fc, fp, ps.M, ps.Q, a.niter, a.coord_shift != 0, a.kaiser_approx != 0,
+                                    a.rsd == VK_RSD_EUCLID, a.from_data != 0, s_par, sperp2);
+      } else if (mode_is_dispersion(MODE)) {
         for (int k = 0; k < a.n_xg; ++k) {
           const VelocityNode xw = load_node(a.xgw, k);
           gs += disp_value<NLR, GRID, MODE == kModeDispersionFromData>(lds, lds + pl.da, fc, fp, a.niter, fma(-xw.x, fp.Bk, s_par), s_par,

@@ -405,20 +405,28 @@ __device__ __forceinline__ double uni_point(const double* __restrict__ lds, cons
 // q(r) = aH^-1 v_r(r)/r, started at the redshift-space separation and repeated `niter` more times, and the Jacobian
 // 1 / (1 + q + mu_r^2 (dq - q)) with dq = aH^-1 v_r'(r).  `da` = LDS table of Da = delta - 2 Delta/3 on the unified
 // grid, [uni_n][4].  All lengths in index units (FULL units: fc and fp made with half = false); `num` = s_par' - x_k' Bk.
-// The fixed-point iteration amplifies rounding, so 1/r and the reciprocals keep their third-order refinements here.
+// The LAST pass of the iteration, the evaluation behind it and the Jacobian keep the third-order 1/sqrt and reciprocals (where
+// 1 + q comes close to zero the result is ill-conditioned in them); the earlier passes run on the second-order forms - the map
+// is a contraction wherever the reference itself converges, so what they leave in the last bits is damped by the passes that
+// follow.  Same-box A/B (tools/gpu_rsd_ab.py, BOSS, 16384 points): 17.06 -> 16.31 ms, max rel dchi2 between the builds 4.9e-13
+// (budget 1e-10), tests/test_gpu_options.py::test_dispersion_model_where_it_is_ill_conditioned unchanged and green
+// (profiles/r04/c_early_passes_second_order_ab.txt).
 template <int NLR, int GRID, int FD>
 __device__ __forceinline__ double disp_value(const double* __restrict__ lds, const double* __restrict__ da,
                                              const FastConsts& fc, const FastPoint& fp, int niter, double num,
                                              double s_par, double sperp2, double xk) {
   double tq;
   int qi;
-  auto q_at = [&](double r2) {
-    const double inv_r = vkm::rsqrt3(r2);
+  auto pass = [&](double rp, bool last) {
+    const double r2 = fma(rp, rp, sperp2);
+    const double inv_r = last ? vkm::rsqrt3(r2) : vkm::rsqrt_nr(r2);
     const double* rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(r2, inv_r, fc.off) : r2 * inv_r, tq, qi);
-    return -fp.Gk * cubic_b128(rec + 4, tq) * inv_r;
+    const double den = 1.0 + -fp.Gk * cubic_b128(rec + 4, tq) * inv_r;
+    return num * (last ? vkm::recip(den) : vkm::recip_nr(den));
   };
-  double r_par = num * vkm::recip(1.0 + q_at(fma(s_par, s_par, sperp2)));
-  for (int it = 0; it < niter; ++it) r_par = num * vkm::recip(1.0 + q_at(fma(r_par, r_par, sperp2)));
+  double r_par = s_par;
+  for (int it = 0; it < niter; ++it) r_par = pass(r_par, false);
+  r_par = pass(r_par, true);
   const double r2 = fma(r_par, r_par, sperp2);
   const double inv_r = vkm::rsqrt3(r2);
   const double mu_r = r_par * inv_r;
@@ -445,9 +453,71 @@ __device__ __forceinline__ double disp_value(const double* __restrict__ lds, con
   return inv_sv * jac * (e * xi1);
 }
 
-// MODE of the kernels that own a point per workgroup: streaming, streaming on a measured real-space ccf, dispersion
-constexpr int kModeStreaming = 0, kModeFromData = 1, kModeDispersion = 2, kModeDispersionFromData = 3;
-__host__ __device__ constexpr bool mode_is_dispersion(int mode) { return mode >= kModeDispersion; }
+// The models without a velocity integral - kaiser (ccf_model.py:692-741) and euclid_special (:743-784) - on the same records:
+// ONE evaluation per (s, mu) cell.  With q(r) = aH^-1 v_r(r)/r = -Gk V(u)/r' and dq(r) = aH^-1 v_r'(r) = -gD Da(u) the
+// reference's expressions read
+//   coordinate shift (kaiser_coord_shift, `niter` + 1 passes, started at the redshift-space separation)
+//       r_par <- s_par / (1 + M q(r))
+//   kaiser          J = M q + M Q mu_r^2 (dq - q);   xi^s + 1 = (1 + M xi^r) / (1 + J),  or linearised 1 + M xi^r - J
+//   euclid_special  J = 3 M q + 2 M Q mu_r^2 (dq - q);   xi^s + 1 = 1 + M xi^r - J
+// Lengths in index units, FULL units (fc and fp made with half = false), as in disp_value; `da`: the LDS table of Da (or of
+// Ge1 + av Ge2 with empirical_corr).  from_data (`fd`, wave-uniform): xi^r at the fiducial coordinates as in uni_point.
+// Returns xi^s + 1 of the cell (the projection subtracts sum_i W_l[i] like everywhere else).
+template <int NLR, int GRID>
+__device__ __forceinline__ double kaiser_value(const double* __restrict__ lds, const double* __restrict__ da, const FastConsts& fc,
+                                               const FastPoint& fp, double M, double Q, int niter, bool coord_shift, bool linear,
+                                               bool euclid, bool fd, double s_par, double sperp2) {
+  double tq;
+  int qi;
+  // One pass of the coordinate shift.  The map r_par -> s_par / (1 + M q(r)) is a contraction (|M r dq/dr| << 1 wherever the
+  // reference itself converges), so what an early pass leaves behind in the last bits is damped by every later one: all passes
+  // but the last run on the second-order 1/sqrt and reciprocal (two instructions less each, vk_devmath.h), the last one and the
+  // evaluation behind it on the third-order forms (same-box A/B: 0.4585 -> 0.442 ms per 16384 BOSS points, max rel dchi2
+  // between the builds 3.3e-15; profiles/r04/c_early_passes_second_order_ab.txt).
+  const double MG = -M * fp.Gk;
+  auto pass = [&](double rp, bool last) {
+    const double r2 = fma(rp, rp, sperp2);
+    const double inv_r = last ? vkm::rsqrt3(r2) : vkm::rsqrt_nr(r2);
+    const double* rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(r2, inv_r, fc.off) : r2 * inv_r, tq, qi);
+    const double den = fma(cubic_b128(rec + 4, tq) * inv_r, MG, 1.0);
+    return s_par * (last ? vkm::recip(den) : vkm::recip_nr(den));
+  };
+  double r_par = s_par;
+  if (coord_shift) {
+    for (int it = 0; it < niter; ++it) r_par = pass(r_par, false);
+    r_par = pass(r_par, true);
+  }
+  const double r2 = fma(r_par, r_par, sperp2);
+  const double inv_r = vkm::rsqrt3(r2);
+  const double mu_r = r_par * inv_r;
+  const double* rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(r2, inv_r, fc.off) : r2 * inv_r, tq, qi);
+  const double q = -fp.Gk * cubic_b128(rec + 4, tq) * inv_r;
+  const double dq = -fp.gD * cubic_b128(da + 4 * qi, tq);
+  const double m2 = mu_r * mu_r;
+  double mx2 = 4.0 * m2;                        // the records hold the coefficients of powers of (2 mu)^2, see uni_point
+  if (fd) {
+    const double rp = r_par * fp.fa;
+    const double r2x = fma(rp, rp, sperp2 * fp.fp2);
+    const double inv_rx = vkm::rsqrt3(r2x);
+    const double mu_x = rp * inv_rx;
+    mx2 = 4.0 * (mu_x * mu_x);
+    rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(r2x, inv_rx, fc.off) : r2x * inv_rx, tq, qi);
+  }
+  double xi1 = cubic_b128(rec + 8, tq);          // 1 + xi^r_0 (the "+1" sits in the constant coefficient)
+  if (NLR == 2) xi1 = fma(cubic_b128(rec + 12, tq), mx2, xi1);
+  if (NLR == 3) xi1 = fma(fma(cubic_b128(rec + 16, tq), mx2, cubic_b128(rec + 12, tq)), mx2, xi1);
+  const double mxi = M * (xi1 - 1.0);             // M xi^r
+  const double J = euclid ? 3.0 * M * q + 2.0 * M * Q * m2 * (dq - q) : M * q + M * Q * m2 * (dq - q);
+  if (linear || euclid) return 1.0 + (mxi - J);
+  return (1.0 + mxi) * vkm::recip(1.0 + J);
+}
+
+// MODE of the kernels that own a point per workgroup: streaming, streaming on a measured real-space ccf, dispersion (both),
+// and the models without a velocity integral (cells kernel only; kaiser / euclid_special, from_data or not: wave-uniform flags)
+constexpr int kModeStreaming = 0, kModeFromData = 1, kModeDispersion = 2, kModeDispersionFromData = 3, kModeKaiser = 4;
+__host__ __device__ constexpr bool mode_is_dispersion(int mode) { return mode == kModeDispersion || mode == kModeDispersionFromData; }
+// modes that read the Da table (v_r') and work in full index units with the unscaled V cubics
+__host__ __device__ constexpr bool mode_has_da(int mode) { return mode >= kModeDispersion; }
 
 template <int NLR>
 __device__ __forceinline__ void stage_da(const TheoryArgs& a, double* da) {

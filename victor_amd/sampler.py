@@ -61,11 +61,19 @@ def parse_cobaya_params(params_block):
 class EnsembleMetropolis:
     """W independent random-walk Metropolis chains advanced together, one likelihood batch per step.
 
-    ``evaluate(batch) -> lnL`` receives a dict ``name -> array(W')`` (sampled + fixed parameters) for the W'
-    proposals that lie inside the prior box and returns their log-likelihoods.
+    ``evaluate(batch) -> lnL`` receives a dict ``name -> array(W')`` (sampled + fixed parameters) for the W' proposals that lie
+    inside the prior box and returns their log-likelihoods.
+
+    ``fit`` (a :class:`victor_amd.CCFFit`): the step's likelihood batch goes straight to the engine instead - a preallocated
+    ``(W, VK_NPAR)`` row array whose sampled columns are overwritten in place, preallocated result buffers, no dictionary and
+    no option merging per step; ``evaluate`` is then unused.  A step of 8 walkers is one ~20 us launch: every NumPy call on the
+    way counts (BENCH ``walker_ensembles``).  Both routes draw their random numbers in the same blocks and form the rows with
+    the same NumPy expressions, so a chain is the same chain whichever route evaluates it (tests/test_gpu_workloads.py).
     """
 
-    def __init__(self, evaluate, specs, n_walkers, seed=0, fixed=None):
+    BLOCK = 64          # steps whose proposal increments and acceptance levels are drawn together
+
+    def __init__(self, evaluate, specs, n_walkers, seed=0, fixed=None, fit=None):
         self.evaluate = evaluate
         self.specs = list(specs)
         self.fixed = dict(fixed or {})
@@ -79,6 +87,11 @@ class EnsembleMetropolis:
         self.n_accept = 0
         self.n_steps = 0
         self.n_evals = 0
+        self._fit = fit
+        self._direct = None
+        self._dz = None
+        self._logu = None
+        self._at = self.BLOCK
 
     @property
     def names(self):
@@ -90,12 +103,80 @@ class EnsembleMetropolis:
             batch[k] = v
         return batch
 
+    # ---- the direct route: rows written in place, results into preallocated buffers ------------------------------------
+    _COLUMNS = {"fsigma8": 0, "sigma_v": 1, "beta": 5, "astar": 6, "M": 7, "Q": 8, "bias": 9, "Av": 10}
+
+    def _bind(self, x):
+        """Set up the direct route for the fit given at construction; False when the sampled parameters are not ones whose
+        row columns are known here (the dictionary route then serves)."""
+        fit = self._fit
+        plan = fit._single_point_plan() if fit is not None else None
+        if plan is None or plan[0] is None:
+            return False
+        names = self.names
+        idx, cols, eps = [], [], None
+        for j, name in enumerate(names):
+            if name in self._COLUMNS:
+                idx.append(j)
+                cols.append(self._COLUMNS[name])
+            elif name == "epsilon" and not ({"alpha", "aperp", "apar"} & set(names)):
+                eps = j
+            else:
+                return False
+        if eps is None and "epsilon" in self.fixed and {"aperp", "apar"} & set(names):
+            return False
+        from . import _native as N
+        rows = np.array(fit._fit_rows(self._batch(x), fit.model), dtype=np.float64, order="C")     # fixed values and defaults
+        if rows.shape != (self.n_walkers, N.VK_NPAR):
+            return False
+        out = np.empty((2, self.n_walkers))
+        alpha = self.fixed.get("alpha", 1)
+        self._direct = {"rows": rows, "pairs": list(zip(idx, cols)), "eps": eps, "alpha": None if alpha == 1 else alpha, "out": out,
+                        "engine": plan[0], "opts": plan[1], "p_rows": N.as_dp(rows), "p_lnl": N.as_dp(out[0]), "p_chi": N.as_dp(out[1]),
+                        "t1": np.empty_like(x), "t2": np.empty_like(x), "e": np.empty(self.n_walkers), "a": np.empty(self.n_walkers)}
+        return True
+
+    def _lnl_direct(self, x):
+        d = self._direct
+        rows = d["rows"]
+        for j, c in d["pairs"]:
+            rows[:, c] = x[:, j]
+        if d["eps"] is not None:                      # the expressions of CCFModel._param_rows, on the same (contiguous) arrays
+            eps, apar = d["e"], d["a"]
+            np.copyto(eps, x[:, d["eps"]])            # as _batch() hands it over: the same loop of np.power
+            np.power(eps, -2 / 3, out=apar)
+            if d["alpha"] is not None:
+                np.multiply(d["alpha"], apar, out=apar)
+            np.multiply(eps, apar, out=rows[:, 2])
+            rows[:, 3] = apar
+            rows[:, 4] = eps
+        eng = d["engine"]
+        rc = eng._lib.vk_eval_batch(eng._ctx, d["opts"], d["p_rows"], self.n_walkers, d["p_lnl"], d["p_chi"], None)
+        if rc != 0:
+            eng._check(rc)
+        self.n_evals += self.n_walkers
+        return d["out"][0]
+
     def _lnl(self, x):
-        inside = np.all((x >= self.lo) & (x <= self.hi), axis=1)
+        """log-likelihoods of the rows of ``x`` (-inf outside the prior box).  The result may be a view of a reused buffer: callers
+        that keep it copy it."""
+        d = self._direct
+        if d is not None:                             # every walker inside the box <=> min(x - lo, hi - x) >= 0: four small ufuncs
+            np.subtract(x, self.lo, out=d["t1"])
+            np.subtract(self.hi, x, out=d["t2"])
+            np.minimum(d["t1"], d["t2"], out=d["t1"])
+            if d["t1"].min() >= 0.0:
+                return self._lnl_direct(x)
+        inside = ((x >= self.lo) & (x <= self.hi)).all(axis=1)
+        n_in = int(np.count_nonzero(inside))
         out = np.full(len(x), -np.inf)
-        if np.any(inside):
-            out[inside] = np.asarray(self.evaluate(self._batch(x[inside])), dtype=float)
-            self.n_evals += int(inside.sum())
+        if n_in:
+            if self._direct is not None:              # some proposals outside the prior: evaluate all rows that are inside
+                fit = self._fit
+                out[inside] = fit.log_likelihood_batch(self._batch(x[inside]))[0]
+            else:
+                out[inside] = np.asarray(self.evaluate(self._batch(x[inside])), dtype=float)
+            self.n_evals += n_in
         return out
 
     def initialise(self):
@@ -112,19 +193,30 @@ class EnsembleMetropolis:
                 raise InputError("reference distribution lies outside the prior")
             x[w] = cand
         self.x = x
-        self.lnl = self._lnl(x)
+        if self._fit is not None and self._direct is None:
+            self._bind(x)
+        self.lnl = np.array(self._lnl(x), dtype=float)
         return self
+
+    def _refill(self):
+        """Proposal increments and log acceptance levels of the next BLOCK steps (one draw each instead of two per step)."""
+        self._dz = self.width * self.rng.standard_normal((self.BLOCK,) + self.x.shape)
+        self._logu = np.log(self.rng.random((self.BLOCK, self.n_walkers)))
+        self._at = 0
 
     def step(self):
         if self.x is None:
             self.initialise()
-        prop = self.x + self.width * self.rng.standard_normal(self.x.shape)
-        logu = np.log(self.rng.random(self.n_walkers))
+        if self._at >= self.BLOCK:
+            self._refill()
+        t = self._at
+        self._at = t + 1
+        prop = self.x + self._dz[t]
         lnl_prop = self._lnl(prop)
-        accept = logu < lnl_prop - self.lnl
-        self.x = np.where(accept[:, None], prop, self.x)
-        self.lnl = np.where(accept, lnl_prop, self.lnl)
-        self.n_accept += int(accept.sum())
+        accept = self._logu[t] < lnl_prop - self.lnl
+        np.copyto(self.x, prop, where=accept[:, None])
+        np.copyto(self.lnl, lnl_prop, where=accept)
+        self.n_accept += int(np.count_nonzero(accept))
         self.n_steps += 1
         return accept
 
@@ -154,8 +246,8 @@ class EnsembleStretch(EnsembleMetropolis):
     ``evaluate`` / ``specs`` / prior-box conventions as :class:`EnsembleMetropolis`; W must be even and >= 2 (P + 1).
     """
 
-    def __init__(self, evaluate, specs, n_walkers, seed=0, fixed=None, a=2.0):
-        super().__init__(evaluate, specs, n_walkers, seed=seed, fixed=fixed)
+    def __init__(self, evaluate, specs, n_walkers, seed=0, fixed=None, a=2.0, fit=None):
+        super().__init__(evaluate, specs, n_walkers, seed=seed, fixed=fixed)        # half-ensemble batches: the dictionary route
         if self.n_walkers % 2 or self.n_walkers < 2 * (len(self.specs) + 1):
             raise InputError("the stretch move needs an even number of walkers, at least 2 (n_params + 1)")
         self.a = float(a)
@@ -202,10 +294,10 @@ class DistributedEnsemble:
     """
 
     def __init__(self, evaluate, specs, walkers_per_rank, dist, seed=0, fixed=None, gather=None,
-                 sampler=None):
+                 sampler=None, fit=None):
         self.dist = dist
         self.local = (sampler or EnsembleMetropolis)(evaluate, specs, walkers_per_rank, seed=seed + 7919 * dist.rank,
-                                                     fixed=fixed)
+                                                     fixed=fixed, fit=fit)
         self.gather = gather or (lambda v: dist.allgather_host(v, len(v)))
         self.all_lnl = []
 
