@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 15
+#define VK_ABI_VERSION 16
 
 /* error codes */
 #define VK_OK 0
@@ -241,6 +241,14 @@ void vk_default_opts(vk_eval_opts* opts);
  * the launch still retiring on the context's stream; every later call, vk_sync and vk_destroy are ordered behind it.) */
 int vk_eval_batch(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, int64_t n,
                   double* lnl, double* chi2, double* theory);
+
+/* The same call in two halves for callers that have host work to overlap with the launch (the walker ensembles of
+ * victor_amd/sampler.py advance one half of their walkers while the other half is on the GPU): vk_eval_batch_begin copies the
+ * rows and enqueues the launch (1 <= n <= 4096), vk_eval_batch_finish waits for lnl / chi2 (either may be NULL).  One batch
+ * per context at a time - several contexts may each have one in flight; nothing else may be called on a context between
+ * its begin and its finish. */
+int vk_eval_batch_begin(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, int64_t n);
+int vk_eval_batch_finish(vk_ctx* ctx, double* lnl, double* chi2);
 
 /* Theory multipoles on a caller-supplied s grid: out[n][n_ell][n_s] with the caller's own
  * projection weights w_ell[n_ell][n_mu] on mu[n_mu] (host buffers). */

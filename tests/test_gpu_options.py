@@ -186,7 +186,7 @@ def test_rmu_real_space_input_on_gpu(tmp_path, with_beta):
 @pytest.mark.parametrize("non_uniform_mu", [False, True])
 def test_anisotropic_sigma_v_template_on_gpu(tmp_path, non_uniform_mu):
     """3-key sigma_v(r, mu) template (bicubic, box-clamped; uniform and non-uniform mu knots) vs the oracle: streaming model on
-    the fast kernels (patches in LDS, SVA instantiations), dispersion model on the generic kernel."""
+    the fast kernels, dispersion model on the cells kernel (patches in LDS, SVA instantiations)."""
     import sys
     import os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
@@ -197,13 +197,13 @@ def test_anisotropic_sigma_v_template_on_gpu(tmp_path, non_uniform_mu):
     fit = victor_amd.CCFFit(model, data)
     ora = vo.OracleFit(model, data)
     hp = cases.halton_params(40)
-    for i, kw, kernel in ((3, {}, "vk_theory_fast_kernel"), (11, {"rsd_model": "dispersion"}, "vk_theory_kernel"),
-                          (29, {"assume_isotropic": True}, "vk_theory_fast_kernel")):
+    for i, kw, kernel in ((3, {}, "vk_theory_fast_kernel"), (11, {"rsd_model": "dispersion"}, "vk_theory_cells_kernel"),
+                          (29, {"assume_isotropic": True}, "vk_theory_fast_kernel"), (30, {"rsd_model": "kaiser"}, "vk_theory_cells_kernel")):
         p = cases.point(hp, i)
         got = fit.log_likelihood(dict(p), **kw)
         want = ora.log_likelihood(dict(p), **kw)
         assert abs(got[1] / want[1] - 1) < RTOL and abs(got[0] / want[0] - 1) < RTOL, (i, kw)
-        # streaming: the patches ride in LDS on the fast kernels (uniform r grid, lattice form); dispersion: generic kernel
+        # the patches ride in LDS (uniform r grid, lattice form); kaiser does not read sigma_v at all
         assert fit._get_engine().last_kernel() == kernel, (kw, fit._get_engine().last_kernel())
     # a batch through every mapping that can take it: oracle on a few rows, mapping against mapping on all of them
     # (rows with |mu_r| beyond the template's box and r beyond its r range are clamped as FITPACK's bispeu does)
@@ -227,6 +227,23 @@ def test_anisotropic_sigma_v_template_on_gpu(tmp_path, non_uniform_mu):
         assert np.max(np.abs(res[mapping] - res["point"])) < 1e-10 * np.max(np.abs(res["point"])), mapping
     fit.theory_vector_batch(rows)
     assert fit._get_engine().last_kernel() == "vk_theory_cells_kernel"        # the default at this size
+    # the dispersion model on the same template: cells kernel at every batch size against the generic kernel and the oracle
+    got = fit.log_likelihood_batch(rows, rsd_model="dispersion")
+    assert fit._get_engine().last_kernel() == "vk_theory_cells_kernel"
+    few = fit.log_likelihood_batch(rows[:3], rsd_model="dispersion")
+    assert fit._get_engine().last_kernel() == "vk_theory_cells_kernel"
+    _native.set_knob("VICTOR_HIP_FORCE_GENERIC", "1")
+    try:
+        ref = fit.log_likelihood_batch(rows, rsd_model="dispersion")
+        assert fit._get_engine().last_kernel() == "vk_theory_kernel"
+    finally:
+        _native.set_knob("VICTOR_HIP_FORCE_GENERIC", None)
+    bound = chi2_bound(fit, rows, ulps=4096, rsd_model="dispersion")       # another arithmetic, and an iteration that amplifies it
+    assert_same_chi2(got[1], ref[1], bound, what="dispersion x sigma_v(r, mu): cells vs generic")
+    assert_same_chi2(few[1], got[1][:3], bound[:3], what="dispersion x sigma_v(r, mu): 3 rows vs 600")
+    for i in (0, 17, 599):
+        want = ora.log_likelihood(cases.point(hb, i), rsd_model="dispersion")
+        assert abs(got[1][i] / want[1] - 1) < RTOL, i
     _native.set_knob("VICTOR_HIP_MAPPING", "lanes")                            # the lanes kernel cannot take it: generic
     try:
         fit.theory_vector_batch(rows[:64])

@@ -43,16 +43,30 @@ def test_walker_ensemble_matches_oracle_driven_chain():
     assert np.array_equal(cg, cc)
     assert np.max(np.abs(lg / lc - 1)) < 1e-9
     assert g.n_accept == c.n_accept and g.n_evals == c.n_evals
-    # the direct route (rows written in place, straight to the engine - what bench.py and run_walkers.py use): the same chain,
-    # bit for bit the values of the dictionary route (same rows, same kernel), over enough steps to cross a block of
-    # pre-drawn random numbers and to meet proposals outside the prior
+    # the direct route (what bench.py and run_walkers.py use): rows written in place, the ensemble as two halves on two
+    # contexts, run() pipelined over the steps.  Same random numbers, same rows: the same chain - positions and decisions
+    # identical, log-likelihoods to rounding (half-batches of 4 take another work split than one batch of 8) - over enough steps
+    # to cross a block of pre-drawn random numbers and to meet proposals outside the prior; step() and run() evaluate the
+    # same half-batches and agree bit for bit.
     d = EnsembleMetropolis(None, specs, 8, seed=2024, fixed=fixed, fit=fit).initialise()
-    assert d._direct is not None
+    assert d._direct is not None and len(d._direct["engines"]) == 2
     g2 = EnsembleMetropolis(gpu_eval, specs, 8, seed=2024, fixed=fixed).initialise()
     cd, ld = d.run(150)
     cg2, lg2 = g2.run(150)
-    assert np.array_equal(cd[:5], cg) and np.array_equal(cd, cg2) and np.array_equal(ld, lg2)
-    assert d.n_accept == g2.n_accept and d.n_evals == g2.n_evals and 0 < d.n_accept < 150 * 8
+    assert np.array_equal(cd[:5], cg) and np.array_equal(cd, cg2)
+    assert np.max(np.abs(ld - lg2)) < 1e-9 * np.max(np.abs(lg2))
+    assert d.n_accept == g2.n_accept and d.n_evals == g2.n_evals and 0 < d.n_accept < 150 * 8 and d.n_steps == 150
+    s1 = EnsembleMetropolis(None, specs, 8, seed=2024, fixed=fixed, fit=fit).initialise()
+    for t in range(70):
+        s1.step()
+        assert np.array_equal(s1.x, cd[t]) and np.array_equal(s1.lnl, ld[t]), t
+    # an odd number of walkers (halves of 3 and 4) and a single walker
+    for w in (7, 1):
+        a = EnsembleMetropolis(None, specs, w, seed=5, fixed=fixed, fit=fit).initialise()
+        b = EnsembleMetropolis(gpu_eval, specs, w, seed=5, fixed=fixed).initialise()
+        ca, la = a.run(30)
+        cb, lb = b.run(30)
+        assert np.array_equal(ca, cb) and np.max(np.abs(la - lb)) < 1e-9 * np.max(np.abs(lb)), w
 
 
 def test_cobaya_plugin_calculate_on_gpu():

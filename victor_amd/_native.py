@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-VK_ABI_VERSION = 15
+VK_ABI_VERSION = 16
 VK_NPAR = 12
 (P_FSIGMA8, P_SIGMAV, P_APERP, P_APAR, P_EPSILON, P_BETA, P_ASTAR, P_M, P_Q, P_BIAS, P_AV, P_SPARE) = range(12)
 MATTER = {"template": 0, "linear_bias": 1, "velocity_template": 2}
@@ -103,6 +103,8 @@ SYMBOLS = {
     "vk_last_fused": (C.c_int, [_vp]),
     "vk_default_opts": (None, [_optp]),
     "vk_eval_batch": (C.c_int, [_vp, _optp, _dp, C.c_int64, _dp, _dp, _dp]),
+    "vk_eval_batch_begin": (C.c_int, [_vp, _optp, _dp, C.c_int64]),
+    "vk_eval_batch_finish": (C.c_int, [_vp, _dp, _dp]),
     "vk_theory_batch": (C.c_int, [_vp, _optp, _dp, C.c_int64, _dp, C.c_int32, _dp, C.c_int32, _dp, C.c_int32, _dp]),
     "vk_xi_smu_batch": (C.c_int, [_vp, _optp, _dp, C.c_int64, _dp, C.c_int32, _dp, C.c_int32, _dp]),
     "vk_device_alloc": (_vp, [_vp, C.c_size_t]),

@@ -220,6 +220,8 @@ struct vk_ctx {
   double* d_zc = nullptr;                       // the same memory through the device's eyes
   bool zero_copy_off = false;
   bool spin_off = false;               // results did not become visible to polling on this system (eval_batch_zero_copy)
+  int64_t begun_n = 0;                 // vk_eval_batch_begin: rows of the batch awaiting vk_eval_batch_finish (< 0: evaluated already)
+  std::vector<double> begun_sync;      // ... their results in that case
   bool zc_spin = false;                // the in-place launch in flight polls for its results (zc_begin / zc_finish)
   std::chrono::steady_clock::time_point zc_t0;
   int spin_timeouts = 0;
@@ -416,8 +418,20 @@ int launch_fast_sva(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   return fail(ctx, VK_E_ARG, "n_ell must be 1..3 (or a VK_LITE development build)");
 }
 
+// ... and the dispersion model with it (cells kernel only)
+template <int NLR>
+int launch_cells_sva_disp(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
+  switch (a.n_ell) {
+    case 1: if constexpr (VK_LITE_KEEP(NLR, 1, 1, 2)) return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 1, 0, kModeDispersion, 1>, grid, lds, a); break;
+    case 2: if constexpr (VK_LITE_KEEP(NLR, 2, 1, 2)) return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 2, 0, kModeDispersion, 1>, grid, lds, a); break;
+    case 3: if constexpr (VK_LITE_KEEP(NLR, 3, 1, 2)) return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 3, 0, kModeDispersion, 1>, grid, lds, a); break;
+  }
+  return fail(ctx, VK_E_ARG, "n_ell must be 1..3 (or a VK_LITE development build)");
+}
+
 template <int NLR>
 int launch_cells_sva(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
+  if (a.rsd == VK_RSD_DISPERSION) return launch_cells_sva_disp<NLR>(ctx, a, grid, lds);
   switch (a.n_ell) {
     case 1: if constexpr (VK_LITE_KEEP(NLR, 1, 1, 0)) return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 1, 0, kModeStreaming, 1>, grid, lds, a); break;
     case 2: if constexpr (VK_LITE_KEEP(NLR, 2, 1, 0)) return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 2, 0, kModeStreaming, 1>, grid, lds, a); break;
@@ -632,7 +646,9 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
   const bool emp_ok = !a.empirical || (a.vr_beta_dep ? a.uni_empb != nullptr : a.uni_v2 != nullptr);
   // anisotropic sigma_v(r, mu): its bicubic patches ride in LDS for the streaming model on the lattice form (SVA instantiations)
   const bool sva = a.sv_n_mu > 0 && !kais;
-  const bool sva_ok = !sva || (a.sva_doubles > 0 && a.rsd == VK_RSD_STREAMING && !a.from_data && a.uni_lut_n == 0);
+  // (the dispersion model with it: the cells kernel only, at every batch size)
+  const bool sva_disp = sva && disp;
+  const bool sva_ok = !sva || (a.sva_doubles > 0 && (a.rsd == VK_RSD_STREAMING || disp) && !a.from_data && a.uni_lut_n == 0);
   const int n_sva = sva ? a.sva_doubles : 0;
   bool fast = (a.rsd == VK_RSD_STREAMING || disp || kais) && ctx->fast_ok && emp_ok && sva_ok &&
               a.n_mu <= 1024 && a.n_x <= 2048 && !ctx->knobs.force_generic;
@@ -702,7 +718,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
   // (re-measured after both kernels lost their grid-stride loops, tools/gpu_cells_min_sweep.py, profiles/r03/z_*: point-major
   // ahead up to 12 / 16 points, level at 20, the cells kernel ahead from 24 / 28 on)
   const long long cells_min = ctx->knobs.cells_min >= 0 ? ctx->knobs.cells_min : 20;
-  const bool cells = cells_ok && (kais || (mapping ? mapping == 2 : n_dec >= cells_min));   // kaiser: this kernel only
+  const bool cells = cells_ok && (kais || sva_disp || (mapping ? mapping == 2 : n_dec >= cells_min));   // kaiser, dispersion x sigma_v(r, mu): this kernel only
   if (cells) {
     ctx->last_kernel = "vk_theory_cells_kernel";
     // A point's n_s * n_mu cells may be cut into `parts` ranges, one workgroup each (vk_kernel_cells.h): enough ranges to give
@@ -747,7 +763,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
       case 3: return launch_cells_nl<3>(ctx, a, grid_c, lds_c);
     }
   }
-  if (kais) fast = false;               // grids the cells kernel cannot take (n_mu < 64): the generic kernel
+  if (kais || sva_disp) fast = false;   // grids the cells kernel cannot take (n_mu < 64): the generic kernel
   ctx->last_kernel = fast ? "vk_theory_fast_kernel" : "vk_theory_kernel";
   if (fast) {
     const long long groups = (a.n_s + a.sbins_per_item - 1) / a.sbins_per_item;
@@ -1686,6 +1702,47 @@ int vk_eval_batch(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, i
   if (chi2) VK_HIP(ctx, hipMemcpyAsync(chi2, d_chi, nb_out, hipMemcpyDeviceToHost, ctx->stream));
   if (theory) VK_HIP(ctx, hipMemcpyAsync(theory, d_th, nb_th, hipMemcpyDeviceToHost, ctx->stream));
   return vk_sync(ctx);
+}
+
+// ---- a small host-buffer batch in two halves: enqueue now, collect later (include/victor_hip.h) ------------------------
+int vk_eval_batch_begin(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, int64_t n) {
+  if (!ctx) return VK_E_ARG;
+  sync_knobs(ctx);
+  int rc = check_opts(ctx, opts);
+  if (rc) return rc;
+  if (ctx->begun_n != 0) return fail(ctx, VK_E_ARG, "vk_eval_batch_begin: the previous batch of this context has not been collected");
+  if (n < 1 || n > kZeroCopyCap || !params) return fail(ctx, VK_E_ARG, "vk_eval_batch_begin: 1 <= n <= %lld rows", (long long)kZeroCopyCap);
+  if (!ctx->d_data) return fail(ctx, VK_E_ARG, "context was created without a data vector");
+  VK_HIP(ctx, hipSetDevice(ctx->device));
+  HostScratch sc;
+  rc = host_scratch(ctx, n, &sc);
+  if (rc) return rc;
+  rc = zc_begin(ctx, opts, params, n, true, sc.d_th);
+  if (rc < 0) return rc;
+  if (rc == 0) {          // no in-place buffers on this system: evaluate now, hand the results over in finish
+    ctx->begun_sync.resize((size_t)2 * n);
+    rc = vk_eval_batch(ctx, opts, params, n, ctx->begun_sync.data(), ctx->begun_sync.data() + n, nullptr);
+    if (rc) return rc;
+    ctx->begun_n = -n;
+    return VK_OK;
+  }
+  ctx->begun_n = n;
+  return VK_OK;
+}
+
+int vk_eval_batch_finish(vk_ctx* ctx, double* lnl, double* chi2) {
+  if (!ctx) return VK_E_ARG;
+  const int64_t n = ctx->begun_n;
+  if (n == 0) return fail(ctx, VK_E_ARG, "vk_eval_batch_finish: nothing was begun on this context");
+  ctx->begun_n = 0;
+  if (n < 0) {
+    if (lnl) memcpy(lnl, ctx->begun_sync.data(), (size_t)(-n) * sizeof(double));
+    if (chi2) memcpy(chi2, ctx->begun_sync.data() + (-n), (size_t)(-n) * sizeof(double));
+    return VK_OK;
+  }
+  VK_HIP(ctx, hipSetDevice(ctx->device));
+  const int rc = zc_finish(ctx, n, lnl, chi2, true);
+  return rc < 0 ? rc : VK_OK;
 }
 
 // ---- mailboxes: many one-point callers, one launch (include/victor_hip.h) ---------------------------------------------

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kBlock, (MODE == kModeStreaming && !SVA) || MODE ==
       } else if (mode_is_dispersion(MODE)) {
         for (int k = 0; k < a.n_xg; ++k) {
           const VelocityNode xw = load_node(a.xgw, k);
-          gs += disp_value<NLR, GRID, MODE == kModeDispersionFromData>(lds, lds + pl.da, fc, fp, a.niter, fma(-xw.x, fp.Bk, s_par), s_par,
+          gs += disp_value<NLR, GRID, MODE == kModeDispersionFromData, SVA>(lds, lds + pl.da, fc, fp, a.niter, fma(-xw.x, fp.Bk, s_par), s_par,
                                                                      sperp2, xw.x);
           if (xw.last != 0) {            // wave-uniform: a scalar branch, taken at the last node of a group
             asm volatile("" ::: "memory");            // (keeps the compiler from turning it into per-lane selects)

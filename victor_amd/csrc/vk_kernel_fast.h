@@ -411,7 +411,8 @@ __device__ __forceinline__ double uni_point(const double* __restrict__ lds, cons
 // follow.  Same-box A/B (tools/gpu_rsd_ab.py, BOSS, 16384 points): 17.06 -> 16.31 ms, max rel dchi2 between the builds 4.9e-13
 // (budget 1e-10), tests/test_gpu_options.py::test_dispersion_model_where_it_is_ill_conditioned unchanged and green
 // (profiles/r04/c_early_passes_second_order_ab.txt).
-template <int NLR, int GRID, int FD>
+// SVA = 1: sigma_v from the anisotropic template's bicubic patches (sv_aniso) as in uni_point; lattice form only.
+template <int NLR, int GRID, int FD, int SVA = 0>
 __device__ __forceinline__ double disp_value(const double* __restrict__ lds, const double* __restrict__ da,
                                              const FastConsts& fc, const FastPoint& fp, int niter, double num,
                                              double s_par, double sperp2, double xk) {
@@ -430,8 +431,9 @@ __device__ __forceinline__ double disp_value(const double* __restrict__ lds, con
   const double r2 = fma(r_par, r_par, sperp2);
   const double inv_r = vkm::rsqrt3(r2);
   const double mu_r = r_par * inv_r;
-  const double* rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(r2, inv_r, fc.off) : r2 * inv_r, tq, qi);
-  const double SV = cubic_b128(rec, tq);
+  const double rp = SVA ? r2 * inv_r : 0.0;
+  const double* rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? (SVA ? rp + fc.off : fma(r2, inv_r, fc.off)) : r2 * inv_r, tq, qi);
+  const double SV = SVA ? sv_aniso(lds, fc, rp, 2.0 * mu_r) : cubic_b128(rec, tq);
   const double q = -fp.Gk * cubic_b128(rec + 4, tq) * inv_r;
   const double dq = -fp.gD * cubic_b128(da + 4 * qi, tq);
   const double m2 = mu_r * mu_r;

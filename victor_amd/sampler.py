@@ -13,6 +13,8 @@ deterministic for a given seed, so that a chain driven by the HIP path can be co
 the same chain driven by the CPU oracle (tests/test_gpu_workloads.py).
 """
 
+import ctypes as C
+
 import numpy as np
 
 from .utils import InputError
@@ -103,7 +105,7 @@ class EnsembleMetropolis:
             batch[k] = v
         return batch
 
-    # ---- the direct route: rows written in place, results into preallocated buffers ------------------------------------
+    # ---- the direct route: rows written in place, two half-ensembles on two contexts, results into preallocated buffers ----
     _COLUMNS = {"fsigma8": 0, "sigma_v": 1, "beta": 5, "astar": 6, "M": 7, "Q": 8, "bias": 9, "Av": 10}
 
     def _bind(self, x):
@@ -114,11 +116,10 @@ class EnsembleMetropolis:
         if plan is None or plan[0] is None:
             return False
         names = self.names
-        idx, cols, eps = [], [], None
+        pairs, eps = [], None
         for j, name in enumerate(names):
             if name in self._COLUMNS:
-                idx.append(j)
-                cols.append(self._COLUMNS[name])
+                pairs.append((j, self._COLUMNS[name]))
             elif name == "epsilon" and not ({"alpha", "aperp", "apar"} & set(names)):
                 eps = j
             else:
@@ -126,54 +127,98 @@ class EnsembleMetropolis:
         if eps is None and "epsilon" in self.fixed and {"aperp", "apar"} & set(names):
             return False
         from . import _native as N
+        from .engine import Engine
         rows = np.array(fit._fit_rows(self._batch(x), fit.model), dtype=np.float64, order="C")     # fixed values and defaults
-        if rows.shape != (self.n_walkers, N.VK_NPAR):
+        W = self.n_walkers
+        if rows.shape != (W, N.VK_NPAR):
             return False
-        out = np.empty((2, self.n_walkers))
+        # The walkers are independent, so the ensemble advances as two halves on two contexts (streams): while one half is on
+        # the GPU the host accepts / rejects the other half and forms its next proposals - a step costs one launch latency
+        # instead of a launch latency plus the host's work (run()); step() overlaps the two launches only.
+        h = W // 2 if W >= 2 else W
+        bounds = [(0, h)] + ([(h, W)] if h < W else [])
+        first = plan[0]
+        engines = [first]
+        if len(bounds) == 2:
+            key = fit._engine_key(fit._merged({}))
+            engines.append(Engine(fit, fit, device=first.device, matter_model=key, simpson_even=first.simpson_even))
+        out = np.empty((2, W))
         alpha = self.fixed.get("alpha", 1)
-        self._direct = {"rows": rows, "pairs": list(zip(idx, cols)), "eps": eps, "alpha": None if alpha == 1 else alpha, "out": out,
-                        "engine": plan[0], "opts": plan[1], "p_rows": N.as_dp(rows), "p_lnl": N.as_dp(out[0]), "p_chi": N.as_dp(out[1]),
-                        "t1": np.empty_like(x), "t2": np.empty_like(x), "e": np.empty(self.n_walkers), "a": np.empty(self.n_walkers)}
+        stride = N.VK_NPAR * 8
+        self._direct = {
+            "rows": rows, "pairs": pairs, "eps": eps, "alpha": None if alpha == 1 else alpha, "out": out, "bounds": bounds,
+            "engines": engines, "opts": plan[1], "mask": [None] * len(bounds),
+            "p_rows": [C.cast(rows.ctypes.data + lo * stride, N._dp) for lo, _ in bounds],
+            "p_lnl": [C.cast(out[0].ctypes.data + lo * 8, N._dp) for lo, _ in bounds],
+            "p_chi": [C.cast(out[1].ctypes.data + lo * 8, N._dp) for lo, _ in bounds],
+            "t1": np.empty_like(x), "t2": np.empty_like(x), "e": [np.empty(hi - lo) for lo, hi in bounds],
+            "a": [np.empty(hi - lo) for lo, hi in bounds]}
         return True
 
-    def _lnl_direct(self, x):
+    def _half_begin(self, k, prop):
+        """Enqueue the likelihood of rows lo:hi of the proposals ``prop`` (a (W, P) array, or the half itself)."""
         d = self._direct
-        rows = d["rows"]
+        lo, hi = d["bounds"][k]
+        xs = prop[lo:hi] if len(prop) == self.n_walkers else prop
+        t1 = d["t1"][lo:hi]
+        np.subtract(xs, self.lo, out=t1)              # every walker inside the box <=> min(x - lo, hi - x) >= 0
+        np.subtract(self.hi, xs, out=d["t2"][lo:hi])
+        np.minimum(t1, d["t2"][lo:hi], out=t1)
+        mask = None
+        if t1.min() < 0.0:                            # a proposal outside the prior: its row keeps the walker's position (a valid
+            mask = t1.min(axis=1) >= 0.0              # point; the result is discarded) and its log-likelihood reads -inf
+            xs = np.where(mask[:, None], xs, self.x[lo:hi])
+        d["mask"][k] = mask
+        rows = d["rows"][lo:hi]
         for j, c in d["pairs"]:
-            rows[:, c] = x[:, j]
+            rows[:, c] = xs[:, j]
         if d["eps"] is not None:                      # the expressions of CCFModel._param_rows, on the same (contiguous) arrays
-            eps, apar = d["e"], d["a"]
-            np.copyto(eps, x[:, d["eps"]])            # as _batch() hands it over: the same loop of np.power
+            eps, apar = d["e"][k], d["a"][k]
+            np.copyto(eps, xs[:, d["eps"]])           # as _batch() hands it over: the same loop of np.power
             np.power(eps, -2 / 3, out=apar)
             if d["alpha"] is not None:
                 np.multiply(d["alpha"], apar, out=apar)
             np.multiply(eps, apar, out=rows[:, 2])
             rows[:, 3] = apar
             rows[:, 4] = eps
-        eng = d["engine"]
-        rc = eng._lib.vk_eval_batch(eng._ctx, d["opts"], d["p_rows"], self.n_walkers, d["p_lnl"], d["p_chi"], None)
+        eng = d["engines"][k]
+        rc = eng._lib.vk_eval_batch_begin(eng._ctx, d["opts"], d["p_rows"][k], hi - lo)
         if rc != 0:
             eng._check(rc)
-        self.n_evals += self.n_walkers
-        return d["out"][0]
+
+    def _half_finish(self, k):
+        """log-likelihoods of the half begun last (a view of a reused buffer)."""
+        d = self._direct
+        lo, hi = d["bounds"][k]
+        eng = d["engines"][k]
+        rc = eng._lib.vk_eval_batch_finish(eng._ctx, d["p_lnl"][k], d["p_chi"][k])
+        if rc != 0:
+            eng._check(rc)
+        lnl = d["out"][0][lo:hi]
+        mask = d["mask"][k]
+        if mask is None:
+            self.n_evals += hi - lo
+        else:
+            lnl[~mask] = -np.inf
+            self.n_evals += int(np.count_nonzero(mask))
+        return lnl
 
     def _lnl(self, x):
         """log-likelihoods of the rows of ``x`` (-inf outside the prior box).  The result may be a view of a reused buffer: callers
         that keep it copy it."""
         d = self._direct
-        if d is not None:                             # every walker inside the box <=> min(x - lo, hi - x) >= 0: four small ufuncs
-            np.subtract(x, self.lo, out=d["t1"])
-            np.subtract(self.hi, x, out=d["t2"])
-            np.minimum(d["t1"], d["t2"], out=d["t1"])
-            if d["t1"].min() >= 0.0:
-                return self._lnl_direct(x)
+        if d is not None and len(x) == self.n_walkers:
+            for k in range(len(d["bounds"])):
+                self._half_begin(k, x)
+            for k in range(len(d["bounds"])):
+                self._half_finish(k)
+            return d["out"][0]
         inside = ((x >= self.lo) & (x <= self.hi)).all(axis=1)
         n_in = int(np.count_nonzero(inside))
         out = np.full(len(x), -np.inf)
         if n_in:
-            if self._direct is not None:              # some proposals outside the prior: evaluate all rows that are inside
-                fit = self._fit
-                out[inside] = fit.log_likelihood_batch(self._batch(x[inside]))[0]
+            if d is not None:
+                out[inside] = self._fit.log_likelihood_batch(self._batch(x[inside]))[0]
             else:
                 out[inside] = np.asarray(self.evaluate(self._batch(x[inside])), dtype=float)
             self.n_evals += n_in
@@ -198,25 +243,30 @@ class EnsembleMetropolis:
         self.lnl = np.array(self._lnl(x), dtype=float)
         return self
 
-    def _refill(self):
-        """Proposal increments and log acceptance levels of the next BLOCK steps (one draw each instead of two per step)."""
-        self._dz = self.width * self.rng.standard_normal((self.BLOCK,) + self.x.shape)
-        self._logu = np.log(self.rng.random((self.BLOCK, self.n_walkers)))
-        self._at = 0
+    def _next_randoms(self):
+        """(proposal increments (W, P), log acceptance levels (W,)) of the next step, drawn BLOCK steps at a time."""
+        if self._at >= self.BLOCK:
+            self._dz = self.width * self.rng.standard_normal((self.BLOCK,) + self.x.shape)
+            self._logu = np.log(self.rng.random((self.BLOCK, self.n_walkers)))
+            self._at = 0
+        t = self._at
+        self._at = t + 1
+        return self._dz[t], self._logu[t]
+
+    def _accept(self, lo, hi, prop, lnl_prop, logu):
+        accept = logu < lnl_prop - self.lnl[lo:hi]
+        np.copyto(self.x[lo:hi], prop, where=accept[:, None])
+        np.copyto(self.lnl[lo:hi], lnl_prop, where=accept)
+        self.n_accept += int(np.count_nonzero(accept))
+        return accept
 
     def step(self):
         if self.x is None:
             self.initialise()
-        if self._at >= self.BLOCK:
-            self._refill()
-        t = self._at
-        self._at = t + 1
-        prop = self.x + self._dz[t]
+        dz, logu = self._next_randoms()
+        prop = self.x + dz
         lnl_prop = self._lnl(prop)
-        accept = self._logu[t] < lnl_prop - self.lnl
-        np.copyto(self.x, prop, where=accept[:, None])
-        np.copyto(self.lnl, lnl_prop, where=accept)
-        self.n_accept += int(np.count_nonzero(accept))
+        accept = self._accept(0, self.n_walkers, prop, lnl_prop, logu)
         self.n_steps += 1
         return accept
 
@@ -226,12 +276,37 @@ class EnsembleMetropolis:
             self.initialise()
         chain = np.empty((n_steps, self.n_walkers, len(self.specs)))
         lnl = np.empty((n_steps, self.n_walkers))
+        d = self._direct
+        if d is None or len(d["bounds"]) != 2 or type(self).step is not EnsembleMetropolis.step or n_steps < 1:
+            for t in range(n_steps):
+                self.step()
+                chain[t] = self.x
+                lnl[t] = self.lnl
+                if on_step is not None:
+                    on_step(t, self)
+            return chain, lnl
+        # Two halves, pipelined over the steps: the same half-batches as step() evaluates - the same chain - but half A of
+        # step t + 1 is on the GPU while the host finishes half B of step t.
+        (a0, a1), (b0, b1) = d["bounds"]
+        dz, logu = self._next_randoms()
+        prop_a = self.x[a0:a1] + dz[a0:a1]
+        self._half_begin(0, prop_a)
         for t in range(n_steps):
-            self.step()
+            prop_b = self.x[b0:b1] + dz[b0:b1]
+            self._half_begin(1, prop_b)
+            self._accept(a0, a1, prop_a, self._half_finish(0), logu[a0:a1])
+            if t + 1 < n_steps:
+                dz_next, logu_next = self._next_randoms()
+                prop_a = self.x[a0:a1] + dz_next[a0:a1]
+                self._half_begin(0, prop_a)
+            self._accept(b0, b1, prop_b, self._half_finish(1), logu[b0:b1])
+            self.n_steps += 1
             chain[t] = self.x
             lnl[t] = self.lnl
             if on_step is not None:
                 on_step(t, self)
+            if t + 1 < n_steps:
+                dz, logu = dz_next, logu_next
         return chain, lnl
 
     @property
