@@ -62,7 +62,7 @@ class _Header(C.Structure):
         ("digest", C.c_char * 64),
         ("stats", N.vk_serve_stats),
         ("gather_window_us", C.c_double),
-        ("depth", C.c_uint32), ("max_batch", C.c_uint32),
+        ("depth", C.c_uint32), ("max_batch", C.c_uint32), ("threads", C.c_uint32), ("pad1", C.c_uint32),
         ("error", C.c_char * 512),
     ]
 
@@ -166,11 +166,17 @@ class Broker:
     ``attach_existing``: the segment was created (state STARTING) by the chain that elected itself to start this process.
     """
 
-    def __init__(self, model, data, name, n_slots=64, device=0, gather_window_us=3.0, attach_existing=False, depth=4, max_batch=4):
-        """``depth``: contexts (streams) of the owner = launches that may be in flight at once (1..8); ``max_batch``: requests per
-        launch (0: the library's limit, 32).  Defaults from tools/gpu_broker_sweep.py (profiles/r04/broker_sweep.txt)."""
+    def __init__(self, model, data, name, n_slots=64, device=0, gather_window_us=3.0, attach_existing=False, depth=4, max_batch=4,
+                 threads=1):
+        """``depth``: contexts (streams) per serving thread = launches it may have in flight at once (1..8); ``max_batch``:
+        requests per launch (0: the library's limit, 32); ``threads``: serving threads, each with its own contexts and its own
+        contiguous share of the mailboxes.  Defaults from tools/gpu_broker_sweep.py (profiles/r04/broker_sweep.txt,
+        broker_sweep_threads.txt): more threads or more contexts buy nothing - 8 chains saturate near 2.6e5 evaluations/s whether
+        they travel one per launch on 4 threads x 2 contexts or four per launch on one thread, because what is short is the GPU's
+        latency for eight single-point work splits in flight at once, not the host's time to enqueue them."""
         self.name = name
         depth = max(1, min(int(depth), 8))
+        threads = max(1, min(int(threads), 8))
         path = shm_path(name)
         self.seg = _Segment(path, create=not attach_existing, n_slots=n_slots)
         h = self.seg.header
@@ -191,12 +197,14 @@ class Broker:
             # one context (stream, device tables, pinned buffers) per launch in flight
             from .engine import Engine
             key = self.fit._engine_key(self.fit._merged({}))
+            threads = min(threads, self.seg.n_slots)
             self.engines = [self.engine] + [Engine(self.fit, self.fit, device=device, matter_model=key,
-                                                   simpson_even=self.engine.simpson_even) for _ in range(depth - 1)]
+                                                   simpson_even=self.engine.simpson_even) for _ in range(depth * threads - 1)]
             # first evaluation here, not under the first client's clock (runtime, code object, LDS image)
             for eng in self.engines:
                 eng.eval_point(plan[1], [0.5, 380.0, 1.0, 1.0, 1.0, 0.4, 1.0, 1.0, 1.0, float(self.fit.model["bias"]), 0.0, 0.0])
             h.depth = depth
+            h.threads = threads
             h.max_batch = max(0, int(max_batch))
         except Exception as exc:
             h.error = str(exc).encode()[:500]
@@ -208,20 +216,44 @@ class Broker:
     def serve(self, linger=None, parent_pid=None, slice_s=0.25):
         """Serve until the header's stop word is set - or, with ``linger``, until that many seconds have passed without any
         client attached after at least one had been (``parent_pid``: also when that process has gone and nobody is attached)."""
+        import threading
         seg, lib = self.seg, self.engine._lib
         h = seg.header
-        stats = N.vk_serve_stats()
-        boxes_addr = C.addressof(seg.boxes)
         stop_addr = C.addressof(h) + _Header.stop.offset
-        ctxs = (C.c_void_p * len(self.engines))(*[e._ctx for e in self.engines])
+        n_thr, depth = int(h.threads) or 1, int(h.depth)
+        bounds = thread_bounds(seg.n_slots, n_thr)
+        stats = [N.vk_serve_stats() for _ in range(n_thr)]
+        ctxs = [(C.c_void_p * depth)(*[e._ctx for e in self.engines[g * depth:(g + 1) * depth]]) for g in range(n_thr)]
+        boxes_addr = C.addressof(seg.boxes)
+        errors, quit_flag = [], []
         ever, empty_since = False, time.time()
+
+        def serve(g):
+            """Thread g: slices of the native loop over its mailboxes (ctypes releases the GIL for their duration)."""
+            lo, hi = bounds[g]
+            while not quit_flag and not errors and not h.stop:
+                rc = lib.vk_serve_mailboxes(ctxs[g], depth, C.byref(self.opts), boxes_addr + lo * BOX_BYTES, hi - lo, stop_addr,
+                                            float(h.gather_window_us), int(h.max_batch), float(slice_s), C.byref(stats[g]))
+                if rc != 0:
+                    errors.append((g, rc))
+
+        workers = [threading.Thread(target=serve, args=(g,), daemon=True) for g in range(n_thr)]
+        for t in workers:
+            t.start()
         try:
             while True:
-                rc = lib.vk_serve_mailboxes(ctxs, len(self.engines), C.byref(self.opts), boxes_addr, seg.n_slots, stop_addr,
-                                            float(h.gather_window_us), int(h.max_batch), float(slice_s), C.byref(stats))
-                if rc != 0:
-                    self.engine._check(rc)
-                h.stats = stats
+                time.sleep(slice_s)
+                if errors:
+                    g, rc = errors[0]
+                    self.engines[g * depth]._check(rc)
+                total = N.vk_serve_stats()
+                for st in stats:
+                    total.batches += st.batches
+                    total.evals += st.evals
+                    total.max_batch = max(total.max_batch, st.max_batch)
+                    total.windows_timed_out += st.windows_timed_out
+                    total.busy_seconds += st.busy_seconds
+                h.stats = total
                 now = time.time()
                 h.heartbeat = now
                 attached = 0
@@ -241,6 +273,10 @@ class Broker:
                 if parent_pid and not attached and not _pid_alive(parent_pid) and now - empty_since > (linger or 0.0):
                     break
         finally:
+            quit_flag.append(1)
+            h.stop = 1
+            for t in workers:
+                t.join(timeout=5)
             h.state = STOPPED
             self.close()
 
@@ -255,6 +291,18 @@ class Broker:
 
 
 N_BOX_FREE, N_BOX_ATTACHED = 0, 1      # VK_BOX_* of include/victor_hip.h
+
+
+def thread_bounds(n_slots, n_threads):
+    """Contiguous ranges of mailboxes, one per serving thread: [(lo, hi), ...]."""
+    n_threads = max(1, min(int(n_threads) or 1, n_slots))
+    base, extra = divmod(n_slots, n_threads)
+    out, lo = [], 0
+    for g in range(n_threads):
+        hi = lo + base + (1 if g < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
 
 
 # ======================================================================================================================
@@ -292,13 +340,19 @@ class BrokerClient:
         lock_fd = os.open(path + ".lock", os.O_CREAT | os.O_RDWR, 0o600)
         try:
             fcntl.flock(lock_fd, fcntl.LOCK_EX)
-            for i, box in enumerate(self.seg.boxes):
-                if box.state == N_BOX_FREE:
-                    box.req_seq = box.resp_seq = 0
-                    box.client_pid = os.getpid()
-                    box.state = N_BOX_ATTACHED
-                    self.slot = i
-                    break
+            # a free mailbox in the share of the serving thread that has the fewest chains
+            best, boxes = None, self.seg.boxes
+            for lo, hi in thread_bounds(self.seg.n_slots, int(h.threads) or 1):
+                used = sum(1 for i in range(lo, hi) if boxes[i].state == N_BOX_ATTACHED)
+                free = next((i for i in range(lo, hi) if boxes[i].state == N_BOX_FREE), None)
+                if free is not None and (best is None or used < best[0]):
+                    best = (used, free)
+            if best is not None:
+                box = boxes[best[1]]
+                box.req_seq = box.resp_seq = 0
+                box.client_pid = os.getpid()
+                box.state = N_BOX_ATTACHED
+                self.slot = best[1]
         finally:
             fcntl.flock(lock_fd, fcntl.LOCK_UN)
             os.close(lock_fd)
@@ -353,7 +407,8 @@ class BrokerClient:
             pass
 
 
-def spawn_broker(model, data, name, device=0, n_slots=64, linger=5.0, gather_window_us=3.0, log=None, depth=4, max_batch=4):
+def spawn_broker(model, data, name, device=0, n_slots=64, linger=5.0, gather_window_us=3.0, log=None, depth=4, max_batch=4,
+                 threads=1):
     """Start ``python -m victor_amd.broker`` for a segment this process has just created (election winner) or will create.
     The child is a fresh interpreter: it is the only process that initialises the GPU."""
     import subprocess
@@ -362,7 +417,7 @@ def spawn_broker(model, data, name, device=0, n_slots=64, linger=5.0, gather_win
     json.dump({"model": model, "data": data}, cfg, default=str)
     cfg.close()
     cmd = [sys.executable, "-m", "victor_amd.broker", "--config-json", cfg.name, "--name", name, "--device", str(device),
-           "--slots", str(n_slots), "--linger", str(linger), "--window-us", str(gather_window_us), "--depth", str(depth), "--max-batch", str(max_batch),
+           "--slots", str(n_slots), "--linger", str(linger), "--window-us", str(gather_window_us), "--depth", str(depth), "--max-batch", str(max_batch), "--threads", str(threads),
            "--attach-existing",
            "--parent-pid", str(os.getpid()), "--delete-config"]
     env = dict(os.environ)
@@ -408,7 +463,8 @@ def connect(model, data, spec, timeout=300.0):
         seg.close()
         spawn_broker(model, data, name, device=device, n_slots=int(os.environ.get("VICTOR_HIP_BROKER_SLOTS", "64")),
                      log=os.environ.get("VICTOR_HIP_BROKER_LOG"), depth=int(os.environ.get("VICTOR_HIP_BROKER_DEPTH", "4")),
-                     max_batch=int(os.environ.get("VICTOR_HIP_BROKER_MAX_BATCH", "4")))
+                     max_batch=int(os.environ.get("VICTOR_HIP_BROKER_MAX_BATCH", "4")),
+                     threads=int(os.environ.get("VICTOR_HIP_BROKER_THREADS", "1")))
         return BrokerClient(name, digest, timeout=timeout)
     raise N.NativeError(f"could not start or reach broker {name}")
 
@@ -425,6 +481,7 @@ def main(argv=None):
     ap.add_argument("--linger", type=float, default=None, help="exit this many seconds after the last client has gone")
     ap.add_argument("--window-us", type=float, default=3.0, help="how long a round waits for the other chains' requests")
     ap.add_argument("--depth", type=int, default=4, help="contexts (streams) of the owner = launches in flight at once")
+    ap.add_argument("--threads", type=int, default=1, help="serving threads, each with `depth` contexts and its share of the mailboxes")
     ap.add_argument("--max-batch", type=int, default=4, help="requests per launch (0: the library's limit of 32); measured "
                                                              "best at 4 for 8 and 16 chains (tools/gpu_broker_sweep.py)")
     ap.add_argument("--attach-existing", action="store_true")
@@ -448,7 +505,7 @@ def main(argv=None):
     name = args.name or auto_name(config_digest(model, data), args.device)
     try:
         broker = Broker(model, data, name, n_slots=args.slots, device=args.device, gather_window_us=args.window_us,
-                        attach_existing=args.attach_existing, depth=args.depth, max_batch=args.max_batch)
+                        attach_existing=args.attach_existing, depth=args.depth, max_batch=args.max_batch, threads=args.threads)
     except Exception as exc:
         if args.attach_existing:            # tell the chains that are waiting for READY
             try:
@@ -460,7 +517,7 @@ def main(argv=None):
                 pass
         raise
     print(f"victor broker '{name}' ready: pid {os.getpid()}, device {args.device}, {broker.seg.n_slots} mailboxes, "
-          f"{len(broker.engines)} launches in flight", file=sys.stderr, flush=True)
+          f"{int(broker.seg.header.threads)} serving thread(s) x {int(broker.seg.header.depth)} launches in flight", file=sys.stderr, flush=True)
     broker.serve(linger=args.linger, parent_pid=args.parent_pid or None)
 
 
