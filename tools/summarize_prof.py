@@ -69,8 +69,12 @@ if points:
             continue
         per = {c: cs[c]["avg"] * 64.0 / points for c in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD") if c in cs}
         busy = {}
-        if "SQ_ACTIVE_INST_VALU" in cs and "SQ_BUSY_CYCLES" in cs:
-            busy["valu_busy_of_sq_busy_x4"] = 4.0 * cs["SQ_ACTIVE_INST_VALU"]["avg"] / cs["SQ_BUSY_CYCLES"]["avg"]
+        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs' clocks
+        if "SQ_ACTIVE_INST_VALU" in cs and "GRBM_GUI_ACTIVE" in cs:
+            cycles = cs["GRBM_GUI_ACTIVE"]["avg"] / 8.0
+            busy["valu_busy"] = 4.0 * cs["SQ_ACTIVE_INST_VALU"]["avg"] / (1024.0 * cycles)
+            if "SQ_ACTIVE_INST_LDS" in cs:
+                busy["lds_busy"] = 4.0 * cs["SQ_ACTIVE_INST_LDS"]["avg"] / (256.0 * cycles)
         if "SQ_LDS_BANK_CONFLICT" in cs and "SQ_LDS_IDX_ACTIVE" in cs and cs["SQ_LDS_IDX_ACTIVE"]["avg"] > 0:
             busy["lds_bank_conflict_frac"] = cs["SQ_LDS_BANK_CONFLICT"]["avg"] / cs["SQ_LDS_IDX_ACTIVE"]["avg"]
         summary.setdefault("per_point", {})[k] = {"points_per_launch": points, **per, **busy}
