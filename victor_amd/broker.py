@@ -437,36 +437,46 @@ def connect(model, data, spec, timeout=300.0):
     device = broker_device()
     name = auto_name(digest, device)
     path = shm_path(name)
-    for _ in range(3):
-        try:
-            seg = _Segment(path, create=True, n_slots=int(os.environ.get("VICTOR_HIP_BROKER_SLOTS", "64")))
-        except FileExistsError:
-            # somebody else won the election - unless what is there is the leftover of a job that died
+    n_slots = int(os.environ.get("VICTOR_HIP_BROKER_SLOTS", "64"))
+    # The election - look at what is there, clear a leftover, create the segment, start the owner - is one critical section
+    # under a file lock: two chains that both find the leftover of a dead job must not remove each other's fresh segment.
+    lock_fd = os.open(path + ".elect", os.O_CREAT | os.O_RDWR, 0o600)
+    try:
+        fcntl.flock(lock_fd, fcntl.LOCK_EX)
+        for _ in range(3):
             try:
-                old = _Segment(path)
-            except (FileNotFoundError, InputError):
-                time.sleep(0.05)
-                continue
-            h = old.header
-            dead_server = h.state in (READY, STARTING) and h.server_pid > 0 and not _pid_alive(int(h.server_pid))
-            never_started = h.state == STARTING and h.server_pid == 0 and time.time() - h.created > 120.0
-            stale = dead_server or never_started or h.state in (FAILED, STOPPED)
-            old.close()
-            if not stale:
-                return BrokerClient(name, digest, timeout=timeout)
-            for p in (path, path + ".lock"):
+                seg = _Segment(path, create=True, n_slots=n_slots)
+            except FileExistsError:
                 try:
-                    os.unlink(p)
-                except OSError:
-                    pass
-            continue
-        seg.close()
-        spawn_broker(model, data, name, device=device, n_slots=int(os.environ.get("VICTOR_HIP_BROKER_SLOTS", "64")),
-                     log=os.environ.get("VICTOR_HIP_BROKER_LOG"), depth=int(os.environ.get("VICTOR_HIP_BROKER_DEPTH", "4")),
-                     max_batch=int(os.environ.get("VICTOR_HIP_BROKER_MAX_BATCH", "4")),
-                     threads=int(os.environ.get("VICTOR_HIP_BROKER_THREADS", "1")))
-        return BrokerClient(name, digest, timeout=timeout)
-    raise N.NativeError(f"could not start or reach broker {name}")
+                    old = _Segment(path)
+                except (FileNotFoundError, InputError):
+                    time.sleep(0.05)
+                    continue
+                h = old.header
+                dead_server = h.state in (READY, STARTING) and h.server_pid > 0 and not _pid_alive(int(h.server_pid))
+                never_started = h.state == STARTING and h.server_pid == 0 and time.time() - h.created > 120.0
+                stale = dead_server or never_started or h.state in (FAILED, STOPPED)
+                old.close()
+                if not stale:
+                    break                                   # somebody else's owner is (or is becoming) ready: attach below
+                for p in (path, path + ".lock"):
+                    try:
+                        os.unlink(p)
+                    except OSError:
+                        pass
+                continue
+            seg.close()
+            spawn_broker(model, data, name, device=device, n_slots=n_slots, log=os.environ.get("VICTOR_HIP_BROKER_LOG"),
+                         depth=int(os.environ.get("VICTOR_HIP_BROKER_DEPTH", "4")),
+                         max_batch=int(os.environ.get("VICTOR_HIP_BROKER_MAX_BATCH", "4")),
+                         threads=int(os.environ.get("VICTOR_HIP_BROKER_THREADS", "1")))
+            break
+        else:
+            raise N.NativeError(f"could not start or reach broker {name}")
+    finally:
+        fcntl.flock(lock_fd, fcntl.LOCK_UN)
+        os.close(lock_fd)
+    return BrokerClient(name, digest, timeout=timeout)
 
 
 def main(argv=None):

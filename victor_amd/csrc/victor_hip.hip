@@ -1676,6 +1676,7 @@ int vk_eval_batch(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, i
   if (rc) return rc;
   if (n < 0 || (n > 0 && !params)) return fail(ctx, VK_E_ARG, "params is NULL");
   if (n == 0) return VK_OK;
+  if (ctx->begun_n != 0) return fail(ctx, VK_E_ARG, "a batch begun with vk_eval_batch_begin is awaiting vk_eval_batch_finish on this context");
   if ((lnl || chi2) && !ctx->d_data) return fail(ctx, VK_E_ARG, "context was created without a data vector");
   VK_HIP(ctx, hipSetDevice(ctx->device));
   const size_t nb_par = (size_t)n * VK_NPAR * sizeof(double);
@@ -1932,6 +1933,7 @@ static int general_grid(vk_ctx* ctx, const vk_eval_opts* opts, const double* par
   int rc = check_opts(ctx, opts);
   if (rc) return rc;
   if (n < 0 || n_s < 1 || n_mu < 2 || !params || !s || !mu || !out) return fail(ctx, VK_E_ARG, "bad arguments");
+  if (ctx->begun_n != 0) return fail(ctx, VK_E_ARG, "a batch begun with vk_eval_batch_begin is awaiting vk_eval_batch_finish on this context");
   if (project && (n_ell < 1 || n_ell > kMaxEll || !w_ell)) return fail(ctx, VK_E_ARG, "n_ell must be 1..3 (or a VK_LITE development build)");
   if (n == 0) return VK_OK;
   VK_HIP(ctx, hipSetDevice(ctx->device));
