@@ -147,3 +147,65 @@ print(json.dumps({"logp": state["logp"], "chi2": state["derived"]["chi2_ccf_corr
     while os.path.exists(path) and time.time() < deadline:
         time.sleep(0.25)
     assert not os.path.exists(path), "the auto-started broker did not leave after its chains had gone"
+
+
+def test_broker_survives_a_killed_chain_and_hands_its_mailbox_on(tmp_path):
+    """A chain that dies without detaching (SIGKILL in the middle of its loop) must cost nothing but its mailbox for a moment:
+    the owner's reaper frees it (the pid is gone), the other chain's values stay correct throughout, and a chain that comes
+    later gets a mailbox even though the segment has only two."""
+    import signal
+    import victor_amd
+    from victor_amd import broker as B
+    name = f"victor_test_kill_{os.getpid()}"
+    env = dict(os.environ, PYTHONPATH=ROOT + (os.pathsep + os.environ["PYTHONPATH"] if os.environ.get("PYTHONPATH") else ""))
+    env.pop("VICTOR_HIP_BROKER", None)
+    srv = subprocess.Popen([sys.executable, "-m", "victor_amd.broker", "--config", "config/boss_cobaya_config.yaml", "--name", name,
+                            "--slots", "2"], cwd=ROOT, env=env, stdin=subprocess.DEVNULL)
+    loop = r'''
+import os, sys, json, time
+root, name, seconds = sys.argv[1], sys.argv[2], float(sys.argv[3])
+os.chdir(root); sys.path.insert(0, root)
+os.environ["VICTOR_HIP_BROKER"] = name
+import victor_amd
+from tests import cases
+info = cases.cobaya_info()["likelihood"]["CCFLikelihood"]
+fit = victor_amd.CCFFit(info["model"], info["data"])
+p = {"fsigma8": 0.47, "beta": 0.37, "sigma_v": 380, "epsilon": 1.0}
+first = fit.log_likelihood(dict(p))
+print(json.dumps({"ready": first}), flush=True)
+n, t_end = 0, time.time() + seconds
+while time.time() < t_end:
+    assert fit.log_likelihood(dict(p)) == first
+    n += 1
+print(json.dumps({"calls": n, "slot": fit._broker_client.slot}), flush=True)
+'''
+    try:
+        victim = subprocess.Popen([sys.executable, "-c", loop, ROOT, name, "60"], env=env, stdout=subprocess.PIPE, text=True)
+        steady = subprocess.Popen([sys.executable, "-c", loop, ROOT, name, "4"], env=env, stdout=subprocess.PIPE, text=True)
+        ready = json_line(victim.stdout.readline())
+        assert "ready" in ready
+        time.sleep(0.5)
+        victim.send_signal(signal.SIGKILL)                 # in the middle of its loop, mailbox attached, maybe a request pending
+        victim.wait(timeout=30)
+        out, _ = steady.communicate(timeout=120)
+        lines = [json_line(ln) for ln in out.strip().splitlines()]
+        assert steady.returncode == 0 and lines[0]["ready"] == ready["ready"] and lines[-1]["calls"] > 1000
+        # both mailboxes were taken; the reaper must have freed the victim's by now (it runs every 0.25 s)
+        late = subprocess.run([sys.executable, "-c", loop, ROOT, name, "0.2"], env=env, capture_output=True, text=True, timeout=120)
+        assert late.returncode == 0, late.stderr[-2000:]
+        assert json_line(late.stdout.strip().splitlines()[0])["ready"] == ready["ready"]
+        g, _ = cases.golden_outputs()
+        assert abs(ready["ready"][0] - g["boss_cobaya_lnl"][0]) < 1e-9 * abs(ready["ready"][0])
+        seg = B._Segment(B.shm_path(name))
+        seg.header.stop = 1
+        seg.close()
+        assert srv.wait(timeout=30) == 0
+    finally:
+        for p in (srv,):
+            if p.poll() is None:
+                p.kill()
+
+
+def json_line(text):
+    import json
+    return json.loads(text)

@@ -153,6 +153,15 @@ class EnsembleMetropolis:
             "p_chi": [C.cast(out[1].ctypes.data + lo * 8, N._dp) for lo, _ in bounds],
             "t1": np.empty_like(x), "t2": np.empty_like(x), "e": [np.empty(hi - lo) for lo, hi in bounds],
             "a": [np.empty(hi - lo) for lo, hi in bounds]}
+        # views of the halves, made once: a slice is a new array object every time it is written down
+        d = self._direct
+        d["t1h"] = [d["t1"][lo:hi] for lo, hi in bounds]
+        d["t2h"] = [d["t2"][lo:hi] for lo, hi in bounds]
+        d["colv"] = [[(j, rows[lo:hi, c]) for j, c in pairs] for lo, hi in bounds]
+        d["derived"] = [(rows[lo:hi, 2], rows[lo:hi, 3], rows[lo:hi, 4]) for lo, hi in bounds]
+        d["lnlh"] = [out[0][lo:hi] for lo, hi in bounds]
+        d["small"] = [(hi - lo) * x.shape[1] <= 64 for lo, hi in bounds]
+        d["box"] = [list(zip(np.tile(self.lo, hi - lo).tolist(), np.tile(self.hi, hi - lo).tolist())) for lo, hi in bounds]
         return True
 
     def _half_begin(self, k, prop):
@@ -160,27 +169,37 @@ class EnsembleMetropolis:
         d = self._direct
         lo, hi = d["bounds"][k]
         xs = prop[lo:hi] if len(prop) == self.n_walkers else prop
-        t1 = d["t1"][lo:hi]
-        np.subtract(xs, self.lo, out=t1)              # every walker inside the box <=> min(x - lo, hi - x) >= 0
-        np.subtract(self.hi, xs, out=d["t2"][lo:hi])
-        np.minimum(t1, d["t2"][lo:hi], out=t1)
+        t1, t2 = d["t1h"][k], d["t2h"][k]
+        if d["small"][k]:                             # a handful of numbers: a Python loop over a list beats four NumPy calls
+            outside = False
+            for v, (a, b) in zip(xs.ravel().tolist(), d["box"][k]):
+                if not (a <= v <= b):
+                    outside = True
+                    break
+        else:                                         # every walker inside the box <=> min(x - lo, hi - x) >= 0
+            np.subtract(xs, self.lo, out=t1)
+            np.subtract(self.hi, xs, out=t2)
+            outside = min(t1.min(), t2.min()) < 0.0
         mask = None
-        if t1.min() < 0.0:                            # a proposal outside the prior: its row keeps the walker's position (a valid
-            mask = t1.min(axis=1) >= 0.0              # point; the result is discarded) and its log-likelihood reads -inf
+        if outside:                                   # a proposal outside the prior: its row keeps the walker's position (a valid
+            np.subtract(xs, self.lo, out=t1)          # point; the result is discarded) and its log-likelihood reads -inf
+            np.subtract(self.hi, xs, out=t2)
+            np.minimum(t1, t2, out=t1)
+            mask = t1.min(axis=1) >= 0.0
             xs = np.where(mask[:, None], xs, self.x[lo:hi])
         d["mask"][k] = mask
-        rows = d["rows"][lo:hi]
-        for j, c in d["pairs"]:
-            rows[:, c] = xs[:, j]
+        for j, col in d["colv"][k]:
+            col[:] = xs[:, j]
         if d["eps"] is not None:                      # the expressions of CCFModel._param_rows, on the same (contiguous) arrays
             eps, apar = d["e"][k], d["a"][k]
+            c_aperp, c_apar, c_eps = d["derived"][k]
             np.copyto(eps, xs[:, d["eps"]])           # as _batch() hands it over: the same loop of np.power
             np.power(eps, -2 / 3, out=apar)
             if d["alpha"] is not None:
                 np.multiply(d["alpha"], apar, out=apar)
-            np.multiply(eps, apar, out=rows[:, 2])
-            rows[:, 3] = apar
-            rows[:, 4] = eps
+            np.multiply(eps, apar, out=c_aperp)
+            c_apar[:] = apar
+            c_eps[:] = eps
         eng = d["engines"][k]
         rc = eng._lib.vk_eval_batch_begin(eng._ctx, d["opts"], d["p_rows"][k], hi - lo)
         if rc != 0:
@@ -194,7 +213,7 @@ class EnsembleMetropolis:
         rc = eng._lib.vk_eval_batch_finish(eng._ctx, d["p_lnl"][k], d["p_chi"][k])
         if rc != 0:
             eng._check(rc)
-        lnl = d["out"][0][lo:hi]
+        lnl = d["lnlh"][k]
         mask = d["mask"][k]
         if mask is None:
             self.n_evals += hi - lo
@@ -253,11 +272,13 @@ class EnsembleMetropolis:
         self._at = t + 1
         return self._dz[t], self._logu[t]
 
-    def _accept(self, lo, hi, prop, lnl_prop, logu):
-        accept = logu < lnl_prop - self.lnl[lo:hi]
-        np.copyto(self.x[lo:hi], prop, where=accept[:, None])
-        np.copyto(self.lnl[lo:hi], lnl_prop, where=accept)
-        self.n_accept += int(np.count_nonzero(accept))
+    def _accept(self, lo, hi, prop, lnl_prop, logu, x_h=None, lnl_h=None):
+        if x_h is None:
+            x_h, lnl_h = self.x[lo:hi], self.lnl[lo:hi]
+        accept = logu < lnl_prop - lnl_h
+        np.copyto(x_h, prop, where=accept[:, None])
+        np.copyto(lnl_h, lnl_prop, where=accept)
+        self.n_accept += int(accept.sum()) if len(accept) > 64 else accept.tolist().count(True)
         return accept
 
     def step(self):
@@ -288,18 +309,19 @@ class EnsembleMetropolis:
         # Two halves, pipelined over the steps: the same half-batches as step() evaluates - the same chain - but half A of
         # step t + 1 is on the GPU while the host finishes half B of step t.
         (a0, a1), (b0, b1) = d["bounds"]
+        xa, xb, la, lb = self.x[a0:a1], self.x[b0:b1], self.lnl[a0:a1], self.lnl[b0:b1]       # views, made once
         dz, logu = self._next_randoms()
-        prop_a = self.x[a0:a1] + dz[a0:a1]
+        prop_a = xa + dz[a0:a1]
         self._half_begin(0, prop_a)
         for t in range(n_steps):
-            prop_b = self.x[b0:b1] + dz[b0:b1]
+            prop_b = xb + dz[b0:b1]
             self._half_begin(1, prop_b)
-            self._accept(a0, a1, prop_a, self._half_finish(0), logu[a0:a1])
+            self._accept(a0, a1, prop_a, self._half_finish(0), logu[a0:a1], xa, la)
             if t + 1 < n_steps:
                 dz_next, logu_next = self._next_randoms()
-                prop_a = self.x[a0:a1] + dz_next[a0:a1]
+                prop_a = xa + dz_next[a0:a1]
                 self._half_begin(0, prop_a)
-            self._accept(b0, b1, prop_b, self._half_finish(1), logu[b0:b1])
+            self._accept(b0, b1, prop_b, self._half_finish(1), logu[b0:b1], xb, lb)
             self.n_steps += 1
             chain[t] = self.x
             lnl[t] = self.lnl
