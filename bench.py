@@ -562,7 +562,10 @@ def main():
     # the reference's own calling convention under load (P chains, one point per call): child processes again, so before the GPU
     chains = None
     if rank == 0 and total == 1 and not args.no_boss and not args.no_chains:
-        chains = chains_sharing_one_gpu()
+        try:
+            chains = chains_sharing_one_gpu()
+        except Exception as exc:       # noqa: BLE001 - a secondary leg must not take the headline measurement down with it
+            chains = {"error": repr(exc)}
 
     # one context per GPU; on a box with fewer GPUs than contexts (rehearsals) contexts share devices and no RCCL
     # communicator can be built, which exercises the host-gather fallback below

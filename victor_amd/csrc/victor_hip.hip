@@ -364,9 +364,15 @@ void choose_split(const vk_ctx* ctx, long long n, int n_s, int* spi, int* team, 
   if (n >= want) { *spi = n_s; *team = 1; return; }
   if (n * ((n_s + 3) / 4) >= want / 2) { *spi = 4; *team = 1; return; }
   *spi = 1; *team = 4;
+  // Workgroups per (mu, v) plane for a handful of points.  Rounds 2-3 spread a single point over up to four per plane
+  // (>= 160 workgroups: the shortest launch for ONE point in flight).  The reference's calling convention under load is
+  // several chains with one point each (section 6 of DESIGN.md), and what counts there is how many such launches are resident
+  // at once: two per plane cost a single call +0.9 us (20.2 -> 21.2 us) and give 8 / 16 chains through the GPU owner
+  // process +15 % / +14 % (260 -> 300 k, 415 -> 474 k evaluations/s; tools/gpu_single_split_ab.py,
+  // profiles/r04/f_single_point_split_ab.txt).
   const long long wgs = n * n_s;
   long long q = (160 + wgs - 1) / wgs;
-  *parts = (int)(q < 1 ? 1 : (q > 4 ? 4 : q));
+  *parts = (int)(q < 1 ? 1 : (q > 2 ? 2 : q));
 }
 
 // VK_LITE: development build that compiles only the instantiations the two bench workloads (BOSS: isotropic xi^r, l = 0,2;
