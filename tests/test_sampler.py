@@ -106,3 +106,102 @@ def test_stretch_move_recovers_a_correlated_gaussian():
         EnsembleStretch(evaluate, specs, 7)
     with pytest.raises(InputError):
         EnsembleStretch(evaluate, specs, 6)
+
+
+class _RowsEngine:
+    """Stand-in for victor_amd.engine.Engine on the CPU: the two halves of a small host-buffer batch (vk_eval_batch_begin /
+    _finish), evaluating a simple function of the parameter ROWS - so the direct route of the sampler (rows written in place,
+    half-ensembles on two contexts, pipelined run) is exercised end to end without a GPU."""
+    device, simpson_even = 0, "simpson"
+
+    def __init__(self, log):
+        import ctypes as C
+        self.C, self.log, self._ctx, self._pending = C, log, None, None
+        self._lib = self
+
+    @staticmethod
+    def lnl_of_rows(rows):          # fsigma8, sigma_v, aperp, apar, epsilon, beta: every column the sampler writes matters
+        return -0.5 * (((rows[:, 0] - 0.47) / 0.05) ** 2 + ((rows[:, 1] - 380.0) / 30.0) ** 2 + ((rows[:, 5] - 0.4) / 0.08) ** 2
+                       + ((rows[:, 2] - 1.0) / 0.05) ** 2 + ((rows[:, 3] - 1.0) / 0.07) ** 2 + (rows[:, 4] - 1.0) ** 2)
+
+    def vk_eval_batch_begin(self, ctx, opts, p_rows, n):
+        assert self._pending is None, "one batch per context at a time"
+        rows = np.ctypeslib.as_array(p_rows, shape=(n, 12)).copy()
+        self._pending = self.lnl_of_rows(rows)
+        self.log.append(n)
+        return 0
+
+    def vk_eval_batch_finish(self, ctx, p_lnl, p_chi):
+        out = np.ctypeslib.as_array(p_lnl, shape=(len(self._pending),))
+        out[:] = self._pending
+        self._pending = None
+        return 0
+
+    def _check(self, rc):
+        assert rc == 0
+
+
+class _RowsFit:
+    """The parts of CCFFit the sampler's direct route uses, with CCFModel's own row building."""
+
+    def __init__(self, log):
+        from victor_amd.ccf_model import CCFModel
+        self.model = {"bias": 1.9}
+        self._engine = _RowsEngine(log)
+        self._rows = CCFModel._param_rows.__get__(self)
+        self._scalar_row = CCFModel._scalar_row.__get__(self)
+        self.log = log
+
+    def _single_point_plan(self):
+        return (self._engine, None, True, True, None)
+
+    def _fit_rows(self, params, model):
+        return self._rows(params, True, True)
+
+    def _merged(self, kw):
+        return dict(self.model)
+
+    def _engine_key(self, model):
+        return "template"
+
+    def log_likelihood_batch(self, params):
+        rows = self._rows(params, True, True)
+        return _RowsEngine.lnl_of_rows(rows), None
+
+
+@pytest.mark.parametrize("walkers", [8, 7, 2, 1])
+def test_direct_route_is_the_dictionary_route_chain(monkeypatch, walkers):
+    """Rows written in place, two half-ensembles, run() pipelined over the steps: same random numbers, same rows - the chain of
+    the dictionary route, value for value (the stand-in engine is a function of the row alone), through proposals outside the
+    prior, across a block boundary of the pre-drawn random numbers, for odd ensembles and a single walker; step() and run() agree."""
+    import victor_amd.engine as E
+    info = cases.cobaya_info()
+    specs, fixed = parse_cobaya_params(info["params"])
+    # narrow the prior of sigma_v so that proposals leave the box often
+    specs = [ParamSpec(s.name, s.lo, s.hi, s.ref_loc, s.ref_scale, s.proposal) if s.name != "sigma_v"
+             else ParamSpec("sigma_v", 360.0, 400.0, 380.0, 5.0, 25.0) for s in specs]
+    log = []
+    monkeypatch.setattr(E, "Engine", lambda *a, **k: _RowsEngine(log))
+    fit = _RowsFit(log)
+
+    def evaluate(batch):
+        return fit.log_likelihood_batch(batch)[0]
+
+    d = EnsembleMetropolis(None, specs, walkers, seed=9, fixed=fixed, fit=fit).initialise()
+    g = EnsembleMetropolis(evaluate, specs, walkers, seed=9, fixed=fixed).initialise()
+    assert d._direct is not None and len(d._direct["engines"]) == (2 if walkers >= 2 else 1)
+    cd, ld = d.run(150)
+    cg, lg = g.run(150)
+    assert np.array_equal(cd, cg) and np.array_equal(ld, lg)
+    assert d.n_accept == g.n_accept and d.n_evals == g.n_evals and d.n_steps == g.n_steps == 150
+    assert 0 < d.n_accept < 150 * walkers and d.n_evals < 151 * walkers            # some proposals were outside the prior
+    if walkers >= 2:
+        assert set(log) <= {walkers // 2, walkers - walkers // 2}                   # only half-ensemble batches were launched
+    s1 = EnsembleMetropolis(None, specs, walkers, seed=9, fixed=fixed, fit=fit).initialise()
+    for t in range(70):
+        s1.step()
+        assert np.array_equal(s1.x, cd[t]) and np.array_equal(s1.lnl, ld[t]), t
+    # an unknown sampled parameter keeps the dictionary route
+    odd = [ParamSpec("alpha", 0.9, 1.1, 1.0, 0.01, 0.01)] + specs
+    e = EnsembleMetropolis(evaluate, odd, walkers, seed=1, fixed=fixed, fit=fit).initialise()
+    assert e._direct is None
