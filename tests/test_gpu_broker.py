@@ -209,3 +209,21 @@ print(json.dumps({"calls": n, "slot": fit._broker_client.slot}), flush=True)
 def json_line(text):
     import json
     return json.loads(text)
+
+
+def test_chains_example_gives_the_same_chains_brokered_and_direct():
+    """examples/run_chains.py - independent Metropolis chains, one process each, one ``calculate`` per step, the reference's way
+    of sampling: through the shared GPU owner (VICTOR_HIP_BROKER=auto) and with a GPU context per chain the SAME chains come
+    out, sample for sample (every likelihood value is bit-identical, so every accept / reject decision is)."""
+    import json
+    runs = {}
+    for tag, extra in (("brokered", []), ("direct", ["--direct"])):
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "run_chains.py"), "--chains", "3", "--steps", "250"] + extra,
+                             capture_output=True, text=True, timeout=600, env={k: v for k, v in os.environ.items() if k != "VICTOR_HIP_BROKER"})
+        assert res.returncode == 0, res.stderr[-3000:] + res.stdout[-500:]
+        runs[tag] = json.loads(res.stdout.strip().splitlines()[-1])
+    a, b = runs["brokered"], runs["direct"]
+    assert a["chains_never_loaded_the_gpu_library"] is True and b["chains_never_loaded_the_gpu_library"] is False
+    assert a["last_logp"] == b["last_logp"] and a["mean"] == b["mean"] and a["acceptance"] == b["acceptance"]
+    assert a["likelihood_evaluations"] == b["likelihood_evaluations"] > 600 and 0.02 < a["acceptance"] < 0.9
+    assert all(250 < v < 300 for v in a["last_logp"])            # the chains sit near the maximum (lnL = 284.8 at the reference point)

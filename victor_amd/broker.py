@@ -167,7 +167,7 @@ class Broker:
     """
 
     def __init__(self, model, data, name, n_slots=64, device=0, gather_window_us=3.0, attach_existing=False, depth=4, max_batch=4,
-                 threads=1):
+                 threads=1, digest=None):
         """``depth``: contexts (streams) per serving thread = launches it may have in flight at once (1..8); ``max_batch``:
         requests per launch (0: the library's limit, 32); ``threads``: serving threads, each with its own contexts and its own
         contiguous share of the mailboxes.  Defaults from tools/gpu_broker_sweep.py (profiles/r04/broker_sweep.txt,
@@ -185,7 +185,8 @@ class Broker:
         h.server_pid = os.getpid()
         h.device = int(device)
         h.gather_window_us = float(gather_window_us)
-        h.digest = config_digest(model, data).encode()
+        # (an owner started by a chain is told that chain's digest: its own copy of the blocks came through a JSON file)
+        h.digest = (digest or config_digest(model, data)).encode()
         self.fit = None
         try:
             from .ccf_fit import CCFFit
@@ -335,6 +336,9 @@ class BrokerClient:
         if bytes(h.digest).decode() != digest:
             raise InputError(f"broker {name} serves another (model, data) configuration than this chain's")
         self.server_pid = int(h.server_pid)
+        if not _pid_alive(self.server_pid):
+            raise N.NativeError(f"broker {name}: its owner process (pid {self.server_pid}) is gone - remove {path} or use "
+                                "VICTOR_HIP_BROKER=auto, which clears such leftovers")
         # claim a free mailbox; chains of one job race for them, so under a file lock
         self.slot = None
         lock_fd = os.open(path + ".lock", os.O_CREAT | os.O_RDWR, 0o600)
@@ -408,7 +412,7 @@ class BrokerClient:
 
 
 def spawn_broker(model, data, name, device=0, n_slots=64, linger=5.0, gather_window_us=3.0, log=None, depth=4, max_batch=4,
-                 threads=1):
+                 threads=1, digest=None):
     """Start ``python -m victor_amd.broker`` for a segment this process has just created (election winner) or will create.
     The child is a fresh interpreter: it is the only process that initialises the GPU."""
     import subprocess
@@ -418,7 +422,7 @@ def spawn_broker(model, data, name, device=0, n_slots=64, linger=5.0, gather_win
     cfg.close()
     cmd = [sys.executable, "-m", "victor_amd.broker", "--config-json", cfg.name, "--name", name, "--device", str(device),
            "--slots", str(n_slots), "--linger", str(linger), "--window-us", str(gather_window_us), "--depth", str(depth), "--max-batch", str(max_batch), "--threads", str(threads),
-           "--attach-existing",
+           "--attach-existing", "--digest", digest or config_digest(model, data),
            "--parent-pid", str(os.getpid()), "--delete-config"]
     env = dict(os.environ)
     env.pop("VICTOR_HIP_BROKER", None)
@@ -469,7 +473,7 @@ def connect(model, data, spec, timeout=300.0):
             spawn_broker(model, data, name, device=device, n_slots=n_slots, log=os.environ.get("VICTOR_HIP_BROKER_LOG"),
                          depth=int(os.environ.get("VICTOR_HIP_BROKER_DEPTH", "4")),
                          max_batch=int(os.environ.get("VICTOR_HIP_BROKER_MAX_BATCH", "4")),
-                         threads=int(os.environ.get("VICTOR_HIP_BROKER_THREADS", "1")))
+                         threads=int(os.environ.get("VICTOR_HIP_BROKER_THREADS", "1")), digest=digest)
             break
         else:
             raise N.NativeError(f"could not start or reach broker {name}")
@@ -495,6 +499,7 @@ def main(argv=None):
     ap.add_argument("--max-batch", type=int, default=4, help="requests per launch (0: the library's limit of 32); measured "
                                                              "best at 4 for 8 and 16 chains (tools/gpu_broker_sweep.py)")
     ap.add_argument("--attach-existing", action="store_true")
+    ap.add_argument("--digest", default=None, help="configuration digest to publish (set by the chain that starts the owner)")
     ap.add_argument("--parent-pid", type=int, default=0)
     ap.add_argument("--delete-config", action="store_true")
     args = ap.parse_args(argv)
@@ -515,7 +520,8 @@ def main(argv=None):
     name = args.name or auto_name(config_digest(model, data), args.device)
     try:
         broker = Broker(model, data, name, n_slots=args.slots, device=args.device, gather_window_us=args.window_us,
-                        attach_existing=args.attach_existing, depth=args.depth, max_batch=args.max_batch, threads=args.threads)
+                        attach_existing=args.attach_existing, depth=args.depth, max_batch=args.max_batch, threads=args.threads,
+                        digest=args.digest)
     except Exception as exc:
         if args.attach_existing:            # tell the chains that are waiting for READY
             try:
@@ -526,6 +532,13 @@ def main(argv=None):
             except Exception:
                 pass
         raise
+    import signal
+
+    def leave(signum, frame):            # SIGTERM / SIGINT: finish what is in flight, remove the segment, go
+        broker.seg.header.stop = 1
+
+    signal.signal(signal.SIGTERM, leave)
+    signal.signal(signal.SIGINT, leave)
     print(f"victor broker '{name}' ready: pid {os.getpid()}, device {args.device}, {broker.seg.n_slots} mailboxes, "
           f"{int(broker.seg.header.threads)} serving thread(s) x {int(broker.seg.header.depth)} launches in flight", file=sys.stderr, flush=True)
     broker.serve(linger=args.linger, parent_pid=args.parent_pid or None)

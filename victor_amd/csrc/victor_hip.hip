@@ -1777,7 +1777,6 @@ int vk_serve_mailboxes(vk_ctx* const* ctxs, int32_t n_ctx, const vk_eval_opts* o
   // like those of separate processes (each context has its own stream), and chains that post together still share one.
   struct Flight {
     bool active = false;
-    bool sync = false;               // evaluated with the blocking call (the in-place path was not available)
     int n = 0;
     clock::time_point t0;
     std::vector<int> idx;
@@ -1816,7 +1815,7 @@ int vk_serve_mailboxes(vk_ctx* const* ctxs, int32_t n_ctx, const vk_eval_opts* o
   auto t_first_pending = t_start;
   bool waiting = false;
   int last_batch = 0;
-  for (unsigned it = 0;; ++it) {
+  for (;;) {
     // results that have arrived
     int in_flight = 0, served = 0;       // launches in flight, requests they carry
     for (int c = 0; c < n_ctx; ++c) {
