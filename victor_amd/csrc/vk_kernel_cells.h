@@ -212,9 +212,10 @@ __global__ __launch_bounds__(kBlock, (MODE == kModeStreaming && !SVA) || MODE ==
         g = kaiser_value<NLR, GRID>(lds, lds + pl.da, fc, fp, ps.M, ps.Q, a.niter, a.coord_shift != 0, a.kaiser_approx != 0,
                                     a.rsd == VK_RSD_EUCLID, a.from_data != 0, s_par, sperp2);
       } else if (mode_is_dispersion(MODE)) {
+        const double inv_den0 = disp_first_pass<NLR, GRID>(lds, fc, fp, a.niter, s_par, sperp2);     // once per cell, not per node
         for (int k = 0; k < a.n_xg; ++k) {
           const VelocityNode xw = load_node(a.xgw, k);
-          gs += disp_value<NLR, GRID, MODE == kModeDispersionFromData, SVA>(lds, lds + pl.da, fc, fp, a.niter, fma(-xw.x, fp.Bk, s_par), s_par,
+          gs += disp_value<NLR, GRID, MODE == kModeDispersionFromData, SVA>(lds, lds + pl.da, fc, fp, a.niter, fma(-xw.x, fp.Bk, s_par), inv_den0,
                                                                      sperp2, xw.x);
           if (xw.last != 0) {            // wave-uniform: a scalar branch, taken at the last node of a group
             asm volatile("" ::: "memory");            // (keeps the compiler from turning it into per-lane selects)

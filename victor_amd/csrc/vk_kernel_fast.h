@@ -411,11 +411,28 @@ __device__ __forceinline__ double uni_point(const double* __restrict__ lds, cons
 // follow.  Same-box A/B (tools/gpu_rsd_ab.py, BOSS, 16384 points): 17.06 -> 16.31 ms, max rel dchi2 between the builds 4.9e-13
 // (budget 1e-10), tests/test_gpu_options.py::test_dispersion_model_where_it_is_ill_conditioned unchanged and green
 // (profiles/r04/c_early_passes_second_order_ab.txt).
+// The FIRST pass starts from the redshift-space separation - r^2 = s_par^2 + s_perp^2, the same for every velocity node of an
+// (s, mu) cell: 1 / (1 + q(s)) does not depend on v.  The kernels whose node loop is the inner loop (cells) take it once per cell
+// and hand it to disp_value (`inv_den0`): five table look-ups per integrand point instead of six, the same arithmetic.
+// It is an early pass (second-order forms) unless it is the only one (niter = 0).
+template <int NLR, int GRID>
+__device__ __forceinline__ double disp_first_pass(const double* __restrict__ lds, const FastConsts& fc, const FastPoint& fp,
+                                                  int niter, double s_par, double sperp2) {
+  double tq;
+  int qi;
+  const bool last = niter == 0;
+  const double r2 = fma(s_par, s_par, sperp2);
+  const double inv_r = last ? vkm::rsqrt3(r2) : vkm::rsqrt_nr(r2);
+  const double* rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(r2, inv_r, fc.off) : r2 * inv_r, tq, qi);
+  const double den = 1.0 + -fp.Gk * cubic_b128(rec + 4, tq) * inv_r;
+  return last ? vkm::recip(den) : vkm::recip_nr(den);
+}
+
 // SVA = 1: sigma_v from the anisotropic template's bicubic patches (sv_aniso) as in uni_point; lattice form only.
 template <int NLR, int GRID, int FD, int SVA = 0>
 __device__ __forceinline__ double disp_value(const double* __restrict__ lds, const double* __restrict__ da,
                                              const FastConsts& fc, const FastPoint& fp, int niter, double num,
-                                             double s_par, double sperp2, double xk) {
+                                             double inv_den0, double sperp2, double xk) {
   double tq;
   int qi;
   auto pass = [&](double rp, bool last) {
@@ -425,9 +442,9 @@ __device__ __forceinline__ double disp_value(const double* __restrict__ lds, con
     const double den = 1.0 + -fp.Gk * cubic_b128(rec + 4, tq) * inv_r;
     return num * (last ? vkm::recip(den) : vkm::recip_nr(den));
   };
-  double r_par = s_par;
-  for (int it = 0; it < niter; ++it) r_par = pass(r_par, false);
-  r_par = pass(r_par, true);
+  double r_par = num * inv_den0;                 // the first pass (disp_first_pass)
+  for (int it = 1; it < niter; ++it) r_par = pass(r_par, false);
+  if (niter >= 1) r_par = pass(r_par, true);
   const double r2 = fma(r_par, r_par, sperp2);
   const double inv_r = vkm::rsqrt3(r2);
   const double mu_r = r_par * inv_r;
@@ -749,7 +766,8 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 3 : 2) voi
           const double num = fma(-xw.x, fp.Bk, s_par);
           double f;
           if (mode_is_dispersion(MODE)) {
-            f = xw.y * disp_value<NLR, GRID, MODE == kModeDispersionFromData>(lds, lds + pl.da, fc, fp, a.niter, num, s_par, sperp2, xw.x);
+            f = xw.y * disp_value<NLR, GRID, MODE == kModeDispersionFromData>(lds, lds + pl.da, fc, fp, a.niter, num,
+                                                                              disp_first_pass<NLR, GRID>(lds, fc, fp, a.niter, s_par, sperp2), sperp2, xw.x);
           } else {
             double inv_sv;
             const double p = uni_point<NLR, GRID, MODE == kModeFromData, 1, 1, 0, SVA>(lds, fc, 0.0, num, sperp2, xw.x, fp.fa, sperp2 * fp.fp2, 0u, inv_sv);
