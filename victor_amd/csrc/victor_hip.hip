@@ -66,12 +66,12 @@ __global__ __launch_bounds__(kBlock) void vk_image_kernel(TheoryArgs a, int kind
   extern __shared__ double lds[];
   for (int e = threadIdx.x; e < n; e += kBlock) lds[e] = 0.0;
   __syncthreads();
-  const int n_sva = (with_da & 2) ? a.sva_doubles : 0;        // bit 1: the SVA instantiation's layout
-  with_da &= 1;
+  const int n_sva = (with_da & 4) ? a.sva_doubles : 0;        // bit 2: the SVA instantiation's layout
+  with_da &= 3;                                               // the mode's layout (vk_kernel_fast.h: mode_layout)
   if (kind == 0) {
-    stage_fast<NLR>(a, make_fast_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, with_da, 0, n_sva), lds, with_da != 0);
+    stage_fast<NLR>(a, make_fast_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, with_da, 0, n_sva), lds, with_da);
   } else if (kind == 1) {
-    stage_cells<NLR>(a, make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, with_da, 64, 0, n_sva), lds, with_da != 0);
+    stage_cells<NLR>(a, make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, with_da, 64, 0, n_sva), lds, with_da);
   } else {
     stage_lanes<NLR>(a, make_lanes_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.uni_lut_n), lds);
   }
@@ -576,9 +576,10 @@ int theory_args(vk_ctx* ctx, const vk_eval_opts* o, TheoryArgs* a, int* nlr) {
 
 // LDS image for launches on the context's own grid (NULL: the kernel stages entry by entry).  Built on first use, never
 // while the stream is being captured into a graph (the first, eager call of a shape has built it by then).
-const double* get_image(vk_ctx* ctx, const TheoryArgs& a, int kind, int nlr, bool with_da, int image_end, bool sva = false) {
+// with_da: the mode's LDS layout (vk_kernel_fast.h: mode_layout - 0 streaming, 1 kaiser / euclid_special, 2 dispersion)
+const double* get_image(vk_ctx* ctx, const TheoryArgs& a, int kind, int nlr, int with_da, int image_end, bool sva = false) {
   if (!a.stage_mu || image_end <= 0) return nullptr;
-  const int key = kind * 100 + nlr * 10 + (with_da ? 1 : 0) + (sva ? 2 : 0);
+  const int key = kind * 100 + nlr * 10 + with_da + (sva ? 4 : 0);
   auto hit = ctx->images.find(key);
   if (hit != ctx->images.end()) return hit->second;
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
@@ -590,15 +591,15 @@ const double* get_image(vk_ctx* ctx, const TheoryArgs& a, int kind, int nlr, boo
   switch (nlr) {
     case 1:
       if (lds > 64 * 1024) ok = hipFuncSetAttribute(reinterpret_cast<const void*>(vk_image_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-      if (ok) hipLaunchKernelGGL(vk_image_kernel<1>, dim3(1), dim3(kBlock), lds, ctx->stream, a, kind, (with_da ? 1 : 0) | (sva ? 2 : 0), img, image_end);
+      if (ok) hipLaunchKernelGGL(vk_image_kernel<1>, dim3(1), dim3(kBlock), lds, ctx->stream, a, kind, with_da | (sva ? 4 : 0), img, image_end);
       break;
     case 2:
       if (lds > 64 * 1024) ok = hipFuncSetAttribute(reinterpret_cast<const void*>(vk_image_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-      if (ok) hipLaunchKernelGGL(vk_image_kernel<2>, dim3(1), dim3(kBlock), lds, ctx->stream, a, kind, (with_da ? 1 : 0) | (sva ? 2 : 0), img, image_end);
+      if (ok) hipLaunchKernelGGL(vk_image_kernel<2>, dim3(1), dim3(kBlock), lds, ctx->stream, a, kind, with_da | (sva ? 4 : 0), img, image_end);
       break;
     default:
       if (lds > 64 * 1024) ok = hipFuncSetAttribute(reinterpret_cast<const void*>(vk_image_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-      if (ok) hipLaunchKernelGGL(vk_image_kernel<3>, dim3(1), dim3(kBlock), lds, ctx->stream, a, kind, (with_da ? 1 : 0) | (sva ? 2 : 0), img, image_end);
+      if (ok) hipLaunchKernelGGL(vk_image_kernel<3>, dim3(1), dim3(kBlock), lds, ctx->stream, a, kind, with_da | (sva ? 4 : 0), img, image_end);
       break;
   }
   if (!ok || hipGetLastError() != hipSuccess) {
@@ -654,6 +655,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
   const bool sva = a.sv_n_mu > 0 && !kais;
   // (the dispersion model with it: the cells kernel only, at every batch size)
   const bool sva_disp = sva && disp;
+  const int layout = disp ? 2 : (kais ? 1 : 0);               // LDS layout of the mode (vk_kernel_fast.h: mode_layout)
   const bool sva_ok = !sva || (a.sva_doubles > 0 && (a.rsd == VK_RSD_STREAMING || disp) && !a.from_data && a.uni_lut_n == 0);
   const int n_sva = sva ? a.sva_doubles : 0;
   bool fast = (a.rsd == VK_RSD_STREAMING || disp || kais) && ctx->fast_ok && emp_ok && sva_ok &&
@@ -702,7 +704,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
   if (lanes) {
     ctx->last_kernel = "vk_theory_lanes_kernel";
     a.parts = 1;
-    a.image = get_image(ctx, a, 2, nlr, false, make_lanes_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.uni_lut_n).image_end);
+    a.image = get_image(ctx, a, 2, nlr, 0, make_lanes_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.uni_lut_n).image_end);
     a.lanes_per_block = ctx->knobs.lanes_by_chunk ? a.n_s : kWaves;
     const long long blocks = ctx->knobs.lanes_by_chunk ? (a.n + 63) >> 6 : blocks_l;
     // One workgroup per four items, never a grid-stride loop by default: letting the dispatcher refill CUs as
@@ -756,10 +758,10 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
     a.cells_per_item = cpi;
     a.fuse = want_fuse ? 1 : 0;
     const bool tail = a.fuse || R > 1;
-    const CellsPlan plc = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, disp || kais, cpi, tail ? N : 0, n_sva);
+    const CellsPlan plc = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, layout, cpi, tail ? N : 0, n_sva);
     const size_t lds_c = (size_t)plc.total * sizeof(double);
     if (lds_c > 160 * 1024) return fail(ctx, VK_E_ARG, "tables need %zu bytes of LDS (> 160 KiB)", lds_c);
-    a.image = get_image(ctx, a, 1, nlr, disp || kais, plc.image_end, sva);
+    a.image = get_image(ctx, a, 1, nlr, layout, plc.image_end, sva);
     const long long items_c = a.n * R;
     const int grid_c = (int)items_c;                                       // one item per workgroup, always (vk_kernel_cells.h)
     if (fused) *fused = a.fuse != 0;
@@ -778,10 +780,10 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
     const bool need_counters = groups * a.parts > 1;
     a.fuse = want_fuse && (!need_counters || a.n <= kCounterCap) ? 1 : 0;   // counters[point] exists for point < kCounterCap only
     const bool tail = a.fuse || a.parts > 1;
-    const FastPlan plf = make_fast_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, disp, tail ? N : 0, n_sva);
+    const FastPlan plf = make_fast_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, layout, tail ? N : 0, n_sva);
     const size_t lds = (size_t)plf.total * sizeof(double);
     if (lds > 160 * 1024) return fail(ctx, VK_E_ARG, "tables need %zu bytes of LDS (> 160 KiB)", lds);
-    a.image = get_image(ctx, a, 0, nlr, disp, plf.image_end, sva);
+    a.image = get_image(ctx, a, 0, nlr, layout, plf.image_end, sva);
     const long long items = a.n * groups * a.parts;
     const int grid = (int)items;                                            // one item per workgroup, always (vk_kernel_fast.h)
     if (fused) *fused = a.fuse != 0;

@@ -168,6 +168,15 @@ __device__ __forceinline__ double rsqrt_nr_x2(double x) {
   return y * w;
 }
 
+// Twice the third-order 1/sqrt(x) (rsqrt3) in the same six instructions: y (2 + e p2) with p2 = 1 + 3/4 e.  For the half-unit
+// callers whose result is ill-conditioned in 1/r (the dispersion model's last pass and final evaluation, vk_kernel_fast.h).
+__device__ __forceinline__ double rsqrt3_x2(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(-(x * y), y, 1.0);
+  const double p2 = fma(0.75, e, 1.0);
+  return y * fma(e, p2, 2.0);
+}
+
 // exp(-z^2/2) for callers that carry ynum and 1/SV with z = ynum / SV in units of kExpScale, i.e. y = kExpScale * z
 // (kExpScale^2 = 128/ln2 * 2^-18, folded into the per-point amplitude and the velocity nodes).
 //   * y' = min(|ynum| |inv_sv|, 1) comes out of ONE v_mul_f64: abs modifiers on the inputs and the VOP3 clamp bit on the

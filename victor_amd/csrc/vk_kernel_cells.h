@@ -38,7 +38,7 @@ __host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s,
   p.s = o;     o += (n_s + 1) & ~1;
   p.betar = o; o += (n_beta_r + 1) & ~1;
   p.da = o;    o += with_da ? uni_n * 4 : 0;      // Da table of the dispersion model
-  p.v1 = o;    o += with_da ? 0 : uni_n * 4;      // unscaled V1 cubics (streaming modes, see scale_uni_v)
+  p.v1 = o;    o += with_da == 1 ? 0 : uni_n * 4; // unscaled V1 cubics (streaming and dispersion modes, see scale_uni_v)
   o = (o + 1) & ~1;
   p.sva = o;   o += (n_sva + 1) & ~1;             // anisotropic sigma_v patches + mu knots (SVA instantiations)
   p.image_end = o;                                 // batch-constant up to here (LDS image, see vk_kernel_fast.h)
@@ -52,7 +52,7 @@ __host__ __device__ inline CellsPlan make_cells_plan(int n_mu, int n_x, int n_s,
 }
 
 template <int NLR>
-__device__ __forceinline__ void stage_cells(const TheoryArgs& a, const CellsPlan& pl, double* lds, bool with_da) {
+__device__ __forceinline__ void stage_cells(const TheoryArgs& a, const CellsPlan& pl, double* lds, int with_da) {
   const int tid = threadIdx.x;
   for (int i = tid; i < a.n_mu; i += kBlock) {
     const double m = a.mu[i];
@@ -64,7 +64,7 @@ __device__ __forceinline__ void stage_cells(const TheoryArgs& a, const CellsPlan
   for (int j = tid; j < a.n_s; j += kBlock) lds[pl.s + j] = a.s[j];
   stage_uni_records<NLR>(a, lds);
   if (with_da) stage_da<NLR>(a, lds + pl.da);
-  else for (int e = tid; e < a.uni_n * 4; e += kBlock) lds[pl.v1 + e] = a.uni_sv_v[(e >> 2) * 8 + 4 + (e & 3)];
+  if (with_da != 1) for (int e = tid; e < a.uni_n * 4; e += kBlock) lds[pl.v1 + e] = a.uni_sv_v[(e >> 2) * 8 + 4 + (e & 3)];
   if (a.n_beta_r > 0)
     for (int i = tid; i < a.n_beta_r; i += kBlock) lds[pl.betar + i] = a.beta_r[i];
   if (pl.image_end > pl.sva)
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kBlock, (MODE == kModeStreaming && !SVA) || MODE ==
   const int R = a.parts;
   const int cpi = a.cells_per_item;
   const bool tail = a.fuse || R > 1;
-  CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, mode_has_da(MODE), cpi,
+  CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, mode_layout(MODE), cpi,
                                  tail ? N : 0, SVA ? a.sva_doubles : 0);
   // the offset behind the accumulators depends on an integer division by n_mu, which the compiler evaluates on the vector ALU:
   // wave-uniform, but held - and once spilled - as a vector register unless it is made a scalar here
@@ -153,8 +153,8 @@ __global__ __launch_bounds__(kBlock, (MODE == kModeStreaming && !SVA) || MODE ==
   const int tid = threadIdx.x;
   VK_STAMP(a, 0);
   if (a.image) copy_image(lds, a.image, pl.image_end);
-  else stage_cells<NLR>(a, pl, lds, mode_has_da(MODE));
-  constexpr bool kHalf = !mode_has_da(MODE);              // streaming modes: half units (vk_kernel_fast.h: FastPoint)
+  else stage_cells<NLR>(a, pl, lds, mode_layout(MODE));
+  constexpr bool kHalf = MODE != kModeKaiser;             // streaming and dispersion modes: half units (vk_kernel_fast.h: FastPoint)
   const FastConsts fc = make_fast_consts<NLR>(a, kHalf, SVA ? pl.sva : 0);
   __syncthreads();
   VK_STAMP(a, 1);
@@ -183,9 +183,11 @@ __global__ __launch_bounds__(kBlock, (MODE == kModeStreaming && !SVA) || MODE ==
     const double* row = a.params + point * VK_NPAR;
     const PointScalars ps = point_scalars(a, row);
     const FastPoint fp = make_fast_point(ps, fc, kHalf);
-    constexpr int PV = mode_has_da(MODE) ? 0 : 1;
+    // the V cubics carry the point's factor: AVk (streaming), -Gk (dispersion, see disp_value), none (kaiser / euclid_special)
+    constexpr int PV = MODE == kModeKaiser ? 0 : 1;
     __syncthreads();      // every wave is done with the previous item's records and accumulators
-    rebuild_point_tables<NLR, PV>(a, lds, pl.betar, pl.v1, row[VK_P_BETA], ps.av, fp.AVk, mode_has_da(MODE) ? lds + pl.da : nullptr);
+    rebuild_point_tables<NLR, PV>(a, lds, pl.betar, pl.v1, row[VK_P_BETA], ps.av, mode_is_dispersion(MODE) ? -fp.Gk : fp.AVk,
+                                  mode_has_da(MODE) ? lds + pl.da : nullptr);
     if (mode_has_da(MODE) && a.empirical && !a.vr_beta_dep) rebuild_da_emp(a, lds + pl.da, ps.av);
     for (int e = lane; e < kMaxEll * slots; e += 64) l_acc[e * kWaves + wave] = 0.0;
     __syncthreads();

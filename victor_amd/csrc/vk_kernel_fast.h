@@ -271,11 +271,11 @@ __device__ __forceinline__ void rebuild_point_tables(const TheoryArgs& a, double
 // the lanes kernel).  The streaming modes work in HALF units - every length times k/2, so that twice the refined 1/sqrt comes
 // out of four instructions (vkm::rsqrt_nr_x2) and the factors of two land where they cost nothing: X = r'^2/4,
 // yy = 4/r', X yy = r', (num/2) yy = 2 mu_r, AVk halved, and the mu_r^2-power coefficients of the records divided by 4 and
-// 16 on the host (vk_tables.uni_xic) - all exact.  The dispersion modes keep full units (their fixed-point iteration
-// needs r itself).
+// 16 on the host (vk_tables.uni_xic) - all exact.  The dispersion modes too (disp_value); kaiser / euclid_special keep full units.
 struct FastPoint {
   double fa, fp2;         // from_data: c/apar and (c/aperp)^2 (fiducial coordinates of xi^r, see uni_point)
-  double Gk, gD;          // dispersion model: aH^-1 v_r/r = -Gk V(u) / r' and aH^-1 v_r' = -gD Da(u) (see disp_value)
+  double Gk, gD;          // dispersion model: aH^-1 v_r/r = -Gk V(u) / r' (half units: -Gk V(u) (4 / r'), Gk carries the 1/4)
+                          // and aH^-1 v_r' = -gD Da(u) (see disp_value, kaiser_value)
   double k_perp, k_par;   // aperp k, apar k: s_perp' = s sqrt(1-mu^2) k_perp, s_par' = s mu k_par
   double Bk;              // sigma_v iaH_true k / kExpScale: r_par' = s_par' - x_k' Bk with x_k' = kExpScale x_k
   double AVk;             // kExpScale g / (3 iaH_true sigma_v): y = (x_k' + AVk V mu_r) / SV
@@ -293,7 +293,7 @@ __device__ __forceinline__ FastPoint make_fast_point(const PointScalars& ps, con
   const double c = 1.0 / ps.inv_c;
   fp.fa = c * ps.inv_apar;
   fp.fp2 = (c * ps.inv_aperp) * (c * ps.inv_aperp);
-  fp.Gk = ps.G * k;
+  fp.Gk = ps.G * k * (half ? 0.25 : 1.0);
   fp.gD = ps.gD;
   return fp;
 }
@@ -404,7 +404,11 @@ __device__ __forceinline__ double uni_point(const double* __restrict__ lds, cons
 // real-space coordinate from the reference's fixed-point iteration r_par <- (s_par - v/aH) / (1 + q(r)),
 // q(r) = aH^-1 v_r(r)/r, started at the redshift-space separation and repeated `niter` more times, and the Jacobian
 // 1 / (1 + q + mu_r^2 (dq - q)) with dq = aH^-1 v_r'(r).  `da` = LDS table of Da = delta - 2 Delta/3 on the unified
-// grid, [uni_n][4].  All lengths in index units (FULL units: fc and fp made with half = false); `num` = s_par' - x_k' Bk.
+// grid, [uni_n][4].  All lengths in index units, HALF units as in uni_point (fc and fp made with half = true): `num` = r_par'/2
+// before the iteration, `sperp2` = s_perp'^2 / 4, X = r'^2 / 4, yy = 4 / r' (vkm::rsqrt_nr_x2 in the early passes, rsqrt3_x2 -
+// third order - in the last pass and behind it), X yy = r', r_par yy = 2 mu_r; r_par <- num / (1 + q) keeps its halved scale.
+// The V cubics of the records carry the point's factor -Gk / 4 (rebuild_point_tables with vs = -fp.Gk, once per work item):
+// q = V yy is one multiply, 1 + q one fma - a multiply less in every pass and in the evaluation behind them.
 // The LAST pass of the iteration, the evaluation behind it and the Jacobian keep the third-order 1/sqrt and reciprocals (where
 // 1 + q comes close to zero the result is ill-conditioned in them); the earlier passes run on the second-order forms - the map
 // is a contraction wherever the reference itself converges, so what they leave in the last bits is damped by the passes that
@@ -421,10 +425,10 @@ __device__ __forceinline__ double disp_first_pass(const double* __restrict__ lds
   double tq;
   int qi;
   const bool last = niter == 0;
-  const double r2 = fma(s_par, s_par, sperp2);
-  const double inv_r = last ? vkm::rsqrt3(r2) : vkm::rsqrt_nr(r2);
-  const double* rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(r2, inv_r, fc.off) : r2 * inv_r, tq, qi);
-  const double den = 1.0 + -fp.Gk * cubic_b128(rec + 4, tq) * inv_r;
+  const double X = fma(s_par, s_par, sperp2);
+  const double yy = last ? vkm::rsqrt3_x2(X) : vkm::rsqrt_nr_x2(X);
+  const double* rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(X, yy, fc.off) : X * yy, tq, qi);
+  const double den = fma(cubic_b128(rec + 4, tq), yy, 1.0);          // the records hold -Gk V / 4 (see disp_value)
   return last ? vkm::recip(den) : vkm::recip_nr(den);
 }
 
@@ -436,32 +440,34 @@ __device__ __forceinline__ double disp_value(const double* __restrict__ lds, con
   double tq;
   int qi;
   auto pass = [&](double rp, bool last) {
-    const double r2 = fma(rp, rp, sperp2);
-    const double inv_r = last ? vkm::rsqrt3(r2) : vkm::rsqrt_nr(r2);
-    const double* rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(r2, inv_r, fc.off) : r2 * inv_r, tq, qi);
-    const double den = 1.0 + -fp.Gk * cubic_b128(rec + 4, tq) * inv_r;
+    const double X = fma(rp, rp, sperp2);
+    const double yy = last ? vkm::rsqrt3_x2(X) : vkm::rsqrt_nr_x2(X);
+    const double* rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(X, yy, fc.off) : X * yy, tq, qi);
+    const double den = fma(cubic_b128(rec + 4, tq), yy, 1.0);
     return num * (last ? vkm::recip(den) : vkm::recip_nr(den));
   };
   double r_par = num * inv_den0;                 // the first pass (disp_first_pass)
-  for (int it = 1; it < niter; ++it) r_par = pass(r_par, false);
+  // the trip count is a kernel argument: kept in a scalar register (the compiler otherwise counts the passes in a vector
+  // register - two vector instructions per pass for a wave-uniform loop)
+  for (int it = __builtin_amdgcn_readfirstlane(niter) - 1; it > 0; --it) r_par = pass(r_par, false);
   if (niter >= 1) r_par = pass(r_par, true);
-  const double r2 = fma(r_par, r_par, sperp2);
-  const double inv_r = vkm::rsqrt3(r2);
-  const double mu_r = r_par * inv_r;
-  const double rp = SVA ? r2 * inv_r : 0.0;
-  const double* rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? (SVA ? rp + fc.off : fma(r2, inv_r, fc.off)) : r2 * inv_r, tq, qi);
-  const double SV = SVA ? sv_aniso(lds, fc, rp, 2.0 * mu_r) : cubic_b128(rec, tq);
-  const double q = -fp.Gk * cubic_b128(rec + 4, tq) * inv_r;
+  const double X = fma(r_par, r_par, sperp2);
+  const double yy = vkm::rsqrt3_x2(X);           // 4 / r'
+  const double mu2 = r_par * yy;                 // 2 mu_r
+  const double rp = SVA ? X * yy : 0.0;
+  const double* rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? (SVA ? rp + fc.off : fma(X, yy, fc.off)) : X * yy, tq, qi);
+  const double SV = SVA ? sv_aniso(lds, fc, rp, mu2) : cubic_b128(rec, tq);
+  const double q = cubic_b128(rec + 4, tq) * yy;
   const double dq = -fp.gD * cubic_b128(da + 4 * qi, tq);
-  const double m2 = mu_r * mu_r;
-  double mx2 = 4.0 * m2;                        // the records hold the coefficients of powers of (2 mu)^2, see uni_point
+  double mx2 = mu2 * mu2;                        // the records hold the coefficients of powers of (2 mu)^2, see uni_point
+  const double m2 = 0.25 * mx2;
   if (FD) {   // xi^r at the fiducial coordinates, as in uni_point
-    const double rp = r_par * fp.fa;
-    const double r2x = fma(rp, rp, sperp2 * fp.fp2);
-    const double inv_rx = vkm::rsqrt3(r2x);
-    const double mu_x = rp * inv_rx;
-    mx2 = 4.0 * (mu_x * mu_x);
-    rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(r2x, inv_rx, fc.off) : r2x * inv_rx, tq, qi);
+    const double rpx = r_par * fp.fa;
+    const double Xx = fma(rpx, rpx, sperp2 * fp.fp2);
+    const double yyx = vkm::rsqrt3_x2(Xx);
+    const double mu_x = rpx * yyx;
+    mx2 = mu_x * mu_x;
+    rec = locate<NLR, GRID>(lds, fc, GRID == 0 ? fma(Xx, yyx, fc.off) : Xx * yyx, tq, qi);
   }
   double xi1 = cubic_b128(rec + 8, tq);          // 1 + xi^r_0 (the "+1" sits in the constant coefficient)
   if (NLR == 2) xi1 = fma(cubic_b128(rec + 12, tq), mx2, xi1);
@@ -537,6 +543,8 @@ constexpr int kModeStreaming = 0, kModeFromData = 1, kModeDispersion = 2, kModeD
 __host__ __device__ constexpr bool mode_is_dispersion(int mode) { return mode == kModeDispersion || mode == kModeDispersionFromData; }
 // modes that read the Da table (v_r') and work in full index units with the unscaled V cubics
 __host__ __device__ constexpr bool mode_has_da(int mode) { return mode >= kModeDispersion; }
+// LDS layout of a mode (make_fast_plan / make_cells_plan `with_da`): 0 V1 copy, 1 Da table, 2 both
+__host__ __device__ constexpr int mode_layout(int mode) { return mode_is_dispersion(mode) ? 2 : (mode_has_da(mode) ? 1 : 0); }
 
 template <int NLR>
 __device__ __forceinline__ void stage_da(const TheoryArgs& a, double* da) {
@@ -632,6 +640,7 @@ struct FastPlan {
 };
 
 // n_sva: doubles of the anisotropic sigma_v block (TheoryArgs::sva_doubles) for the SVA instantiations, else 0
+// with_da: LDS layout of the mode (mode_layout): 0 streaming (V1 copy), 1 kaiser / euclid_special (Da table), 2 dispersion (both)
 __host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int uni_n, int nlr, int n_beta_r, int lut_n,
                                                    int with_da, int n_like, int n_sva = 0) {
   FastPlan p;
@@ -641,7 +650,7 @@ __host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int uni_n,
   p.xrec = o;  o += n_x * 2;
   p.betar = o; o += (n_beta_r + 1) & ~1;
   p.da = o;    o += with_da ? uni_n * 4 : 0;  // Da table of the dispersion model
-  p.v1 = o;    o += with_da ? 0 : uni_n * 4;  // unscaled V1 cubics (streaming modes: the records hold AVk * V, see scale_uni_v)
+  p.v1 = o;    o += with_da == 1 ? 0 : uni_n * 4;  // unscaled V1 cubics (the records hold AVk * V - streaming - or -Gk * V - dispersion, see scale_uni_v)
   o = (o + 1) & ~1;
   p.sva = o;   o += (n_sva + 1) & ~1;         // anisotropic sigma_v patches + mu knots
   p.image_end = o;                            // everything up to here is batch-constant (or rebuilt per point)
@@ -654,7 +663,7 @@ __host__ __device__ inline FastPlan make_fast_plan(int n_mu, int n_x, int uni_n,
 
 // batch-constant LDS contents of the point-major kernel (entry by entry: the image builder and the general-grid calls)
 template <int NLR>
-__device__ __forceinline__ void stage_fast(const TheoryArgs& a, const FastPlan& pl, double* lds, bool with_da) {
+__device__ __forceinline__ void stage_fast(const TheoryArgs& a, const FastPlan& pl, double* lds, int with_da) {
   const int tid = threadIdx.x;
   if (a.stage_mu) {
     for (int e = tid; e < a.n_mu * kMuRec; e += kBlock) lds[pl.murec + e] = a.stage_mu[e];
@@ -672,7 +681,7 @@ __device__ __forceinline__ void stage_fast(const TheoryArgs& a, const FastPlan& 
   for (int e = tid; e < 2 * a.n_x; e += kBlock) lds[pl.xrec + e] = a.xw_scaled[e];     // {kExpScale x_k, w_k}
   stage_uni_records<NLR>(a, lds);
   if (with_da) stage_da<NLR>(a, lds + pl.da);
-  else for (int e = tid; e < a.uni_n * 4; e += kBlock) lds[pl.v1 + e] = a.uni_sv_v[(e >> 2) * 8 + 4 + (e & 3)];
+  if (with_da != 1) for (int e = tid; e < a.uni_n * 4; e += kBlock) lds[pl.v1 + e] = a.uni_sv_v[(e >> 2) * 8 + 4 + (e & 3)];
   if (a.n_beta_r > 0)
     for (int i = tid; i < a.n_beta_r; i += kBlock) lds[pl.betar + i] = a.beta_r[i];
   if (pl.image_end > pl.sva)
@@ -687,7 +696,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 3 : 2) voi
   const int N = a.n_ell * a.n_s;
   const int Q = a.parts;
   const bool tail = a.fuse || Q > 1;
-  const FastPlan pl = make_fast_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, mode_is_dispersion(MODE), tail ? N : 0,
+  const FastPlan pl = make_fast_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, mode_layout(MODE), tail ? N : 0,
                                      SVA ? a.sva_doubles : 0);
   const int tid = threadIdx.x;
   VK_STAMP(a, 0);
@@ -700,8 +709,8 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 3 : 2) voi
   PointScalars ps = point_scalars(a, param_row(a, point));
   // ---- batch-constant tables: from the context's LDS image when there is one ------------------------
   if (a.image) copy_image(lds, a.image, pl.image_end);
-  else stage_fast<NLR>(a, pl, lds, mode_is_dispersion(MODE));
-  constexpr bool kHalf = !mode_is_dispersion(MODE);       // streaming modes: half units (FastPoint)
+  else stage_fast<NLR>(a, pl, lds, mode_layout(MODE));
+  constexpr bool kHalf = true;                            // streaming and dispersion modes: half units (FastPoint)
   const FastConsts fc = make_fast_consts<NLR>(a, kHalf, SVA ? pl.sva : 0);
   __syncthreads();
   VK_STAMP(a, 1);
@@ -731,10 +740,11 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 3 : 2) voi
     const int g = (int)(pg - (unsigned)point * (unsigned)groups);
     const double* row = param_row(a, point);
     const FastPoint fp = make_fast_point(ps, fc, kHalf);
-    constexpr int PV = mode_is_dispersion(MODE) ? 0 : 1;
+    constexpr int PV = 1;      // the V cubics carry the point's factor: AVk (streaming) or -Gk (dispersion, see disp_value)
     if (PV || a.n_beta_r > 0 || a.empirical) {
       __syncthreads();  // previous item's readers are done with the per-point records
-      rebuild_point_tables<NLR, PV>(a, lds, pl.betar, pl.v1, row[VK_P_BETA], ps.av, fp.AVk, mode_is_dispersion(MODE) ? lds + pl.da : nullptr);
+      rebuild_point_tables<NLR, PV>(a, lds, pl.betar, pl.v1, row[VK_P_BETA], ps.av, mode_is_dispersion(MODE) ? -fp.Gk : fp.AVk,
+                                    mode_is_dispersion(MODE) ? lds + pl.da : nullptr);
       if (mode_is_dispersion(MODE) && a.empirical && !a.vr_beta_dep) rebuild_da_emp(a, lds + pl.da, ps.av);
       __syncthreads();
     }
