@@ -807,3 +807,33 @@ def test_single_point_shortcut_does_not_change_the_result(synth_fit, boss_fit):
         bound = chi2_bound(fit, hp)
         assert_same_chi2(chi2, one[:, 1], bound, what="batch of 12 vs single-point calls")
         assert_same_lnl(lnl, one[:, 0], bound, what="batch of 12 vs single-point calls")
+
+
+@pytest.mark.gpu
+def test_polling_handoff_gives_the_bits_of_the_counter_handoff(synth_fit, boss_fit):
+    """Launches of a few points whose planes are split over workgroups hand their partial sums over by polling (vk_common.h:
+    kPollEmpty) instead of the completion counters: the same sums added in the same order, so not a bit may change - single
+    points, the small batches that still split, call after call on one context (the polling area must be left empty every
+    time), and interleaved with launches that use the counters."""
+    for fit, beta in ((synth_fit[3], False), (boss_fit["config"], True)):
+        hp = cases.halton_params(24, with_beta=beta)
+        pts = [cases.point(hp, i) for i in range(24)]
+
+        def run():
+            out = [fit.log_likelihood(p) for p in pts]                      # one point per call, 24 times over
+            for n in (2, 3, 5):                                             # small batches (split planes, several points)
+                sub = {k: v[:n] for k, v in hp.items()}
+                out.append(tuple(np.concatenate(fit.log_likelihood_batch(sub)).tolist()))
+                out.append(fit.log_likelihood(pts[n]))                      # ... and a single point right behind each
+            fit.log_likelihood_batch({k: v[:16] for k, v in hp.items()})     # 16 points: counters (too many workgroups to poll)
+            out.append(fit.log_likelihood(pts[7]))
+            return out
+
+        polled = run()
+        _native.set_knob("VICTOR_HIP_NO_POLL", "1")
+        try:
+            counted = run()
+        finally:
+            _native.set_knob("VICTOR_HIP_NO_POLL", None)
+        assert polled == counted
+        assert all(np.all(np.isfinite(np.asarray(v))) for v in polled)

@@ -141,6 +141,7 @@ struct Knobs {
   bool no_zero_copy = false;           // VICTOR_HIP_NO_ZERO_COPY: small host-buffer batches through the copy / graph path
   long long zero_copy_max = -1;        // VICTOR_HIP_ZERO_COPY_MAX: largest host-buffer batch on the in-place path (-1 = default)
   long long spin_max = -1;             // VICTOR_HIP_SPIN_MAX: largest in-place batch whose results are polled for (-1 = default, 0 = never)
+  bool no_poll = false;                // VICTOR_HIP_NO_POLL: split single-point launches hand over through the completion counters (A/B)
 };
 
 struct vk_ctx {
@@ -191,6 +192,10 @@ struct vk_ctx {
   unsigned* d_counters = nullptr;      // [kCounterCap], zero between launches
   double* d_partial = nullptr;         // [partial_doubles]
   size_t partial_doubles = 0;
+  double* d_poll = nullptr;            // [poll_doubles] polling area of the launches that hand over without counters (kPollEmpty
+  size_t poll_doubles = 0;             // between launches; vk_common.h), or NULL
+  int* h_poll_failed = nullptr;        // pinned, device-mapped word a polling workgroup sets when it gives up; d_poll_failed: the
+  int* d_poll_failed = nullptr;        // same word through the device's eyes
   double wsum[3] = {0, 0, 0};
   int depth_mult = 1;                // joint fits: launches of this many contexts share the GPU (vk_joint_eval_device_async)
   hipEvent_t ev_joint = nullptr;
@@ -232,6 +237,7 @@ constexpr int64_t kZeroCopyCap = 4096;     // capacity of the in-place buffers (
 constexpr long long kCounterCap = 16384;   // points per launch that may share work between workgroups (completion counters)
 constexpr long long kPartialPoints = 2048;  // batches up to this many points may split a point's work over workgroups (partial sums)
 constexpr int kServeMaxBatch = 32;          // requests one launch of the mailbox server carries (vk_ctx::split_as_single)
+constexpr long long kPollPoints = kServeMaxBatch;   // points per launch whose split work is handed over by polling (TheoryArgs::poll)
 
 namespace {
 
@@ -265,6 +271,7 @@ void load_knobs(vk_ctx* ctx) {
   k.no_zero_copy = getenv("VICTOR_HIP_NO_ZERO_COPY") != nullptr;
   if (const char* env = getenv("VICTOR_HIP_ZERO_COPY_MAX")) k.zero_copy_max = atoll(env);
   if (const char* env = getenv("VICTOR_HIP_SPIN_MAX")) k.spin_max = atoll(env);
+  if (const char* env = getenv("VICTOR_HIP_NO_POLL")) k.no_poll = atoi(env) != 0;
   k.force_generic = getenv("VICTOR_HIP_FORCE_GENERIC") != nullptr;
   if (const char* env = getenv("VICTOR_HIP_POINT_CAP")) k.point_cap = atoll(env);
   if (const char* env = getenv("VICTOR_HIP_LANES_CAP")) k.lanes_cap = atoll(env);
@@ -631,6 +638,11 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
   a.nmu_magic = div_magic(a.n_mu);
   a.counters = ctx->d_counters;
   a.partial = ctx->d_partial;
+  a.poll = 0;
+  a.poll_failed = ctx->d_poll_failed;
+  if (ctx->h_poll_failed && *ctx->h_poll_failed)
+    return fail(ctx, VK_E_HIP, "a workgroup waited %.0f s for partial sums that never arrived (an earlier launch of this context); "
+                               "the context is unusable", (double)kPollTicks * 1e-8);
   a.fuse = 0;
   a.image = nullptr;
 #ifdef VK_PHASES
@@ -786,6 +798,14 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
     a.image = get_image(ctx, a, 0, nlr, layout, plf.image_end, sva);
     const long long items = a.n * groups * a.parts;
     const int grid = (int)items;                                            // one item per workgroup, always (vk_kernel_fast.h)
+    // Hand-off by polling instead of the completion counters (vk_common.h: kPollEmpty): launches of a few points whose
+    // workgroups are all resident at once (two per CU fit whatever the tables' size) - one point per call and the mailbox
+    // server's launches.  Same partial sums, added in the same order: the results do not change by a bit.
+    if (a.parts > 1 && a.n <= kPollPoints && items <= 2LL * ctx->n_cu && ctx->d_poll && !ctx->knobs.no_poll &&
+        (size_t)a.n * a.n_s * kMaxParts * kMaxEll <= ctx->poll_doubles) {
+      a.poll = 1;
+      a.partial = ctx->d_poll;
+    }
     if (fused) *fused = a.fuse != 0;
     switch (nlr) {
       case 1: return launch_fast_nl<1>(ctx, a, grid, lds);
@@ -1279,10 +1299,29 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
     const size_t n_stage = (size_t)t->n_mu * kMuRec;
     ctx->partial_doubles = (size_t)kPartialPoints * t->n_s * kMaxParts * kMaxEll;
     const size_t n_exp = vkm::ExpCfg<0>::kDoubles + vkm::ExpCfg<1>::kDoubles;
-    const size_t aux_doubles = n_exp + n_stage + ctx->partial_doubles + (kCounterCap * sizeof(unsigned) + 7) / 8 + 2;
+    ctx->poll_doubles = (size_t)kPollPoints * t->n_s * kMaxParts * kMaxEll;
+    const size_t counter_doubles = (kCounterCap * sizeof(unsigned) + 7) / 8 + 2;
+    const size_t aux_doubles = n_exp + n_stage + ctx->partial_doubles + counter_doubles + ctx->poll_doubles;
     if ((rc = hipMalloc((void**)&ctx->d_aux, aux_doubles * sizeof(double))) != hipSuccess) return hip_bail(rc, "hipMalloc(aux)");
     if ((rc = hipMemsetAsync(ctx->d_aux, 0, aux_doubles * sizeof(double), ctx->stream)) != hipSuccess)
       return hip_bail(rc, "hipMemset(aux)");
+    // the polling area (behind the counters) starts out empty; without the pinned word for its alarm there is no polling
+    {
+      void* dev = nullptr;
+      if (hipHostMalloc((void**)&ctx->h_poll_failed, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+          hipHostGetDevicePointer(&dev, ctx->h_poll_failed, 0) == hipSuccess) {
+        *ctx->h_poll_failed = 0;
+        ctx->d_poll_failed = static_cast<int*>(dev);
+        ctx->d_poll = ctx->d_aux + (aux_doubles - ctx->poll_doubles);
+        if ((rc = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->d_poll), (int)(kPollEmpty & 0xffffffffu), ctx->poll_doubles * 2,
+                                    ctx->stream)) != hipSuccess)
+          return hip_bail(rc, "hipMemsetD32(polling area)");
+      } else {
+        (void)hipGetLastError();
+        if (ctx->h_poll_failed) (void)hipHostFree(ctx->h_poll_failed);
+        ctx->h_poll_failed = nullptr;
+      }
+    }
     double* exp_tab = ctx->d_aux;
     double* exp_tab_rep = exp_tab + vkm::ExpCfg<0>::kDoubles;
     double* stage_mu = exp_tab + n_exp;
@@ -1325,6 +1364,7 @@ void vk_destroy(vk_ctx* ctx) {
   if (ctx->h_zc) (void)hipHostFree(ctx->h_zc);
   if (ctx->d_tables) (void)hipFree(ctx->d_tables);
   if (ctx->d_aux) (void)hipFree(ctx->d_aux);
+  if (ctx->h_poll_failed) (void)hipHostFree(ctx->h_poll_failed);
   for (auto& kv : ctx->images) (void)hipFree(kv.second);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   for (auto& evt : ctx->ev)
@@ -1371,6 +1411,8 @@ int vk_sync(vk_ctx* ctx) {
   if (!ctx) return VK_E_ARG;
   VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   harvest_timing(ctx);
+  if (ctx->h_poll_failed && *ctx->h_poll_failed)
+    return fail(ctx, VK_E_HIP, "a workgroup waited %.0f s for partial sums that never arrived; the context is unusable", (double)kPollTicks * 1e-8);
   return VK_OK;
 }
 
@@ -1557,6 +1599,8 @@ static int eval_batch_graph(vk_ctx* ctx, const vk_eval_opts* opts, const double*
   VK_HIP(ctx, hipGraphLaunch(hit->second, ctx->stream));
   VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->last_kernel = ctx->graph_kernel[key];
+  if (ctx->h_poll_failed && *ctx->h_poll_failed)      // (set before the results were written, see finish_point)
+    return fail(ctx, VK_E_HIP, "a workgroup waited %.0f s for partial sums that never arrived; the context is unusable", (double)kPollTicks * 1e-8);
   if (lnl) memcpy(lnl, h_out, (size_t)n * sizeof(double));
   if (chi2) memcpy(chi2, h_out + n, (size_t)n * sizeof(double));
   return 1;
@@ -1650,6 +1694,8 @@ static int zc_finish(vk_ctx* ctx, int64_t n, double* lnl, double* chi2, bool blo
   } else {
     ctx->spin_timeouts = 0;
   }
+  if (ctx->h_poll_failed && *ctx->h_poll_failed)      // (set before the results were written, see finish_point)
+    return fail(ctx, VK_E_HIP, "a workgroup waited %.0f s for partial sums that never arrived; the context is unusable", (double)kPollTicks * 1e-8);
   if (lnl) memcpy(lnl, h_out, (size_t)n * sizeof(double));
   if (chi2) memcpy(chi2, h_out + n, (size_t)n * sizeof(double));
   return 1;

@@ -133,6 +133,11 @@ struct TheoryArgs {
   int fuse;               // 1: the workgroup that completes a point's theory vector also computes its chi2 / lnL (`like`)
   unsigned* counters;     // [n] workgroups finished per point; zero on entry, reset to zero by the finishing workgroup
   double* partial;        // [n][n_s][parts][kMaxEll] partial projections (point-major, parts > 1)
+  // 1 (point-major kernel, parts > 1, launches whose workgroups are all resident at once): no completion counter - `partial`
+  // is the context's polling area, whose slots hold kPollEmpty between launches; the workgroup of a point's LAST work item
+  // waits for every partial sum of the point to appear and puts kPollEmpty back (finish_point)
+  int poll;
+  int* poll_failed;       // pinned host word, set when a polling workgroup gave up (kPollTicks): the context then reports an error
   LikeArgs like;
   // A single-point call through host buffers carries its parameter row HERE, in the kernel arguments: read from the pinned
   // host buffer it is a PCIe round trip of ~2.7 us in front of every workgroup's loads (vector loads return in order, so
@@ -298,6 +303,18 @@ __device__ __forceinline__ void load_shared_x8(const double* p, double (&v)[8]) 
 // The finishing workgroup resets counters[point] for the next launch.  `flag`: one int of LDS.
 // (The round-2 form - a workgroup-scope release fence without the vmcnt wait - measured the same speed and is not ordered:
 // profiles/r03/a_handoff_drain_ab.txt.  It is gone from the source; there is no build switch that removes the wait.)
+// Hand-off by POLLING (TheoryArgs::poll; one point per call - the reference's calling convention - and the mailbox server's
+// launches): a slot of the polling area holds kPollEmpty, a NaN pattern no sum can take (hardware NaNs are 0x7ff8000000000000;
+// only a caller's NaN parameter with exactly this payload could propagate it, and then the wait below ends in the time-out), until
+// its producer's ONE 8-byte write-through store lands; the finishing workgroup re-reads its slots (sc1 loads) until none is
+// empty.  Every slot vouches for itself, so no ordering between stores is needed - no drain, no barrier, no counter round trip:
+// a single point's launch is 1.5 us shorter.  Deadlock-free by construction: the finisher is the workgroup of the point's LAST
+// work item, and the host only polls in launches that fit on the chip at once.  kPollTicks (wall_clock64 counts 100 MHz: 5 s)
+// is a guard against waiting for ever on a broken launch, not a code path: it fails the call (TheoryArgs::poll_failed).
+constexpr unsigned long long kPollEmpty = 0x7ff8a5a57ff8a5a5ULL;    // both halves equal: the area is filled by hipMemsetD32
+constexpr long long kPollTicks = 500000000LL;
+__device__ __forceinline__ bool poll_is_empty(double v) { return (unsigned long long)__double_as_longlong(v) == kPollEmpty; }
+
 __device__ __forceinline__ void drain_shared_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // parameter row of a point (see TheoryArgs::row0)

@@ -578,7 +578,7 @@ __device__ __forceinline__ double* partial_slot(const TheoryArgs& a, long long p
 
 template <int NL, int RB = kLikeRows>
 __device__ __forceinline__ void finish_point(const TheoryArgs& a, long long point, double beta, double poison, double* th,
-                                             bool gather_partials, const double* lds_beta_r) {
+                                             bool gather_partials, const double* lds_beta_r, bool poll = false) {
   const int N = a.n_ell * a.n_s;
   double* red = th + ((N + 1) & ~1);
   const double w0 = a.wsum[0], w1 = a.wsum[1], w2 = a.wsum[2];
@@ -589,7 +589,31 @@ __device__ __forceinline__ void finish_point(const TheoryArgs& a, long long poin
     if (gather_partials) {
       const int l = (e >= 2 * a.n_s) ? 2 : (e >= a.n_s ? 1 : 0), j = e - l * a.n_s;
       double part[8];
-      load_shared_x8(partial_slot(a, point, l, j), part);
+      double* slot = partial_slot(a, point, l, j);
+      load_shared_x8(slot, part);
+      if (poll) {                                      // hand-off by polling (vk_common.h: kPollEmpty)
+        long long t0 = 0;
+        for (unsigned it = 1;; ++it) {
+          bool empty = false;
+#pragma unroll
+          for (int q = 0; q < kMaxParts; ++q) empty = empty || (q < a.parts && poll_is_empty(part[q]));
+          if (!empty) break;
+          if ((it & 63u) == 0) {                       // the clock is looked at every 64th round trip (~50 us) only
+            const long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            if (now - t0 > kPollTicks) {               // never in a sound launch: fail the call, loudly
+              *a.poll_failed = 1;
+              __threadfence_system();
+              break;
+            }
+          }
+          load_shared_x8(slot, part);
+        }
+        const double empty_v = __longlong_as_double((long long)kPollEmpty);
+#pragma unroll
+        for (int q = 0; q < kMaxParts; ++q)
+          if (q < a.parts) store_shared(slot + q, empty_v);       // the area is left as it was found, for the next launch
+      }
       v = 0.0;
 #pragma unroll
       for (int q = 0; q < kMaxParts; ++q) v += (q < a.parts) ? part[q] : 0.0;   // fixed order: independent of which part finished last
@@ -839,12 +863,15 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 3 : 2) voi
       if (groups * Q == 1) {
         drain_shared_stores();
         __syncthreads();
+      } else if (a.poll) {
+        // no counter: the workgroup of the point's last work item collects the partial sums as they appear (vk_common.h)
+        last = g == groups - 1 && q == Q - 1;
       } else {
         last = point_completed(a.counters, point, (unsigned)(groups * Q), flag);
       }
       VK_STAMP(a, 4);
       if (last) {
-        finish_point<NL>(a, point, row[VK_P_BETA], ps.poison, th, Q > 1, a.n_beta_r > 0 ? lds + pl.betar : nullptr);
+        finish_point<NL>(a, point, row[VK_P_BETA], ps.poison, th, Q > 1, a.n_beta_r > 0 ? lds + pl.betar : nullptr, a.poll != 0);
         VK_STAMP(a, 5);
       }
       return;
