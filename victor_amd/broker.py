@@ -166,12 +166,13 @@ class Broker:
     ``attach_existing``: the segment was created (state STARTING) by the chain that elected itself to start this process.
     """
 
-    def __init__(self, model, data, name, n_slots=64, device=0, gather_window_us=3.0, attach_existing=False, depth=4, max_batch=4,
+    def __init__(self, model, data, name, n_slots=64, device=0, gather_window_us=3.0, attach_existing=False, depth=4, max_batch=8,
                  threads=1, digest=None):
         """``depth``: contexts (streams) per serving thread = launches it may have in flight at once (1..8); ``max_batch``:
         requests per launch (0: the library's limit, 32); ``threads``: serving threads, each with its own contexts and its own
         contiguous share of the mailboxes.  Defaults from tools/gpu_broker_sweep.py (profiles/r04/broker_sweep.txt,
-        broker_sweep_threads.txt): more threads or more contexts buy nothing - 8 chains saturate near 2.6e5 evaluations/s whether
+        broker_sweep_threads.txt; max_batch 4 -> 8 with the polling hand-off, broker_sweep_poll.txt: 16 chains 505 -> 520-600 k
+        evaluations/s, 4 and 8 chains unchanged): more threads or more contexts buy nothing - 8 chains saturate near 2.6e5 evaluations/s whether
         they travel one per launch on 4 threads x 2 contexts or four per launch on one thread, because what is short is the GPU's
         latency for eight single-point work splits in flight at once, not the host's time to enqueue them."""
         self.name = name
@@ -411,7 +412,7 @@ class BrokerClient:
             pass
 
 
-def spawn_broker(model, data, name, device=0, n_slots=64, linger=5.0, gather_window_us=3.0, log=None, depth=4, max_batch=4,
+def spawn_broker(model, data, name, device=0, n_slots=64, linger=5.0, gather_window_us=3.0, log=None, depth=4, max_batch=8,
                  threads=1, digest=None):
     """Start ``python -m victor_amd.broker`` for a segment this process has just created (election winner) or will create.
     The child is a fresh interpreter: it is the only process that initialises the GPU."""
@@ -472,7 +473,7 @@ def connect(model, data, spec, timeout=300.0):
             seg.close()
             spawn_broker(model, data, name, device=device, n_slots=n_slots, log=os.environ.get("VICTOR_HIP_BROKER_LOG"),
                          depth=int(os.environ.get("VICTOR_HIP_BROKER_DEPTH", "4")),
-                         max_batch=int(os.environ.get("VICTOR_HIP_BROKER_MAX_BATCH", "4")),
+                         max_batch=int(os.environ.get("VICTOR_HIP_BROKER_MAX_BATCH", "8")),
                          threads=int(os.environ.get("VICTOR_HIP_BROKER_THREADS", "1")), digest=digest)
             break
         else:
@@ -496,8 +497,9 @@ def main(argv=None):
     ap.add_argument("--window-us", type=float, default=3.0, help="how long a round waits for the other chains' requests")
     ap.add_argument("--depth", type=int, default=4, help="contexts (streams) of the owner = launches in flight at once")
     ap.add_argument("--threads", type=int, default=1, help="serving threads, each with `depth` contexts and its share of the mailboxes")
-    ap.add_argument("--max-batch", type=int, default=4, help="requests per launch (0: the library's limit of 32); measured "
-                                                             "best at 4 for 8 and 16 chains (tools/gpu_broker_sweep.py)")
+    ap.add_argument("--max-batch", type=int, default=8, help="requests per launch (0: the library's limit of 32); 8 BOSS "
+                                                             "requests are the most one launch hands over by polling "
+                                                             "(tools/gpu_broker_sweep.py, profiles/r04/broker_sweep_poll.txt)")
     ap.add_argument("--attach-existing", action="store_true")
     ap.add_argument("--digest", default=None, help="configuration digest to publish (set by the chain that starts the owner)")
     ap.add_argument("--parent-pid", type=int, default=0)
