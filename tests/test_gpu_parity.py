@@ -743,10 +743,11 @@ def test_nan_beta_reports_a_failed_row_in_every_chi_square_kernel(synth_fit):
 
 @pytest.mark.gpu
 def test_quadratic_form_for_other_sizes_of_the_data_vector(tmp_path, oracle):
-    """The fused tail and the wide K2 take chi2 on the precision matrix folded onto its upper triangle, two triangle rows per
-    combined row (vk_kernel_like.h): N = 120 and 60 are the shipped sizes; here N = 135 (odd: a zero row and column make it
-    even; more than 64 entry pairs per row: two chunks of lanes), N = 150 (even, two chunks) and N = 21 (odd, fewer rows than
-    waves x rows in flight) against the oracle, through the single-point call, a fused small batch and a large batch (tiled K2)."""
+    """The fused tail and the wide K2 take chi2 on the precision matrix folded onto its upper triangle and stored by circular
+    diagonals, the residual twice over in LDS (vk_kernel_like.h): N = 120 and 60 are the shipped sizes; here N = 135 (odd: a
+    zero row and column make it even; more than 64 entry pairs per row: two chunks of lanes), N = 150 (even, two chunks) and
+    N = 21 (odd, fewer rows than waves x rows in flight: the zeros behind the doubled residual are read) against the oracle,
+    through the single-point call, a fused small batch and a large batch (tiled K2)."""
     import victor_amd
     rng = np.random.default_rng(7)
     for n_s, poles in ((45, 3), (50, 3), (7, 3)):

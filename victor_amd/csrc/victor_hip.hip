@@ -237,7 +237,10 @@ constexpr int64_t kZeroCopyCap = 4096;     // capacity of the in-place buffers (
 constexpr long long kCounterCap = 16384;   // points per launch that may share work between workgroups (completion counters)
 constexpr long long kPartialPoints = 2048;  // batches up to this many points may split a point's work over workgroups (partial sums)
 constexpr int kServeMaxBatch = 32;          // requests one launch of the mailbox server carries (vk_ctx::split_as_single)
-constexpr long long kPollPoints = kServeMaxBatch;   // points per launch whose split work is handed over by polling (TheoryArgs::poll)
+// Points per launch whose split work is handed over by polling (TheoryArgs::poll): one waiting workgroup per point.  Few, so
+// that the waiting workgroups of every launch in flight on the GPU - other contexts, other processes - can never fill an
+// XCD (64 workgroup slots at least) and keep the workgroups they wait for off it.
+constexpr long long kPollPoints = 8;
 
 namespace {
 
@@ -1224,26 +1227,26 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
       o_prec = up.add(t->prec, (size_t)N * N);
     }
   }
-  // the quadratic form of every precision slice folded onto its upper triangle, two triangle rows per "combined row" of
-  // M + 1 entries (+ 1 of padding), M = N rounded up to even (a zero row and column for an odd N): what the fused tail and
-  // the wide K2 read (vk_kernel_like.h: LikePrefetch), half the bytes of the slice
+  // the quadratic form of every precision slice folded onto its upper triangle and stored by circular diagonals, M/2 + 1 rows
+  // of M entries (+ 2 of padding), M = N rounded up to even (a zero row and column for an odd N): what the fused tail and the
+  // wide K2 read (vk_kernel_like.h: LikePrefetch), half the bytes of the slice
   size_t o_tri = 0;
   const bool have_tri = t->data != nullptr;
   if (have_tri) {
     const int slices = t->n_beta_c > 0 ? t->n_beta_c : 1;
     const int M = (N + 1) & ~1, half = M / 2, W = M + 2;
-    std::vector<double> tri((size_t)slices * half * W, 0.0);
+    const size_t slice = like_slice_doubles(N);
+    std::vector<double> tri((size_t)slices * slice, 0.0);
     for (int sl = 0; sl < slices; ++sl) {
       const double* P = t->prec + (size_t)sl * N * N;
       auto fold = [&](int i, int j) {
         if (i >= N || j >= N) return 0.0;
         return i == j ? P[(size_t)i * N + i] : P[(size_t)i * N + j] + P[(size_t)j * N + i];
       };
-      for (int c = 0; c < half; ++c) {
-        double* row = tri.data() + ((size_t)sl * half + c) * W;
-        for (int j = c; j < M; ++j) row[j - c] = fold(c, j);                        // triangle row c: entries [0, M - c)
-        const int i = M - 1 - c;
-        for (int j = i; j < M; ++j) row[(M - c) + (j - i)] = fold(i, j);            // triangle row M - 1 - c: the next c + 1 entries
+      for (int k = 0; k <= half; ++k) {
+        double* row = tri.data() + (size_t)sl * slice + (size_t)k * W;
+        const int n_i = k == half ? half : M;            // the diagonal half-way round pairs every i with i + M/2 once
+        for (int i = 0; i < n_i; ++i) row[i] = fold(i, (i + k) % M);
       }
     }
     o_tri = up.add(tri.data(), tri.size());

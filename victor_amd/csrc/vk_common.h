@@ -49,7 +49,7 @@ struct LikeArgs {
   const double* prec;
   int grids_in_lds;       // bit 0 / 1: beta_d / beta_c equal the real-space tables' grid beta_r bit for bit (BOSS: one 31-value grid
                           // serves all three) - a fused tail then searches the copy its kernel holds in LDS instead of global memory
-  const double* tri;      // [slices][M/2][M+2], M = N rounded up to even: every slice's quadratic form folded onto its upper triangle (vk_kernel_like.h)
+  const double* tri;      // [slices][M/2+1][M+2], M = N rounded up to even: every slice's quadratic form folded onto its upper triangle, by circular diagonals (vk_kernel_like.h)
   const double* logdet;
   const double* eig;
   int like_form;

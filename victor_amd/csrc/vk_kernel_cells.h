@@ -95,7 +95,7 @@ __device__ __forceinline__ void finish_point_ranges(const TheoryArgs& a, long lo
     th[e] = v;
   }
   __syncthreads();
-  if (a.fuse) like_point_workgroup(a.like, point, beta, th, th + ((N + 1) & ~1), pf);
+  if (a.fuse) like_point_workgroup(a.like, point, beta, th, th + like_red_off(N), pf);
 }
 
 // Projection of one trip: sum_lanes W_l[i] g over the lanes of the trip's first s bin and over those of its second, for every
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(kBlock, (MODE == kModeStreaming && !SVA) || MODE ==
       // fused / split launches run one item per workgroup and leave from here (see vk_kernel_fast.h)
       bool last = true;
       if (R > 1) {
-        int* flag = reinterpret_cast<int*>(th + ((N + 1) & ~1) + kLikeRed + 2);
+        int* flag = reinterpret_cast<int*>(th + like_red_off(N) + kLikeRed + 2);
         last = point_completed(a.counters, point, (unsigned)R, flag);
       }
       VK_STAMP(a, 4);

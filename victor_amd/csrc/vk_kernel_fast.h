@@ -564,9 +564,10 @@ __device__ __forceinline__ void rebuild_da_emp(const TheoryArgs& a, double* da, 
 // is complete - in this workgroup's LDS, or in the global workspace after the last of the workgroups sharing the point
 // has finished (point_completed) - the same workgroup takes the chi-square and the log-likelihood
 // (like_point_workgroup), so a batch needs ONE launch and the theory vector makes no round trip through HBM before it
-// is used.  `th`: LDS, N doubles + kLikeRed + 4 (reduction scratch, completion flag).
+// is used.  `th`: LDS, like_lds_doubles(N): the theory vector / residual TWICE over (2 M doubles, M = N rounded up to even: the
+// quadratic form reads r[(i + k) mod M] as r2[i + k], vk_kernel_like.h), kLikeRed of reduction scratch, the completion flag.
 // --------------------------------------------------------------------------------------------------
-__host__ __device__ constexpr int like_lds_doubles(int N) { return ((N + 1) & ~1) + kLikeRed + 4; }
+// (like_red_off, like_lds_doubles: vk_kernel_like.h)
 
 // partial projections of a split plane: [point][l][s bin][kMaxParts], the parts of one (l, s bin) adjacent (64 bytes)
 __device__ __forceinline__ double* partial_slot(double* partial, int n_s, long long point, int l, int j) {
@@ -580,7 +581,7 @@ template <int NL, int RB = kLikeRows>
 __device__ __forceinline__ void finish_point(const TheoryArgs& a, long long point, double beta, double poison, double* th,
                                              bool gather_partials, const double* lds_beta_r, bool poll = false) {
   const int N = a.n_ell * a.n_s;
-  double* red = th + ((N + 1) & ~1);
+  double* red = th + like_red_off(N);
   const double w0 = a.wsum[0], w1 = a.wsum[1], w2 = a.wsum[2];
   LikePrefetch<RB> pf;
   if (a.fuse) pf.issue(a.like, beta, late_tid(), lds_beta_r);   // everything the chi-square needs besides the theory vector travels with the gather
@@ -856,7 +857,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeStreaming && !SVA ? 3 : 2) voi
       // Fused / split launches run ONE item per workgroup (the host sizes the grid so) and leave from here: nothing is
       // live after the tail, so its registers (the chi-square needs ~100) do not spill the state of the loop above.
       double* th = lds + pl.like;
-      int* flag = reinterpret_cast<int*>(th + ((N + 1) & ~1) + kLikeRed + 2);
+      int* flag = reinterpret_cast<int*>(th + like_red_off(N) + kLikeRed + 2);
       // a point owned by this workgroup alone needs no counter (and batches beyond the counter array have none): its theory
       // vector is re-read from L2 once this workgroup's own write-through stores have landed
       bool last = true;

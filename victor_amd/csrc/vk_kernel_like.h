@@ -109,14 +109,27 @@ __device__ __forceinline__ void block_sum4(double (&v)[4], double* red) {
 //                         is requested BEFORE the theory vector is gathered, and travels with it;
 //   like_point_workgroup  residual, quadratic form, reductions, likelihood form, once the theory vector sits in LDS.
 //
-// The quadratic form on the folded triangle.  The host folds every precision slice onto its upper triangle, T_ii = P_ii,
-// T_ij = P_ij + P_ji (i < j), so that chi2 = sum_{i <= j} T_ij r_i r_j needs half the bytes, and stores row c of the triangle
-// (M - c entries) together with row M - 1 - c (c + 1 entries) as one "combined row" of M + 1 entries (+ one zero of padding):
-// M / 2 combined rows of EQUAL length, M = N rounded up to even (an odd N gets a zero row and column; vk_create).  Waves take
-// the combined rows round-robin, lanes the entry pairs (16-byte loads; more than 64 pairs - N > 126 - in chunks); RB rows
-// per lane are in flight (4 RB registers; blended slices: RB / 2 of each), the first RB from the prefetch: N = 120 costs one
-// exposed round trip more (the wave's last 7 rows), the full-matrix rolling window it replaces cost four.
+// The quadratic form on the folded DIAGONALS.  With M = N rounded up to even (an odd N gets a zero row and column; vk_create) the
+// host folds every precision slice onto its upper triangle, T_ii = P_ii, T_ij = P_ij + P_ji, and stores it by circular
+// diagonals: row k (k = 0 .. M/2) holds D_k[i] = T[i][(i + k) mod M] for i = 0 .. M - 1 (row M/2: i < M/2 only, zeros behind -
+// every unordered pair exactly once), M + 2 doubles per row with the padding.  Then
+//     chi2 = sum_i r_i t_i,   t_i = sum_k D_k[i] r_((i + k) mod M),
+// half the bytes of the slice, M/2 + 1 rows of EQUAL length, and the factor of entry i of row k is the residual k places on:
+// with the residual stored twice in LDS (r2 = r | r) a lane's two factors are ONE ds_read2_b64 at an immediate offset and
+// its two entries two fmas - three instructions per row where the triangle's two-rows-in-one layout (round 3) cost 22 (a
+// select between "row c" and "row M - 1 - c" per entry, four LDS reads with computed addresses): the tail of a single
+// point's launch spent 1.2 us of its 2.2 issuing them from one wave per SIMD.  Waves take the rows round-robin, lanes the entry
+// pairs (16-byte loads; more than 64 pairs - N > 126 - in chunks); RB rows per lane are in flight (4 RB registers; blended
+// slices: RB / 2 of each), the first RB from the prefetch: N = 120 (61 rows, 16 for the first wave) in ONE batch.
 // --------------------------------------------------------------------------------------------------
+// LDS of a fused tail / the wide K2: residual twice over (2 M doubles) and kLikeSlack zeros behind it - the rows a wave's last
+// batch holds beyond the last diagonal are zeros whose factors are read up to kWaves (rows in flight - 1) + 1 places further
+// on, and those must be finite -, kLikeRed of reduction scratch, 4 more (completion flag)
+constexpr int kLikeSlack = 4 * 16 + 4;       // kWaves * kLikeRows + 4 (static_assert below)
+__host__ __device__ constexpr int like_red_off(int N) { return 2 * ((N + 1) & ~1) + kLikeSlack; }
+__host__ __device__ constexpr int like_lds_doubles(int N) { return like_red_off(N) + kLikeRed + 4; }
+__host__ __device__ constexpr size_t like_slice_doubles(int N) { return (size_t)((((N + 1) & ~1) >> 1) + 1) * (((N + 1) & ~1) + 2); }
+
 typedef double like_d2 __attribute__((ext_vector_type(2)));
 
 template <int RB>
@@ -131,18 +144,18 @@ struct LikePrefetch {
   const double* T1;
   like_d2 rows[RB];       // t == 0: rows wave, wave + 4, ... of T0; else RB / 2 rows of T0, then the same rows of T1
 
-  // rows c0, c0 + kWaves, ... of this wave, entry pair e0 / 2 of this lane; M = N rounded up to even
+  // rows (diagonals) c0, c0 + kWaves, ... of this wave, entry pair e0 / 2 of this lane; M = N rounded up to even
   template <bool BLEND>
   __device__ __forceinline__ void load_rows(int M, int c0, int e0) {
     constexpr int R = BLEND ? RB / 2 : RB;
-    const int half = M >> 1, W = M + 2;
+    const int n_rows = (M >> 1) + 1, W = M + 2;
     const char* b0 = reinterpret_cast<const char*>(T0);   // a slice is far below 4 GB: 32-bit byte offsets from the uniform bases
     const char* b1 = reinterpret_cast<const char*>(T1);
     unsigned off = ((unsigned)c0 * (unsigned)W + (unsigned)e0) * 8u;
     const unsigned stride = (unsigned)(kWaves * W) * 8u;
 #pragma unroll
     for (int s = 0; s < R; ++s) {
-      const bool live = c0 + kWaves * s < half && e0 < W;
+      const bool live = c0 + kWaves * s < n_rows && e0 < W;
       rows[s] = live ? *reinterpret_cast<const like_d2*>(b0 + off) : like_d2{0.0, 0.0};
       if (BLEND) rows[R + s] = live ? *reinterpret_cast<const like_d2*>(b1 + off) : like_d2{0.0, 0.0};
       off += stride;
@@ -193,7 +206,7 @@ struct LikePrefetch {
     // the first rows of the quadratic form
     {
       const int M = (a.N + 1) & ~1;
-      const size_t slice = (size_t)(M >> 1) * (M + 2);
+      const size_t slice = like_slice_doubles(a.N);
       T0 = a.tri + (a.n_beta_c > 0 ? (size_t)lo * slice : 0);
       T1 = a.tri + (a.n_beta_c > 0 ? (size_t)last * slice : 0);
       if (t != 0.0) load_rows<true>(M, tid >> 6, 2 * lane); else load_rows<false>(M, tid >> 6, 2 * lane);
@@ -212,45 +225,43 @@ struct LikePrefetch {
     }
   }
 
-  // sum_{i <= j} T_ij r_i r_j, this thread's share; `r` = residual in LDS, r[N] = 0 when N is odd.  The first batch of rows
-  // (of the first chunk of entry pairs) is in rows[] already (issue); further batches are loaded here, one exposed round trip
-  // each - N = 120: one more, 7 rows.  (Refilling a slot as soon as its row is consumed would hide that trip, but the
-  // loop-carried register array costs the cells kernel its 96-register budget: 141 registers measured.)
+  // sum_{i <= j} T_ij r_i r_j, this thread's share; `r2` = the residual twice over in LDS (2 M doubles, r2[N] = r2[M + N] = 0
+  // when N is odd).  The first batch of rows (of the first chunk of entry pairs) is in rows[] already (issue); further batches
+  // are loaded here, one exposed round trip each.  A row beyond the last one holds zeros (load_rows) and reads residuals
+  // that exist, so there is no branch per row; lanes beyond the last entry pair read the pair at M (zeros in the rows).
   template <bool BLEND>
-  __device__ __forceinline__ double quadratic(const LikeArgs& a, const double* r, int tid) {
+  __device__ __forceinline__ double quadratic(const LikeArgs& a, const double* r2, int tid) {
     constexpr int R = BLEND ? RB / 2 : RB;
-    const int M = (a.N + 1) & ~1, half = M >> 1, W = M + 2;
+    const int M = (a.N + 1) & ~1, n_rows = (M >> 1) + 1, W = M + 2;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const double omt = 1.0 - t;
     double part = 0.0;
     for (int e0 = 2 * (tid & 63); e0 < W; e0 += 128) {     // one chunk of 64 entry pairs up to N = 126
-      // Entry e of combined row c is T[c][c + e] for e < M - c, else T[M-1-c][e - 1]: this lane's two entries are in the
-      // second triangle row from row c = M - e0 (resp. M - e0 - 1) on, where their column no longer depends on the row
-      const int first0 = M - e0, first1 = M - e0 - 1;
-      const double q0 = r[max(e0 - 1, 0)], q1 = r[min(e0, M - 1)];      // (entry 0 is never in a second row; entry M + 1 is the padding)
-      const double* rl = r + e0;
-      for (int base = wave; base < half; base += kWaves * R) {
+      const int ec = min(e0, M);                           // (entries M, M + 1 are the padding: zeros)
+      double t0 = 0.0, t1 = 0.0;
+      for (int base = wave; base < n_rows; base += kWaves * R) {
         if (e0 >= 128 || base != wave) load_rows<BLEND>(M, base, e0);
+        // row k = base + kWaves s: this lane's factors are r2[ec + k], r2[ec + k + 1] - immediate offsets from one address
+        // (k < M/2 + 1 + kWaves (R - 1): inside the doubled residual and its kLikeSlack zeros)
+        const double* rl = r2 + ec + base;
 #pragma unroll
         for (int s = 0; s < R; ++s) {
-          // no branch per row: a row beyond the last one holds zeros (load_rows) and reads the last row's residuals, so the
-          // LDS reads of several rows can be in flight together - eight at a time (registers)
-          const int c = min(base + kWaves * s, half - 1);    // wave-uniform
           const double x = BLEND ? omt * rows[s].x + t * rows[R + s].x : rows[s].x;
           const double y = BLEND ? omt * rows[s].y + t * rows[R + s].y : rows[s].y;
-          const double u1 = r[c], u2 = r[M - 1 - c];         // the factors of triangle rows c and M - 1 - c (broadcast reads)
-          const double v0 = rl[min(c, M - 1 - e0)], v1 = rl[min(c + 1, M - 1 - e0)];
-          part = fma(x, c < first0 ? u1 * v0 : u2 * q0, part);
-          part = fma(y, c < first1 ? u1 * v1 : u2 * q1, part);
-          if ((s & 7) == 7) asm volatile("" ::: "memory");
+          t0 = fma(x, rl[kWaves * s], t0);
+          t1 = fma(y, rl[kWaves * s + 1], t1);
         }
       }
+      part = fma(t0, r2[ec], part);
+      part = fma(t1, r2[ec + 1], part);
     }
     return part;
   }
 };
 
-constexpr int kLikeRows = 16;  // rows in flight in the point-major kernel and the wide K2, where the tail's latency is the launch's: N = 120
+constexpr int kLikeRows = 16;
+static_assert(kLikeSlack >= kWaves * kLikeRows + 2, "kLikeSlack: zeros behind the doubled residual (vk_kernel_like.h)");
+constexpr int kLikeRows_doc = 0;  // rows in flight in the point-major kernel and the wide K2, where the tail's latency is the launch's: N = 120
                                // (15 rows per wave) in ONE batch.  64 registers: affordable since those kernels lost their
                                // grid-stride loops (128 in all).  The cells kernel (96 registers, tail never latency-critical:
                                // it fuses batches of 24-512 points) keeps 4 in flight.
@@ -273,19 +284,32 @@ __device__ __forceinline__ void like_point_workgroup(const LikeArgs& a, long lon
   const double inf = __longlong_as_double(0x7ff0000000000000LL);
   const double t = pf.t;
   const int lo = pf.lo;
-  // residual against the (beta-interpolated) data vector, ccf_fit.py:166-193, 323
+  // residual against the (beta-interpolated) data vector, ccf_fit.py:166-193, 323 - stored twice, M = N rounded up to even
+  // places apart (LikePrefetch::quadratic reads r[(i + k) mod M] as r2[i + k]), with zeros behind (kLikeSlack)
+  const int M = (a.N + 1) & ~1;
   if (pf.data_in_regs) {
-    if (tid < a.N) th[tid] -= fma(fma(fma(pf.c[3], pf.db, pf.c[2]), pf.db, pf.c[1]), pf.db, pf.c[0]);
+    if (tid < a.N) {
+      const double v = th[tid] - fma(fma(fma(pf.c[3], pf.db, pf.c[2]), pf.db, pf.c[1]), pf.db, pf.c[0]);
+      th[tid] = v;
+      th[M + tid] = v;
+    }
   } else if (a.n_beta_d > 0) {
     const double* piece = a.data + (size_t)pf.k * a.N * 4;
     for (int e = tid; e < a.N; e += kBlock) {
       const double* c = piece + (size_t)e * 4;
-      th[e] -= fma(fma(fma(c[3], pf.db, c[2]), pf.db, c[1]), pf.db, c[0]);
+      const double v = th[e] - fma(fma(fma(c[3], pf.db, c[2]), pf.db, c[1]), pf.db, c[0]);
+      th[e] = v;
+      th[M + e] = v;
     }
   } else {
-    for (int e = tid; e < a.N; e += kBlock) th[e] -= a.data[e];
+    for (int e = tid; e < a.N; e += kBlock) {
+      const double v = th[e] - a.data[e];
+      th[e] = v;
+      th[M + e] = v;
+    }
   }
-  if ((a.N & 1) && tid == 0) th[a.N] = 0.0;            // the zero row / column that makes an odd N even (the slot exists: like_lds_doubles)
+  if ((a.N & 1) && tid == 0) th[a.N] = th[M + a.N] = 0.0;    // the zero row / column that makes an odd N even
+  if (tid >= kBlock - kLikeSlack) th[2 * M + (kBlock - 1 - tid)] = 0.0;     // (threads from the far end: the first N are busy above)
   __syncthreads();
   VK_LIKE_STAMP(a, 10);
   double sums[4] = {0.0, 0.0, 0.0, 0.0};               // chi2 share, log |factors|, negative factors, zero / NaN factors
@@ -327,7 +351,7 @@ __device__ __forceinline__ void like_point_workgroup(const LikeArgs& a, long lon
 __global__ __launch_bounds__(kBlock, 2) void vk_like_wide_kernel(LikeArgs a) {
   extern __shared__ double lds[];
   double* th = lds;
-  double* red = lds + ((a.N + 1) & ~1);
+  double* red = lds + like_red_off(a.N);
   {
     const long long point = blockIdx.x;               // one point per workgroup (the host launches n of them)
     if (point >= a.n) return;
