@@ -683,3 +683,30 @@ def test_plugin_stand_in_has_cobayas_shape():
     assert lk.params == defaults["params"] and lk.output_params == ["chi2_ccf_correct"]
     assert {"fsigma8", "beta", "epsilon", "aperp", "apar", "alpha"} <= set(lk.input_params)
     assert lk.get_can_provide_params() == ["fsigma8"]
+
+
+def test_quadratic_form_on_circular_diagonals_is_the_quadratic_form():
+    """The layout the fused tail reads (vk_kernel_like.h, built in vk_create): the precision matrix folded onto its upper
+    triangle, T_ii = P_ii, T_ij = P_ij + P_ji, stored by circular diagonals D_k[i] = T[i][(i + k) mod M] for k = 0 .. M/2 (the
+    last one for i < M/2 only), M = N rounded up to even.  Restated here in NumPy: every unordered pair appears exactly once
+    and sum_i r_i sum_k D_k[i] r_((i + k) mod M) is r.P.r - for even and odd N and an unsymmetric P."""
+    rng = np.random.default_rng(11)
+    for N in (60, 21, 135):
+        P = rng.standard_normal((N, N))
+        r = rng.standard_normal(N)
+        M = (N + 1) & ~1
+        Pm = np.zeros((M, M))
+        Pm[:N, :N] = P
+        rm = np.zeros(M)
+        rm[:N] = r
+        seen = np.zeros((M, M), dtype=int)
+        chi = 0.0
+        for k in range(M // 2 + 1):
+            n_i = M // 2 if k == M // 2 else M
+            for i in range(n_i):
+                j = (i + k) % M
+                d = Pm[i, i] if i == j else Pm[i, j] + Pm[j, i]
+                seen[min(i, j), max(i, j)] += 1
+                chi += d * rm[i] * rm[j]
+        assert np.array_equal(seen, np.triu(np.ones((M, M), dtype=int)))
+        assert abs(chi - r @ P @ r) <= 1e-12 * np.sum(np.abs(np.outer(r, r) * P))

@@ -61,7 +61,7 @@ def main():
         finally:
             if srv.poll() is None:
                 srv.kill()
-        print(f"split {split or 'default (1,4,4)':16s} single call {us:6.2f} us   chains: " +
+        print(f"split {split or 'default (1,4,2)':16s} single call {us:6.2f} us   chains: " +
               "  ".join(f"P={P} {r / 1e3:6.1f} k/s" for P, r in rates.items()), flush=True)
 
 
