@@ -54,6 +54,8 @@ def evaluate(rows):                       # stand-in for CCFFit.log_likelihood_b
 dist = Dist()
 dist.connect()
 assert dist.world == 2
+# a single-node job: RCCL's bootstrap sockets go over the loopback interface unless the user has chosen one (Dist.connect)
+assert os.environ["NCCL_SOCKET_IFNAME"] == os.environ.get("EXPECT_IFNAME", "lo")
 rng = np.random.default_rng(5)
 out = []
 for n in (1, 2, 9, 1000, 1001):
@@ -88,6 +90,9 @@ def test_two_rank_socket_gather(tmp_path):
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=port, OMP_NUM_THREADS="1")
+        env.pop("NCCL_SOCKET_IFNAME", None)
+        if rank == 1:                               # a user's own choice is left alone
+            env.update(NCCL_SOCKET_IFNAME="eth7", EXPECT_IFNAME="eth7")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]

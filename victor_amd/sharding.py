@@ -66,8 +66,14 @@ class Dist:
 
     def connect(self, where=None, timeout=120.0):
         """Meet the other ranks (a collective; no-op for a single rank)."""
-        from .rendezvous import SocketGroup
+        from .rendezvous import SocketGroup, endpoint
         if self.group is None:
+            where = where or endpoint()
+            # A single-node job (its ranks meet over a Unix socket): RCCL's bootstrap sockets - the only thing it uses the
+            # network for inside a node, the data travels over xGMI - go over the loopback interface unless the user has
+            # chosen one: always there, never filtered.  (RCCL's own default is the first other interface, e.g. a pod's veth.)
+            if where[0] == "unix" and self.world > 1:
+                os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
             self.group = SocketGroup(self.rank, self.world, where=where, timeout=timeout)
         return self
 
