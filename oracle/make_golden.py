@@ -31,6 +31,8 @@ Writes
     python oracle/make_golden.py --set more  # only the third one
     python oracle/make_golden.py --set disp  # only the fourth one: tests/golden/ref_outputs_disp.npz from
                                              # tests/golden/disp_worst_rows.json (see main_disp)
+    python oracle/make_golden.py --set box   # only the fifth one: tests/golden/ref_outputs_box.npz - 48 Halton points of the
+                                             # cobaya prior box (five parameters), BOSS, the four RSD models (see main_box)
 """
 
 import json
@@ -353,6 +355,42 @@ def main_disp():
     np.savez_compressed(os.path.join(GOLD, "ref_outputs_disp.npz"), **out)
 
 
+def halton5(n):
+    """tests/cases.py: halton_params(n, with_beta=True) - the prior box of boss_cobaya_config.yaml:51-97 with beta."""
+    h = halton(n, bases=(2, 3, 5, 7, 11))
+    return [dict(fsigma8=0.05 + 1.45 * a, sigma_v=100 + 400 * b, aperp=0.8 + 0.4 * c, apar=0.8 + 0.4 * d, beta=0.2 + 0.4 * e)
+            for a, b, c, d, e in h]
+
+
+def main_box():
+    """The reference over the whole prior box, not a handful of hand-picked points: 48 Halton points (five parameters, beta
+    sampled) on the BOSS configuration of config/boss_config.yaml, theory vector + (lnL, chi2) for the streaming, dispersion,
+    kaiser and euclid_special models.  ~1 minute of the reference."""
+    ref_shim.set_simpson_rule("simpson")
+    v = ref_shim.load()
+    model, data = boss_options("config")
+    model["dir"] = data["dir"] = GOLD
+    fit = v.CCFFit(model, data)
+    pts = halton5(48)
+    out = {"meta_json": np.array(json.dumps({"n": len(pts), "generator": "halton bases 2,3,5,7,11, skip 1 (tests/cases.py: "
+                                                                          "halton_params(48, with_beta=True))"}))}
+    import warnings
+    for rsd in ("streaming", "dispersion", "kaiser", "euclid_special"):
+        th, lnl, chi = [], [], []
+        for p in pts:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                th.append(fit.theory_multipole_vector(fit.s, dict(p), fit.poles_s, rsd_model=rsd))
+                l, c = fit.log_likelihood(dict(p), rsd_model=rsd)
+            lnl.append(l)
+            chi.append(c)
+        out[f"{rsd}_theory"] = np.array(th)
+        out[f"{rsd}_lnl"] = np.array(lnl)
+        out[f"{rsd}_chi2"] = np.array(chi)
+        print(rsd, "chi2 range", np.nanmin(chi), np.nanmax(chi), "non-finite rows", int(np.sum(~np.isfinite(chi))))
+    np.savez_compressed(os.path.join(GOLD, "ref_outputs_box.npz"), **out)
+
+
 def main():
     ref_shim.set_simpson_rule("simpson")
     v = ref_shim.load()
@@ -559,7 +597,7 @@ def main():
 if __name__ == "__main__":
     import argparse
     ap = argparse.ArgumentParser()
-    ap.add_argument("--set", choices=["all", "default", "avg", "more", "disp"], default="all")
+    ap.add_argument("--set", choices=["all", "default", "avg", "more", "disp", "box"], default="all")
     which = ap.parse_args().set
     if which in ("all", "default"):
         main()
@@ -569,3 +607,5 @@ if __name__ == "__main__":
         main_more()
     if which in ("all", "disp"):
         main_disp()
+    if which in ("all", "box"):
+        main_box()

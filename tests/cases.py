@@ -110,7 +110,8 @@ def golden_outputs(simpson_even="simpson"):
     """Reference outputs: ``'simpson'`` = the reference with SciPy >= 1.11's ``simps`` (the default rule of this repo),
     ``'avg'`` = with SciPy < 1.11's (oracle/make_golden.py --set avg); same inputs.  ``'more'`` = the remaining shipped
     combinations of model, data and covariance files (SHIPPED_COMBINATIONS; default rule)."""
-    name = {"simpson": "ref_outputs.npz", "avg": "ref_outputs_avg.npz", "more": "ref_outputs_more.npz"}[simpson_even]
+    name = {"simpson": "ref_outputs.npz", "avg": "ref_outputs_avg.npz", "more": "ref_outputs_more.npz",
+            "box": "ref_outputs_box.npz"}[simpson_even]       # 'box': 48 Halton points of the cobaya prior box, four RSD models
     g = np.load(os.path.join(GOLDEN, name))
     meta = json.loads(str(g["meta_json"]))
     return g, meta

@@ -838,3 +838,25 @@ def test_polling_handoff_gives_the_bits_of_the_counter_handoff(synth_fit, boss_f
             _native.set_knob("VICTOR_HIP_NO_POLL", None)
         assert polled == counted
         assert all(np.all(np.isfinite(np.asarray(v))) for v in polled)
+
+
+@pytest.mark.gpu
+def test_reference_outputs_over_the_prior_box(boss_fit):
+    """The reference itself on 48 Halton points of the cobaya prior box (tests/golden/ref_outputs_box.npz, five parameters
+    sampled, BOSS configuration), four RSD models: theory vectors, lnL and chi2 through the single-point call and the batch
+    call.  rtol 1e-9 (the contract is 1e-6)."""
+    g, meta = cases.golden_outputs("box")
+    fit = boss_fit["config"]
+    hp = cases.halton_params(meta["n"], with_beta=True)
+    for rsd in ("streaming", "dispersion", "kaiser", "euclid_special"):
+        lnl_b, chi_b = fit.log_likelihood_batch(hp, rsd_model=rsd)
+        assert np.max(np.abs(chi_b / g[f"{rsd}_chi2"] - 1)) <= RTOL, (rsd, float(np.max(np.abs(chi_b / g[f"{rsd}_chi2"] - 1))))
+        assert np.max(np.abs(lnl_b - g[f"{rsd}_lnl"]) / np.maximum(np.abs(g[f"{rsd}_lnl"]), 1.0)) <= RTOL, rsd
+        for i in range(meta["n"]):
+            p = cases.point(hp, i)
+            t = fit.theory_multipole_vector(fit.s, dict(p), fit.poles_s, rsd_model=rsd)
+            assert vec_close(t, g[f"{rsd}_theory"][i]), (rsd, i)
+            if i % 4 == 0:
+                lnl, chi2 = fit.log_likelihood(dict(p), rsd_model=rsd)
+                assert abs(chi2 - g[f"{rsd}_chi2"][i]) <= RTOL * g[f"{rsd}_chi2"][i], (rsd, i)
+                assert abs(lnl - g[f"{rsd}_lnl"][i]) <= RTOL * max(abs(g[f"{rsd}_lnl"][i]), 1.0), (rsd, i)

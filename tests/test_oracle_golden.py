@@ -241,3 +241,21 @@ def test_dispersion_model_where_it_is_ill_conditioned():
                 continue
             spread = float(g[f"{name}_spread_theory"][i])
             assert np.max(np.abs(t - ref)) <= max(1e-10, 20 * spread) * np.max(np.abs(ref)), (name, i)
+
+
+def test_oracle_reproduces_the_reference_over_the_prior_box(boss):
+    """tests/golden/ref_outputs_box.npz (oracle/make_golden.py --set box): the unmodified reference on 48 Halton points of the
+    cobaya prior box (fsigma8, sigma_v, aperp, apar and beta all sampled), BOSS configuration, for the streaming, dispersion,
+    kaiser and euclid_special models - theory vector, lnL and chi2.  The oracle must reproduce every one of them (a third of
+    the points here, all of them on the GPU: test_gpu_parity.py)."""
+    g, meta = cases.golden_outputs("box")
+    hp = cases.halton_params(meta["n"], with_beta=True)
+    for rsd in ("streaming", "dispersion", "kaiser", "euclid_special"):
+        for i in range(0, meta["n"], 3):
+            p = cases.point(hp, i)
+            t = boss.theory_multipole_vector(boss.s, dict(p), boss.poles_s, rsd_model=rsd)
+            lnl, chi = boss.log_likelihood(dict(p), rsd_model=rsd)
+            want = g[f"{rsd}_theory"][i]
+            assert np.max(np.abs(t - want)) <= TOL * np.max(np.abs(want)), (rsd, i)
+            assert abs(chi - g[f"{rsd}_chi2"][i]) <= 1e-11 * chi, (rsd, i)
+            assert abs(lnl - g[f"{rsd}_lnl"][i]) <= 1e-11 * max(abs(lnl), 1.0), (rsd, i)
