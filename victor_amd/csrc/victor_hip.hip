@@ -200,6 +200,7 @@ struct vk_ctx {
   int depth_mult = 1;                // joint fits: launches of this many contexts share the GPU (vk_joint_eval_device_async)
   hipEvent_t ev_joint = nullptr;
   std::map<int, double*> images;     // LDS images per (kernel kind, real-space multipoles, dispersion tables), built on first use
+  std::map<const void*, int> lds_opt_in;   // dynamic LDS above 64 KiB a kernel has been opted in for (launch_on_stream)
   const char* last_kernel = "none";  // theory kernel variant of the most recent launch
   bool last_fused = false;           // ... and whether it took the chi-square as well
   // scratch for the host-buffer entry points
@@ -351,8 +352,13 @@ int check_opts(vk_ctx* ctx, const vk_eval_opts* o) {
 // (gfx950 has 160 KiB per CU).
 template <typename Kern, typename Args>
 int launch_on_stream(vk_ctx* ctx, Kern kern, int grid, size_t lds, const Args& a) {
-  if (lds > 64 * 1024)
-    VK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (lds > 64 * 1024) {
+    int& granted = ctx->lds_opt_in[reinterpret_cast<const void*>(kern)];      // (the opt-in is per kernel and sticky: asked for once)
+    if ((int)lds > granted) {
+      VK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      granted = (int)lds;
+    }
+  }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, ctx->stream, a);
   VK_HIP(ctx, hipGetLastError());
   return VK_OK;
