@@ -15,7 +15,7 @@ for name, opts, beta in (("config3", cases.synth_options(3), False), ("boss", ca
     bufs = [eng.alloc(rows.size), eng.alloc(nmax), eng.alloc(nmax), eng.alloc(nmax * eng.n_data)]
     eng.upload(bufs[0], rows)
     _native.set_knob("VICTOR_HIP_MAPPING", "cells")
-    for batch in (1024, 8192, 65536):
+    for batch in ([int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else (1024, 8192, 65536)):
         line = f"{name} cells kernel, batch {batch:6d}:"
         for rnd in range(2):
             for tag, knob in (("two launches", {"VICTOR_HIP_NO_FUSE": "1"}), ("fused", {"VICTOR_HIP_FUSE_MAX": "10000000"})):
