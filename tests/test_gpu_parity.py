@@ -822,7 +822,7 @@ def test_polling_handoff_gives_the_bits_of_the_counter_handoff(synth_fit, boss_f
 
         def run():
             out = [fit.log_likelihood(p) for p in pts]                      # one point per call, 24 times over
-            for n in (2, 3, 5):                                             # small batches (split planes, several points)
+            for n in (2, 3, 5, 8):                                          # small batches (split planes, several points)
                 sub = {k: v[:n] for k, v in hp.items()}
                 out.append(tuple(np.concatenate(fit.log_likelihood_batch(sub)).tolist()))
                 out.append(fit.log_likelihood(pts[n]))                      # ... and a single point right behind each

@@ -808,9 +808,11 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
     const long long items = a.n * groups * a.parts;
     const int grid = (int)items;                                            // one item per workgroup, always (vk_kernel_fast.h)
     // Hand-off by polling instead of the completion counters (vk_common.h: kPollEmpty): launches of a few points whose
-    // workgroups are all resident at once (two per CU fit whatever the tables' size) - one point per call and the mailbox
-    // server's launches.  Same partial sums, added in the same order: the results do not change by a bit.
-    if (a.parts > 1 && a.n <= kPollPoints && items <= 2LL * ctx->n_cu && ctx->d_poll && !ctx->knobs.no_poll &&
+    // workgroups are all resident at once - one point per call and the mailbox server's launches.  Same partial sums, added in the same order: the results do not change by a bit.
+    // (resident at once: the kernel's launch bounds give the streaming instantiations three workgroups per CU, the others two,
+    // if their LDS fits as often)
+    const long long per_cu = std::min<long long>((a.rsd == VK_RSD_STREAMING && !sva && !a.from_data) ? 3 : 2, (160 * 1024) / (long long)(lds ? lds : 1));
+    if (a.parts > 1 && a.n <= kPollPoints && items <= per_cu * ctx->n_cu && ctx->d_poll && !ctx->knobs.no_poll &&
         (size_t)a.n * a.n_s * kMaxParts * kMaxEll <= ctx->poll_doubles) {
       a.poll = 1;
       a.partial = ctx->d_poll;
