@@ -746,11 +746,12 @@ def test_quadratic_form_for_other_sizes_of_the_data_vector(tmp_path, oracle):
     """The fused tail and the wide K2 take chi2 on the precision matrix folded onto its upper triangle and stored by circular
     diagonals, the residual twice over in LDS (vk_kernel_like.h): N = 120 and 60 are the shipped sizes; here N = 135 (odd: a
     zero row and column make it even; more than 64 entry pairs per row: two chunks of lanes), N = 150 (even, two chunks) and
-    N = 21 (odd, fewer rows than waves x rows in flight: the zeros behind the doubled residual are read) against the oracle,
-    through the single-point call, a fused small batch and a large batch (tiled K2)."""
+    N = 21 (odd, fewer rows than waves x rows in flight: the zeros behind the doubled residual are read) and N = 270 (more
+    entries than threads: the data vector no longer sits in registers, three chunks of lanes, several batches of rows per
+    wave) against the oracle, through the single-point call, a fused small batch and a large batch (tiled K2)."""
     import victor_amd
     rng = np.random.default_rng(7)
-    for n_s, poles in ((45, 3), (50, 3), (7, 3)):
+    for n_s, poles in ((45, 3), (50, 3), (7, 3), (90, 3)):
         N = n_s * poles
         s = np.linspace(3.0, 115.0, n_s)
         data = {"s": s}
