@@ -50,7 +50,7 @@ def cpu_worker(args):
     warnings.filterwarnings("ignore")
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import victor_oracle as vo
-    from tests import cases
+    import workloads as cases
     model, data = cases.synth_options(CONFIG)
     model["numerics"] = {"simpson_even": rule}
     fit = vo.OracleFit(model, data)
@@ -75,7 +75,7 @@ def chain_worker(idx, n_chains, seconds, broker, barrier, queue):
             os.environ.pop("VICTOR_HIP_BROKER", None)
         sys.path.insert(0, os.path.join(ROOT, "victor", "likelihoods"))
         from CCFLikelihood import CCFLikelihood
-        from tests import cases
+        import workloads as cases
         info = cases.cobaya_info()["likelihood"]["CCFLikelihood"]
         lk = CCFLikelihood({"model": info["model"], "data": info["data"]})
         h = cases.halton(4096 + 64 * idx, bases=(2, 3, 5, 7))[64 * idx:]         # every chain its own points of the prior box
@@ -285,7 +285,7 @@ def boss_measurement(args, batch=16384, steps=20):
     (config/boss_config.yaml: 30 s bins x 100 mu x 50 v, l = 0,2, reconstruction-beta dependent tables, data and
     covariance, Sellentin-Heavens likelihood).  Inputs resident in HBM; same timing discipline as the main line."""
     import victor_amd
-    from tests import cases
+    import workloads as cases
     fit = victor_amd.CCFFit(*cases.boss_options("config"))
     eng = fit._get_engine()
     opts = eng.make_opts(fit.model, fit.fit_options)
@@ -320,7 +320,7 @@ def batch_sweep():
     """evals/s with inputs resident in HBM at the batch sizes SURVEY.md 8(d) asks for: BASELINE config [1]
     (batch 1024, isotropic xi_r, l = 0,2) and the metric grid (config 3) at batch 1, 64 and 1024."""
     import victor_amd
-    from tests import cases
+    import workloads as cases
     res = {}
     for config, batches in ((2, (1024,)), (3, (1, 64, 1024))):
         fit = victor_amd.CCFFit(*cases.synth_options(config))
@@ -347,8 +347,9 @@ def batch_sweep():
 def api_latency():
     """Wall-clock of the reference's calling convention - one parameter point per call (CCFLikelihood.py:32-39) - through the
     Python API, host buffers in and out, and the PCIe-inclusive rate of a full host-buffer batch."""
+    import numpy as np
     import victor_amd
-    from tests import cases
+    import workloads as cases
     res = {}
     for name, opts, beta in (("config3", cases.synth_options(CONFIG), False), ("boss_cmass", cases.boss_options("config"), True)):
         fit = victor_amd.CCFFit(*opts)
@@ -368,9 +369,26 @@ def api_latency():
         for _ in range(5):
             fit.log_likelihood_batch(rows)
         full = (time.perf_counter() - t0) / 5
+        # CCFModel.theory_xi (ccf_model.py:538-563), the public face of the integrand: xi^s on the fit's own (s, 100 mu) grid for
+        # one point and for 1024 (host buffers in, [n][100][n_s] out), and the kernel that served it
+        mu = np.linspace(0, 1, 100)
+        for _ in range(20):
+            fit.theory_xi(fit.s, mu, p)
+        t0 = time.perf_counter()
+        for _ in range(200):
+            fit.theory_xi(fit.s, mu, p)
+        xi_one = (time.perf_counter() - t0) / 200
+        sub = {k: v[:1024] for k, v in hp.items()}
+        fit.theory_xi_batch(fit.s, mu, sub)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            fit.theory_xi_batch(fit.s, mu, sub)
+        xi_1024 = (time.perf_counter() - t0) / 5
         res[name] = {"log_likelihood_single_point_us": single * 1e6,
                      "log_likelihood_batch_65536_host_buffers_ms": full * 1e3,
-                     "host_buffer_evals_per_s": BATCH_PER_GPU / full}
+                     "host_buffer_evals_per_s": BATCH_PER_GPU / full,
+                     "theory_xi_single_point_us": xi_one * 1e6, "theory_xi_1024_points_ms": xi_1024 * 1e3,
+                     "theory_xi_kernel": fit._get_engine().last_kernel()}
     return res
 
 
@@ -381,7 +399,7 @@ def walker_rates(steps=150):
     process (runtime, code object, tables) is timed apart."""
     import victor_amd
     from victor_amd.sampler import EnsembleMetropolis, parse_cobaya_params
-    from tests import cases
+    import workloads as cases
     info = cases.cobaya_info()
     lk = info["likelihood"]["CCFLikelihood"]
     cwd = os.getcwd()
@@ -412,7 +430,7 @@ def option_rates(batch=16384, steps=4):
     configuration (and the measured real-space ccf with the model + data covariance), resident, batch 16384 - evals/s and the
     theory kernel that served them."""
     import victor_amd
-    from tests import cases
+    import workloads as cases
     res = {}
 
     def run(fit, label, **kw):
@@ -452,7 +470,7 @@ def dsplit_measurement(batch=16384, steps=10):
     import numpy as np
     import victor_amd
     from victor_amd.joint import JointFit
-    from tests import cases
+    import workloads as cases
     joint = JointFit([victor_amd.CCFFit(*cases.dsplit_options(q)) for q in range(5)])
     engines, opts = joint._plan({})
     rows = joint.fits[0]._fit_rows(cases.halton_params(batch), joint.fits[0].model)
@@ -502,6 +520,211 @@ class Slot:
                 self.eng.free(p)
 
 
+def make_gather(dist, engines, launched, d_send, d_recv, n):
+    """Build the all-gather for the engines this process drives (victor_amd/sharding.py: DeviceGather) and run the first
+    collective - it builds RCCL's rings and logs - with stdout routed to stderr.  A rendezvous that never completes is fatal."""
+    from victor_amd import _native
+    from victor_amd.sharding import DeviceGather
+    os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")   # RCCL logs go to stdout by default; stdout is the JSON line's
+    with stdout_to_stderr():
+        try:
+            g = DeviceGather(dist, engines, launched, log=lambda msg: print(msg, file=sys.stderr))
+        except _native.CommInitTimeout as exc:   # a thread is stuck inside RCCL on this context: fatal, no fallback
+            print(f"rank {dist.rank}: {exc}", file=sys.stderr)
+            sys.stderr.flush()
+            os._exit(4)
+        if g.mode in ("rank", "group"):
+            failed = False
+            try:
+                g(d_send, d_recv, n)
+                for e in engines:
+                    e.sync()
+            except Exception as exc:       # noqa: BLE001
+                print(f"rank {dist.rank}: first RCCL all-gather failed ({exc})", file=sys.stderr)
+                failed = True
+            g.degrade(failed)
+    return g
+
+
+def timed_steps(dist, engines, step, steps):
+    """``steps`` calls of ``step()`` bracketed by a synchronisation of every engine and a barrier on both sides; the MAX over
+    the ranks of the elapsed seconds."""
+    for e in engines:
+        e.sync()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    for e in engines:
+        e.sync()
+    dist.barrier()
+    return dist.max_float(time.perf_counter() - t0)
+
+
+def dsplit_sharded(dist, launched, n_local, n_dev, total, steps, warmup, global_batch=16384):
+    """BASELINE config 5 on N GPUs: the density-split joint fit (five table sets sharing one parameter batch, block-diagonal
+    covariance, N = 5 x 120) with its GLOBAL batch of 16384 Halton points sharded over the GPUs - rank g evaluates rows
+    [g B/N, (g+1) B/N) on its five contexts (vk_joint_eval_device_async: the blocks on their own streams, sums on the device) -
+    and one all-gather of the joint lnL per step on the lead context's stream, no host synchronisation in between."""
+    import numpy as np
+    import workloads as cases
+    import victor_amd
+    from victor_amd.joint import JointFit
+    rank = dist.rank
+    Bs = max(1, global_batch // total)
+    hp_all = cases.halton_params(Bs * total)
+    js = []
+    for i in range(n_local):
+        g = rank * n_local + i
+        device = (dist.local_rank if launched else i) % n_dev
+        joint = JointFit([victor_amd.CCFFit(*cases.dsplit_options(q), device=device) for q in range(5)])
+        engines, opts = joint._plan({})
+        mine = {k: v[g * Bs:(g + 1) * Bs] for k, v in hp_all.items()}
+        _, (d_rows, d_out, d_ws) = joint._device_buffers(engines, Bs)
+        lead = engines[0]
+        lead.upload(d_rows, joint.fits[0]._fit_rows(mine, joint.fits[0].model))
+        js.append({"g": g, "joint": joint, "engines": engines, "opts": opts, "lead": lead, "d_rows": d_rows, "d_out": d_out,
+                   "d_chi": d_out + 8 * Bs, "d_ws": d_ws, "d_all": lead.alloc(Bs * total)})
+    leads = [j["lead"] for j in js]
+    gat = make_gather(dist, leads, launched, [j["d_out"] for j in js], [j["d_all"] for j in js], Bs)
+
+    def step():
+        for j in js:
+            j["joint"].eval_device_async(j["engines"], j["opts"], j["d_rows"], Bs, j["d_out"], j["d_chi"], j["d_ws"])
+        gat([j["d_out"] for j in js], [j["d_all"] for j in js], Bs)
+
+    warm_up(leads[0], step, 0.2)
+    for _ in range(warmup):
+        step()
+    el = timed_steps(dist, leads, step, steps)
+    # every GPU checks the WHOLE gathered vector: its own shard bit for bit, rows of every other shard against its own evaluation
+    good = True
+    for j in js:
+        mine_l = j["lead"].download(j["d_out"], Bs)
+        gathered = j["lead"].download(j["d_all"], Bs * total)
+        good = good and bool(np.array_equal(gathered[j["g"] * Bs:(j["g"] + 1) * Bs], mine_l)) and bool(np.all(np.isfinite(gathered)))
+        probe = np.unique(np.linspace(0, Bs - 1, 4).astype(int))
+        for other in range(total):
+            if other == j["g"]:
+                continue
+            theirs = {k: v[other * Bs + probe] for k, v in hp_all.items()}
+            own_l, _ = j["joint"].log_likelihood_batch(theirs)
+            good = good and bool(np.max(np.abs(gathered[other * Bs + probe] - own_l)) <= 1e-9 * np.max(np.abs(own_l)))
+    good = bool(dist.min_float(1.0 if good else 0.0))
+    kernel = leads[0].last_kernel()
+    gat.close()
+    for j in js:
+        j["lead"].free(j["d_all"])
+    return {"workload": "BASELINE config 5: density-split joint fit, 5 table sets x N = 120, block-diagonal covariance",
+            "global_batch": Bs * total, "batch_per_gpu": Bs, "blocks": 5, "steps": steps,
+            "joint_evals_per_s": Bs * total * steps / el, "block_evals_per_s": 5 * Bs * total * steps / el,
+            "ms_per_step": 1e3 * el / steps, "scaling": "strong", "kernel": kernel, "gather": gat.NAMES[gat.mode],
+            "collectives_per_step": 0 if gat.mode == "none" else 1, "gather_matches_local": good}
+
+
+def walkers_distributed(dist, launched, n_local, n_dev, total, walkers=8, steps=640):
+    """BASELINE config 4 on N GPUs: 8 Metropolis walkers per GPU on config/boss_cobaya_config.yaml.  One process per GPU (the
+    driver's layout; the reference's own scale-out is N chains under mpirun, README.md:30): every rank advances its own walkers
+    on its own GPU and the ranks exchange the log-likelihoods of a 64-step block in ONE RCCL all-gather
+    (victor_amd/sampler.py: DistributedEnsemble) - timed with that gather and, beside it, without any.  One process driving all
+    GPUs: a single ensemble of 8 N walkers whose proposals are sharded over the devices, gathered on the GPUs every step."""
+    import numpy as np
+    import workloads as cases
+    import victor_amd
+    from victor_amd import _native
+    from victor_amd.sampler import DistributedEnsemble, EnsembleMetropolis, parse_cobaya_params
+    from victor_amd.sharding import MultiGPUFit, RcclGather
+    info = cases.cobaya_info()
+    lk = info["likelihood"]["CCFLikelihood"]
+    specs, fixed = parse_cobaya_params(info["params"])
+    cwd = os.getcwd()
+    os.chdir(ROOT)                       # the data paths in the config are relative to the repository root
+    try:
+        if launched:
+            fit = victor_amd.CCFFit(lk["model"], lk["data"], device=dist.local_rank % n_dev)
+        else:
+            multi = MultiGPUFit(lk["model"], lk["data"], devices=[i % n_dev for i in range(n_local)])
+    finally:
+        os.chdir(cwd)
+    out = {"workload": "BASELINE config 4: Metropolis walkers on config/boss_cobaya_config.yaml, host proposals",
+           "walkers_per_gpu": walkers, "walkers_total": walkers * total, "steps": steps}
+    if not launched:
+        with stdout_to_stderr():
+            rccl = multi.enable_rccl()
+        ens = EnsembleMetropolis(multi.log_likelihood_gathered, specs, walkers * total, seed=1, fixed=fixed)
+        ens.initialise()
+        t_end = time.perf_counter() + 0.4
+        while time.perf_counter() < t_end:
+            ens.run(10)
+        e0 = ens.n_evals
+        t0 = time.perf_counter()
+        ens.run(steps)
+        dt = time.perf_counter() - t0
+        multi.close()
+        out.update({"layout": "one process, one ensemble sharded over the devices, grouped all-gather every step",
+                    "gather": "rccl (grouped)" if rccl else "host", "evals_per_s": (ens.n_evals - e0) / dt,
+                    "us_per_step": 1e6 * dt / steps, "acceptance": ens.acceptance, "gather_matches_local": None})
+        return out
+    engine = fit._get_engine()
+    block = EnsembleMetropolis.BLOCK
+    gather, ok = None, 1.0
+    with stdout_to_stderr():
+        try:
+            gather = RcclGather(engine, dist, walkers * block)
+        except _native.CommInitTimeout as exc:
+            print(f"rank {dist.rank}: {exc}", file=sys.stderr)
+            sys.stderr.flush()
+            os._exit(4)
+        except Exception as exc:       # noqa: BLE001 - every rank must take the same branch
+            print(f"rank {dist.rank}: RCCL gather unavailable ({exc}); using the socket group", file=sys.stderr)
+            ok = 0.0
+        if dist.min_float(ok) == 0.0:
+            if gather is not None:
+                gather.close()
+            gather = None
+
+    def evaluate(batch):
+        return fit.log_likelihood_batch(batch)[0]
+
+    # the check first, on fresh chains: this rank's slice of the gathered history is its own history bit for bit, and the next
+    # rank's slice is the chain this rank gets when it runs that rank's walkers (same seed) itself
+    chk = DistributedEnsemble(evaluate, specs, walkers, dist, seed=1, fixed=fixed, gather=gather, fit=fit, gather_block=block)
+    n_chk = 2 * block
+    _, lnl_own, all_chk = chk.run(n_chk)
+    good = bool(np.array_equal(all_chk[:, dist.rank * walkers:(dist.rank + 1) * walkers], lnl_own)) and chk.n_collectives == 2
+    other = (dist.rank + 1) % dist.world
+    twin = EnsembleMetropolis(evaluate, specs, walkers, seed=1 + 7919 * other, fixed=fixed, fit=fit)
+    _, lnl_twin = twin.run(n_chk)
+    theirs = all_chk[:, other * walkers:(other + 1) * walkers]
+    good = good and bool(np.all(np.abs(theirs - lnl_twin) <= 1e-9 * np.abs(lnl_twin)))
+    good = bool(dist.min_float(1.0 if good else 0.0))
+    # timing: the same ensemble, first without any gather, then with the block gather
+    ens = chk
+    t_end = time.perf_counter() + 0.4
+    while time.perf_counter() < t_end:
+        ens.local.run(10)
+    dist.barrier()
+    t0 = time.perf_counter()
+    ens.local.run(steps)
+    dt_plain = dist.max_float(time.perf_counter() - t0)
+    c0, e0 = ens.n_collectives, ens.local.n_evals
+    dist.barrier()
+    t0 = time.perf_counter()
+    ens.run(steps)
+    dist.barrier()
+    dt = dist.max_float(time.perf_counter() - t0)
+    evals = dist.allgather_host(np.array([float(ens.local.n_evals - e0)]), 1).sum()
+    out.update({"layout": "one process per GPU, independent walkers, block gather of lnL",
+                "gather": "rccl" if gather is not None else "host (socket group)", "gather_block": block,
+                "collectives": ens.n_collectives - c0, "collectives_per_step": (ens.n_collectives - c0) / steps,
+                "evals_per_s": float(evals) / dt, "us_per_step": 1e6 * dt / steps,
+                "us_per_step_without_gather": 1e6 * dt_plain / steps, "gather_cost_ratio": dt / dt_plain,
+                "acceptance": ens.local.acceptance, "gather_matches_local": good})
+    if gather is not None:
+        gather.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -540,7 +763,7 @@ def main():
     import victor_amd  # noqa: F401
     from victor_amd.build import build_native
     from victor_amd.engine import Engine
-    from tests import cases
+    import workloads as cases
     if rank == 0:
         build_native()
     dist.barrier()
@@ -578,62 +801,13 @@ def main():
     fit, eng = lead.fit, lead.eng
     N = eng.n_data
 
-    # the gather: "rank" = one communicator per process, "group" = one process, grouped calls, "host" = degraded mode
-    # (RCCL unavailable or refused), "none" = a single GPU started without a launcher
-    gather = "none"
-    if total > 1 or launched:
-        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")   # RCCL logs go to stdout by default; stdout is the JSON line's
-        with stdout_to_stderr():
-            rccl_ok = 1.0
-            try:
-                if launched:
-                    from victor_amd.sharding import one_device_per_rank
-                    if not one_device_per_rank(dist, eng):
-                        raise RuntimeError("two ranks share a GPU: RCCL needs one device per rank")
-                    try:
-                        uid = eng.comm_unique_id() if rank == 0 else None
-                    except Exception as exc:                # librccl missing: every rank must learn about it
-                        print(f"rank {rank}: RCCL unavailable ({exc})", file=sys.stderr)
-                        uid, rccl_ok = bytes(128), 0.0
-                    uid = dist.broadcast_bytes(uid, src=0, nbytes=128)
-                    rccl_ok = dist.min_float(rccl_ok)
-                    if rccl_ok:
-                        try:
-                            eng.comm_init(uid, rank, world)
-                        except _native.CommInitTimeout as exc:   # a thread is stuck inside RCCL on this context: fatal, no fallback
-                            print(f"rank {rank}: {exc}", file=sys.stderr)
-                            sys.stderr.flush()
-                            os._exit(4)
-                        except Exception as exc:
-                            print(f"rank {rank}: ncclCommInitRank failed ({exc})", file=sys.stderr)
-                            rccl_ok = 0.0
-                        rccl_ok = dist.min_float(rccl_ok)    # no collective before every rank holds a communicator
-                        if rccl_ok:
-                            eng.comm_allgather_async(lead.d_lnl, lead.d_all, B)   # first collective builds the rings (and logs) here
-                            eng.sync()
-                else:
-                    Engine.comm_init_all(engines)
-                    Engine.comm_allgather_group_async(engines, [s.d_lnl for s in slots], [s.d_all for s in slots], B)
-                    for e in engines:
-                        e.sync()
-            except Exception as exc:
-                print(f"rank {rank}: RCCL communicator failed ({exc})", file=sys.stderr)
-                rccl_ok = 0.0
-            rccl_ok = dist.min_float(rccl_ok)
-        gather = ("rank" if launched else "group") if rccl_ok else "host"
-
-    state = {}
+    # the gather (victor_amd/sharding.py: DeviceGather): "rank" = one communicator per process, "group" = one process, grouped
+    # calls, "host" = degraded mode (RCCL unavailable or refused), "none" = a single GPU started without a launcher
+    gatherer = make_gather(dist, engines, launched, [s.d_lnl for s in slots], [s.d_all for s in slots], B)
+    gather = gatherer.mode
 
     def gather_step(n):
-        if gather == "rank":
-            eng.comm_allgather_async(lead.d_lnl, lead.d_all, n)
-        elif gather == "group":
-            Engine.comm_allgather_group_async(engines, [s.d_lnl for s in slots], [s.d_all for s in slots], n)
-        elif gather == "host":
-            for e in engines:
-                e.sync()
-            local = np.concatenate([s.eng.download(s.d_lnl, n) for s in slots])
-            state["gathered"] = dist.allgather_host(local, len(local)) if launched else local
+        gatherer([s.d_lnl for s in slots], [s.d_all for s in slots], n)
 
     def step(n=B):
         for s in slots:
@@ -684,7 +858,7 @@ def main():
         ok = ok and bool(np.all(np.isfinite(mine_l)) and np.all(s.eng.download(s.d_chi, B) > 0))
         if gather == "none":
             continue
-        gathered = s.eng.download(s.d_all, B * total) if gather in ("rank", "group") else state["gathered"]
+        gathered = s.eng.download(s.d_all, B * total)
         good = good and bool(np.array_equal(gathered[s.g * B:(s.g + 1) * B], mine_l)) and bool(np.all(np.isfinite(gathered)))
         probe = np.unique(np.linspace(0, B - 1, 6).astype(int))
         for other in range(total):
@@ -713,6 +887,18 @@ def main():
         strong = {"global_batch": Bs * total, "batch_per_gpu": Bs, "value": Bs * total * args.steps / el_s, "unit": "evals/s",
                   "ms_per_step": 1e3 * el_s / args.steps, "scaling": "strong", "kernel": eng.last_kernel(),
                   "theory_kernel_ms_per_rank": ks}
+
+    # BASELINE configs 4 and 5 at N > 1: the density-split joint fit with its global batch of 16384 sharded over the GPUs, and
+    # 8 Metropolis walkers per GPU on the BOSS cobaya configuration with the block gather of their log-likelihoods
+    dsplit_n = walkers_n = None
+    if total > 1 and not args.no_boss:
+        comm_info = _native.comm_info() if rank == 0 else None
+        gatherer.close()                      # one communicator at a time: every leg builds its own on its own contexts
+        for s_ in slots:
+            s_.free()
+        slots = []
+        dsplit_n = dsplit_sharded(dist, launched, n_local, n_dev, total, args.steps, max(args.warmup, 1))
+        walkers_n = walkers_distributed(dist, launched, n_local, n_dev, total)
 
     if rank == 0:
         value = B * total * args.steps / elapsed
@@ -756,10 +942,13 @@ def main():
         if gathered_ok is not None:
             out["gather_matches_local"] = gathered_ok       # every rank, every slot (see above)
         if kernel_ms_ranks is not None:
-            out["config"]["rccl"] = _native.comm_info()
+            out["config"]["rccl"] = comm_info if total > 1 and not args.no_boss else _native.comm_info()
             out["theory_kernel_ms_per_rank"] = kernel_ms_ranks
         if strong is not None:
             out["strong_scaling"] = strong
+        if dsplit_n is not None:
+            out["dsplit5"] = dsplit_n
+            out["walker_ensembles"] = walkers_n
         if total == 1 and not args.no_boss:
             out["boss_cmass"] = boss_measurement(args)
             out["batch_sweep"] = batch_sweep()
@@ -791,14 +980,13 @@ def main():
             out["max_rel_dxi_ell_vs_oracle"] = float(dxi.max())      # relative to max|xi_l| of each multipole
         print(json.dumps(out))
 
-    if gather in ("rank", "group"):
-        for e in engines:
-            e.comm_destroy()
+    gatherer.close()
     for s_ in slots:
         s_.free()
     dist.barrier()
     dist.close()
-    if not ok or gathered_ok is False:
+    legs_ok = all(leg is None or leg.get("gather_matches_local") is not False for leg in (dsplit_n, walkers_n))
+    if not ok or gathered_ok is False or not legs_ok:
         sys.exit(1)
 
 

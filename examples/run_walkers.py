@@ -5,9 +5,9 @@ Single GPU:      python examples/run_walkers.py --steps 200
 Several GPUs:    python examples/run_walkers.py --gpus 8 --steps 200          (one process, one context per GPU)
              or  mpirun -n 8 python examples/run_walkers.py --steps 200      (one process per GPU; also srun, torchrun)
 
-One process per GPU: every rank drives its own walkers on its own GPU (likelihood batches through libvictor_hip.so); after
-each step the log-likelihoods of all walkers are all-gathered over RCCL so that every rank can monitor the whole ensemble;
-the ranks find each other through a standard-library socket group (victor_amd/rendezvous.py: MASTER_ADDR / MASTER_PORT or
+One process per GPU: every rank drives its own walkers on its own GPU (likelihood batches through libvictor_hip.so); the
+log-likelihoods of all walkers are all-gathered over RCCL - one collective per block of 64 steps, the walkers never read it -
+so that every rank can monitor the whole ensemble; the ranks find each other through a standard-library socket group (victor_amd/rendezvous.py: MASTER_ADDR / MASTER_PORT or
 VICTOR_RDZV), no torch and no MPI binding.  One process for all GPUs: a single ensemble of gpus x walkers walkers whose
 proposals are sharded over the devices, the log-likelihoods all-gathered on the GPUs by a grouped RCCL call.
 Priors, starting distributions and proposal widths come from config/boss_cobaya_config.yaml, the file cobaya itself
@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1, help="GPUs driven by THIS process (ignored under a launcher: one per rank)")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--gather-block", type=int, default=64,
+                    help="steps whose log-likelihoods are exchanged in one collective (1 = a blocking gather after every step)")
     ap.add_argument("--sampler", choices=["metropolis", "stretch"], default="metropolis",
                     help="random-walk Metropolis walkers, or the affine-invariant stretch-move ensemble")
     args = ap.parse_args()
@@ -64,7 +66,7 @@ def main():
         if not multi.enable_rccl():
             print(f"RCCL gather unavailable ({multi._rccl_error}); gathering through the host", file=sys.stderr)
         ens = DistributedEnsemble(multi.log_likelihood_gathered, specs, args.walkers * args.gpus, dist, seed=args.seed,
-                                  fixed=fixed, sampler=sampler)
+                                  fixed=fixed, sampler=sampler, gather_block=args.gather_block)
         gather_name = "rccl (grouped, one process)" if multi._rccl else "host"
     else:
         from victor_amd import _native
@@ -76,7 +78,7 @@ def main():
         if dist.world > 1:
             ok = 1.0
             try:
-                gather = RcclGather(engine, dist, args.walkers)
+                gather = RcclGather(engine, dist, args.walkers * args.gather_block)
             except _native.CommInitTimeout as exc:                     # a thread is stuck inside RCCL on this context: fatal
                 print(f"rank {dist.rank}: {exc}", file=sys.stderr)
                 sys.stderr.flush()
@@ -89,7 +91,8 @@ def main():
                     gather.close()
                 gather = None
         ens = DistributedEnsemble(lambda batch: fit.log_likelihood_batch(batch)[0], specs, args.walkers, dist,
-                                  seed=args.seed, fixed=fixed, gather=gather, sampler=sampler, fit=fit)
+                                  seed=args.seed, fixed=fixed, gather=gather, sampler=sampler, fit=fit,
+                                  gather_block=args.gather_block)
         gather_name = "rccl" if gather is not None else "host"
     # the first evaluation of a process pays for the HIP runtime, the code object and the device tables (~0.25 s): timed apart
     t0 = time.perf_counter()
@@ -113,8 +116,8 @@ def main():
             "max_Rminus1": float(np.max(gelman_rubin(chain[burn:]))),
             "mean": dict(zip(ens.local.names, chain[burn:].mean(axis=(0, 1)).round(4).tolist())),
             "best_lnl_over_all_ranks": float(all_lnl.max()),
-            "gathered_shape": list(all_lnl.shape),
-            "gather": gather_name}))
+            "gathered_shape": list(all_lnl.shape), "gathered_sum": float(all_lnl.sum()),
+            "gather": gather_name, "gather_block": ens.gather_block, "collectives": ens.n_collectives}))
     dist.barrier()
     dist.close()
 

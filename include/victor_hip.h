@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 16
+#define VK_ABI_VERSION 17
 
 /* error codes */
 #define VK_OK 0
@@ -224,6 +224,32 @@ int vk_device_count(void);
  * changing one in a running process and every context re-reads them at its next entry point. */
 void vk_knobs_refresh(void);
 
+/* ---- the polling hand-off's launch rule (pure functions: no context, no GPU) -----------------------------------------------
+ * Launches of at most 8 points whose (mu, v) planes are split over workgroups - one point per call, the reference's calling
+ * convention (CCFLikelihood.py:32-39), the mailbox server's launches, the half-ensembles of victor_amd/sampler.py - may hand
+ * their partial sums over by POLLING: the workgroup of a point's last work item waits, resident, for the other workgroups'
+ * sums.  Waiting workgroups are harmless as long as they can never hold ALL workgroup slots of an XCD while the workgroups
+ * they wait for are not placed yet.  The rule that guarantees it:
+ *   - a launch polls only if at least two of its workgroups fit on a CU, so an XCD (32 CUs) offers 64 slots at least, if it
+ *     fits on the chip at once, and if its context holds a reservation for its points (one waiter per point);
+ *   - a context reserves on demand, up to 8 waiters, out of a budget of 32 per PROCESS (enforced here; a context's launches
+ *     are stream-ordered, so its reservation bounds what it has resident); without reservation the launch hands over through
+ *     completion counters - the same sums in the same order, bit-identical results, ~1.2 us slower;
+ *   - across processes the library cannot count: the OPERATOR keeps the sum of the budgets in use on one GPU below 64 - one
+ *     process with the full budget (the GPU owner, victor_amd/broker.py: 4 contexts x 8 requests) plus up to 31 processes
+ *     that evaluate one point per call in one context, or up to 63 such processes (vk_poll_budget returns 1: the number of
+ *     full-budget processes per device).
+ * Failure mode if the rule is broken (or a launch is lost): a waiting workgroup gives up after 5 s of wall clock, the call -
+ * or, for enqueued work, the next call / vk_sync on that context - returns VK_E_HIP ("waited ... for partial sums that never
+ * arrived") and the context stays unusable: destroy it and create a new one.  No result of such a launch is delivered.
+ * vk_poll_rule: 1 when a launch of `n_points` points, `parts` workgroups per plane and `workgroups` workgroups in all, of
+ * which `workgroups_per_cu` fit on a CU of a device with `n_cu` CUs, polls under a context reservation of `reserved` waiters.
+ * vk_poll_grant: how many MORE waiters a context holding `ctx_reserved` is granted when it wants `want` and the process has
+ * `process_reserved` reserved in all (0 or want - ctx_reserved: all or nothing). */
+int32_t vk_poll_rule(int64_t n_points, int32_t parts, int64_t workgroups, int32_t workgroups_per_cu, int32_t n_cu, int32_t reserved);
+int32_t vk_poll_grant(int32_t process_reserved, int32_t ctx_reserved, int32_t want);
+int32_t vk_poll_budget(int32_t* per_process, int32_t* xcd_slots);
+
 /* Copies every table to `device`.  On failure returns NULL and writes a message to err. */
 vk_ctx* vk_create(const vk_tables* tables, int device, char* err, size_t errlen);
 void vk_destroy(vk_ctx* ctx);
@@ -232,6 +258,8 @@ const char* vk_last_error(const vk_ctx* ctx);
 const char* vk_last_kernel(const vk_ctx* ctx);
 /* 1 when that launch also took the chi-square / log-likelihood (fused tail), 0 when K2 ran as its own launch */
 int vk_last_fused(const vk_ctx* ctx);
+/* 1 when that launch handed the partial sums of its split planes over by polling (vk_poll_rule below), 0 otherwise */
+int vk_last_polled(const vk_ctx* ctx);
 void vk_default_opts(vk_eval_opts* opts);
 
 /* Full likelihood for n parameter rows (host buffers).  Any of lnl/chi2/theory may be NULL.
@@ -291,7 +319,9 @@ int vk_joint_eval_device_async(vk_ctx* const* ctxs, int32_t n_ctx, const vk_eval
  * bumps `req_seq`; the owner evaluates everything that is pending as ONE launch and answers each mailbox by
  * writing lnl / chi2 / status and then `resp_seq = req_seq`.  The chains never touch the GPU (or this library).
  *
- * Protocol of one mailbox (all fields naturally aligned; x86-64 / aarch64 release-acquire on the two sequence words):
+ * Protocol of one mailbox (all fields naturally aligned; release / acquire accesses on the two sequence words - this library's
+ * side uses them on every architecture; the Python client of victor_amd/broker.py writes plain stores and relies on x86-64's
+ * total store order: on another architecture use a native client):
  *   client   state = VK_BOX_ATTACHED once, with its pid;  per call: row[] <- parameters, then req_seq <- req_seq + 1 (release);
  *            wait until resp_seq == req_seq (acquire), then read lnl, chi2, status.  One call in flight per mailbox.
  *   server   sees req_seq != resp_seq (acquire), copies row[], evaluates, writes lnl, chi2, status, then resp_seq <- the
@@ -302,7 +332,8 @@ int vk_joint_eval_device_async(vk_ctx* const* ctxs, int32_t n_ctx, const vk_eval
 #define VK_BOX_ATTACHED 1
 typedef struct vk_mailbox {          /* 256 bytes: the client's and the server's words on different cache lines */
   volatile uint64_t req_seq;         /* client -> server                                                      */
-  volatile uint32_t state;           /* VK_BOX_*; written by the client (attach / detach) and by the owner's reaper */
+  volatile uint32_t state;           /* VK_BOX_*; written by the client (attach / detach) and by vk_serve_mailboxes, which frees
+                                        the boxes of dead clients at the start of a call (no launch of its own in flight then) */
   uint32_t reserved0;
   volatile int64_t client_pid;
   uint64_t reserved1[5];
@@ -364,7 +395,7 @@ int vk_comm_allgather_group_async(vk_ctx* const* ctxs, int32_t n, const double* 
 /* Writes a JSON object naming the HIP runtime this process mapped (path, runtime/driver version, the HIP version the
  * library was built with) and the RCCL that vk_comm_* uses (path, ncclGetVersion).  RCCL is looked up next to the mapped
  * HIP runtime first, so both come from one ROCm install (PyTorch's bundled pair when torch was imported before this
- * library, /opt/rocm's otherwise); VICTOR_HIP_RCCL_LIB overrides.  Returns VK_E_RCCL (buffer still filled) if no RCCL
+ * library, /opt/rocm's otherwise); VICTOR_HIP_RCCL_LIB names another one in development runs only (VICTOR_HIP_DEV=1).  Returns VK_E_RCCL (buffer still filled) if no RCCL
  * could be loaded. */
 int vk_comm_info(char* buf, size_t len);
 

@@ -116,6 +116,35 @@ def test_client_refuses_another_configuration_and_reports_failures():
         B.BrokerClient(_name(), digest, timeout=0.2)
 
 
+def test_a_chain_does_not_wait_for_an_owner_that_died_while_starting():
+    """A segment in state STARTING whose owner process has gone (crashed or was killed during HIP initialisation, before it could
+    write FAILED): the chains of the job learn it at once instead of waiting out the five-minute time-out."""
+    import subprocess
+    import sys
+    name, digest = _name(), "d" * 64
+    seg = B._Segment(B.shm_path(name), create=True, n_slots=2)
+    try:
+        dead = subprocess.Popen([sys.executable, "-c", "pass"])
+        dead.wait()
+        seg.header.digest = digest.encode()
+        seg.header.server_pid = dead.pid
+        seg.header.state = B.STARTING
+        t0 = time.monotonic()
+        with pytest.raises(N.NativeError, match="died while starting"):
+            B.BrokerClient(name, digest, timeout=300)
+        assert time.monotonic() - t0 < 5
+        # an owner that is alive and still starting is waited for (here: until the caller's own time-out)
+        seg.header.server_pid = os.getpid()
+        with pytest.raises(N.NativeError, match="did not become ready"):
+            B.BrokerClient(name, digest, timeout=0.3)
+    finally:
+        path = seg.path
+        seg.close()
+        for p in (path, path + ".lock"):
+            if os.path.exists(p):
+                os.unlink(p)
+
+
 def test_an_error_status_reaches_the_caller():
     name, digest = _name(), "d" * 64
     seg = _ready_segment(name, digest, n_slots=1)

@@ -10,6 +10,7 @@ import pytest
 import victor_amd
 from victor_amd import _native
 from tests import cases
+from tests.devlib import KERNEL_OF, mapped
 from tests.tolerances import assert_same_chi2, assert_same_theory, chi2_bound
 
 pytestmark = pytest.mark.gpu
@@ -36,11 +37,14 @@ def test_inherited_knobs_are_ignored_without_the_development_switch():
         assert eng.last_fused()                                        # NO_FUSE ignored as well
         assert_same_chi2(one[1], base[1][3], chi2_bound(fit, {k: v[3:4] for k, v in hp.items()}), what="single point vs batch row")
         os.environ["VICTOR_HIP_DEV"] = "1"                             # the switch on: the same variables now act
+        os.environ["VICTOR_HIP_MAPPING"] = "point"
         _native.load().vk_knobs_refresh()
+        fit.log_likelihood_batch(hp)
+        assert eng.last_kernel() == "vk_theory_kernel"                 # FORCE_GENERIC
         os.environ.pop("VICTOR_HIP_FORCE_GENERIC")
         _native.load().vk_knobs_refresh()
         fit.log_likelihood_batch(hp)
-        assert eng.last_kernel() == "vk_theory_lanes_kernel"
+        assert eng.last_kernel() == "vk_theory_fast_kernel"            # MAPPING=point
     finally:
         for k in ("VICTOR_HIP_MAPPING", "VICTOR_HIP_FORCE_GENERIC", "VICTOR_HIP_NO_FUSE"):
             os.environ.pop(k, None)
@@ -67,15 +71,9 @@ def test_quadrature_rule_with_zero_weights(monkeypatch):
     fit = victor_amd.CCFFit(*cases.synth_options(3))
     out = {}
     for mapping in ("generic", "point", "cells", "lanes"):
-        env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
-        _native.set_knob(env, "1" if mapping == "generic" else mapping)
-        try:
-            out[mapping] = fit.log_likelihood_batch(hp)
-            want = {"generic": "vk_theory_kernel", "point": "vk_theory_fast_kernel", "cells": "vk_theory_cells_kernel",
-                    "lanes": "vk_theory_lanes_kernel"}[mapping]
-            assert fit._get_engine().last_kernel() == want
-        finally:
-            _native.set_knob(env, None)
+        with mapped(fit, mapping) as f:                  # "lanes": the development build of the library (tests/devlib.py)
+            out[mapping] = f.log_likelihood_batch(hp)
+            assert f._get_engine().last_kernel() == KERNEL_OF[mapping]
     bound = chi2_bound(fit, hp, ulps=1024)                           # against the generic kernel: another arithmetic
     for mapping in ("point", "cells", "lanes"):
         assert_same_chi2(out[mapping][1], out["generic"][1], bound, what=f"zero-weight rule, {mapping} vs generic")

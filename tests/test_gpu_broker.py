@@ -227,3 +227,78 @@ def test_chains_example_gives_the_same_chains_brokered_and_direct():
     assert a["last_logp"] == b["last_logp"] and a["mean"] == b["mean"] and a["acceptance"] == b["acceptance"]
     assert a["likelihood_evaluations"] == b["likelihood_evaluations"] > 600 and 0.02 < a["acceptance"] < 0.9
     assert all(250 < v < 300 for v in a["last_logp"])            # the chains sit near the maximum (lnL = 284.8 at the reference point)
+
+
+_MAILBOX_CHAIN = r'''
+import json, os, sys, time
+root, name, digest, rows_file, reps = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5])
+sys.path.insert(0, root)
+from victor_amd import broker as B
+rows = json.load(open(rows_file))
+cl = B.BrokerClient(name, digest, timeout=120)
+print("attached", flush=True)
+sys.stdin.readline()                          # the parent releases all chains together: their requests share launches
+out = [cl.eval_point(r) for _ in range(reps) for r in rows]
+cl.close()
+print(json.dumps(out))
+'''
+
+
+@pytest.mark.parametrize("rsd_model", ["kaiser", "euclid_special"])
+def test_models_on_the_cells_kernel_are_served_with_the_single_point_split(rsd_model, tmp_path):
+    """kaiser / euclid_special always take the cells kernel, whose ranges per point follow the batch size: through the mailbox
+    server they must follow the SINGLE-point rule whatever shares the launch (round-4 advice: with a.n the ranges went from 256
+    to 1024 cells once eight requests shared a launch - a chain's value then depended, at rounding level, on how many other
+    chains posted at the same moment).  Sixteen chains on one launch at a time fill launches of eight; every value equals the
+    single-process one bit for bit."""
+    import json
+    import victor_amd
+    from victor_amd import broker as B
+    info = cases.cobaya_info()["likelihood"]["CCFLikelihood"]
+    model = dict(info["model"], rsd_model=rsd_model, dir=ROOT)          # (the file paths of the configuration are relative)
+    data = dict(info["data"], dir=ROOT)
+    fit = victor_amd.CCFFit(model, data, broker=False)
+    h = cases.halton(12, bases=(2, 3, 5, 7, 11))
+    pts = [{"fsigma8": 0.05 + 1.45 * a, "beta": 0.2 + 0.4 * b, "sigma_v": 100 + 400 * c, "epsilon": 0.8 + 0.4 * d, "M": 0.9 + 0.2 * e,
+            "Q": 1.1 - 0.2 * e} for a, b, c, d, e in h.tolist()]
+    alone = [fit.log_likelihood(dict(p)) for p in pts]
+    assert fit._get_engine().last_kernel() == "vk_theory_cells_kernel"
+    rows = [[float(x) for x in fit._fit_rows(dict(p), fit.model)[0]] for p in pts]
+    rows_file = tmp_path / "rows.json"
+    rows_file.write_text(json.dumps(rows))
+    cfg = tmp_path / "cfg.json"
+    cfg.write_text(json.dumps({"model": model, "data": data}, default=str))
+    name = f"victor_test_{rsd_model}_{os.getpid()}"
+    digest = B.config_digest(model, data)
+    env = dict(os.environ, PYTHONPATH=ROOT + (os.pathsep + os.environ["PYTHONPATH"] if os.environ.get("PYTHONPATH") else ""))
+    env.pop("VICTOR_HIP_BROKER", None)
+    srv = subprocess.Popen([sys.executable, "-m", "victor_amd.broker", "--config-json", str(cfg), "--name", name, "--slots", "16",
+                            "--depth", "1", "--max-batch", "8", "--digest", digest], cwd=ROOT, env=env, stdin=subprocess.DEVNULL)
+    chains = []
+    try:
+        chains = [subprocess.Popen([sys.executable, "-c", _MAILBOX_CHAIN, ROOT, name, digest, str(rows_file), "40"], env=env,
+                                   stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for _ in range(16)]
+        for c in chains:
+            assert c.stdout.readline().strip() == "attached"
+        for c in chains:
+            c.stdin.write("go\n")
+            c.stdin.flush()
+        for c in chains:
+            out, _ = c.communicate(timeout=300)
+            assert c.returncode == 0
+            got = json.loads(out.strip().splitlines()[-1])
+            assert len(got) == 40 * len(pts)
+            for k, (lnl, chi2) in enumerate(got):
+                assert (lnl, chi2) == alone[k % len(pts)], (k, lnl, chi2, alone[k % len(pts)])       # bit for bit
+        seg = B._Segment(B.shm_path(name))
+        deadline = time.time() + 5
+        while int(seg.header.stats.evals) < 16 * 40 * len(pts) and time.time() < deadline:      # the header is refreshed every 0.25 s
+            time.sleep(0.05)
+        assert int(seg.header.stats.max_batch) == 8, int(seg.header.stats.max_batch)        # launches of eight did happen
+        seg.header.stop = 1
+        seg.close()
+        assert srv.wait(timeout=30) == 0
+    finally:
+        for p in chains + [srv]:
+            if p.poll() is None:
+                p.kill()

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from tests import cases
+from tests.devlib import mapped
 from tests.tolerances import assert_same_chi2, chi2_bound
 from victor_amd import _native
 
@@ -77,13 +78,9 @@ def test_beta_dependent_velocity_tables_run_on_the_fast_kernels(gold):
         batch = np.vstack([fit._fit_rows(dict(p), model) for p in pts] + [fit._fit_rows(hp, model)])
         res = {}
         for mapping in ("point", "cells", "generic"):
-            env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
-            _native.set_knob(env, "1" if mapping == "generic" else mapping)
-            try:
-                res[mapping] = fit.theory_vector_batch(batch, **kw)
+            with mapped(fit, mapping) as f:
+                res[mapping] = f.theory_vector_batch(batch, **kw)
                 assert eng.last_kernel().endswith({"point": "fast_kernel", "cells": "cells_kernel", "generic": "vk_theory_kernel"}[mapping]), (tag, mapping)
-            finally:
-                _native.set_knob(env, None)
             assert close(res[mapping][:3], g[f"opt_boss_{tag}"]), (tag, mapping)
         fit.theory_vector_batch(batch, **kw)                               # the default choice at this size
         assert eng.last_kernel() == "vk_theory_cells_kernel", (tag, eng.last_kernel())
@@ -148,14 +145,10 @@ def test_realspace_ccf_from_data_with_md_covariance(gold):
     res = {}
     for aniso in (False, True):
         for mapping in ("point", "cells", "generic"):
-            env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
-            _native.set_knob(env, "1" if mapping == "generic" else mapping)
-            try:
-                res[mapping] = fit.theory_vector_batch(rows, assume_isotropic=not aniso)
-                assert fit._get_engine().last_kernel().endswith(
+            with mapped(fit, mapping) as f:
+                res[mapping] = f.theory_vector_batch(rows, assume_isotropic=not aniso)
+                assert f._get_engine().last_kernel().endswith(
                     {"point": "fast_kernel", "cells": "cells_kernel", "generic": "vk_theory_kernel"}[mapping])
-            finally:
-                _native.set_knob(env, None)
             want = g["opt_fromdata_aniso_theory"] if aniso else g["opt_fromdata_theory"][:3]
             assert close(res[mapping][:3], want), (aniso, mapping)
         for mapping in ("cells", "generic"):
@@ -211,14 +204,10 @@ def test_anisotropic_sigma_v_template_on_gpu(tmp_path, non_uniform_mu):
     rows = fit._fit_rows(hb, fit.model)
     res = {}
     for mapping in ("point", "cells", "generic"):
-        env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
-        _native.set_knob(env, "1" if mapping == "generic" else mapping)
-        try:
-            res[mapping] = fit.theory_vector_batch(rows)
-            assert fit._get_engine().last_kernel().endswith(
+        with mapped(fit, mapping) as f:
+            res[mapping] = f.theory_vector_batch(rows)
+            assert f._get_engine().last_kernel().endswith(
                 {"point": "fast_kernel", "cells": "cells_kernel", "generic": "vk_theory_kernel"}[mapping]), mapping
-        finally:
-            _native.set_knob(env, None)
     for i in (0, 17, 599):
         want = ora.theory_multipole_vector(ora.s, cases.point(hb, i), ora.poles_s)
         for mapping in res:
@@ -244,12 +233,9 @@ def test_anisotropic_sigma_v_template_on_gpu(tmp_path, non_uniform_mu):
     for i in (0, 17, 599):
         want = ora.log_likelihood(cases.point(hb, i), rsd_model="dispersion")
         assert abs(got[1][i] / want[1] - 1) < RTOL, i
-    _native.set_knob("VICTOR_HIP_MAPPING", "lanes")                            # the lanes kernel cannot take it: generic
-    try:
-        fit.theory_vector_batch(rows[:64])
-        assert fit._get_engine().last_kernel() != "vk_theory_lanes_kernel"
-    finally:
-        _native.set_knob("VICTOR_HIP_MAPPING", None)
+    with mapped(fit, "lanes") as f:                      # (development build) the lanes kernel cannot take it
+        f.theory_vector_batch(rows[:64])
+        assert f._get_engine().last_kernel() != "vk_theory_lanes_kernel"
 
 
 def test_velocity_template_mean_model_on_gpu(tmp_path):
@@ -330,11 +316,8 @@ def test_special_amplitudes_in_every_fast_mapping(tmp_path, gold):
     batch = dict({k: np.concatenate([[p[k] for p in pts], v]) for k, v in hp.items()}, beta=0.4, bias=1.7)
     res = {}
     for mapping in ("point", "cells", "lanes"):
-        _native.set_knob("VICTOR_HIP_MAPPING", mapping)
-        try:
-            th = fit.theory_vector_batch(batch, matter_model="linear_bias")
-        finally:
-            _native.set_knob("VICTOR_HIP_MAPPING", None)
+        with mapped(fit, mapping) as f:
+            th = f.theory_vector_batch(batch, matter_model="linear_bias")
         assert close(th[:3], g["opt_synth_lb_stream"]), mapping
         res[mapping] = th
     assert close(res["cells"], res["point"]) and close(res["lanes"], res["point"])
@@ -346,13 +329,10 @@ def test_special_amplitudes_in_every_fast_mapping(tmp_path, gold):
     ora = vo.OracleFit(model, data)
     res = {}
     for mapping in ("point", "cells", "lanes"):
-        _native.set_knob("VICTOR_HIP_MAPPING", mapping)
-        try:
-            res[mapping] = fit.log_likelihood_batch(hp)
-            assert fit._get_engine("velocity_template").last_kernel().endswith(
+        with mapped(fit, mapping) as f:
+            res[mapping] = f.log_likelihood_batch(hp)
+            assert f._get_engine("velocity_template").last_kernel().endswith(
                 {"point": "fast_kernel", "cells": "cells_kernel", "lanes": "lanes_kernel"}[mapping])
-        finally:
-            _native.set_knob("VICTOR_HIP_MAPPING", None)
     for i in (0, 4000, 8202):
         want = ora.log_likelihood(cases.point(hp, i))
         for mapping in res:
@@ -385,13 +365,10 @@ def test_offset_commensurate_grids_in_every_fast_mapping(tmp_path):
     hp = cases.halton_params(4096 + 5)
     res = {}
     for mapping in ("point", "cells", "lanes"):
-        _native.set_knob("VICTOR_HIP_MAPPING", mapping)
-        try:
-            res[mapping] = fit.log_likelihood_batch(hp)
-            assert fit._get_engine().last_kernel().endswith(
+        with mapped(fit, mapping) as f:
+            res[mapping] = f.log_likelihood_batch(hp)
+            assert f._get_engine().last_kernel().endswith(
                 {"point": "fast_kernel", "cells": "cells_kernel", "lanes": "lanes_kernel"}[mapping])
-        finally:
-            _native.set_knob("VICTOR_HIP_MAPPING", None)
     for i in (0, 1, 2047, 4100):
         want = ora.log_likelihood(cases.point(hp, i))
         for mapping in res:
@@ -449,15 +426,11 @@ def test_non_uniform_grids_in_every_fast_mapping(tmp_path):
     hp = cases.halton_params(4096 + 5)
     res = {}
     for mapping in ("point", "cells", "lanes", "generic"):
-        env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
-        _native.set_knob(env, "1" if mapping == "generic" else mapping)
-        try:
-            res[mapping] = fit.log_likelihood_batch(hp)
-            assert fit._get_engine().last_kernel().endswith(
+        with mapped(fit, mapping) as f:
+            res[mapping] = f.log_likelihood_batch(hp)
+            assert f._get_engine().last_kernel().endswith(
                 {"point": "fast_kernel", "cells": "cells_kernel", "lanes": "lanes_kernel",
                  "generic": "vk_theory_kernel"}[mapping])
-        finally:
-            _native.set_knob(env, None)
     for i in (0, 1, 2047, 4100):
         want = ora.log_likelihood(cases.point(hp, i))
         for mapping in res:
@@ -492,12 +465,8 @@ def test_fine_grids_need_more_than_64k_of_lds(tmp_path):
     hp = cases.halton_params(1024 + 3)
     res = {}
     for mapping in ("point", "cells", "lanes", "generic"):
-        env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
-        _native.set_knob(env, "1" if mapping == "generic" else mapping)
-        try:
-            res[mapping] = fit.log_likelihood_batch(hp)
-        finally:
-            _native.set_knob(env, None)
+        with mapped(fit, mapping) as f:
+            res[mapping] = f.log_likelihood_batch(hp)
     for i in (0, 1026):
         want = ora.log_likelihood(cases.point(hp, i))
         for mapping in res:
@@ -520,14 +489,10 @@ def test_boss_linear_bias_runs_on_the_fast_kernels(gold):
     batch = np.vstack([fit._fit_rows(dict(p), lb_model) for p in pts] + [fit._fit_rows(dict(hp, bias=2.1), lb_model)])
     res = {}
     for mapping in ("point", "cells", "generic"):
-        env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
-        _native.set_knob(env, "1" if mapping == "generic" else mapping)
-        try:
-            res[mapping] = fit.theory_vector_batch(batch, matter_model="linear_bias")
-            assert fit._get_engine("linear_bias").last_kernel().endswith(
+        with mapped(fit, mapping) as f:
+            res[mapping] = f.theory_vector_batch(batch, matter_model="linear_bias")
+            assert f._get_engine("linear_bias").last_kernel().endswith(
                 {"point": "fast_kernel", "cells": "cells_kernel", "generic": "vk_theory_kernel"}[mapping])
-        finally:
-            _native.set_knob(env, None)
         assert close(res[mapping][:3], g["opt_boss_lb_stream"]), mapping
     for mapping in ("cells", "generic"):
         assert np.max(np.abs(res[mapping] - res["point"])) < 1e-10 * np.max(np.abs(res["point"])), mapping
@@ -552,14 +517,10 @@ def test_empirical_corr_runs_on_the_fast_kernels(gold):
         batch = np.vstack([fit._fit_rows(dict(p), model) for p in pts] + [fit._fit_rows(hp, model)])
         res = {}
         for mapping in ("point", "cells", "generic"):
-            env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
-            _native.set_knob(env, "1" if mapping == "generic" else mapping)
-            try:
-                res[mapping] = fit.theory_vector_batch(batch, empirical_corr=True)
-                assert fit._get_engine().last_kernel().endswith(
+            with mapped(fit, mapping) as f:
+                res[mapping] = f.theory_vector_batch(batch, empirical_corr=True)
+                assert f._get_engine().last_kernel().endswith(
                     {"point": "fast_kernel", "cells": "cells_kernel", "generic": "vk_theory_kernel"}[mapping])
-            finally:
-                _native.set_knob(env, None)
             assert close(res[mapping][:3], g[key]), (name, mapping)
         # Mapping against mapping: rounding-level agreement, except for the isolated rows where a velocity node puts the
         # fixed-point iteration of ccf_model.py:660-664 next to r = 0 (mu = 1): there the five iterations amplify a 1-ulp
@@ -595,13 +556,9 @@ def test_dispersion_model_where_it_is_ill_conditioned():
         sp_t, sp_c = g[f"{name}_spread_theory"], g[f"{name}_spread_chi2"]
         res = {}
         for mapping in ("point", "cells", "generic"):
-            env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
-            _native.set_knob(env, "1" if mapping == "generic" else mapping)
-            try:
-                th = fit.theory_vector_batch(rows, **kw)
-                lnl, chi = fit.log_likelihood_batch(rows, **kw)
-            finally:
-                _native.set_knob(env, None)
+            with mapped(fit, mapping) as f:
+                th = f.theory_vector_batch(rows, **kw)
+                lnl, chi = f.log_likelihood_batch(rows, **kw)
             res[mapping] = th
             for i in range(len(rows)):
                 if not np.all(np.isfinite(ref_t[i])):
@@ -645,14 +602,10 @@ def test_dispersion_model_runs_on_the_fast_kernels(gold):
         rows = np.vstack(parts)
         res = {}
         for mapping in ("point", "cells", "generic"):
-            env = "VICTOR_HIP_FORCE_GENERIC" if mapping == "generic" else "VICTOR_HIP_MAPPING"
-            _native.set_knob(env, "1" if mapping == "generic" else mapping)
-            try:
-                res[mapping] = fit.theory_vector_batch(rows, **kw)
-                assert fit._get_engine().last_kernel().endswith(
+            with mapped(fit, mapping) as f:
+                res[mapping] = f.theory_vector_batch(rows, **kw)
+                assert f._get_engine().last_kernel().endswith(
                     {"point": "fast_kernel", "cells": "cells_kernel", "generic": "vk_theory_kernel"}[mapping])
-            finally:
-                _native.set_knob(env, None)
             if key:
                 assert close(res[mapping][:npts], g[key]), (name, mapping)
         # Mapping against mapping: rounding-level agreement, except for the isolated rows where a velocity node puts the

@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 from tests import cases
+from tests.devlib import mapped
 from tests.tolerances import assert_same_chi2, assert_same_lnl, assert_same_theory, chi2_bound
 from victor_amd import _native
 
@@ -154,9 +155,49 @@ def test_boss_theory_xi_grid(boss_fit, gold):
     mu = np.linspace(0, 1, 100)
     for tag, idx in (("p0", 0), ("p2", 2)):
         xi = fit.theory_xi(*np.meshgrid(fit.s, mu), dict(meta["boss_points"][idx]))
+        assert fit._get_engine().last_kernel() == "vk_theory_cells_kernel"          # round 5: theory_xi on the fast kernels
         ref = g[f"boss_config_xi_smu_{tag}"]
         assert xi.shape == ref.shape == (100, 30)
         assert np.max(np.abs(xi - ref)) < RTOL * np.max(np.abs(ref))
+
+
+def test_theory_xi_on_the_cells_kernel(synth_fit, boss_fit, oracle):
+    """CCFModel.theory_xi (ccf_model.py:538-690) is served by the cells kernel's store-every-cell form: every RSD model, per-point
+    (beta-dependent) and batch-constant tables, mu grids of any length and sign (no projection: the n_mu >= 64 of the projected
+    launches does not apply), batches whose points are cut into ranges and batches of whole points - against the generic kernel
+    on the whole array and against the oracle on single cells."""
+    cases_ = [(boss_fit["config"], True, "boss"), (synth_fit[3], False, "config3")]
+    grids = [(None, np.linspace(0, 1, 100)), (np.linspace(3.0, 110.0, 17), np.linspace(-1, 1, 41)),
+             (np.array([5.0, 11.5, 40.0, 77.7]), np.array([0.0, 0.3, 1.0]))]
+    for fit, beta, tag in cases_:
+        ora = oracle.OracleFit(*(cases.boss_options("config") if beta else cases.synth_options(3)))
+        hp = cases.halton_params(300, with_beta=beta)
+        for rsd in ("streaming", "dispersion", "kaiser", "euclid_special"):
+            kw = {"rsd_model": rsd}
+            for s, mu in grids:
+                s = fit.s if s is None else s
+                for n in (1, 5, 300):
+                    sub = {k: v[:n] for k, v in hp.items()}
+                    xi = fit.theory_xi_batch(s, mu, sub, **kw)
+                    assert fit._get_engine().last_kernel() == "vk_theory_cells_kernel", (tag, rsd, len(mu), n)
+                    assert xi.shape == (n, len(mu), len(s)) and np.all(np.isfinite(xi))
+                    _native.set_knob("VICTOR_HIP_FORCE_GENERIC", "1")
+                    try:
+                        ref = fit.theory_xi_batch(s, mu, sub, **kw)
+                        assert fit._get_engine().last_kernel() == "vk_xi_smu_kernel"
+                    finally:
+                        _native.set_knob("VICTOR_HIP_FORCE_GENERIC", None)
+                    tol = 1e-9 if rsd != "dispersion" else 1e-8           # (the dispersion iteration amplifies roundings near r = 0)
+                    assert np.max(np.abs(xi - ref)) < tol * np.max(np.abs(ref)), (tag, rsd, len(mu), n)
+                    if n == 5:
+                        for pt, i, j in ((0, 0, 0), (3, len(mu) - 1, len(s) - 1), (4, len(mu) // 2, 1)):
+                            want = ora.theory_xi(np.array([s[j]]), np.array([mu[i]]), cases.point(sub, pt), **kw)[0, 0]
+                            assert abs(xi[pt, i, j] - want) < RTOL * max(abs(want), 1e-2), (tag, rsd, pt, i, j, xi[pt, i, j], want)
+        # a NaN parameter poisons every cell of its point and nothing else
+        bad = {k: v[:3].copy() for k, v in hp.items()}
+        bad["sigma_v"][1] = np.nan
+        xi = fit.theory_xi_batch(fit.s, np.linspace(0, 1, 100), bad)
+        assert np.all(np.isnan(xi[1])) and np.all(np.isfinite(xi[0])) and np.all(np.isfinite(xi[2]))
 
 
 def test_boss_anisotropic_kwarg(boss_fit, gold):
@@ -407,23 +448,17 @@ def test_lanes_over_batch_mapping_matches_point_major(synth_fit, gold):
     for config in (2, 3):
         fit = synth_fit[config]
         for mapping in ("point", "lanes", "cells"):
-            _native.set_knob("VICTOR_HIP_MAPPING", mapping)
-            try:
-                out[mapping] = fit.log_likelihood_batch(hp)
-                assert fit._get_engine().last_kernel() == {"point": "vk_theory_fast_kernel", "lanes": "vk_theory_lanes_kernel",
+            with mapped(fit, mapping) as f:
+                out[mapping] = f.log_likelihood_batch(hp)
+                assert f._get_engine().last_kernel() == {"point": "vk_theory_fast_kernel", "lanes": "vk_theory_lanes_kernel",
                                                            "cells": "vk_theory_cells_kernel"}[mapping]
-            finally:
-                _native.set_knob("VICTOR_HIP_MAPPING", None)
             # golden points through each mapping as well
             pts = list(meta["synth_points"])
             if config == 3:
                 pts = [{"fsigma8": 0.47, "sigma_v": 380, "aperp": 1.02, "apar": 0.97}] + pts
             batch = {k: np.array([p[k] for p in pts]) for k in pts[0]}
-            _native.set_knob("VICTOR_HIP_MAPPING", mapping)
-            try:
-                lnl, chi2 = fit.log_likelihood_batch(batch)
-            finally:
-                _native.set_knob("VICTOR_HIP_MAPPING", None)
+            with mapped(fit, mapping) as f:
+                lnl, chi2 = f.log_likelihood_batch(batch)
             assert np.max(np.abs(chi2 / g[f"synth{config}_chi2"] - 1)) < RTOL, (config, mapping)
         bound = chi2_bound(fit, hp)
         assert_same_chi2(out["lanes"][1], out["point"][1], bound, what=f"lanes vs point, config {config}")
@@ -442,11 +477,8 @@ def test_empty_and_ragged_batches(synth_fit):
     bound = chi2_bound(fit, hp)
     for n in (1, 2, 63, 64, 65, 127, 129):
         for mapping in ("point", "lanes", "cells"):
-            _native.set_knob("VICTOR_HIP_MAPPING", mapping)
-            try:
-                lnl, chi2 = fit.log_likelihood_batch({k: v[:n] for k, v in hp.items()})
-            finally:
-                _native.set_knob("VICTOR_HIP_MAPPING", None)
+            with mapped(fit, mapping) as f:
+                lnl, chi2 = f.log_likelihood_batch({k: v[:n] for k, v in hp.items()})
             assert lnl.shape == (n,)
             assert_same_chi2(chi2, full[1][:n], bound[:n], what=f"ragged {n} {mapping}")
 
@@ -462,11 +494,8 @@ def test_bad_rows_do_not_contaminate_neighbours(synth_fit, boss_fit):
     bad["sigma_v"][77] = np.inf
     bad["aperp"][8999] = np.nan
     for mapping in ("point", "lanes", "cells"):
-        _native.set_knob("VICTOR_HIP_MAPPING", mapping)
-        try:
-            lnl, chi2 = fit.log_likelihood_batch(bad)
-        finally:
-            _native.set_knob("VICTOR_HIP_MAPPING", None)
+        with mapped(fit, mapping) as f:
+            lnl, chi2 = f.log_likelihood_batch(bad)
         for i in (5, 77, 8999):
             assert lnl[i] == -np.inf and chi2[i] == np.inf, (mapping, i)
         keep = np.ones(9000, bool)
@@ -505,12 +534,9 @@ def test_cells_mapping_on_beta_dependent_tables(boss_fit, gold):
         rows = np.concatenate([fit._fit_rows(dict(p), fit.model) for p in meta["boss_points"]])
         res = {}
         for mapping in ("point", "cells"):
-            _native.set_knob("VICTOR_HIP_MAPPING", mapping)
-            try:
-                res[mapping] = fit.log_likelihood_batch(rows)
-                th = fit.theory_vector_batch(rows, assume_isotropic=False)
-            finally:
-                _native.set_knob("VICTOR_HIP_MAPPING", None)
+            with mapped(fit, mapping) as f:
+                res[mapping] = f.log_likelihood_batch(rows)
+                th = f.theory_vector_batch(rows, assume_isotropic=False)
             assert np.max(np.abs(res[mapping][1] / g[f"boss_{variant}_chi2"] - 1)) < RTOL, (variant, mapping)
             if variant == "config":
                 assert vec_close(th[:3], g["boss_aniso_theory"]), mapping
@@ -832,9 +858,16 @@ def test_polling_handoff_gives_the_bits_of_the_counter_handoff(synth_fit, boss_f
             return out
 
         polled = run()
+        eng = fit._get_engine()
+        assert eng.last_polled()                                            # the single point behind the 16-point batch
+        fit.log_likelihood_batch({k: v[:8] for k, v in hp.items()})
+        assert eng.last_polled()                                            # eight points: the context's reservation covers them
+        fit.log_likelihood_batch({k: v[:16] for k, v in hp.items()})
+        assert not eng.last_polled()
         _native.set_knob("VICTOR_HIP_NO_POLL", "1")
         try:
             counted = run()
+            assert not eng.last_polled()
         finally:
             _native.set_knob("VICTOR_HIP_NO_POLL", None)
         assert polled == counted

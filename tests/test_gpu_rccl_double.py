@@ -37,7 +37,7 @@ def test_double_provides_every_entry_point_the_library_looks_up(tmp_path):
 
 
 def _env(double, tmp_path):
-    return {"VICTOR_HIP_RCCL_LIB": double, "VICTOR_HIP_RCCL_SHARED_DEVICE_OK": "1", "RCCL_DOUBLE_DIR": str(tmp_path)}
+    return {"VICTOR_HIP_DEV": "1", "VICTOR_HIP_RCCL_LIB": double, "VICTOR_HIP_RCCL_SHARED_DEVICE_OK": "1", "RCCL_DOUBLE_DIR": str(tmp_path)}
 
 
 @pytest.mark.gpu
@@ -64,14 +64,50 @@ def test_bench_two_ranks_gather_through_the_communicator(tmp_path):
 
 @pytest.mark.gpu
 def test_walker_example_two_ranks_gather_through_the_communicator(tmp_path):
+    """examples/run_walkers.py as two launched ranks: the steps' log-likelihoods cross the communicator in blocks of 64 steps
+    (DistributedEnsemble) - the gathered history is the one a blocking gather after every step gives, bit for bit, for a
+    64th of the collectives."""
     from tests.test_gpu_workloads import _launch_ranks
     double = build_double(tmp_path)
-    res = _launch_ranks([os.path.join(ROOT, "examples", "run_walkers.py"), "--steps", "20"], 2, extra_env=_env(double, tmp_path))
+    got = {}
+    for block in (1, 64):
+        res = _launch_ranks([os.path.join(ROOT, "examples", "run_walkers.py"), "--steps", "130", "--gather-block", str(block)], 2,
+                            extra_env=_env(double, tmp_path))
+        for rc, out, err in res:
+            assert rc == 0, err[-3000:]
+        r0 = json.loads(res[0][1].strip().splitlines()[-1])
+        assert r0["gather"] == "rccl" and r0["walkers_total"] == 16 and r0["gathered_shape"] == [130, 16]
+        assert r0["gather_block"] == block and r0["best_lnl_over_all_ranks"] > 200
+        got[block] = r0
+    assert got[1]["collectives"] == 130 and got[64]["collectives"] == 3          # <= 1 collective per 64 steps (+ the remainder)
+    assert got[64]["gathered_sum"] == got[1]["gathered_sum"] and got[64]["mean"] == got[1]["mean"]
+    assert not list(tmp_path.glob("rccl_double_*.sock"))
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_sharded_joint_fit_and_walker_legs(tmp_path):
+    """bench.py at N = 2 with its BASELINE config 4 / 5 legs, through the communicator of the stand-in: the density-split joint
+    fit with the global batch of 16384 sharded over the ranks and gathered on the lead context's stream, and 8 walkers per
+    rank with the block gather - one collective per 64 steps, every rank's check of the gathered data green, and a step with
+    the gather costing at most 1.1 x a step without."""
+    from tests.test_gpu_workloads import _launch_ranks
+    double = build_double(tmp_path)
+    res = _launch_ranks([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4096",
+                         "--no-cpu-baseline"], 2, extra_env=_env(double, tmp_path), timeout=600)
     for rc, out, err in res:
         assert rc == 0, err[-3000:]
-    r0 = json.loads(res[0][1].strip().splitlines()[-1])
-    assert r0["gather"] == "rccl" and r0["walkers_total"] == 16 and r0["gathered_shape"] == [20, 16]
-    assert r0["best_lnl_over_all_ranks"] > 200
+    out = json.loads([ln for ln in res[0][1].splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["gather_matches_local"] is True
+    d5 = out["dsplit5"]
+    assert d5["global_batch"] == 16384 and d5["batch_per_gpu"] == 8192 and d5["blocks"] == 5
+    assert d5["gather"].startswith("rccl allgather of lnL (ncclCommInitRank") and d5["gather_matches_local"] is True
+    assert d5["joint_evals_per_s"] > 0 and d5["collectives_per_step"] == 1
+    w = out["walker_ensembles"]
+    assert w["gather"] == "rccl" and w["walkers_total"] == 16 and w["gather_block"] == 64 and w["gather_matches_local"] is True
+    assert w["collectives"] == w["steps"] // 64 and w["collectives_per_step"] <= 1 / 64
+    assert w["gather_cost_ratio"] <= 1.1, w
+    assert out["config"]["rccl"]["rccl"].endswith("librccl_double.so")
+    assert not list(tmp_path.glob("rccl_double_*.sock"))          # every leg destroyed its communicator
 
 
 _SHARDED = r'''

@@ -710,3 +710,77 @@ def test_quadratic_form_on_circular_diagonals_is_the_quadratic_form():
                 chi += d * rm[i] * rm[j]
         assert np.array_equal(seen, np.triu(np.ones((M, M), dtype=int)))
         assert abs(chi - r @ P @ r) <= 1e-12 * np.sum(np.abs(np.outer(r, r) * P))
+
+
+def test_rccl_hooks_need_the_development_switch(lib, tmp_path, monkeypatch):
+    """The two RCCL test hooks are development switches like every other VICTOR_HIP_* knob: an inherited
+    VICTOR_HIP_RCCL_SHARED_DEVICE_OK=1 without VICTOR_HIP_DEV=1 leaves ``one_device_per_rank`` strict, and an inherited
+    VICTOR_HIP_RCCL_LIB does not swap the collective library (``vk_comm_info`` still names the ROCm install's RCCL)."""
+    from victor_amd.sharding import one_device_per_rank
+
+    class Group:
+        def allgather_bytes(self, mine, tag):
+            return [mine, mine]                     # two ranks on the same GPU
+
+    class Two:
+        world, rank, group = 2, 0, Group()
+
+    class Eng:
+        def bus_id(self):
+            return "0000:05:00.0"
+
+    monkeypatch.delenv("VICTOR_HIP_DEV", raising=False)
+    monkeypatch.setenv("VICTOR_HIP_RCCL_SHARED_DEVICE_OK", "1")
+    assert one_device_per_rank(Two(), Eng()) is False
+    monkeypatch.setenv("VICTOR_HIP_DEV", "1")
+    assert one_device_per_rank(Two(), Eng()) is True
+
+    # the library side, in child processes (the choice of library is made once per process)
+    from tests.test_gpu_rccl_double import build_double
+    double = build_double(tmp_path)
+    code = ("import json, sys; sys.path.insert(0, %r); from victor_amd import _native; print(json.dumps(_native.comm_info()))" % _ROOT)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("VICTOR_HIP_")}
+    env["VICTOR_HIP_RCCL_LIB"] = double
+    import json
+    plain = json.loads(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
+    assert plain["rccl_loaded"] and "rccl_double" not in plain["rccl"] and "rccl_double" not in plain["rccl_opened_as"]
+    assert os.path.basename(plain["rccl"]).startswith("librccl.so") and plain["rccl_next_to_hip_runtime"] is True
+    env["VICTOR_HIP_DEV"] = "1"
+    dev = json.loads(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
+    assert dev["rccl"].endswith("librccl_double.so")
+
+
+def test_polling_handoff_launch_rule(lib):
+    """The rule that keeps waiting workgroups from ever filling an XCD (include/victor_hip.h: vk_poll_rule / vk_poll_grant; DESIGN.md
+    section 5), as the pure host functions the launcher itself calls: a launch polls only with >= 2 workgroups per CU (64 slots per
+    XCD), resident at once, at most 8 points, all of them covered by its context's reservation; a process's contexts reserve at
+    most 32 waiters between them, all or nothing per request; one full-budget process per device (plus single-point contexts
+    of others) stays below the 64 slots."""
+    import ctypes as C
+    per_process, slots = C.c_int32(), C.c_int32()
+    full = lib.vk_poll_budget(C.byref(per_process), C.byref(slots))
+    assert (per_process.value, slots.value, full) == (32, 64, 1)
+    assert per_process.value * full + 31 < slots.value              # the owner's budget + 31 single waiters: below an XCD's slots
+    rule = lib.vk_poll_rule
+    assert rule(1, 2, 80, 3, 256, 1) == 1                            # one point per call: 40 s bins x 2 parts
+    assert rule(8, 2, 480, 2, 256, 8) == 1                           # eight BOSS requests of the mailbox server: 8 x 30 x 2
+    assert rule(8, 2, 480, 2, 256, 7) == 0                           # ... not covered by the reservation
+    assert rule(9, 2, 540, 3, 256, 9) == 0                           # more than eight waiters per launch: never
+    assert rule(1, 1, 40, 3, 256, 8) == 0                            # nothing to hand over
+    assert rule(8, 2, 640, 2, 256, 8) == 0                           # 640 workgroups do not fit on 256 CUs x 2 at once
+    assert rule(1, 2, 80, 1, 256, 8) == 0                            # tables so large that one workgroup fills a CU: 32 slots per XCD
+    assert rule(1, 2, 80, 3, 64, 8) == 0                             # a device whose XCDs offer fewer than 64 slots
+    assert rule(0, 2, 0, 3, 256, 8) == 0
+    grant = lib.vk_poll_grant
+    assert grant(0, 0, 1) == 1 and grant(0, 0, 8) == 8 and grant(0, 1, 8) == 7
+    assert grant(0, 8, 4) == 0                                       # already covered
+    assert grant(24, 0, 8) == 8 and grant(25, 0, 8) == 0             # all or nothing at the budget's edge
+    assert grant(31, 0, 1) == 1 and grant(32, 0, 1) == 0
+    assert grant(0, 0, 100) == 8                                     # a context never reserves more than a launch may hold
+    # four contexts of an owner process reserving eight each exhaust the budget; a fifth gets nothing and falls back to counters
+    total, ctxs = 0, []
+    for _ in range(5):
+        g = grant(total, 0, 8)
+        total += g
+        ctxs.append(g)
+    assert ctxs == [8, 8, 8, 8, 0] and total == 32

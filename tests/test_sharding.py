@@ -114,14 +114,27 @@ def evaluate(batch):
 dist = Dist()
 dist.connect()
 specs = [ParamSpec("a", -1, 1, 0.2, 0.05, 0.1), ParamSpec("b", -4, 2, -1.0, 0.2, 0.5)]
-ens = DistributedEnsemble(evaluate, specs, walkers_per_rank=8, dist=dist, seed=5)
-chain, lnl, all_lnl = ens.run(25)
-assert chain.shape == (25, 8, 2) and all_lnl.shape == (25, 16)
-# every rank sees the whole ensemble's log-likelihoods, its own slice in its own slot
-assert np.array_equal(all_lnl[:, dist.rank * 8:(dist.rank + 1) * 8], lnl)
-other = all_lnl[:, (1 - dist.rank) * 8:(2 - dist.rank) * 8]
-assert not np.array_equal(other, lnl)          # the ranks run different walkers (different seeds)
-print("rank", dist.rank, "ok", float(all_lnl.sum()))
+# the steps' log-likelihoods are exchanged in blocks of `gather_block` steps (default 64, the random-number block): the
+# chain and the gathered history must not depend on the block length, and 150 steps are ceil(150 / K) collectives
+runs = {{}}
+for K in (1, 7, 64, None):
+    ens = DistributedEnsemble(evaluate, specs, walkers_per_rank=8, dist=dist, seed=5, gather_block=K)
+    chain, lnl, all_lnl = ens.run(150)
+    K = ens.gather_block
+    assert chain.shape == (150, 8, 2) and all_lnl.shape == (150, 16) and np.all(np.isfinite(all_lnl))
+    assert ens.n_collectives == -(-150 // K), (K, ens.n_collectives)
+    # every rank sees the whole ensemble's log-likelihoods, its own slice in its own slot
+    assert np.array_equal(all_lnl[:, dist.rank * 8:(dist.rank + 1) * 8], lnl)
+    other = all_lnl[:, (1 - dist.rank) * 8:(2 - dist.rank) * 8]
+    assert not np.array_equal(other, lnl)          # the ranks run different walkers (different seeds)
+    runs[K] = (chain, all_lnl)
+assert sorted(runs) == [1, 7, 64]              # None = the sampler's 64-step block
+for K in (7, 64):
+    assert np.array_equal(runs[K][0], runs[1][0]) and np.array_equal(runs[K][1], runs[1][1]), K
+# a second run() continues the history (two more collectives at K = 64: 100 steps)
+more = ens.run(100)[2]
+assert more.shape == (250, 16) and ens.n_collectives == 3 + 2 and np.array_equal(more[:150], runs[64][1])
+print("rank", dist.rank, "ok", float(runs[1][1].sum()))
 '''
 
 

@@ -1,5 +1,5 @@
 """Single-rank RCCL communicator through the C ABI with RCCL's own logging on: which HIP call fails, with which library.
-Usage: gpu_rccl_diag.py            (VICTOR_HIP_RCCL_LIB selects another librccl; NCCL_DEBUG etc. are honoured)"""
+Usage: gpu_rccl_diag.py            (VICTOR_HIP_DEV=1 VICTOR_HIP_RCCL_LIB=... selects another librccl; NCCL_DEBUG etc. are honoured)"""
 import os, sys
 os.environ.setdefault("NCCL_DEBUG", "INFO")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-VK_ABI_VERSION = 16
+VK_ABI_VERSION = 17
 VK_NPAR = 12
 (P_FSIGMA8, P_SIGMAV, P_APERP, P_APAR, P_EPSILON, P_BETA, P_ASTAR, P_M, P_Q, P_BIAS, P_AV, P_SPARE) = range(12)
 MATTER = {"template": 0, "linear_bias": 1, "velocity_template": 2}
@@ -96,11 +96,15 @@ SYMBOLS = {
     "vk_abi_version": (C.c_int, []),
     "vk_device_count": (C.c_int, []),
     "vk_knobs_refresh": (None, []),
+    "vk_poll_rule": (C.c_int32, [C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    "vk_poll_grant": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
+    "vk_poll_budget": (C.c_int32, [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "vk_create": (_vp, [C.POINTER(vk_tables), C.c_int, C.c_char_p, C.c_size_t]),
     "vk_destroy": (None, [_vp]),
     "vk_last_error": (C.c_char_p, [_vp]),
     "vk_last_kernel": (C.c_char_p, [_vp]),
     "vk_last_fused": (C.c_int, [_vp]),
+    "vk_last_polled": (C.c_int, [_vp]),
     "vk_default_opts": (None, [_optp]),
     "vk_eval_batch": (C.c_int, [_vp, _optp, _dp, C.c_int64, _dp, _dp, _dp]),
     "vk_eval_batch_begin": (C.c_int, [_vp, _optp, _dp, C.c_int64]),
@@ -130,14 +134,14 @@ SYMBOLS = {
 }
 
 _lib = None
+_loaded = {}          # path -> CDLL: the product library and, in development runs, other builds of it (load_path)
 
 
-def load():
-    """Load the shared library (once) and declare every prototype."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = library_path()
+def load_path(path):
+    """Load one build of the library (once per path) and declare every prototype."""
+    path = os.path.abspath(path)
+    if path in _loaded:
+        return _loaded[path]
     if not os.path.isfile(path):
         raise NativeError(
             f"{path} not found: the HIP extension has not been built "
@@ -151,9 +155,17 @@ def load():
         fn.restype = res
         fn.argtypes = args
     if lib.vk_abi_version() != VK_ABI_VERSION:
-        raise NativeError("libvictor_hip.so ABI version mismatch; rebuild it")
-    _lib = lib
+        raise NativeError(f"{path}: ABI version mismatch; rebuild it")
+    _loaded[path] = lib
     return lib
+
+
+def load():
+    """Load the shared library (once) and declare every prototype."""
+    global _lib
+    if _lib is None:
+        _lib = load_path(library_path())
+    return _lib
 
 
 def set_knob(name, value):
@@ -166,8 +178,8 @@ def set_knob(name, value):
         os.environ.pop(name, None)
     else:
         os.environ[name] = str(value)
-    if _lib is not None:
-        _lib.vk_knobs_refresh()
+    for lib in _loaded.values():
+        lib.vk_knobs_refresh()
 
 
 def comm_info():

@@ -258,14 +258,10 @@ class Broker:
                 h.stats = total
                 now = time.time()
                 h.heartbeat = now
-                attached = 0
-                for box in seg.boxes:
-                    if box.state == N_BOX_ATTACHED:
-                        if _pid_alive(box.client_pid):
-                            attached += 1
-                        else:                               # the chain died (or was killed) without detaching
-                            box.state = N_BOX_FREE
-                            box.req_seq = box.resp_seq = 0
+                # (the mailbox of a chain that died without detaching is handed on by the native loop itself, at the start of
+                # its next slice, when no launch carries that chain's request any more - vk_serve_mailboxes; here it just
+                # does not count as a client)
+                attached = sum(1 for box in seg.boxes if box.state == N_BOX_ATTACHED and _pid_alive(box.client_pid))
                 if attached:
                     ever, empty_since = True, now
                 if h.stop:
@@ -326,7 +322,18 @@ class BrokerClient:
                     raise N.NativeError(f"no broker segment at {path}")
                 time.sleep(0.05)
         h = self.seg.header
+        # the owner is starting (HIP runtime, tables, first evaluations): wait - but not for a process that is not there.  The
+        # segment is created by the chain that elected itself BEFORE it starts the owner, which writes its pid first thing:
+        # no pid within `unborn` seconds, or a pid whose process has gone (crashed or killed during HIP initialisation, before
+        # it could write FAILED), ends the wait instead of holding every chain of the job for the full time-out.
+        unborn = time.monotonic() + min(timeout, 60.0)
         while h.state == STARTING:
+            pid = int(h.server_pid)
+            if pid > 0 and not _pid_alive(pid):
+                raise N.NativeError(f"broker {name}: its owner process (pid {pid}) died while starting - remove {path} or use "
+                                    "VICTOR_HIP_BROKER=auto, which clears such leftovers")
+            if pid <= 0 and time.monotonic() > unborn:
+                raise N.NativeError(f"broker {name}: no owner process has taken the segment {path}")
             if time.monotonic() > deadline:
                 raise N.NativeError(f"broker {name} did not become ready within {timeout:.0f} s")
             time.sleep(0.02)

@@ -19,6 +19,10 @@ CSRC = os.path.join(HERE, "csrc")
 SRC = os.path.join(CSRC, "victor_hip.hip")
 UNITS = (("victor_hip.hip", ()), ("vk_cells_streaming.hip", ("-mllvm", "-amdgpu-sched-strategy=iterative-ilp")))
 OUT = os.path.join(CSRC, "libvictor_hip.so")
+# development build: the product plus the lanes-over-the-batch yardstick kernel (vk_kernel_lanes.h, -DVK_DEV_LANES) that tools/ and
+# the mapping tests compare against; never loaded by the package itself (tests/devlib.py, VICTOR_HIP_LIB)
+DEV_OUT = os.path.join(CSRC, "libvictor_hip_dev.so")
+DEV_DEFINES = ("-DVK_DEV_LANES",)
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 COMMON = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC")
 
@@ -30,8 +34,10 @@ def hipcc_path():
     raise RuntimeError("hipcc not found")
 
 
-def build_native(force=False, verbose=False, defines=(), out=None):
+def build_native(force=False, verbose=False, defines=(), out=None, dev=False):
     import glob
+    if dev:
+        defines, out = tuple(defines) + DEV_DEFINES, out or DEV_OUT
     out = out or OUT
     deps = [os.path.join(CSRC, u) for u, _ in UNITS] + [os.path.join(INCLUDE, "victor_hip.h")] + glob.glob(os.path.join(CSRC, "*.h"))
     if not force and os.path.isfile(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
@@ -61,4 +67,5 @@ def build_native(force=False, verbose=False, defines=(), out=None):
 
 
 if __name__ == "__main__":
-    print(build_native(force=True, verbose=True))
+    import sys
+    print(build_native(force=True, verbose=True, dev="--dev" in sys.argv))

@@ -333,7 +333,7 @@ class CCFModel:
         if key not in self._engine:
             from .engine import Engine
             self._engine[key] = Engine(self, self._fit_side(), device=self._device, matter_model=matter_model,
-                                       simpson_even=rule)
+                                       simpson_even=rule, lib=getattr(self, "_native_lib", None))
         return self._engine[key]
 
     def _fit_side(self):

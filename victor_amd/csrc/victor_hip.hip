@@ -5,7 +5,8 @@
 //   vk_devmath.h         FP64 sqrt/rsqrt, reciprocal and exp building blocks (<= 2 ulp, measured on hardware)
 //   vk_kernel_generic.h  K1 generic: every RSD model and option, library math, knot search   + K1x xi(s, mu)
 //   vk_kernel_fast.h     K1 point-major fast path (wave = point x s bin, lanes over the (mu, v) plane)
-//   vk_kernel_lanes.h    K1 lanes-over-the-batch (wave = s bin x 64 points; batch-constant tables, large batches)
+//   vk_kernel_lanes.h    K1 lanes-over-the-batch (wave = s bin x 64 points; batch-constant tables, large batches) - the A/B
+//                        yardstick of tools/ and of the mapping tests, compiled into the DEVELOPMENT build only (VK_DEV_LANES)
 //   vk_kernel_cells.h    K1 cells (workgroup = point, lanes over (s, mu) cells, v loop innermost; per-point tables)
 //   vk_kernel_like.h     K2 residual . precision . residual, log det, likelihood form, NaN guard
 //
@@ -22,6 +23,9 @@
 #include <cstddef>
 
 #include <dlfcn.h>
+#include <errno.h>
+#include <signal.h>
+#include <sys/types.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -40,7 +44,9 @@
 #include "vk_kernel_cells.h"
 #include "vk_kernel_fast.h"
 #include "vk_kernel_generic.h"
+#ifdef VK_DEV_LANES          // development build only (libvictor_hip_dev.so: `make dev`, build_native(dev=True)): the yardstick kernel
 #include "vk_kernel_lanes.h"
+#endif
 #include "vk_kernel_like.h"
 
 // The cells kernel's instantiations for the streaming model live in vk_cells_streaming.hip (another machine scheduler for that
@@ -60,7 +66,7 @@ VK_CELLS_STREAMING(3, 1) VK_CELLS_STREAMING(3, 2) VK_CELLS_STREAMING(3, 3)
 using namespace vk;
 
 // LDS image of a kernel variant's batch-constant tables (vk_kernel_fast.h: copy_image): run that variant's own staging
-// code once and keep what it left in LDS.  kind: 0 point-major, 1 cells, 2 lanes.
+// code once and keep what it left in LDS.  kind: 0 point-major, 1 cells, 2 lanes (development build).
 template <int NLR>
 __global__ __launch_bounds__(kBlock) void vk_image_kernel(TheoryArgs a, int kind, int with_da, double* image, int n) {
   extern __shared__ double lds[];
@@ -72,9 +78,12 @@ __global__ __launch_bounds__(kBlock) void vk_image_kernel(TheoryArgs a, int kind
     stage_fast<NLR>(a, make_fast_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, with_da, 0, n_sva), lds, with_da);
   } else if (kind == 1) {
     stage_cells<NLR>(a, make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, with_da, 64, 0, n_sva), lds, with_da);
-  } else {
+  }
+#ifdef VK_DEV_LANES
+  else {
     stage_lanes<NLR>(a, make_lanes_plan(a.n_mu, a.n_x, a.uni_n, NLR, a.uni_lut_n), lds);
   }
+#endif
   __syncthreads();
   for (int e = threadIdx.x; e < n; e += kBlock) image[e] = lds[e];
 }
@@ -196,6 +205,7 @@ struct vk_ctx {
   size_t poll_doubles = 0;             // between launches; vk_common.h), or NULL
   int* h_poll_failed = nullptr;        // pinned, device-mapped word a polling workgroup sets when it gives up; d_poll_failed: the
   int* d_poll_failed = nullptr;        // same word through the device's eyes
+  int poll_reserved = 0;               // waiters this context may have resident at once (its share of kPollBudget; vk_poll_grant)
   double wsum[3] = {0, 0, 0};
   int depth_mult = 1;                // joint fits: launches of this many contexts share the GPU (vk_joint_eval_device_async)
   hipEvent_t ev_joint = nullptr;
@@ -203,6 +213,7 @@ struct vk_ctx {
   std::map<const void*, int> lds_opt_in;   // dynamic LDS above 64 KiB a kernel has been opted in for (launch_on_stream)
   const char* last_kernel = "none";  // theory kernel variant of the most recent launch
   bool last_fused = false;           // ... and whether it took the chi-square as well
+  bool last_polled = false;          // ... and whether its split planes were handed over by polling (vk_poll_rule)
   // scratch for the host-buffer entry points
   double* d_scratch = nullptr;
   size_t scratch_bytes = 0;
@@ -242,10 +253,23 @@ constexpr int kServeMaxBatch = 32;          // requests one launch of the mailbo
 // that the waiting workgroups of every launch in flight on the GPU - other contexts, other processes - can never fill an
 // XCD (64 workgroup slots at least) and keep the workgroups they wait for off it.
 constexpr long long kPollPoints = 8;
+// The bound behind "never fill an XCD" (include/victor_hip.h: vk_poll_rule).  A polling launch is taken only
+// when at least two of its workgroups fit on a CU (LDS and launch bounds), so an XCD of 32 CUs has kPollXcdSlots = 64 workgroup
+// slots at least; a deadlock needs one XCD's slots ALL held by waiting workgroups (one per point of a polling launch in flight)
+// whose producers cannot be placed, so fewer than 64 waiters resident on the whole device exclude it.  What the library
+// enforces is its own process's share: every context reserves the waiters its polling launches may have resident (its launches
+// are stream-ordered: never more than one in flight) out of kPollBudget = 32 per process - an owner process's default four
+// contexts x eight requests -; a launch whose context holds no reservation for its points hands over through the completion
+// counters instead (the same sums in the same order: not a bit changes).  Across processes the sum of the reservations must
+// stay below 64: ONE process with the full budget (the GPU owner of section 6) plus up to 31 single-point contexts of other
+// processes, or up to 63 processes that each evaluate one point per call in one context.
+constexpr int kPollXcdSlots = 64;
+constexpr int kPollBudget = 32;
 
 namespace {
 
 thread_local std::string g_create_err;
+std::atomic<int> g_poll_reserved{0};    // waiters reserved by the contexts of this process (<= kPollBudget)
 #ifdef VK_PHASES
 long long* g_stamps = nullptr;
 #endif
@@ -477,6 +501,7 @@ int launch_fast_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   return a.uni_lut_n > 0 ? launch_fast_ng<NLR, 1>(ctx, a, grid, lds) : launch_fast_ng<NLR, 0>(ctx, a, grid, lds);
 }
 
+#ifdef VK_DEV_LANES
 template <int NLR, int GRID>
 int launch_lanes_ng(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
@@ -491,6 +516,7 @@ template <int NLR>
 int launch_lanes_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   return a.uni_lut_n > 0 ? launch_lanes_ng<NLR, 1>(ctx, a, grid, lds) : launch_lanes_ng<NLR, 0>(ctx, a, grid, lds);
 }
+#endif
 
 template <int NLR, int GRID, int MODE>
 int launch_cells_ngf(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
@@ -526,6 +552,28 @@ int launch_xi_smu(vk_ctx* ctx, const TheoryArgs& a, int nlr, int grid, size_t ld
     case 3: if constexpr (VK_LITE_KEEP(1, 2, 1, 0)) return launch_on_stream(ctx, vk_xi_smu_kernel<RSD, 3>, grid, lds, a); break;
   }
   return fail(ctx, VK_E_ARG, "bad number of real-space multipoles %d", nlr);
+}
+
+// K1x generic: one wave per (point, mu, s) cell, library math, any knot layout (vk_kernel_generic.h) - what serves
+// vk_xi_smu_batch where the cells kernel cannot go
+int launch_xi_generic(vk_ctx* ctx, TheoryArgs a, int nlr) {
+  const LdsPlan pl = make_plan(a.n_mu, a.n_x, a.n_ell, a.sv.n_int, a.vr.n_int, a.xi.n_int, nlr, a.n_beta_r);
+  const size_t lds = (size_t)pl.total * sizeof(double);
+  if (lds > 160 * 1024) return fail(ctx, VK_E_ARG, "tables need %zu bytes of LDS (> 160 KiB)", lds);
+  const long long cap = 8LL * ctx->n_cu;
+  const int grid = (int)(a.n < cap ? a.n : cap);
+  a.xi_out = 0;
+  a.sbins_per_item = 1;
+  a.team = 1;
+  a.parts = 1;
+  a.exp_tab = ctx->d_exp_tab;
+  ctx->last_kernel = "vk_xi_smu_kernel";
+  switch (a.rsd) {
+    case VK_RSD_STREAMING: return launch_xi_smu<VK_RSD_STREAMING>(ctx, a, nlr, grid, lds);
+    case VK_RSD_DISPERSION: return launch_xi_smu<VK_RSD_DISPERSION>(ctx, a, nlr, grid, lds);
+    case VK_RSD_KAISER: return launch_xi_smu<VK_RSD_KAISER>(ctx, a, nlr, grid, lds);
+    default: return launch_xi_smu<VK_RSD_EUCLID>(ctx, a, nlr, grid, lds);
+  }
 }
 
 // fills the grid-independent part of TheoryArgs
@@ -633,6 +681,7 @@ unsigned div_magic(int d) { return (unsigned)((0x100000000ULL + (unsigned)d - 1)
 // chi-square as well (the caller then skips the K2 launch).
 int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool* fused) {
   if (fused) *fused = false;
+  ctx->last_polled = false;
   if (a.n <= 0) return VK_OK;
   if (a.n > (1LL << 31) / ((long long)a.n_s * kMaxParts)) return fail(ctx, VK_E_ARG, "batch of %lld points is too large for one launch", a.n);
   const int N = a.n_ell * a.n_s;
@@ -700,46 +749,68 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
 #endif
   const long long kDefaultCap = 256;                                // VICTOR_HIP_POINT_CAP: workgroups per CU in a launch of the generic kernel (the fast kernels take one item per workgroup)
   const long long cap = (ctx->knobs.point_cap > 0 ? ctx->knobs.point_cap : kDefaultCap) * ctx->n_cu;
-  // lanes-over-batch variant: batch-constant tables and enough points to fill the chip with n_s * n/64 waves
   const int mapping = ctx->knobs.mapping;                           // VICTOR_HIP_MAPPING: 0 = choose by batch size
-  const bool lanes_ok = fast && a.n_beta_r == 0 && !a.empirical && !a.from_data && !disp && !kais && !sva;   // per-point tables need a workgroup per point
-  // One wave per (s bin, 64-point chunk), one workgroup per four of them; 5 workgroups are resident per CU.  Every item
-  // runs for ~0.6 ms, so the launch ends with a ragged tail about one residency round long, while the cells kernel
-  // (one workgroup per point, 2.20-2.25 M evals/s on config 3 from 2000 points on) has none: measured, the lanes kernel
-  // (2.44 M evals/s asymptotically) only pulls ahead once the launch is ~4 rounds deep - 1.85 / 2.14 / 2.03 / 2.23 / 2.33 /
-  // 2.40 M evals/s at 7000 / 8192 / 14000 / 30000 / 50000 / 100000 points (tools/gpu_batch_curve.py).
-  const long long waves = ((a.n + 63) >> 6) * (long long)a.n_s;
-  const long long blocks_l = (waves + kWaves - 1) / kWaves;
-  const size_t lds_l = (size_t)make_lanes_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.uni_lut_n).total * sizeof(double);
-  const long long wg_per_cu = std::max<long long>(1, std::min<long long>(5, (160 * 1024) / (lds_l ? lds_l : 1)));
   // cells variant: one workgroup per point with the velocity loop innermost; needs n_mu >= 64 (a wave's 64 cells must not
   // straddle more than two s bins)
   const bool cells_ok = fast && a.n_mu >= 64 && a.n_mu <= 4096 && a.n_x <= 2048;
-  // Round 3: with the shorter integrand loop the cells kernel is ahead of the lanes kernel at EVERY batch size, also for
-  // batch-constant tables (tools/gpu_lanes_vs_cells.py, same box, M evals/s at 8192 / 65536 / 262144 points: config 3
-  // 2.58 / 2.66 / 2.66 against 2.23 / 2.58 / 2.65, config 2 3.38 / 3.50 / 3.50 against 2.75 / 3.21 / 3.37): it carries the
-  // point's velocity amplitude in its table (one instruction less per integrand point) and has no ragged tail of 0.6 ms
-  // items.  The lanes kernel remains for grids the cells kernel cannot take (n_mu < 64) and as VICTOR_HIP_MAPPING=lanes.
-  const bool lanes = lanes_ok && lds_l <= 160 * 1024 &&
-                     (mapping ? mapping == 3 : (!cells_ok && blocks_l * ctx->depth_mult >= 4 * wg_per_cu * ctx->n_cu));
-  if (lanes) {
-    ctx->last_kernel = "vk_theory_lanes_kernel";
-    a.parts = 1;
-    a.image = get_image(ctx, a, 2, nlr, 0, make_lanes_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.uni_lut_n).image_end);
-    a.lanes_per_block = ctx->knobs.lanes_by_chunk ? a.n_s : kWaves;
-    const long long blocks = ctx->knobs.lanes_by_chunk ? (a.n + 63) >> 6 : blocks_l;
-    // One workgroup per four items, never a grid-stride loop by default: letting the dispatcher refill CUs as
-    // workgroups retire measured 38.1 / 36.0 / 34.6 / 33.8 ms at 4 / 8 / 16 / 64 workgroups per CU on the bench workload
-    // (5 are resident), and a cap that makes workgroups loop leaves a ragged tail of 0.6 ms items - 131072 points ran at
-    // 1.61 M evals/s under a 64-per-CU cap against 2.35 M without (tools/gpu_lanes_big.py)
-    const long long capl = ctx->knobs.lanes_cap > 0 ? ctx->knobs.lanes_cap * ctx->n_cu : (long long)INT32_MAX;   // A/B knob
-    const int grid_l = (int)(blocks < capl ? blocks : capl);
-    switch (nlr) {
-      case 1: return launch_lanes_nl<1>(ctx, a, grid_l, lds_l);
-      case 2: return launch_lanes_nl<2>(ctx, a, grid_l, lds_l);
-      case 3: return launch_lanes_nl<3>(ctx, a, grid_l, lds_l);
+  if (a.xi_out) {
+    // CCFModel.theory_xi (ccf_model.py:538-690) - xi^s on the caller's (s, mu) grid, no projection: the cells kernel's n_ell = 1
+    // instantiations store every cell's value (vk_kernel_cells.h: xi_out), whatever n_mu is (the limit n_mu >= 64 above belongs to
+    // the projection's two-segment reduction).  A point's cells are cut into ranges as for the projected launches - but ranges
+    // hand nothing over here, so neither the counters nor the partial-sum area limit them.  Grids and table forms the fast
+    // kernels cannot take go to the generic kernel.
+    const long long all_cells = (long long)a.n_s * a.n_mu;
+    if (fast && a.n_ell == 1 && all_cells <= (1LL << 24)) {
+      const int whole = (int)((all_cells + 63) / 64 * 64);
+      int cpi = a.n > kPartialPoints ? whole : (a.n < 128 ? 256 : (a.n < 256 ? 512 : 1024));
+      if (cpi > whole) cpi = whole;
+      const int R = (int)((all_cells + cpi - 1) / cpi);
+      const CellsPlan plc = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, nlr, a.n_beta_r, a.uni_lut_n, layout, 0, 0, n_sva);
+      const size_t lds_c = (size_t)plc.total * sizeof(double);
+      if (lds_c <= 160 * 1024 && a.n * R < (1LL << 31)) {
+        ctx->last_kernel = "vk_theory_cells_kernel";
+        a.parts = R;
+        a.cells_per_item = cpi;
+        a.ns_magic = div_magic(a.n_s);
+        a.image = nullptr;                 // the caller's own grid: staged inside the kernel
+        const int grid_c = (int)(a.n * R);
+        switch (nlr) {
+          case 1: return launch_cells_nl<1>(ctx, a, grid_c, lds_c);
+          case 2: return launch_cells_nl<2>(ctx, a, grid_c, lds_c);
+          case 3: return launch_cells_nl<3>(ctx, a, grid_c, lds_c);
+        }
+      }
+    }
+    return launch_xi_generic(ctx, a, nlr);
+  }
+#ifdef VK_DEV_LANES
+  // Development build only: the lanes-over-the-batch kernel (wave = s bin x 64 points; the north star's mapping), behind the cells
+  // kernel at every batch size since round 3 (tools/gpu_lanes_vs_cells.py, same box, M evals/s at 8192 / 65536 / 262144 points:
+  // config 3 2.58 / 2.66 / 2.66 against 2.23 / 2.58 / 2.65) and kept as the yardstick of tools/ and of the mapping tests:
+  // VICTOR_HIP_MAPPING=lanes selects it.  The product library does not contain it (round 5).
+  {
+    const bool lanes_ok = fast && a.n_beta_r == 0 && !a.empirical && !a.from_data && !disp && !kais && !sva;   // per-point tables need a workgroup per point
+    const long long waves = ((a.n + 63) >> 6) * (long long)a.n_s;
+    const long long blocks_l = (waves + kWaves - 1) / kWaves;
+    const size_t lds_l = (size_t)make_lanes_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.uni_lut_n).total * sizeof(double);
+    if (lanes_ok && lds_l <= 160 * 1024 && mapping == 3) {
+      ctx->last_kernel = "vk_theory_lanes_kernel";
+      a.parts = 1;
+      a.image = get_image(ctx, a, 2, nlr, 0, make_lanes_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.uni_lut_n).image_end);
+      a.lanes_per_block = ctx->knobs.lanes_by_chunk ? a.n_s : kWaves;
+      const long long blocks = ctx->knobs.lanes_by_chunk ? (a.n + 63) >> 6 : blocks_l;
+      // One workgroup per four items, never a grid-stride loop by default (a cap that makes workgroups loop leaves a ragged
+      // tail of 0.6 ms items: 131072 points ran at 1.61 M evals/s under a 64-per-CU cap against 2.35 M without)
+      const long long capl = ctx->knobs.lanes_cap > 0 ? ctx->knobs.lanes_cap * ctx->n_cu : (long long)INT32_MAX;   // A/B knob
+      const int grid_l = (int)(blocks < capl ? blocks : capl);
+      switch (nlr) {
+        case 1: return launch_lanes_nl<1>(ctx, a, grid_l, lds_l);
+        case 2: return launch_lanes_nl<2>(ctx, a, grid_l, lds_l);
+        case 3: return launch_lanes_nl<3>(ctx, a, grid_l, lds_l);
+      }
     }
   }
+#endif
   // crossover against the point-major kernel measured between 512 and 768 points (config 3) and near 500 (BOSS),
   // tools/gpu_small_batch_ab.py: one workgroup per point needs ~2.5 workgroups per CU to keep the SIMDs fed
   // crossover against the point-major kernel (whose finer split wins for a handful of points): config 3 / BOSS 8 points
@@ -764,7 +835,10 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
       // below 256, four from there on - 64 points: 56.6 -> 41.7 us against the point-major kernel, 1024 points: 496 -> 462 us
       // against one workgroup per point; whole trips per wave only (a multiple of 256 cells)
       // (kaiser: a cell is one evaluation, not 50 - ranges only for a handful of points)
-      const int cpi_want = kais ? (a.n < 8 ? 256 : (a.n < 32 ? 1024 : all_cells)) : (a.n < 128 ? 256 : (a.n < 256 ? 512 : 1024));
+      // (n_dec, not a.n: the mailbox server's launches split every point as a single-point call does, whatever shares the launch -
+      // with a.n the ranges of a kaiser request changed from 256 to 1024 cells once eight chains posted together, and with them
+      // the rounding of its sums)
+      const int cpi_want = kais ? (n_dec < 8 ? 256 : (n_dec < 32 ? 1024 : all_cells)) : (n_dec < 128 ? 256 : (n_dec < 256 ? 512 : 1024));
       R = (all_cells + cpi_want - 1) / cpi_want;
       R = std::max(1, std::min(R, (all_cells + min_cpi - 1) / min_cpi));
     }
@@ -812,10 +886,21 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
     // (resident at once: the kernel's launch bounds give the streaming instantiations three workgroups per CU, the others two,
     // if their LDS fits as often)
     const long long per_cu = std::min<long long>((a.rsd == VK_RSD_STREAMING && !sva && !a.from_data) ? 3 : 2, (160 * 1024) / (long long)(lds ? lds : 1));
-    if (a.parts > 1 && a.n <= kPollPoints && items <= per_cu * ctx->n_cu && ctx->d_poll && !ctx->knobs.no_poll &&
-        (size_t)a.n * a.n_s * kMaxParts * kMaxEll <= ctx->poll_doubles) {
-      a.poll = 1;
-      a.partial = ctx->d_poll;
+    if (a.parts > 1 && ctx->d_poll && !ctx->knobs.no_poll && (size_t)a.n * a.n_s * kMaxParts * kMaxEll <= ctx->poll_doubles &&
+        a.n <= kPollPoints) {
+      // the context's reservation grows on demand, as far as the process's budget allows (released in vk_destroy)
+      if (ctx->poll_reserved < a.n) {
+        int seen = g_poll_reserved.load(std::memory_order_relaxed), grant;
+        do {
+          grant = vk_poll_grant(seen, ctx->poll_reserved, (int32_t)a.n);
+        } while (grant > 0 && !g_poll_reserved.compare_exchange_weak(seen, seen + grant, std::memory_order_relaxed));
+        ctx->poll_reserved += grant > 0 ? grant : 0;
+      }
+      if (vk_poll_rule(a.n, a.parts, items, (int32_t)per_cu, ctx->n_cu, ctx->poll_reserved)) {
+        a.poll = 1;
+        a.partial = ctx->d_poll;
+        ctx->last_polled = true;
+      }
     }
     if (fused) *fused = a.fuse != 0;
     switch (nlr) {
@@ -938,7 +1023,11 @@ void* open_rccl(std::string* how = nullptr) {
   static std::string chosen;
   if (!lib) {
     std::vector<std::string> names;
-    if (const char* env = getenv("VICTOR_HIP_RCCL_LIB")) names.push_back(env);           // explicit override
+    // development override (tests/rccl_double): like every other VICTOR_HIP_* switch it is honoured only with VICTOR_HIP_DEV=1 -
+    // a variable inherited from somebody's shell must never swap the collective library of a production run
+    const char* dev = getenv("VICTOR_HIP_DEV");
+    if (dev && strcmp(dev, "1") == 0)
+      if (const char* env = getenv("VICTOR_HIP_RCCL_LIB")) names.push_back(env);
     const std::string dir = dir_of(hip_runtime_path());
     if (!dir.empty()) {
       names.push_back(dir + "/librccl.so.1");
@@ -975,6 +1064,30 @@ int vk_debug_read_stamps(long long* out) {
 
 void vk_knobs_refresh(void) { g_knob_gen.fetch_add(1, std::memory_order_relaxed); }
 
+// ---- the launch rule of the polling hand-off: pure functions of their arguments (include/victor_hip.h) --------------------
+int32_t vk_poll_rule(int64_t n_points, int32_t parts, int64_t workgroups, int32_t workgroups_per_cu, int32_t n_cu, int32_t reserved) {
+  if (parts < 2 || n_points < 1 || n_points > kPollPoints) return 0;      // nothing to hand over / more waiters than a launch may hold
+  if (workgroups_per_cu < 2 || n_cu < 8) return 0;                         // an XCD must offer kPollXcdSlots = 32 CUs x 2 slots at least
+  if ((long long)(n_cu / 8) * workgroups_per_cu < kPollXcdSlots) return 0;
+  if (workgroups > (long long)workgroups_per_cu * n_cu) return 0;          // the launch must fit on the chip at once
+  if (n_points > reserved) return 0;                                       // its waiters must be covered by the context's reservation
+  return 1;
+}
+
+int32_t vk_poll_grant(int32_t process_reserved, int32_t ctx_reserved, int32_t want) {
+  if (want > (int32_t)kPollPoints) want = (int32_t)kPollPoints;
+  if (want <= ctx_reserved || process_reserved < 0) return 0;
+  const int32_t room = kPollBudget - process_reserved;
+  const int32_t extra = want - ctx_reserved;
+  return extra <= room ? extra : 0;      // all or nothing: a launch polls for every one of its points or for none
+}
+
+int32_t vk_poll_budget(int32_t* per_process, int32_t* xcd_slots) {
+  if (per_process) *per_process = kPollBudget;
+  if (xcd_slots) *xcd_slots = kPollXcdSlots;
+  return (kPollXcdSlots - 1) / kPollBudget;       // processes per device that may each use their full budget
+}
+
 int vk_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1002,6 +1115,8 @@ const char* vk_last_error(const vk_ctx* ctx) { return ctx ? ctx->err.c_str() : g
 const char* vk_last_kernel(const vk_ctx* ctx) { return ctx ? ctx->last_kernel : "none"; }
 
 int vk_last_fused(const vk_ctx* ctx) { return ctx && ctx->last_fused ? 1 : 0; }
+
+int vk_last_polled(const vk_ctx* ctx) { return ctx && ctx->last_polled ? 1 : 0; }
 
 static int check_pp(const vk_pp* p, const char* name, std::string* err) {
   char buf[256];
@@ -1370,6 +1485,8 @@ void vk_destroy(vk_ctx* ctx) {
   if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
   if (ctx->comm) vk_comm_destroy(ctx);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->poll_reserved) g_poll_reserved.fetch_sub(ctx->poll_reserved, std::memory_order_relaxed);   // (nothing of it is in flight any more)
+  ctx->poll_reserved = 0;
   drop_graphs(ctx);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
   if (ctx->h_zc) (void)hipHostFree(ctx->h_zc);
@@ -1690,17 +1807,35 @@ static int zc_finish(vk_ctx* ctx, int64_t n, double* lnl, double* chi2, bool blo
         if (slots[i] == kSpinSentinel) { arrived = false; break; }
       if (arrived) break;
       const bool late = ((it & 255u) == 0 || !block) && std::chrono::steady_clock::now() - ctx->zc_t0 > std::chrono::milliseconds(2);
-      if (late) break;                  // stop polling: the stream synchronisation below settles it
-      if (!block) return 0;
-      cpu_relax();
+      if (!late) {
+        if (!block) return 0;
+        cpu_relax();
+        continue;
+      }
+      // Nothing after 2 ms.  Either the launch is simply still running (a busy GPU: other contexts, other processes, a slow
+      // kernel variant) - then a non-blocking caller is told "not yet" and asks again, a blocking one waits for the stream -
+      // or the stream HAS completed and the slots still hold the sentinel: the stores do not reach this memory before the
+      // launch ends on this system (or a result carries the sentinel's bit pattern).  Only the latter counts against polling.
+      const hipError_t q = hipStreamQuery(ctx->stream);
+      if (q == hipErrorNotReady) {
+        (void)hipGetLastError();
+        if (!block) return 0;
+        VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        arrived = true;
+        for (int64_t i = 2 * n - 1; i >= 0; --i)
+          if (slots[i] == kSpinSentinel) { arrived = false; break; }
+        if (arrived) break;
+      }
+      break;
     }
   } else if (!block && hipStreamQuery(ctx->stream) == hipErrorNotReady) {
+    (void)hipGetLastError();
     return 0;
   }
   if (!arrived) {
     VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    // three small launches in a row took over 2 ms to show their results (the first call of a context, which also builds
-    // the LDS image, may): the stores evidently do not reach this memory before the launch ends - stop polling it
+    // three small launches in a row had completed before their results showed in the polled slots (the first call of a context,
+    // which also builds the LDS image, may): the stores evidently do not reach this memory before the launch ends - stop polling it
     if (ctx->zc_spin && n <= 64 && ++ctx->spin_timeouts >= 3) ctx->spin_off = true;
   } else {
     ctx->spin_timeouts = 0;
@@ -1812,6 +1947,23 @@ int vk_eval_batch_finish(vk_ctx* ctx, double* lnl, double* chi2) {
 }
 
 // ---- mailboxes: many one-point callers, one launch (include/victor_hip.h) ---------------------------------------------
+// Is process `pid` still there?  kill(pid, 0) answers for zombies as well (a dead child nobody has waited for yet), so the
+// state letter of /proc/<pid>/stat decides for those (victor_amd/broker.py: _pid_alive is the same test).
+static bool process_alive(long long pid) {
+  if (pid <= 0) return false;
+  if (kill((pid_t)pid, 0) != 0) return errno == EPERM;
+  char path[64], buf[512];
+  snprintf(path, sizeof path, "/proc/%lld/stat", pid);
+  FILE* f = fopen(path, "r");
+  if (!f) return true;                       // no /proc here: kill() has spoken
+  const size_t got = fread(buf, 1, sizeof buf - 1, f);
+  fclose(f);
+  buf[got] = 0;
+  const char* close_paren = strrchr(buf, ')');            // the command name may contain anything, also ')'
+  if (!close_paren || close_paren[1] != ' ' || !close_paren[2]) return true;
+  return close_paren[2] != 'Z';
+}
+
 static_assert(sizeof(vk_mailbox) == 256, "vk_mailbox is mirrored field by field in victor_amd/broker.py");
 static_assert(offsetof(vk_mailbox, row) == 64 && offsetof(vk_mailbox, resp_seq) == 192, "vk_mailbox layout");
 
@@ -1831,6 +1983,19 @@ int vk_serve_mailboxes(vk_ctx* const* ctxs, int32_t n_ctx, const vk_eval_opts* o
   const auto t_start = clock::now();
   const auto window = std::chrono::nanoseconds((long long)(std::max(gather_window_us, 0.0) * 1e3));
   const int cap = (max_batch >= 1 && max_batch <= kServeMaxBatch) ? max_batch : kServeMaxBatch;
+  // Mailboxes of clients that died without detaching are handed on HERE, at the start of a slice, when no launch of this loop
+  // carries anybody's request: a box freed while a flight still held its dead owner's request could be claimed by a new client
+  // whose first sequence number equals the one in flight - and would then be answered with the dead client's result.  The
+  // sequence words are zeroed before FREE is published (release); clients only ever claim FREE boxes (under their file lock)
+  // and this only touches ATTACHED boxes of dead processes, so the two never write the same box.
+  for (int b = 0; b < n_boxes; ++b) {
+    vk_mailbox& box = boxes[b];
+    if (box.state == VK_BOX_ATTACHED && !process_alive((long long)box.client_pid)) {
+      box.req_seq = 0;
+      box.resp_seq = 0;
+      __atomic_store_n(&box.state, (uint32_t)VK_BOX_FREE, __ATOMIC_RELEASE);
+    }
+  }
   // One launch per context may be in flight: a round's requests go to a free context at once and its results are handed back
   // when they have arrived, while the requests that come in meanwhile take the next context - the launches overlap on the GPU
   // like those of separate processes (each context has its own stream), and chains that post together still share one.
@@ -2036,27 +2201,9 @@ static int general_grid(vk_ctx* ctx, const vk_eval_opts* opts, const double* par
     if (project && l < n_ell)
       for (int i = 0; i < n_mu; ++i) a.wsum[l] += w_ell[(size_t)l * n_mu + i];
   }
-  if (project) {
-    rc = launch_theory(ctx, a, nlr, nullptr, nullptr);
-    if (rc) return rc;
-  } else {
-    const LdsPlan pl = make_plan(a.n_mu, a.n_x, a.n_ell, a.sv.n_int, a.vr.n_int, a.xi.n_int, nlr, a.n_beta_r);
-    const size_t lds = (size_t)pl.total * sizeof(double);
-    if (lds > 160 * 1024) return fail(ctx, VK_E_ARG, "tables need %zu bytes of LDS (> 160 KiB)", lds);
-    const long long cap = 8LL * ctx->n_cu;
-    const int grid = (int)(n < cap ? n : cap);
-    a.sbins_per_item = 1;
-    a.team = 1;
-    a.parts = 1;
-    a.exp_tab = ctx->d_exp_tab;
-    switch (a.rsd) {
-      case VK_RSD_STREAMING: rc = launch_xi_smu<VK_RSD_STREAMING>(ctx, a, nlr, grid, lds); break;
-      case VK_RSD_DISPERSION: rc = launch_xi_smu<VK_RSD_DISPERSION>(ctx, a, nlr, grid, lds); break;
-      case VK_RSD_KAISER: rc = launch_xi_smu<VK_RSD_KAISER>(ctx, a, nlr, grid, lds); break;
-      default: rc = launch_xi_smu<VK_RSD_EUCLID>(ctx, a, nlr, grid, lds); break;
-    }
-    if (rc) return rc;
-  }
+  a.xi_out = project ? 0 : 1;            // theory_xi: the cells kernel stores every cell, the generic kernel where it cannot go
+  rc = launch_theory(ctx, a, nlr, nullptr, nullptr);
+  if (rc) return rc;
   VK_HIP(ctx, hipMemcpyAsync(out, d_out, out_n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return VK_OK;

@@ -144,8 +144,11 @@ __global__ __launch_bounds__(kBlock, (MODE == kModeStreaming && !SVA) || MODE ==
   const int N = a.n_ell * a.n_s;
   const int R = a.parts;
   const int cpi = a.cells_per_item;
-  const bool tail = a.fuse || R > 1;
-  CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, mode_layout(MODE), cpi,
+  // theory_xi (TheoryArgs::xi_out; the n_ell = 1 instantiations only, wave-uniform): the cells are taken mu-major - the order of
+  // out[n][n_mu][n_s], so a trip's 64 stores are consecutive - and stored as they are; ranges of a point need no hand-over
+  const bool xi_out = NL == 1 && a.xi_out != 0;
+  const bool tail = !xi_out && (a.fuse || R > 1);
+  CellsPlan pl = make_cells_plan(a.n_mu, a.n_x, a.n_s, a.uni_n, NLR, a.n_beta_r, a.uni_lut_n, mode_layout(MODE), xi_out ? 0 : cpi,
                                  tail ? N : 0, SVA ? a.sva_doubles : 0);
   // the offset behind the accumulators depends on an integer division by n_mu, which the compiler evaluates on the vector ALU:
   // wave-uniform, but held - and once spilled - as a vector register unless it is made a scalar here
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(kBlock, (MODE == kModeStreaming && !SVA) || MODE ==
   const double* l_mu = lds + pl.mu;
   const double* l_w = lds + pl.w;
   const double* l_s = lds + pl.s;
-  const int slots = min(cells_range_bins(a.n_mu, cpi), a.n_s) + 1;   // local bins of a range (+ one that only ever receives zeros)
+  const int slots = xi_out ? 1 : min(cells_range_bins(a.n_mu, cpi), a.n_s) + 1;   // local bins of a range (+ one that only ever receives zeros)
   double* l_acc = lds + pl.acc;                              // [l][local bin][wave]: each entry touched by one wave only
   const unsigned items = (unsigned)a.n * (unsigned)R;                // the host keeps n * parts below 2^31
   const int all_cells = a.n_s * a.n_mu;
@@ -196,8 +199,10 @@ __global__ __launch_bounds__(kBlock, (MODE == kModeStreaming && !SVA) || MODE ==
       const int e = base + lane;
       const bool live = e < c1;
       const unsigned ec = (unsigned)(live ? e : c1 - 1);
-      const int j = (int)__umulhi(ec, a.nmu_magic);            // ec / n_mu
-      const int i = (int)ec - j * a.n_mu;
+      const int hi = (int)__umulhi(ec, xi_out ? a.ns_magic : a.nmu_magic);   // ec / n_mu: s bin major (ec / n_s: mu major for xi_out)
+      const int lo = (int)ec - hi * (xi_out ? a.n_s : a.n_mu);
+      const int j = xi_out ? lo : hi;
+      const int i = xi_out ? hi : lo;
       const int jj = j - jf;
       const double sj = l_s[j];
       const vk_d2 mm = *reinterpret_cast<const vk_d2*>(l_mu + 2 * i);
@@ -256,10 +261,15 @@ __global__ __launch_bounds__(kBlock, (MODE == kModeStreaming && !SVA) || MODE ==
           }
         }
       }
+      if (xi_out) {                                  // xi^s = sum - 1 (ccf_model.py:690), cell e = (i, j) of out[point][n_mu][n_s]
+        if (live) a.out[point * (long long)all_cells + e] = g - 1.0 + ps.poison;
+        continue;
+      }
       // projection: this trip's cells belong to local bin jj0 or jj0 + 1 (the latter may be the spill bin)
       const int jj0 = __builtin_amdgcn_readfirstlane(jj);
       project_trip<NL>(g, live && jj == jj0, live && jj != jj0, l_w + i, a.n_mu, l_acc + jj0 * kWaves + wave, slots * kWaves, lane);
     }
+    if (xi_out) return;
     // this range's share of the theory vector is complete in LDS once every wave has finished its trips
     __syncthreads();
     double* th = lds + pl.like;

@@ -326,8 +326,8 @@ def dump_tables(t, path):
 
 
 class Engine:
-    def __init__(self, model, fit=None, device=0, matter_model=None, simpson_even=None):
-        self._lib = N.load()
+    def __init__(self, model, fit=None, device=0, matter_model=None, simpson_even=None, lib=None):
+        self._lib = lib or N.load()        # `lib`: another build of the library (development runs: tests/devlib.py)
         if self._lib.vk_device_count() <= 0:
             raise N.NativeError("no HIP device visible; victor_amd has no CPU fallback")
         tables, keep = build_tables(model, fit, matter_model, simpson_even)
@@ -471,6 +471,9 @@ class Engine:
 
     def last_fused(self):
         return bool(self._lib.vk_last_fused(self._ctx))
+
+    def last_polled(self):
+        return bool(self._lib.vk_last_polled(self._ctx))
 
     def sync(self):
         self._check(self._lib.vk_sync(self._ctx))

@@ -384,22 +384,52 @@ def gelman_rubin(chain):
 
 
 class DistributedEnsemble:
-    """One :class:`EnsembleMetropolis` per rank plus an all-gather of every step's log-likelihoods.
+    """One :class:`EnsembleMetropolis` per rank plus an all-gather of the steps' log-likelihoods.
 
-    ``gather(local_lnl) -> all_lnl`` is ``Dist.allgather_host`` (the ranks' socket group) or an RCCL gather through the engine;
-    the walkers themselves never interact, so the collective is monitoring traffic only (W doubles per rank).
+    ``gather(local) -> all`` takes this rank's doubles and returns every rank's, rank-major (``Dist.allgather_host`` over the
+    ranks' socket group, or :class:`victor_amd.sharding.RcclGather` on the engine's stream).  The walkers of different ranks
+    never interact - the reference's scale-out is N independent chains under ``mpirun`` (README.md:30) - so the collective is
+    monitoring traffic only (W doubles per rank and step) and must not sit in the step: the local log-likelihoods of
+    ``gather_block`` steps (default: the 64-step block the random numbers are drawn in) are kept and exchanged as ONE
+    ``[K, W]`` array, so a step of 8 walkers (26 us) pays a 64th of a collective instead of a blocking one (round 4: upload,
+    all-gather, stream synchronisation and download after EVERY step).  ``all_lnl`` is the same ``[steps, world * W]`` array
+    whatever the block length (tests/test_sharding.py, tests/test_gpu_rccl_double.py); ``n_collectives`` counts the gathers.
     """
 
     def __init__(self, evaluate, specs, walkers_per_rank, dist, seed=0, fixed=None, gather=None,
-                 sampler=None, fit=None):
+                 sampler=None, fit=None, gather_block=None):
         self.dist = dist
         self.local = (sampler or EnsembleMetropolis)(evaluate, specs, walkers_per_rank, seed=seed + 7919 * dist.rank,
                                                      fixed=fixed, fit=fit)
         self.gather = gather or (lambda v: dist.allgather_host(v, len(v)))
+        self.gather_block = int(gather_block if gather_block is not None else EnsembleMetropolis.BLOCK)
+        if self.gather_block < 1:
+            raise InputError("gather_block must be at least 1")
         self.all_lnl = []
+        self.n_collectives = 0
+
+    def _flush(self, buf, k):
+        """One collective for the ``k`` steps held in ``buf[:k]``; appends their ``[k, world * W]`` rows to ``all_lnl``."""
+        W, world = buf.shape[1], self.dist.world
+        K = self.gather_block
+        if k < K:
+            buf[k:] = np.nan                 # a short last block travels at the full count (RCCL: equal counts, fixed buffers)
+        got = np.asarray(self.gather(buf.reshape(K * W))).reshape(world, K, W)
+        self.n_collectives += 1
+        self.all_lnl.extend(np.ascontiguousarray(got[:, t, :]).reshape(world * W) for t in range(k))
 
     def run(self, n_steps):
+        W = self.local.n_walkers
+        buf = np.empty((self.gather_block, W))
+        held = [0]
+
         def on_step(t, ens):
-            self.all_lnl.append(self.gather(np.ascontiguousarray(ens.lnl)))
+            buf[held[0]] = ens.lnl
+            held[0] += 1
+            if held[0] == self.gather_block:
+                self._flush(buf, held[0])
+                held[0] = 0
         chain, lnl = self.local.run(n_steps, on_step=on_step)
+        if held[0]:
+            self._flush(buf, held[0])
         return chain, lnl, np.array(self.all_lnl)

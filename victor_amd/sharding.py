@@ -112,9 +112,10 @@ def one_device_per_rank(dist, engine):
     import socket
     if dist.world == 1 or dist.group is None:
         return True
-    if os.environ.get("VICTOR_HIP_RCCL_SHARED_DEVICE_OK") == "1":
-        # tests only: ranks sharing a GPU may build a communicator of an RCCL stand-in that can live with that
-        # (tests/rccl_double, selected through VICTOR_HIP_RCCL_LIB); the real RCCL refuses such a communicator itself
+    if os.environ.get("VICTOR_HIP_DEV") == "1" and os.environ.get("VICTOR_HIP_RCCL_SHARED_DEVICE_OK") == "1":
+        # tests only, and like every VICTOR_HIP_* switch only under VICTOR_HIP_DEV=1: ranks sharing a GPU may build a
+        # communicator of an RCCL stand-in that can live with that (tests/rccl_double, selected through VICTOR_HIP_RCCL_LIB);
+        # the real RCCL refuses such a communicator itself
         return True
     mine = f"{socket.gethostname()}|{engine.bus_id()}".encode()
     ids = dist.group.allgather_bytes(mine, "devices")
@@ -182,7 +183,9 @@ class ShardedLikelihood:
 
 class RcclGather:
     """All-gather of equal-size double arrays through RCCL on the engine's stream (device staging buffers are
-    allocated once).  ``uid`` comes from rank 0's ``Engine.comm_unique_id()`` broadcast over the host process group."""
+    allocated once).  ``uid`` comes from rank 0's ``Engine.comm_unique_id()`` broadcast over the host process group.
+    ``count`` doubles per rank and call - for :class:`victor_amd.sampler.DistributedEnsemble` a whole block of steps
+    (``gather_block * walkers``): one upload, one ``ncclAllGather``, one download per block."""
 
     def __init__(self, engine, dist, count):
         self.engine, self.dist, self.count = engine, dist, int(count)
@@ -193,6 +196,7 @@ class RcclGather:
         engine.comm_init(uid, dist.rank, dist.world)
         self.d_send = engine.alloc(self.count)
         self.d_recv = engine.alloc(self.count * dist.world)
+        self.calls = 0
 
     def __call__(self, local):
         local = np.ascontiguousarray(local, dtype=np.float64)
@@ -200,12 +204,102 @@ class RcclGather:
         self.engine.upload(self.d_send, local)
         self.engine.comm_allgather_async(self.d_send, self.d_recv, self.count)
         self.engine.sync()
+        self.calls += 1
         return self.engine.download(self.d_recv, self.count * self.dist.world)
 
     def close(self):
         self.engine.free(self.d_send)
         self.engine.free(self.d_recv)
         self.engine.comm_destroy()
+
+
+class DeviceGather:
+    """All-gather of result vectors that stay in HBM, for the engines this process drives - the collective of a sharded batch.
+
+    ``launched`` (one process per GPU under torchrun / mpirun / srun): ``ncclCommInitRank`` on ``engines[0]`` with the id rank 0
+    draws, ``ncclAllGather`` on that context's stream.  Otherwise (ONE process, one context per GPU): ``ncclCommInitAll`` and a
+    grouped all-gather.  ``mode`` says what was built: ``"rank"`` / ``"group"``, ``"host"`` when RCCL is missing or refuses
+    (ranks sharing a device: a rehearsal on a one-GPU box) - the vectors then travel through the ranks' socket group and are
+    written back into every receive buffer, a degraded mode kept so that the callers' checks read the same buffers -, ``"none"``
+    for a single GPU without a launcher.  Every decision is taken collectively: all ranks end up in the same mode.
+    A rendezvous that never completes raises :class:`victor_amd._native.CommInitTimeout`, which is fatal for the process."""
+
+    NAMES = {"rank": "rccl allgather of lnL (ncclCommInitRank, one process per GPU)",
+             "group": "rccl allgather of lnL (ncclCommInitAll, grouped calls, one process)",
+             "host": "host allgather of lnL (RCCL unavailable or refused)",
+             "none": "none (single GPU)"}
+
+    def __init__(self, dist, engines, launched, log=None):
+        from . import _native
+        from .engine import Engine
+        self.dist, self.engines, self.launched = dist, list(engines), bool(launched)
+        self.mode = "none"
+        log = log or (lambda msg: None)
+        if not launched and len(self.engines) < 2:
+            return
+        ok = 1.0
+        try:
+            if launched:
+                eng = self.engines[0]
+                if not one_device_per_rank(dist, eng):
+                    raise RuntimeError("two ranks share a GPU: RCCL needs one device per rank")
+                try:
+                    uid = eng.comm_unique_id() if dist.rank == 0 else None
+                except Exception as exc:                # librccl missing: every rank must learn about it
+                    log(f"rank {dist.rank}: RCCL unavailable ({exc})")
+                    uid, ok = bytes(128), 0.0
+                uid = dist.broadcast_bytes(uid, src=0, nbytes=128)
+                ok = dist.min_float(ok)
+                if ok:
+                    try:
+                        eng.comm_init(uid, dist.rank, dist.world)
+                    except _native.CommInitTimeout:
+                        raise
+                    except Exception as exc:
+                        log(f"rank {dist.rank}: ncclCommInitRank failed ({exc})")
+                        ok = 0.0
+                    ok = dist.min_float(ok)              # no collective before every rank holds a communicator
+                    self._have_comm = True
+            else:
+                Engine.comm_init_all(self.engines)
+                self._have_comm = True
+        except _native.CommInitTimeout:
+            raise
+        except Exception as exc:
+            log(f"rank {dist.rank}: RCCL communicator failed ({exc})")
+            ok = 0.0
+        ok = dist.min_float(ok)
+        self.mode = ("rank" if launched else "group") if ok else "host"
+
+    def degrade(self, failed):
+        """After the first collective: every rank reports whether it failed; one failure sends all of them to the host mode."""
+        if self.mode in ("rank", "group") and self.dist.min_float(0.0 if failed else 1.0) == 0.0:
+            self.mode = "host"
+
+    def __call__(self, d_send, d_recv, n):
+        """Enqueue the all-gather of ``n`` doubles per GPU: ``d_send[i]`` / ``d_recv[i]`` live on ``engines[i]``'s device
+        (``d_recv``: total GPUs x n doubles, rank-major).  ``"host"`` mode synchronises."""
+        from .engine import Engine
+        if self.mode == "rank":
+            self.engines[0].comm_allgather_async(d_send[0], d_recv[0], n)
+        elif self.mode == "group":
+            Engine.comm_allgather_group_async(self.engines, list(d_send), list(d_recv), n)
+        elif self.mode == "host":
+            for e in self.engines:
+                e.sync()
+            local = np.concatenate([e.download(p, n) for e, p in zip(self.engines, d_send)])
+            full = self.dist.allgather_host(local, len(local)) if self.launched else local
+            for e, p in zip(self.engines, d_recv):
+                e.upload(p, full)
+
+    def close(self):
+        if getattr(self, "_have_comm", False):
+            for e in self.engines:
+                try:
+                    e.comm_destroy()
+                except Exception:
+                    pass
+            self._have_comm = False
 
 
 class MultiGPUFit:
