@@ -37,9 +37,41 @@ F_PT_ANISO = 77
 F_PT_ISO = 47
 
 
+PEAK_CLOCK_GHZ = 2.4             # the clock behind PEAK_FP64_VALU_TFLOPS
+
+
 def flops_per_eval(n_s, n_mu, n_x, n_ell, aniso):
     """Algorithmic flops of the theory kernel per evaluation (SURVEY.md 8d without the chi-square term)."""
     return n_s * n_mu * n_x * (F_PT_ANISO if aniso else F_PT_ISO) + 2 * n_ell * n_s * n_mu
+
+
+def model_flops(rsd, n_s, n_mu, n_x, n_ell, aniso=False, niter=5, n_data=0, linearised=False, coord_shift=True):
+    """Algorithmic flops per evaluation of the other RSD models, counted from the reference's expressions with SURVEY.md 8(d)'s
+    conventions (sqrt, divide, exp one flop each; a table look-up 9: index 2, local coordinate 1, cubic Horner 6; an fma 2) -
+    the breakdown is DESIGN.md section 5, "Algorithmic flops of the other RSD models".  ``n_data`` > 0 adds the chi-square
+    (2 N^2 + 3 N) for launches that take it in the same kernel.
+
+    dispersion (ccf_model.py:658-671), per integrand point: numerator s_par - v/aH 2; first pass 1 (its 1 / (1 + q(s)) is per
+        cell: 20); niter passes of [r^2 2, sqrt 1, 1/r 1, u = r/c 1, V look-up 9, q 2, 1 + q 1, divide 1] = 18; final geometry 6
+        (r^2 2, sqrt, 1/r, mu_r, u); four look-ups (sigma_v, V, V', xi_0) 36; zero-mean pdf 6; Jacobian 10; accumulate 5
+        = 66 + 18 niter = 156 at niter = 5;
+    kaiser (:692-741), per (s, mu) cell: s_perp, s_par 4; first pass 18 (s 3, then as a pass without r^2); niter passes 18;
+        final geometry 6; three look-ups (V, V', xi_0) 27; J 7; 1 / (1 + J) and (1 + M xi) J^-1 - 1: 5 = 67 + 18 niter = 157
+        (linearised: 2 instead of 5; without the coordinate shift the 18 (1 + niter) go);
+    euclid_special (:743-784): kaiser's J with other constants, xi = M xi_r - J: 2 = 154.
+    Anisotropic real-space multipoles add two look-ups and the Legendre sum: 30 (as 47 -> 77 for streaming)."""
+    cells = n_s * n_mu
+    extra = 30 if aniso else 0
+    tail = 2 * n_data * n_data + 3 * n_data
+    if rsd == "streaming":
+        return flops_per_eval(n_s, n_mu, n_x, n_ell, aniso) + tail
+    if rsd == "dispersion":
+        return cells * n_x * (66 + 18 * niter + extra) + cells * 20 + 2 * n_ell * cells + tail
+    if rsd in ("kaiser", "euclid_special"):
+        shift = 18 * (1 + niter) if coord_shift else 0
+        last = 2 if (rsd == "euclid_special" or linearised) else 5
+        return cells * (4 + shift + 6 + 27 + 7 + last + extra) + 2 * n_ell * cells + tail
+    raise ValueError(rsd)
 
 
 def cpu_worker(args):
@@ -274,10 +306,27 @@ def profiled_traffic(which, batch):
     if not rec:
         return None
     scale = batch / rec["batch"]
+    from victor_amd.build import sources_digest
+    stored = tj.get("sources_sha256")
     return {"bytes_per_launch": rec["theory_kernel_hbm_bytes_per_launch"] * scale, "batch": batch,
             "profiled_batch": rec["batch"], "algorithmic_bytes_per_launch": rec["algorithmic_bytes_per_launch"] * scale,
             "ratio_to_algorithmic": rec["theory_kernel_hbm_bytes_per_launch"] / rec["algorithmic_bytes_per_launch"],
-            "kernel": rec["kernel"], "commit": tj.get("commit"), "source": tj.get("source")}
+            "kernel": rec["kernel"], "commit": tj.get("commit"), "source": tj.get("source"),
+            # the kernel sources (csrc/*.h, csrc/*.hip, include/victor_hip.h) hash to what the counters were taken at
+            "sources_unchanged": (stored == sources_digest()) if stored else None,
+            "effective_clock_ghz": rec.get("effective_clock_ghz")}
+
+
+def profiled_clock(which):
+    """Sustained shader clock of the workload's theory kernel in the last profile (GRBM_GUI_ACTIVE / 8 / duration,
+    profiles/traffic_latest.json), or None."""
+    tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if not os.path.isfile(tfile):
+        return None
+    with open(tfile) as fh:
+        tj = json.load(fh)
+    rec = tj.get(which) or (tj.get("model_options") or {}).get(which)
+    return (rec or {}).get("effective_clock_ghz")
 
 
 def boss_measurement(args, batch=16384, steps=20):
@@ -312,8 +361,15 @@ def boss_measurement(args, batch=16384, steps=20):
     return {"evals_per_s": batch * steps / dt, "batch": batch, "steps": steps, "kernel": eng.last_kernel() + "<1,2>",
             "kernels_ms": {"theory": k1, "likelihood": k2 / max(launches, 1)},
             "fp64_valu_frac": F * batch / (k1 * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if k1 > 0 else None,
+            "frac_at_sustained_clock": at_sustained_clock(F * batch / (k1 * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if k1 > 0 else None,
+                                                          profiled_clock("boss_cmass")),
             "flops_per_eval": F, "all_finite": bool(np.all(np.isfinite(lnl))), "fused": fused,
             "traffic_profiled": profiled_traffic("boss_cmass", batch)}
+
+
+def at_sustained_clock(frac, clock_ghz):
+    """The same fraction against the peak at the clock the kernel actually sustained (peak x clock / 2.4 GHz)."""
+    return frac * PEAK_CLOCK_GHZ / clock_ghz if (frac and clock_ghz) else None
 
 
 def batch_sweep():
@@ -446,7 +502,24 @@ def option_rates(batch=16384, steps=4):
             eng.eval_device_async(o, bufs[0], batch, bufs[1], bufs[2], bufs[3])
         eng.sync()
         dt = (time.perf_counter() - t0) / steps
-        res[label] = {"evals_per_s": batch / dt, "ms_per_batch": dt * 1e3, "kernel": eng.last_kernel()}
+        # the theory kernel's own duration (HIP events on the context's stream) for the roofline fraction beside the rate
+        eng.timing(True)
+        eng.read_timing(reset=True)
+        for _ in range(steps):
+            eng.eval_device_async(o, bufs[0], batch, bufs[1], bufs[2], bufs[3])
+        eng.sync()
+        k1, k2, launches = eng.read_timing(reset=True)
+        eng.timing(False)
+        k1 /= max(launches, 1)
+        fused = eng.last_fused()
+        rsd = model["rsd_model"]
+        F = model_flops(rsd, len(fit.s), 100, 50, len(fit.poles_s), aniso=not model["assume_isotropic"], niter=int(model.get("niter", 5)),
+                        n_data=eng.n_data if fused else 0, linearised=bool(model.get("kaiser_approximation", False)),
+                        coord_shift=bool(model.get("kaiser_coord_shift", True)))
+        frac = F * batch / (k1 * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if k1 > 0 else None
+        res[label] = {"evals_per_s": batch / dt, "ms_per_batch": dt * 1e3, "kernel": eng.last_kernel(), "fused": fused,
+                      "theory_kernel_ms": k1, "flops_per_eval": F, "fp64_valu_frac": frac,
+                      "frac_at_sustained_clock": at_sustained_clock(frac, profiled_clock(label))}
         for b in bufs:
             eng.free(b)
 
@@ -597,6 +670,7 @@ def dsplit_sharded(dist, launched, n_local, n_dev, total, steps, warmup, global_
     for _ in range(warmup):
         step()
     el = timed_steps(dist, leads, step, steps)
+    kernel = leads[0].last_kernel()
     # every GPU checks the WHOLE gathered vector: its own shard bit for bit, rows of every other shard against its own evaluation
     good = True
     for j in js:
@@ -611,7 +685,6 @@ def dsplit_sharded(dist, launched, n_local, n_dev, total, steps, warmup, global_
             own_l, _ = j["joint"].log_likelihood_batch(theirs)
             good = good and bool(np.max(np.abs(gathered[other * Bs + probe] - own_l)) <= 1e-9 * np.max(np.abs(own_l)))
     good = bool(dist.min_float(1.0 if good else 0.0))
-    kernel = leads[0].last_kernel()
     gat.close()
     for j in js:
         j["lead"].free(j["d_all"])
@@ -653,6 +726,9 @@ def walkers_distributed(dist, launched, n_local, n_dev, total, walkers=8, steps=
             rccl = multi.enable_rccl()
         ens = EnsembleMetropolis(multi.log_likelihood_gathered, specs, walkers * total, seed=1, fixed=fixed)
         ens.initialise()
+        # what the devices gathered among themselves is what the host gets by concatenating the shards: bit for bit
+        probe = ens._batch(ens.x)
+        good = bool(np.array_equal(multi.log_likelihood_gathered(probe), multi.log_likelihood_batch(probe)[0]))
         t_end = time.perf_counter() + 0.4
         while time.perf_counter() < t_end:
             ens.run(10)
@@ -661,9 +737,12 @@ def walkers_distributed(dist, launched, n_local, n_dev, total, walkers=8, steps=
         ens.run(steps)
         dt = time.perf_counter() - t0
         multi.close()
-        out.update({"layout": "one process, one ensemble sharded over the devices, grouped all-gather every step",
+        out.update({"layout": "one process, ONE ensemble whose proposals are sharded over the devices: the host needs every "
+                              "log-likelihood every step, so the (grouped) all-gather is part of the step; a step of 8 walkers per "
+                              "GPU is host-bound (22 of 26 us are NumPy) and one interpreter cannot scale it - one process per GPU "
+                              "(the launched layout, independent walkers, block gather) is the layout for this workload",
                     "gather": "rccl (grouped)" if rccl else "host", "evals_per_s": (ens.n_evals - e0) / dt,
-                    "us_per_step": 1e6 * dt / steps, "acceptance": ens.acceptance, "gather_matches_local": None})
+                    "us_per_step": 1e6 * dt / steps, "acceptance": ens.acceptance, "gather_matches_local": good})
         return out
     engine = fit._get_engine()
     block = EnsembleMetropolis.BLOCK
@@ -929,6 +1008,10 @@ def main():
             "roofline": {"bound": "fp64-valu", "kernel": kernel_name + "<3,3>",
                          "achieved": achieved_tf, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / PEAK_FP64_VALU_TFLOPS if achieved_tf else None,
+                         # against the peak at the clock this kernel sustained in the last profile (peak x clock / 2.4 GHz)
+                         "frac_at_sustained_clock": at_sustained_clock(achieved_tf / PEAK_FP64_VALU_TFLOPS if achieved_tf else None,
+                                                                       profiled_clock("config3")),
+                         "sustained_clock_ghz": profiled_clock("config3"),
                          "traffic": None, "traffic_profiled": traffic_profiled, "flops_per_eval": F, "kernel_ms": k1_ms,
                          "note": "path is FP64 vector-ALU bound (no MFMA, ~1e-5 of HBM peak); sqrt/div/exp counted "
                                  "as one flop each per SURVEY.md 8(d)"},

@@ -24,7 +24,9 @@ def dev_twin(fit):
     twin = getattr(fit, "_dev_twin", None)
     if twin is None:
         twin = copy.copy(fit)
-        twin._engine = None
+        twin._engine = None                # its own device contexts ...
+        twin._plan = None                  # ... and no cached (engine, options) pair of the original's
+        twin._dev_twin = twin
         twin._native_lib = dev_library()
         fit._dev_twin = twin
     return twin

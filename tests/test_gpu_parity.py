@@ -860,8 +860,8 @@ def test_polling_handoff_gives_the_bits_of_the_counter_handoff(synth_fit, boss_f
         polled = run()
         eng = fit._get_engine()
         assert eng.last_polled()                                            # the single point behind the 16-point batch
-        fit.log_likelihood_batch({k: v[:8] for k, v in hp.items()})
-        assert eng.last_polled()                                            # eight points: the context's reservation covers them
+        fit.log_likelihood_batch({k: v[:3] for k, v in hp.items()})
+        assert eng.last_polled()                                            # three points still split their planes: the context's reservation grows to cover them
         fit.log_likelihood_batch({k: v[:16] for k, v in hp.items()})
         assert not eng.last_polled()
         _native.set_knob("VICTOR_HIP_NO_POLL", "1")

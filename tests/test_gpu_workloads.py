@@ -334,6 +334,22 @@ def test_bench_one_process_two_contexts_on_one_gpu():
     assert out["config"]["processes"] == 1 and out["config"]["contexts_per_process"] == 2
 
 
+def test_bench_one_process_two_contexts_with_the_config_4_and_5_legs():
+    """The same start with the BASELINE config 4 / 5 legs: the density-split joint fit sharded over the two contexts (five
+    contexts each, global batch 16384) and one walker ensemble sharded over them - on the one-GPU box both gathers degrade to the
+    host, and every check of what was gathered must still hold."""
+    import json
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--batch", "4096", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    _check_two_gpu_line(out)
+    d5, w = out["dsplit5"], out["walker_ensembles"]
+    assert d5["global_batch"] == 16384 and d5["batch_per_gpu"] == 8192 and d5["gather_matches_local"] is True
+    assert d5["kernel"] == "vk_theory_cells_kernel" and d5["joint_evals_per_s"] > 0
+    assert w["walkers_total"] == 16 and w["gather_matches_local"] is True and w["evals_per_s"] > 0
+
+
 def test_integration_stub_runs_as_written():
     """The ctypes stub printed in INTEGRATION.md (route B) is executed verbatim against a CCFFit and must reproduce
     the package's own batch API."""

@@ -27,6 +27,21 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 COMMON = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC")
 
 
+def sources_digest():
+    """sha256 over the kernel sources (csrc/*.h, csrc/*.hip, include/victor_hip.h; names and contents, sorted): what a profile was
+    taken at.  tools/update_traffic.py stores it with the counters, bench.py recomputes it (`traffic_profiled.sources_unchanged`)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip"))) + [os.path.join(INCLUDE, "victor_hip.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
 def hipcc_path():
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.isfile(cand):
