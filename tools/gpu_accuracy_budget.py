@@ -4,6 +4,9 @@ theory vectors and max relative d chi2 - and against the CPU oracle on a sample.
 1e-6, the parity tests hold 1e-9).  Usage: gpu_accuracy_budget.py [points per case, default 65536] [oracle points, default 64]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _devlib import use_dev_library
+use_dev_library()          # the lanes kernel lives in the development build of the library only
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 import numpy as np
 import victor_amd

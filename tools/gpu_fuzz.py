@@ -2,6 +2,9 @@
 much wider than the bench's, 131072 points per case.  Prints the largest relative deviation of the theory vectors."""
 import os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _devlib import use_dev_library
+use_dev_library()          # the lanes kernel lives in the development build of the library only
 import numpy as np
 import victor_amd
 from tests import cases

@@ -1,6 +1,9 @@
 """Lanes kernel at batch sizes beyond the launch cap (64 workgroups per CU): resident evals/s vs VICTOR_HIP_LANES_CAP."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _devlib import use_dev_library
+use_dev_library()          # the lanes kernel lives in the development build of the library only
 import victor_amd
 from tests import cases
 from victor_amd import _native
