@@ -804,6 +804,10 @@ def walkers_distributed(dist, launched, n_local, n_dev, total, walkers=8, steps=
     return out
 
 
+LEG_TIMEOUT = 300.0              # seconds the N > 1 legs (configs 4 and 5) may take together before rank 0 prints its line without them
+REAL_STDOUT = os.dup(1)          # the stdout this program was started with
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -967,18 +971,8 @@ def main():
                   "ms_per_step": 1e3 * el_s / args.steps, "scaling": "strong", "kernel": eng.last_kernel(),
                   "theory_kernel_ms_per_rank": ks}
 
-    # BASELINE configs 4 and 5 at N > 1: the density-split joint fit with its global batch of 16384 sharded over the GPUs, and
-    # 8 Metropolis walkers per GPU on the BOSS cobaya configuration with the block gather of their log-likelihoods
-    dsplit_n = walkers_n = None
-    if total > 1 and not args.no_boss:
-        comm_info = _native.comm_info() if rank == 0 else None
-        gatherer.close()                      # one communicator at a time: every leg builds its own on its own contexts
-        for s_ in slots:
-            s_.free()
-        slots = []
-        dsplit_n = dsplit_sharded(dist, launched, n_local, n_dev, total, args.steps, max(args.warmup, 1))
-        walkers_n = walkers_distributed(dist, launched, n_local, n_dev, total)
-
+    comm_info = _native.comm_info() if (rank == 0 and (total > 1 or launched)) else None
+    out = None
     if rank == 0:
         value = B * total * args.steps / elapsed
         k1_ms, k2_ms = theory_ms, like_ms
@@ -1025,13 +1019,10 @@ def main():
         if gathered_ok is not None:
             out["gather_matches_local"] = gathered_ok       # every rank, every slot (see above)
         if kernel_ms_ranks is not None:
-            out["config"]["rccl"] = comm_info if total > 1 and not args.no_boss else _native.comm_info()
+            out["config"]["rccl"] = comm_info
             out["theory_kernel_ms_per_rank"] = kernel_ms_ranks
         if strong is not None:
             out["strong_scaling"] = strong
-        if dsplit_n is not None:
-            out["dsplit5"] = dsplit_n
-            out["walker_ensembles"] = walkers_n
         if total == 1 and not args.no_boss:
             out["boss_cmass"] = boss_measurement(args)
             out["batch_sweep"] = batch_sweep()
@@ -1061,15 +1052,64 @@ def main():
             scale = np.max(np.abs(th_o.reshape(len(kk), len(fit.poles_s), -1)), axis=2, keepdims=True)
             dxi = np.abs(th_g - th_o).reshape(len(kk), len(fit.poles_s), -1) / scale
             out["max_rel_dxi_ell_vs_oracle"] = float(dxi.max())      # relative to max|xi_l| of each multipole
-        print(json.dumps(out))
+
+    # The ONE line of rank 0 (written to the stdout this program was started with, whatever a native library's banner has been
+    # routed to meanwhile), exactly once - from here or from the watchdog of the legs below.
+    import threading
+    line_lock, line_out = threading.Lock(), [False]
+    headline_ok = ok and gathered_ok is not False
+
+    def emit(extra=None):
+        with line_lock:
+            if line_out[0]:
+                return
+            line_out[0] = True
+            if rank == 0:
+                if extra:
+                    out.update(extra)
+                os.write(REAL_STDOUT, (json.dumps(out) + "\n").encode())
+
+    # BASELINE configs 4 and 5 at N > 1: the density-split joint fit with its global batch of 16384 sharded over the GPUs, and
+    # 8 Metropolis walkers per GPU on the BOSS cobaya configuration with the block gather of their log-likelihoods.  The headline
+    # above is complete by now; these legs build communicators of their own, so they run under a watchdog: a leg that raises is
+    # reported as {"error": ...}, a collective that hangs costs LEG_TIMEOUT seconds - never the headline's record.
+    legs = {}
+    if total > 1 and not args.no_boss:
+        gatherer.close()                      # one communicator at a time: every leg builds its own on its own contexts
+        for s_ in slots:
+            s_.free()
+        slots = []
+
+        def give_up():
+            msg = f"did not finish within {LEG_TIMEOUT:.0f} s (a hung collective?); the measurements above are unaffected"
+            emit({k: legs.get(k, {"error": msg}) for k in ("dsplit5", "walker_ensembles")})
+            os._exit(0 if headline_ok else 1)
+
+        timer = threading.Timer(LEG_TIMEOUT, give_up)
+        timer.daemon = True
+        timer.start()
+        for name, leg in (("dsplit5", lambda: dsplit_sharded(dist, launched, n_local, n_dev, total, args.steps, max(args.warmup, 1))),
+                          ("walker_ensembles", lambda: walkers_distributed(dist, launched, n_local, n_dev, total))):
+            try:
+                legs[name] = leg()
+            except Exception as exc:       # noqa: BLE001 - reported in the line; the other ranks' watchdogs end a collective left half-way
+                legs[name] = {"error": repr(exc)}
+                print(f"rank {rank}: leg {name} failed: {exc!r}", file=sys.stderr)
+        timer.cancel()
+    emit(legs)
 
     gatherer.close()
     for s_ in slots:
         s_.free()
+    failed_leg = any("error" in leg for leg in legs.values())
+    if failed_leg:                           # ranks may be out of step with each other: no further collective, no destructors
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0 if headline_ok else 1)
     dist.barrier()
     dist.close()
-    legs_ok = all(leg is None or leg.get("gather_matches_local") is not False for leg in (dsplit_n, walkers_n))
-    if not ok or gathered_ok is False or not legs_ok:
+    legs_ok = all(leg.get("gather_matches_local") is not False for leg in legs.values())
+    if not headline_ok or not legs_ok:
         sys.exit(1)
 
 
