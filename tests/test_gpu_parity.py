@@ -193,6 +193,20 @@ def test_theory_xi_on_the_cells_kernel(synth_fit, boss_fit, oracle):
                         for pt, i, j in ((0, 0, 0), (3, len(mu) - 1, len(s) - 1), (4, len(mu) // 2, 1)):
                             want = ora.theory_xi(np.array([s[j]]), np.array([mu[i]]), cases.point(sub, pt), **kw)[0, 0]
                             assert abs(xi[pt, i, j] - want) < RTOL * max(abs(want), 1e-2), (tag, rsd, pt, i, j, xi[pt, i, j], want)
+        # grids at the edges of what the kernel takes: one s bin, two mu nodes; a long mu grid; more cells than one range holds
+        for s, mu, want in ((np.array([33.3]), np.array([0.1, 0.9]), "vk_theory_cells_kernel"),
+                            (np.linspace(2.0, 118.0, 59), np.linspace(0, 1, 1000), "vk_theory_cells_kernel"),
+                            (fit.s, np.linspace(0, 1, 1025), "vk_xi_smu_kernel")):       # n_mu > 1024: the generic kernel's
+            sub = {k: v[:2] for k, v in hp.items()}
+            xi = fit.theory_xi_batch(s, mu, sub)
+            assert fit._get_engine().last_kernel() == want, (tag, len(s), len(mu))
+            _native.set_knob("VICTOR_HIP_FORCE_GENERIC", "1")
+            try:
+                ref = fit.theory_xi_batch(s, mu, sub)
+            finally:
+                _native.set_knob("VICTOR_HIP_FORCE_GENERIC", None)
+            assert xi.shape == ref.shape == (2, len(mu), len(s))
+            assert np.max(np.abs(xi - ref)) < 1e-9 * np.max(np.abs(ref)), (tag, len(s), len(mu))
         # a NaN parameter poisons every cell of its point and nothing else
         bad = {k: v[:3].copy() for k, v in hp.items()}
         bad["sigma_v"][1] = np.nan

@@ -1821,12 +1821,13 @@ static int zc_finish(vk_ctx* ctx, int64_t n, double* lnl, double* chi2, bool blo
         (void)hipGetLastError();
         if (!block) return 0;
         VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        arrived = true;
-        for (int64_t i = 2 * n - 1; i >= 0; --i)
-          if (slots[i] == kSpinSentinel) { arrived = false; break; }
-        if (arrived) break;
       }
-      break;
+      // the stream is complete: whatever the launch wrote is visible now (the last results may have landed between the poll
+      // above and the query) - look once more before calling it a time-out of the polling itself
+      arrived = true;
+      for (int64_t i = 2 * n - 1; i >= 0; --i)
+        if (slots[i] == kSpinSentinel) { arrived = false; break; }
+      break;                                  // arrived: a slow launch or the race - nothing to count; not arrived: counted below
     }
   } else if (!block && hipStreamQuery(ctx->stream) == hipErrorNotReady) {
     (void)hipGetLastError();
