@@ -317,6 +317,52 @@ def profiled_traffic(which, batch):
             "effective_clock_ghz": rec.get("effective_clock_ghz")}
 
 
+def live_traffic(batch, simpson_even, log_dir=None):
+    """HBM bytes per launch of the dominant (theory) kernel, measured NOW: two child runs of this very program on the same
+    batch under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` - separate passes, the program itself directly after `--`,
+    counters only (no trace domains) - corrected as MI355X_MICROARCH.md prescribes (KiB -> bytes, FETCH_SIZE x 2 on gfx950).
+    Child processes: must run before this process touches the GPU.  Returns a dict, or None when the profiler is not there or
+    a pass fails (the line then carries `traffic: null` and the last profiled figure beside it)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.isfile(exe):
+        return None
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out_dir = tempfile.mkdtemp(prefix="victor_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out_dir, "-o", "pmc", "--", sys.executable,
+               os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", str(batch), "--no-cpu-baseline",
+               "--no-boss", "--no-live-traffic", "--simpson-even", simpson_even]
+        try:
+            res = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=300)
+            vals = {}
+            for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if r.get("Counter_Name") == counter and "vk_theory" in r.get("Kernel_Name", ""):
+                            vals.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+            if res.returncode != 0 or not vals:
+                if log_dir:
+                    with open(os.path.join(log_dir, f"live_traffic_{counter}.err"), "w") as fh:
+                        fh.write(res.stdout[-4000:] + "\n" + res.stderr[-4000:])
+                return None
+            kernel = max(vals, key=lambda k: sum(vals[k]))
+            got[counter] = (kernel, sum(vals[kernel]) / len(vals[kernel]), len(vals[kernel]))
+        except (OSError, subprocess.TimeoutExpired, ValueError, KeyError):
+            return None
+        finally:
+            shutil.rmtree(out_dir, ignore_errors=True)
+    fetch, write = 2.0 * got["FETCH_SIZE"][1] * 1024.0, got["WRITE_SIZE"][1] * 1024.0
+    return {"bytes_per_launch": fetch + write, "read_bytes": fetch, "written_bytes": write,
+            "kernel": got["FETCH_SIZE"][0].replace("void ", "").split("(")[0], "launches_averaged": got["FETCH_SIZE"][2],
+            "method": "two child runs of this program under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, "
+                      "counters only); KiB -> bytes, FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md)"}
+
+
 def profiled_clock(which):
     """Sustained shader clock of the workload's theory kernel in the last profile (GRBM_GUI_ACTIVE / 8 / duration,
     profiles/traffic_latest.json), or None."""
@@ -817,6 +863,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-boss", action="store_true", help="skip the secondary BOSS CMASS measurement")
     ap.add_argument("--no-chains", action="store_true", help="skip the chains-sharing-one-GPU measurement (child processes)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="skip the two rocprofv3 --pmc child runs that measure the theory kernel's HBM traffic (roofline.traffic)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="oracle evaluations (default: about 10 per core)")
     ap.add_argument("--simpson-even", default="simpson",
                     help="even-N Simpson convention of the velocity integral: 'simpson' (SciPy >= 1.11, default) or "
@@ -865,6 +913,11 @@ def main():
         sample = [cases.point(hp_all, int(i)) for i in sel]
         base, vals, theory_o = cpu_baseline(sample, args.simpson_even)
         base["single_thread"] = cpu_single_thread(sample[:: max(1, len(sample) // 64)][:64], args.simpson_even)
+    # HBM traffic of the dominant kernel, measured live: two child runs under rocprofv3 --pmc, again before the GPU is touched
+    traffic_live = None
+    if rank == 0 and total == 1 and not args.no_live_traffic and not args.no_boss:
+        gdir = os.path.join(ROOT, "gpurun_out")
+        traffic_live = live_traffic(B, args.simpson_even, gdir if os.path.isdir(gdir) else None)
     # the reference's own calling convention under load (P chains, one point per call): child processes again, so before the GPU
     chains = None
     if rank == 0 and total == 1 and not args.no_boss and not args.no_chains:
@@ -979,8 +1032,8 @@ def main():
         aniso = not fit.model["assume_isotropic"]
         F = flops_per_eval(len(fit.s), 100, 50, len(fit.poles_s), aniso)
         achieved_tf = F * B / (k1_ms * 1e-3) / 1e12 if k1_ms > 0 else None
-        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (MI355X_MICROARCH.md), which this run
-        # does not make: `traffic` is null here and the last profiled figure is reported beside it with its source
+        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (MI355X_MICROARCH.md): made by this run
+        # itself as child processes (live_traffic); the last profiled figure is reported beside it with its source
         traffic_profiled = profiled_traffic("config3", B)
         alg_bytes = (8 * 12 + 16) * B     # a parameter row of VK_NPAR = 12 doubles in, lnL + chi2 out, per evaluation
         out = {
@@ -1006,7 +1059,12 @@ def main():
                          "frac_at_sustained_clock": at_sustained_clock(achieved_tf / PEAK_FP64_VALU_TFLOPS if achieved_tf else None,
                                                                        profiled_clock("config3")),
                          "sustained_clock_ghz": profiled_clock("config3"),
-                         "traffic": None, "traffic_profiled": traffic_profiled, "flops_per_eval": F, "kernel_ms": k1_ms,
+                         # HBM bytes per launch of this kernel from PMC counters: measured in this run (live_traffic) when the
+                         # profiler is there, else null with the last profiled figure beside it
+                         "traffic": traffic_live["bytes_per_launch"] if traffic_live else None,
+                         "traffic_measured": traffic_live,
+                         "traffic_ratio_to_algorithmic": traffic_live["bytes_per_launch"] / alg_bytes if traffic_live else None,
+                         "traffic_profiled": traffic_profiled, "flops_per_eval": F, "kernel_ms": k1_ms,
                          "note": "path is FP64 vector-ALU bound (no MFMA, ~1e-5 of HBM peak); sqrt/div/exp counted "
                                  "as one flop each per SURVEY.md 8(d)"},
             "roofline_hbm": {"bound": "hbm", "achieved": alg_bytes / ((k1_ms + k2_ms) * 1e-3) / 1e9 if k1_ms else None,

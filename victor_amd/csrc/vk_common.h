@@ -127,7 +127,7 @@ struct TheoryArgs {
   double wsum[3];         // sum_i W_l[i]: the "-1" of ccf_model.py:690 projects to -sum_i W_l[i] (not 0 for l > 0)
   unsigned nx_magic;      // ceil(2^32 / n_x):  idx / n_x  == __umulhi(idx, nx_magic)  for every idx of the (mu, v) plane
   unsigned nmu_magic;     // ceil(2^32 / n_mu): cell / n_mu likewise (cells kernel)
-  unsigned ns_magic;      // ceil(2^32 / n_s):  cell / n_s, the mu-major cell order of `xi_out`
+  unsigned ns_magic;      // ceil(2^32 / n_s):  cell / n_s, the mu-major cell order of `xi_out` (unused for n_s = 1, where it does not fit)
   // 1 (cells kernel, n_ell = 1 instantiations): CCFModel.theory_xi (ccf_model.py:538-690) - every cell's xi^s(mu_i, s_j) is the
   // result, stored to out[n][n_mu][n_s], instead of being projected onto multipoles; no partial sums, no tail
   int xi_out;

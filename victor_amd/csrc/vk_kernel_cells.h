@@ -199,7 +199,9 @@ __global__ __launch_bounds__(kBlock, (MODE == kModeStreaming && !SVA) || MODE ==
       const int e = base + lane;
       const bool live = e < c1;
       const unsigned ec = (unsigned)(live ? e : c1 - 1);
-      const int hi = (int)__umulhi(ec, xi_out ? a.ns_magic : a.nmu_magic);   // ec / n_mu: s bin major (ec / n_s: mu major for xi_out)
+      // ec / n_mu: s bin major (ec / n_s: mu major for xi_out; a single s bin has no 32-bit magic number - ceil(2^32 / 1) - and
+      // needs none)
+      const int hi = xi_out ? (a.n_s == 1 ? (int)ec : (int)__umulhi(ec, a.ns_magic)) : (int)__umulhi(ec, a.nmu_magic);
       const int lo = (int)ec - hi * (xi_out ? a.n_s : a.n_mu);
       const int j = xi_out ? lo : hi;
       const int i = xi_out ? hi : lo;
