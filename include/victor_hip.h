@@ -278,6 +278,33 @@ int vk_eval_batch(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, i
 int vk_eval_batch_begin(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, int64_t n);
 int vk_eval_batch_finish(vk_ctx* ctx, double* lnl, double* chi2);
 
+/* ---- lock-step Metropolis walkers, advanced natively --------------------------------------------------------------------
+ * The reference is sampled by cobaya, one likelihood per call (victor/likelihoods/CCFLikelihood.py:32-39);
+ * victor_amd/sampler.py: EnsembleMetropolis advances W random-walk Metropolis chains together, one likelihood batch per step,
+ * from the priors / proposal widths of the same `params:` block (config/boss_cobaya_config.yaml:50-97 of the reference).
+ * vk_walk_run is that sampler's step loop in the library: the ensemble as two halves on two contexts (vk_eval_batch_begin /
+ * _finish: half A of step t + 1 is on the GPU while half B of step t is accepted / rejected), rows formed as
+ * CCFModel._param_rows forms them, the caller's pre-drawn random numbers - the same launches and the same decisions as the
+ * Python loop, hence the same chain (tests/test_gpu_workloads.py), without the host's ~20 NumPy calls per step.
+ *   columns[j]   row column (VK_P_*) the j-th sampled parameter is written to, or VK_WALK_EPSILON: the parameter is epsilon and
+ *                the columns APERP, APAR, EPSILON follow from it (apar = alpha eps^(-2/3), aperp = eps apar, ccf_model.py:589-592)
+ *   lo, hi       uniform prior box; a proposal outside it is evaluated at the walker's position, discarded, and reads -inf
+ *   base_rows    [n_walkers][VK_NPAR]: the fixed parameters and defaults of every row
+ * vk_walk_run: x [W][P] and lnl [W] are the ensemble's state (in / out); dz [n_steps][W][P] the proposal increments, logu
+ * [n_steps][W] the log acceptance levels; chain [n_steps][W][P] and lnl_hist [n_steps][W] receive the state after every step
+ * (either may be NULL); *n_accept and *n_evals are incremented.  One or two contexts holding the same tables (two: the halves
+ * overlap); nothing else may use those contexts during a run.  On error the code is returned, vk_walk_last_error gives the
+ * text, no batch stays begun on the contexts and x / lnl hold the state after the last completed half-step. */
+#define VK_WALK_EPSILON (-1)
+typedef struct vk_walk vk_walk;
+vk_walk* vk_walk_create(vk_ctx* const* ctxs, int32_t n_ctx, const vk_eval_opts* opts, int32_t n_walkers, int32_t n_params,
+                        const int32_t* columns, const double* lo, const double* hi, const double* base_rows, double alpha,
+                        char* err, size_t errlen);
+int vk_walk_run(vk_walk* w, int64_t n_steps, double* x, double* lnl, const double* dz, const double* logu, double* chain,
+                double* lnl_hist, int64_t* n_accept, int64_t* n_evals);
+const char* vk_walk_last_error(const vk_walk* w);
+void vk_walk_destroy(vk_walk* w);
+
 /* Theory multipoles on a caller-supplied s grid: out[n][n_ell][n_s] with the caller's own
  * projection weights w_ell[n_ell][n_mu] on mu[n_mu] (host buffers). */
 int vk_theory_batch(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, int64_t n,

@@ -48,25 +48,44 @@ def test_walker_ensemble_matches_oracle_driven_chain():
     # identical, log-likelihoods to rounding (half-batches of 4 take another work split than one batch of 8) - over enough steps
     # to cross a block of pre-drawn random numbers and to meet proposals outside the prior; step() and run() evaluate the
     # same half-batches and agree bit for bit.
-    d = EnsembleMetropolis(None, specs, 8, seed=2024, fixed=fixed, fit=fit).initialise()
-    assert d._direct is not None and len(d._direct["engines"]) == 2
+    d = EnsembleMetropolis(None, specs, 8, seed=2024, fixed=fixed, fit=fit, native=False).initialise()
+    assert d._direct is not None and len(d._direct["engines"]) == 2 and not d._walk
     g2 = EnsembleMetropolis(gpu_eval, specs, 8, seed=2024, fixed=fixed).initialise()
     cd, ld = d.run(150)
     cg2, lg2 = g2.run(150)
     assert np.array_equal(cd[:5], cg) and np.array_equal(cd, cg2)
     assert np.max(np.abs(ld - lg2)) < 1e-9 * np.max(np.abs(lg2))
     assert d.n_accept == g2.n_accept and d.n_evals == g2.n_evals and 0 < d.n_accept < 150 * 8 and d.n_steps == 150
-    s1 = EnsembleMetropolis(None, specs, 8, seed=2024, fixed=fixed, fit=fit).initialise()
+    s1 = EnsembleMetropolis(None, specs, 8, seed=2024, fixed=fixed, fit=fit, native=False).initialise()
     for t in range(70):
         s1.step()
         assert np.array_equal(s1.x, cd[t]) and np.array_equal(s1.lnl, ld[t]), t
-    # an odd number of walkers (halves of 3 and 4) and a single walker
-    for w in (7, 1):
+    # The same loop inside the library (vk_walk_run; the default with fit=): the same half-batches, the same rows, the same
+    # launches - positions, decisions and counters identical to the Python loop, log-likelihoods to rounding (the library's
+    # pow() and NumPy's may differ in the last bit of apar = eps^(-2/3)) -, run in pieces that do not line up with the blocks
+    # of random numbers, with the per-step callback seeing the state after every step.
+    n = EnsembleMetropolis(None, specs, 8, seed=2024, fixed=fixed, fit=fit).initialise()
+    assert n._walk
+    seen = []
+    parts = [n.run(37, on_step=lambda t, ens: seen.append((ens.x.copy(), ens.lnl.copy()))), n.run(100), n.run(13)]
+    cn = np.concatenate([p[0] for p in parts])
+    ln = np.concatenate([p[1] for p in parts])
+    assert np.array_equal(cn, cd) and np.max(np.abs(ln - ld)) <= 1e-12 * np.max(np.abs(ld))
+    assert (n.n_accept, n.n_evals, n.n_steps) == (d.n_accept, d.n_evals, d.n_steps)
+    assert len(seen) == 37 and all(np.array_equal(sx, cd[t]) and np.array_equal(sl, ln[t]) for t, (sx, sl) in enumerate(seen))
+    assert np.array_equal(n.x, cd[-1])
+    # an odd number of walkers (halves of 3 and 4), a single walker, and an ensemble whose halves take the cells kernel
+    for w in (7, 1, 64):
         a = EnsembleMetropolis(None, specs, w, seed=5, fixed=fixed, fit=fit).initialise()
+        p = EnsembleMetropolis(None, specs, w, seed=5, fixed=fixed, fit=fit, native=False).initialise()
         b = EnsembleMetropolis(gpu_eval, specs, w, seed=5, fixed=fixed).initialise()
         ca, la = a.run(30)
+        cp, lp = p.run(30)
         cb, lb = b.run(30)
+        assert a._walk and not p._walk
         assert np.array_equal(ca, cb) and np.max(np.abs(la - lb)) < 1e-9 * np.max(np.abs(lb)), w
+        assert np.array_equal(ca, cp) and np.max(np.abs(la - lp)) <= 1e-12 * np.max(np.abs(lp)), w
+        assert (a.n_accept, a.n_evals) == (p.n_accept, p.n_evals) == (b.n_accept, b.n_evals), w
 
 
 def test_cobaya_plugin_calculate_on_gpu():

@@ -187,7 +187,7 @@ def test_direct_route_is_the_dictionary_route_chain(monkeypatch, walkers):
     def evaluate(batch):
         return fit.log_likelihood_batch(batch)[0]
 
-    d = EnsembleMetropolis(None, specs, walkers, seed=9, fixed=fixed, fit=fit).initialise()
+    d = EnsembleMetropolis(None, specs, walkers, seed=9, fixed=fixed, fit=fit, native=False).initialise()      # (the stand-in engine has no context for vk_walk_run: tests/test_gpu_workloads.py covers that loop)
     g = EnsembleMetropolis(evaluate, specs, walkers, seed=9, fixed=fixed).initialise()
     assert d._direct is not None and len(d._direct["engines"]) == (2 if walkers >= 2 else 1)
     cd, ld = d.run(150)
@@ -197,11 +197,11 @@ def test_direct_route_is_the_dictionary_route_chain(monkeypatch, walkers):
     assert 0 < d.n_accept < 150 * walkers and d.n_evals < 151 * walkers            # some proposals were outside the prior
     if walkers >= 2:
         assert set(log) <= {walkers // 2, walkers - walkers // 2}                   # only half-ensemble batches were launched
-    s1 = EnsembleMetropolis(None, specs, walkers, seed=9, fixed=fixed, fit=fit).initialise()
+    s1 = EnsembleMetropolis(None, specs, walkers, seed=9, fixed=fixed, fit=fit, native=False).initialise()
     for t in range(70):
         s1.step()
         assert np.array_equal(s1.x, cd[t]) and np.array_equal(s1.lnl, ld[t]), t
     # an unknown sampled parameter keeps the dictionary route
     odd = [ParamSpec("alpha", 0.9, 1.1, 1.0, 0.01, 0.01)] + specs
-    e = EnsembleMetropolis(evaluate, odd, walkers, seed=1, fixed=fixed, fit=fit).initialise()
+    e = EnsembleMetropolis(evaluate, odd, walkers, seed=1, fixed=fixed, fit=fit, native=False).initialise()
     assert e._direct is None

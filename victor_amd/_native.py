@@ -18,6 +18,7 @@ MATTER = {"template": 0, "linear_bias": 1, "velocity_template": 2}
 RSD = {"streaming": 0, "dispersion": 1, "kaiser": 2, "euclid_special": 3}
 LIKE = {"gaussian": 0, "sellentin": 1, "hartlap": 2, "percival": 3}
 VK_COMM_ID_BYTES = 128
+VK_WALK_EPSILON = -1
 
 _dp = C.POINTER(C.c_double)
 
@@ -109,6 +110,11 @@ SYMBOLS = {
     "vk_eval_batch": (C.c_int, [_vp, _optp, _dp, C.c_int64, _dp, _dp, _dp]),
     "vk_eval_batch_begin": (C.c_int, [_vp, _optp, _dp, C.c_int64]),
     "vk_eval_batch_finish": (C.c_int, [_vp, _dp, _dp]),
+    "vk_walk_create": (_vp, [C.POINTER(C.c_void_p), C.c_int32, _optp, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _dp, _dp, _dp,
+                             C.c_double, C.c_char_p, C.c_size_t]),
+    "vk_walk_run": (C.c_int, [_vp, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "vk_walk_last_error": (C.c_char_p, [_vp]),
+    "vk_walk_destroy": (None, [_vp]),
     "vk_theory_batch": (C.c_int, [_vp, _optp, _dp, C.c_int64, _dp, C.c_int32, _dp, C.c_int32, _dp, C.c_int32, _dp]),
     "vk_xi_smu_batch": (C.c_int, [_vp, _optp, _dp, C.c_int64, _dp, C.c_int32, _dp, C.c_int32, _dp]),
     "vk_device_alloc": (_vp, [_vp, C.c_size_t]),

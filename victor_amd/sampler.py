@@ -17,6 +17,7 @@ import ctypes as C
 
 import numpy as np
 
+from . import _native as N
 from .utils import InputError
 
 
@@ -71,11 +72,18 @@ class EnsembleMetropolis:
     no option merging per step; ``evaluate`` is then unused.  A step of 8 walkers is one ~20 us launch: every NumPy call on the
     way counts (BENCH ``walker_ensembles``).  Both routes draw their random numbers in the same blocks and form the rows with
     the same NumPy expressions, so a chain is the same chain whichever route evaluates it (tests/test_gpu_workloads.py).
+
+    ``native`` (default, with ``fit``): :meth:`run` hands each block of pre-drawn random numbers to ``vk_walk_run``
+    (include/victor_hip.h) - the same two half-ensembles, the same pipelining, the same rows and launches as the Python loop
+    below, which remains the definition (``native=False``) and the route of :meth:`step`; what goes are the ~20 NumPy calls per
+    step that made the host the limit of a small ensemble (8 walkers: 26-28 -> 17-18 us per step).
     """
 
     BLOCK = 64          # steps whose proposal increments and acceptance levels are drawn together
 
-    def __init__(self, evaluate, specs, n_walkers, seed=0, fixed=None, fit=None):
+    def __init__(self, evaluate, specs, n_walkers, seed=0, fixed=None, fit=None, native=True):
+        self.native = bool(native)       # with `fit`: run() hands whole blocks of steps to the library (vk_walk_run)
+        self._walk = None
         self.evaluate = evaluate
         self.specs = list(specs)
         self.fixed = dict(fixed or {})
@@ -126,7 +134,6 @@ class EnsembleMetropolis:
                 return False
         if eps is None and "epsilon" in self.fixed and {"aperp", "apar"} & set(names):
             return False
-        from . import _native as N
         from .engine import Engine
         rows = np.array(fit._fit_rows(self._batch(x), fit.model), dtype=np.float64, order="C")     # fixed values and defaults
         W = self.n_walkers
@@ -162,7 +169,65 @@ class EnsembleMetropolis:
         d["lnlh"] = [out[0][lo:hi] for lo, hi in bounds]
         d["small"] = [(hi - lo) * x.shape[1] <= 64 for lo, hi in bounds]
         d["box"] = [list(zip(np.tile(self.lo, hi - lo).tolist(), np.tile(self.hi, hi - lo).tolist())) for lo, hi in bounds]
+        if self.native and type(self).step is EnsembleMetropolis.step and max(hi - lo for lo, hi in bounds) <= 4096:
+            cols = np.full(len(names), N.VK_WALK_EPSILON, dtype=np.int32)
+            for j, c in pairs:
+                cols[j] = c
+            ctxs = (C.c_void_p * len(engines))(*[e._ctx for e in engines])
+            err = C.create_string_buffer(512)
+            lib = first._lib
+            self._walk = lib.vk_walk_create(ctxs, len(engines), C.byref(plan[4]), W, len(names),
+                                            cols.ctypes.data_as(C.POINTER(C.c_int32)), N.as_dp(N.f64(self.lo)), N.as_dp(N.f64(self.hi)),
+                                            N.as_dp(rows), float(alpha), err, len(err))
+            if not self._walk:
+                raise InputError("vk_walk_create failed: " + err.value.decode())
+            self._walk_lib = lib
         return True
+
+    def __del__(self):
+        walk, lib = getattr(self, "_walk", None), getattr(self, "_walk_lib", None)
+        if walk and lib is not None:
+            try:
+                lib.vk_walk_destroy(walk)
+            except Exception:
+                pass
+            self._walk = None
+
+    def _run_native(self, n_steps, on_step):
+        """``run`` through ``vk_walk_run``: the blocks of random numbers are drawn exactly as ``_next_randoms`` draws them."""
+        W, P = self.x.shape
+        chain = np.empty((n_steps, W, P))
+        lnl = np.empty((n_steps, W))
+        lib = self._walk_lib
+        self.x = np.ascontiguousarray(self.x, dtype=np.float64)
+        self.lnl = np.ascontiguousarray(self.lnl, dtype=np.float64)
+        acc, ev = C.c_int64(0), C.c_int64(0)
+        done = 0
+        while done < n_steps:
+            if self._at >= self.BLOCK:
+                self._dz = self.width * self.rng.standard_normal((self.BLOCK,) + self.x.shape)
+                self._logu = np.log(self.rng.random((self.BLOCK, self.n_walkers)))
+                self._at = 0
+            k = min(self.BLOCK - self._at, n_steps - done)
+            dz = np.ascontiguousarray(self._dz[self._at:self._at + k])
+            logu = np.ascontiguousarray(self._logu[self._at:self._at + k])
+            rc = lib.vk_walk_run(self._walk, k, N.as_dp(self.x), N.as_dp(self.lnl), N.as_dp(dz), N.as_dp(logu),
+                                 N.as_dp(chain[done:done + k]), N.as_dp(lnl[done:done + k]), C.byref(acc), C.byref(ev))
+            if rc != 0:
+                msg = (lib.vk_walk_last_error(self._walk) or b"").decode() or f"vk_walk_run failed ({rc})"
+                raise (InputError if rc == -1 else N.NativeError)(msg)
+            self._at += k
+            self.n_steps += k
+            if on_step is not None:                      # the state after every step of the block, one step at a time
+                x_end, l_end = self.x.copy(), self.lnl.copy()
+                for t in range(done, done + k):
+                    self.x[:], self.lnl[:] = chain[t], lnl[t]
+                    on_step(t, self)
+                self.x[:], self.lnl[:] = x_end, l_end
+            done += k
+        self.n_accept += acc.value
+        self.n_evals += ev.value
+        return chain, lnl
 
     def _half_begin(self, k, prop):
         """Enqueue the likelihood of rows lo:hi of the proposals ``prop`` (a (W, P) array, or the half itself)."""
@@ -295,6 +360,8 @@ class EnsembleMetropolis:
         """Advance ``n_steps``; returns ``(chain[n_steps, W, P], lnl[n_steps, W])``."""
         if self.x is None:
             self.initialise()
+        if self._walk and n_steps >= 1:
+            return self._run_native(n_steps, on_step)
         chain = np.empty((n_steps, self.n_walkers, len(self.specs)))
         lnl = np.empty((n_steps, self.n_walkers))
         d = self._direct
