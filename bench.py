@@ -494,7 +494,7 @@ def api_latency():
     return res
 
 
-def walker_rates(steps=150):
+def walker_rates(steps=320):
     """BASELINE config 4's workload on one GPU: lock-step Metropolis walkers on config/boss_cobaya_config.yaml (priors, start
     distributions and proposal widths from the file cobaya reads), proposals made on the host, one host-buffer likelihood
     batch per step.  Likelihood evaluations per second of wall-clock for 8, 64 and 512 walkers; the first evaluation of the
@@ -513,17 +513,23 @@ def walker_rates(steps=150):
     specs, fixed = parse_cobaya_params(info["params"])
     res = {}
     for walkers in (8, 64, 512):
-        ens = EnsembleMetropolis(None, specs, walkers, seed=1, fixed=fixed, fit=fit)      # rows written in place, straight to the engine
-        ens.initialise()
-        t_end = time.perf_counter() + 0.4    # past the first call's one-off costs and the runtime's stall after fresh allocations (see warm_up)
-        while time.perf_counter() < t_end:
-            ens.run(10)
-        e0 = ens.n_evals
-        t0 = time.perf_counter()
-        ens.run(steps)
-        dt = time.perf_counter() - t0
-        res[f"{walkers}_walkers"] = {"evals_per_s": (ens.n_evals - e0) / dt, "us_per_step": 1e6 * dt / steps,
-                                     "acceptance": ens.n_accept / max(ens.n_steps * walkers, 1)}
+        entry = {}
+        for native in (True, False):         # the step loop inside the library (vk_walk_run: the default), and the Python loop beside it
+            ens = EnsembleMetropolis(None, specs, walkers, seed=1, fixed=fixed, fit=fit, native=native)   # rows straight to the engine
+            ens.initialise()
+            t_end = time.perf_counter() + 0.4    # past the first call's one-off costs and the runtime's stall after fresh allocations (see warm_up)
+            while time.perf_counter() < t_end:
+                ens.run(10)
+            e0 = ens.n_evals
+            t0 = time.perf_counter()
+            ens.run(steps)
+            dt = time.perf_counter() - t0
+            if native:
+                entry = {"evals_per_s": (ens.n_evals - e0) / dt, "us_per_step": 1e6 * dt / steps,
+                         "acceptance": ens.n_accept / max(ens.n_steps * walkers, 1), "step_loop": "library (vk_walk_run)"}
+            else:
+                entry["python_loop"] = {"evals_per_s": (ens.n_evals - e0) / dt, "us_per_step": 1e6 * dt / steps}
+        res[f"{walkers}_walkers"] = entry
     return res
 
 
