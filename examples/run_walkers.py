@@ -7,14 +7,15 @@ Several GPUs:    python examples/run_walkers.py --gpus 8 --steps 200          (o
 
 One process per GPU: every rank drives its own walkers on its own GPU (likelihood batches through libvictor_hip.so); the
 log-likelihoods of all walkers are all-gathered over RCCL - one collective per block of 64 steps, the walkers never read it -
-so that every rank can monitor the whole ensemble; the ranks find each other through a standard-library socket group (victor_amd/rendezvous.py: MASTER_ADDR / MASTER_PORT or
-VICTOR_RDZV), no torch and no MPI binding.  One process for all GPUs: a single ensemble of gpus x walkers walkers whose
+so that every rank can monitor the whole ensemble; the ranks find each other through a standard-library socket group
+(victor_amd/rendezvous.py: MASTER_ADDR / MASTER_PORT or VICTOR_RDZV), no torch and no MPI binding.  One process for all GPUs: a single ensemble of gpus x walkers walkers whose
 proposals are sharded over the devices, the log-likelihoods all-gathered on the GPUs by a grouped RCCL call.
 Priors, starting distributions and proposal widths come from config/boss_cobaya_config.yaml, the file cobaya itself
 would read.  Prints one JSON line with the acceptance rate, R-1 and posterior means.
 """
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -117,6 +118,7 @@ def main():
             "mean": dict(zip(ens.local.names, chain[burn:].mean(axis=(0, 1)).round(4).tolist())),
             "best_lnl_over_all_ranks": float(all_lnl.max()),
             "gathered_shape": list(all_lnl.shape), "gathered_sum": float(all_lnl.sum()),
+            "gathered_sha256": hashlib.sha256(np.ascontiguousarray(all_lnl).tobytes()).hexdigest(),
             "gather": gather_name, "gather_block": ens.gather_block, "collectives": ens.n_collectives}))
     dist.barrier()
     dist.close()

@@ -80,7 +80,7 @@ def test_walker_example_two_ranks_gather_through_the_communicator(tmp_path):
         assert r0["gather_block"] == block and r0["best_lnl_over_all_ranks"] > 200
         got[block] = r0
     assert got[1]["collectives"] == 130 and got[64]["collectives"] == 3          # <= 1 collective per 64 steps (+ the remainder)
-    assert got[64]["gathered_sum"] == got[1]["gathered_sum"] and got[64]["mean"] == got[1]["mean"]
+    assert got[64]["gathered_sha256"] == got[1]["gathered_sha256"] and got[64]["mean"] == got[1]["mean"]      # the same array, byte for byte
     assert not list(tmp_path.glob("rccl_double_*.sock"))
 
 

@@ -475,28 +475,32 @@ class DistributedEnsemble:
         self.all_lnl = []
         self.n_collectives = 0
 
-    def _flush(self, buf, k):
-        """One collective for the ``k`` steps held in ``buf[:k]``; appends their ``[k, world * W]`` rows to ``all_lnl``."""
-        W, world = buf.shape[1], self.dist.world
-        K = self.gather_block
-        if k < K:
-            buf[k:] = np.nan                 # a short last block travels at the full count (RCCL: equal counts, fixed buffers)
-        got = np.asarray(self.gather(buf.reshape(K * W))).reshape(world, K, W)
+    def _flush(self, block):
+        """One collective for the steps' log-likelihoods in ``block`` ``[k, W]``, k <= gather_block; appends their
+        ``[k, world * W]`` rows to ``all_lnl``."""
+        k, W = block.shape
+        K, world = self.gather_block, self.dist.world
+        buf = block
+        if k < K:                            # a short last block travels at the full count (RCCL: equal counts, fixed buffers)
+            buf = np.full((K, W), np.nan)
+            buf[:k] = block
+        got = np.asarray(self.gather(np.ascontiguousarray(buf).reshape(K * W))).reshape(world, K, W)
         self.n_collectives += 1
         self.all_lnl.extend(np.ascontiguousarray(got[:, t, :]).reshape(world * W) for t in range(k))
 
     def run(self, n_steps):
-        W = self.local.n_walkers
-        buf = np.empty((self.gather_block, W))
-        held = [0]
-
-        def on_step(t, ens):
-            buf[held[0]] = ens.lnl
-            held[0] += 1
-            if held[0] == self.gather_block:
-                self._flush(buf, held[0])
-                held[0] = 0
-        chain, lnl = self.local.run(n_steps, on_step=on_step)
-        if held[0]:
-            self._flush(buf, held[0])
+        """Advance ``n_steps`` in pieces of ``gather_block`` steps (the local sampler's chain does not depend on the pieces
+        ``run`` is called in), one collective behind each piece."""
+        chains, lnls = [], []
+        done = 0
+        while done < n_steps:
+            k = min(self.gather_block, n_steps - done)
+            c, l = self.local.run(k)
+            self._flush(l)
+            chains.append(c)
+            lnls.append(l)
+            done += k
+        W, P = self.local.n_walkers, len(self.local.specs)
+        chain = np.concatenate(chains) if chains else np.empty((0, W, P))
+        lnl = np.concatenate(lnls) if lnls else np.empty((0, W))
         return chain, lnl, np.array(self.all_lnl)
