@@ -1758,19 +1758,25 @@ constexpr int64_t kZeroCopyMaxDefault = 4096;   // host-buffer batches up to thi
 // The two halves of such a call, separable so that the mailbox server (vk_serve_mailboxes) can have launches of several
 // contexts in flight at once.  zc_begin: 1 = launched (zc_finish brings the results), 0 = this batch cannot go in place (the
 // caller takes another path), < 0 = error.
-static int zc_begin(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, int64_t n, bool want_out, double* d_th) {
-  const int64_t zc_max = ctx->knobs.zero_copy_max >= 0 ? std::min<int64_t>(ctx->knobs.zero_copy_max, kZeroCopyCap) : kZeroCopyMaxDefault;
-  if (n > zc_max || ctx->knobs.no_zero_copy || ctx->zero_copy_off || ctx->timing || !want_out) return 0;
+// the pinned, device-mapped buffers of the in-place paths (kZeroCopyCap x (VK_NPAR + 2) doubles); false: not available here
+static bool ensure_zero_copy(vk_ctx* ctx) {
+  if (ctx->knobs.no_zero_copy || ctx->zero_copy_off) return false;
   if (!ctx->h_zc) {
     void* dev = nullptr;
     if (hipHostMalloc((void**)&ctx->h_zc, (size_t)kZeroCopyCap * (VK_NPAR + 2) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer(&dev, ctx->h_zc, 0) != hipSuccess) {
       (void)hipGetLastError();
       ctx->zero_copy_off = true;
-      return 0;
+      return false;
     }
     ctx->d_zc = static_cast<double*>(dev);
   }
+  return true;
+}
+
+static int zc_begin(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, int64_t n, bool want_out, double* d_th) {
+  const int64_t zc_max = ctx->knobs.zero_copy_max >= 0 ? std::min<int64_t>(ctx->knobs.zero_copy_max, kZeroCopyCap) : kZeroCopyMaxDefault;
+  if (n > zc_max || ctx->timing || !want_out || !ensure_zero_copy(ctx)) return 0;
   double* h_out = ctx->h_zc + (size_t)kZeroCopyCap * VK_NPAR;
   double* d_out = ctx->d_zc + (size_t)kZeroCopyCap * VK_NPAR;
   memcpy(ctx->h_zc, params, (size_t)n * VK_NPAR * sizeof(double));
@@ -2346,7 +2352,13 @@ static int general_grid(vk_ctx* ctx, const vk_eval_opts* opts, const double* par
   const size_t out_n = project ? (size_t)n * n_ell * n_s : (size_t)n * n_mu * n_s;
   const size_t grid_n = (size_t)n_s + n_mu + (size_t)ne * n_mu + 4;
   const size_t total = ((size_t)n * VK_NPAR + grid_n + out_n) * sizeof(double);
-  rc = ensure_scratch(ctx, total);
+  // A call that fits into the context's pinned, device-mapped buffers - theory_xi or theory_multipoles for a point or a few,
+  // what a notebook asks for - goes through them: rows and grids are gathered there and reach the device in ONE copy from pinned
+  // memory (instead of four from pageable memory), and the kernel stores its results straight into the pinned buffer (instead
+  // of a download into pageable memory behind it).  theory_xi, one point on a 40 x 100 grid: DESIGN.md section 5.
+  const size_t in_n = (size_t)n * VK_NPAR + grid_n;
+  const bool in_place = total + 32 <= (size_t)kZeroCopyCap * (VK_NPAR + 2) * sizeof(double) && !ctx->timing && ensure_zero_copy(ctx);
+  rc = ensure_scratch(ctx, in_place ? (in_n + 2) * sizeof(double) : total);
   if (rc) return rc;
   double* d_par = ctx->d_scratch;
   double* d_s = d_par + (size_t)n * VK_NPAR;
@@ -2354,13 +2366,27 @@ static int general_grid(vk_ctx* ctx, const vk_eval_opts* opts, const double* par
   double* d_w = d_mu + n_mu;
   double* d_out = d_w + (size_t)ne * n_mu;
   d_out = (double*)(((uintptr_t)d_out + 15) & ~(uintptr_t)15);
-  VK_HIP(ctx, hipMemcpyAsync(d_par, params, (size_t)n * VK_NPAR * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  VK_HIP(ctx, hipMemcpyAsync(d_s, s, n_s * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  VK_HIP(ctx, hipMemcpyAsync(d_mu, mu, n_mu * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  if (project)
-    VK_HIP(ctx, hipMemcpyAsync(d_w, w_ell, (size_t)n_ell * n_mu * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  else
-    VK_HIP(ctx, hipMemsetAsync(d_w, 0, (size_t)n_mu * sizeof(double), ctx->stream));
+  double* h_out = nullptr;
+  if (in_place) {
+    double* h = ctx->h_zc;
+    memcpy(h, params, (size_t)n * VK_NPAR * sizeof(double));
+    memcpy(h + (d_s - d_par), s, n_s * sizeof(double));
+    memcpy(h + (d_mu - d_par), mu, n_mu * sizeof(double));
+    if (project) memcpy(h + (d_w - d_par), w_ell, (size_t)n_ell * n_mu * sizeof(double));
+    else memset(h + (d_w - d_par), 0, (size_t)n_mu * sizeof(double));
+    VK_HIP(ctx, hipMemcpyAsync(d_par, h, ((size_t)(d_w - d_par) + (size_t)ne * n_mu) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    const size_t out_off = (in_n + 1) & ~(size_t)1;                      // 16-byte aligned behind the inputs
+    h_out = h + out_off;
+    d_out = ctx->d_zc + out_off;
+  } else {
+    VK_HIP(ctx, hipMemcpyAsync(d_par, params, (size_t)n * VK_NPAR * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    VK_HIP(ctx, hipMemcpyAsync(d_s, s, n_s * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    VK_HIP(ctx, hipMemcpyAsync(d_mu, mu, n_mu * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (project)
+      VK_HIP(ctx, hipMemcpyAsync(d_w, w_ell, (size_t)n_ell * n_mu * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    else
+      VK_HIP(ctx, hipMemsetAsync(d_w, 0, (size_t)n_mu * sizeof(double), ctx->stream));
+  }
   TheoryArgs a{};
   int nlr = 1;
   rc = theory_args(ctx, opts, &a, &nlr);
@@ -2380,8 +2406,15 @@ static int general_grid(vk_ctx* ctx, const vk_eval_opts* opts, const double* par
   a.xi_out = project ? 0 : 1;            // theory_xi: the cells kernel stores every cell, the generic kernel where it cannot go
   rc = launch_theory(ctx, a, nlr, nullptr, nullptr);
   if (rc) return rc;
-  VK_HIP(ctx, hipMemcpyAsync(out, d_out, out_n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (in_place) {
+    VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(out, h_out, out_n * sizeof(double));
+  } else {
+    VK_HIP(ctx, hipMemcpyAsync(out, d_out, out_n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (ctx->h_poll_failed && *ctx->h_poll_failed)
+    return fail(ctx, VK_E_HIP, "a workgroup waited %.0f s for partial sums that never arrived; the context is unusable", (double)kPollTicks * 1e-8);
   return VK_OK;
 }
 
