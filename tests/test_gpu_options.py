@@ -711,3 +711,46 @@ def test_kaiser_and_euclid_special_run_on_the_cells_kernel(tmp_path):
     assert tabs.uni_n > 0 and tabs.uni_lut_n > 0
     hp = dict(cases.halton_params(300), M=1.0, Q=1.0)
     run(fit, ora, hp, "union grid", (0, 299), rsd_model="kaiser")
+
+
+def test_theory_xi_with_every_table_option_on_the_cells_kernel(tmp_path):
+    """``CCFModel.theory_xi`` through the cells kernel's store-every-cell form for the table options of SURVEY 8(f3): a measured
+    real-space ccf (``from_data``: the second look-up at the fiducial coordinates), ``linear_bias`` on reconstruction-beta tables
+    (velocity tables rebuilt per point), ``empirical_corr``, the anisotropic sigma_v(r, mu) template (patches in LDS, streaming
+    and dispersion) - every RSD model each, against the generic kernel on the whole array and the oracle on single cells."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import victor_amd
+    import victor_oracle as vo
+    from tests.test_host import _aniso_inputs
+    mu = np.linspace(0, 1, 100)
+    m_fd, d_fd = cases.boss_options("config")
+    m_fd["input_model_data_file"] = "boss/measured_model.npy"
+    m_fd["realspace_ccf"]["from_data"] = True
+    d_fd["covariance_matrix"]["data_file"] = "boss/cov_md_iso.npy"
+    m_an, d_an = _aniso_inputs(tmp_path, False)
+    setups = [("from_data", m_fd, d_fd, True, [{}, {"assume_isotropic": False}, {"matter_model": "linear_bias", "rsd_model": "kaiser"}]),
+              ("boss", *cases.boss_options("config"), True, [{"matter_model": "linear_bias"}, {"empirical_corr": True},
+                                                              {"matter_model": "linear_bias", "empirical_corr": True, "rsd_model": "dispersion"},
+                                                              {"rsd_model": "euclid_special", "kaiser_coord_shift": False},
+                                                              {"rsd_model": "kaiser", "kaiser_approximation": True}]),
+              ("aniso_sigma_v", m_an, d_an, False, [{}, {"rsd_model": "dispersion"}, {"rsd_model": "kaiser"}])]
+    for tag, model, data, beta, variants in setups:
+        fit = victor_amd.CCFFit(model, data)
+        ora = vo.OracleFit(model, data)
+        hp = cases.halton_params(40, with_beta=beta)
+        sub = dict({k: v[:6] for k, v in hp.items()}, bias=2.0, Av=0.6, M=1.04, Q=0.93)
+        for kw in variants:
+            xi = fit.theory_xi_batch(fit.s, mu, sub, **kw)
+            assert fit._get_engine(fit._engine_key(fit._merged(kw))).last_kernel() == "vk_theory_cells_kernel", (tag, kw)
+            _native.set_knob("VICTOR_HIP_FORCE_GENERIC", "1")
+            try:
+                ref = fit.theory_xi_batch(fit.s, mu, sub, **kw)
+            finally:
+                _native.set_knob("VICTOR_HIP_FORCE_GENERIC", None)
+            tol = 1e-8 if kw.get("rsd_model") == "dispersion" else 1e-9
+            assert xi.shape == ref.shape and np.max(np.abs(xi - ref)) < tol * np.max(np.abs(ref)), (tag, kw)
+            for pt, i, j in ((0, 0, 0), (5, 99, len(fit.s) - 1), (2, 37, 4)):
+                want = ora.theory_xi(np.array([fit.s[j]]), np.array([mu[i]]), cases.point(sub, pt), **kw)[0, 0]
+                assert abs(xi[pt, i, j] - want) < RTOL * max(abs(want), 1e-2), (tag, kw, pt, i, j, xi[pt, i, j], want)
