@@ -526,7 +526,8 @@ def walker_rates(steps=320):
             dt = time.perf_counter() - t0
             if native:
                 entry = {"evals_per_s": (ens.n_evals - e0) / dt, "us_per_step": 1e6 * dt / steps,
-                         "acceptance": ens.n_accept / max(ens.n_steps * walkers, 1), "step_loop": "library (vk_walk_run)"}
+                         "acceptance": ens.n_accept / max(ens.n_steps * walkers, 1),
+                         "step_loop": "library (vk_walk_run), " + ("two steps per launch" if ens.speculate else "one step per launch")}
             else:
                 entry["python_loop"] = {"evals_per_s": (ens.n_evals - e0) / dt, "us_per_step": 1e6 * dt / steps}
         res[f"{walkers}_walkers"] = entry

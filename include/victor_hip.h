@@ -290,6 +290,13 @@ int vk_eval_batch_finish(vk_ctx* ctx, double* lnl, double* chi2);
  *                the columns APERP, APAR, EPSILON follow from it (apar = alpha eps^(-2/3), aperp = eps apar, ccf_model.py:589-592)
  *   lo, hi       uniform prior box; a proposal outside it is evaluated at the walker's position, discarded, and reads -inf
  *   base_rows    [n_walkers][VK_NPAR]: the fixed parameters and defaults of every row
+ *   speculate    != 0: TWO steps per launch.  The proposal of step t + 1 starts from the proposal of step t (accepted) or from
+ *                the old position (rejected) - both are known when step t is proposed, so a walker's three points travel in one
+ *                launch and both decisions are taken when the results arrive: two steps per round trip host -> GPU -> host
+ *                (what bounds a small ensemble: the GPU is far from full) for three evaluations instead of two.  The same
+ *                proposals, the same acceptance levels: the chain of the step-by-step loop; n_evals counts the evaluations the
+ *                step-by-step loop would have made.  Worth it while three times the ensemble still fits the idle part of
+ *                the GPU (victor_amd/sampler.py chooses; ignored when a launch would exceed 4096 rows)
  * vk_walk_run: x [W][P] and lnl [W] are the ensemble's state (in / out); dz [n_steps][W][P] the proposal increments, logu
  * [n_steps][W] the log acceptance levels; chain [n_steps][W][P] and lnl_hist [n_steps][W] receive the state after every step
  * (either may be NULL); *n_accept and *n_evals are incremented.  One or two contexts holding the same tables (two: the halves
@@ -299,7 +306,7 @@ int vk_eval_batch_finish(vk_ctx* ctx, double* lnl, double* chi2);
 typedef struct vk_walk vk_walk;
 vk_walk* vk_walk_create(vk_ctx* const* ctxs, int32_t n_ctx, const vk_eval_opts* opts, int32_t n_walkers, int32_t n_params,
                         const int32_t* columns, const double* lo, const double* hi, const double* base_rows, double alpha,
-                        char* err, size_t errlen);
+                        int32_t speculate, char* err, size_t errlen);
 int vk_walk_run(vk_walk* w, int64_t n_steps, double* x, double* lnl, const double* dz, const double* logu, double* chain,
                 double* lnl_hist, int64_t* n_accept, int64_t* n_evals);
 const char* vk_walk_last_error(const vk_walk* w);

@@ -111,7 +111,7 @@ SYMBOLS = {
     "vk_eval_batch_begin": (C.c_int, [_vp, _optp, _dp, C.c_int64]),
     "vk_eval_batch_finish": (C.c_int, [_vp, _dp, _dp]),
     "vk_walk_create": (_vp, [C.POINTER(C.c_void_p), C.c_int32, _optp, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _dp, _dp, _dp,
-                             C.c_double, C.c_char_p, C.c_size_t]),
+                             C.c_double, C.c_int32, C.c_char_p, C.c_size_t]),
     "vk_walk_run": (C.c_int, [_vp, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "vk_walk_last_error": (C.c_char_p, [_vp]),
     "vk_walk_destroy": (None, [_vp]),

@@ -1968,37 +1968,125 @@ struct vk_walk {
   double alpha = 1.0;
   std::vector<double> box_lo, box_hi, rows, prop, lnl_prop, chi_prop;
   std::vector<char> inside;
+  // two steps per launch (vk_walk_create: speculate): per walker the proposal of step t and BOTH proposals of step t + 1 - from
+  // the accepted and from the rejected position - travel in one launch; three rows, proposals, results per walker
+  bool speculate = false;
+  std::vector<double> rows3, prop3, lnl3, chi3;
+  std::vector<char> in3;
   std::string err;
 };
+
+// the sampled columns of one row from the walker's coordinates `xs` (CCFModel._param_rows, ccf_model.py:589-592 of the reference)
+static inline void walk_fill_row(const vk_walk* w, const double* xs, double* row) {
+  for (int j = 0; j < w->P; ++j)
+    if (w->col[j] >= 0) row[w->col[j]] = xs[j];
+  if (w->eps >= 0) {
+    const double e = xs[w->eps];
+    double apar = pow(e, -2.0 / 3.0);
+    if (w->alpha != 1.0) apar = w->alpha * apar;
+    row[VK_P_APERP] = e * apar;
+    row[VK_P_APAR] = apar;
+    row[VK_P_EPSILON] = e;
+  }
+}
+
+static inline bool walk_in_box(const vk_walk* w, const double* p) {
+  bool in = true;
+  for (int j = 0; j < w->P; ++j) in = in && p[j] >= w->box_lo[j] && p[j] <= w->box_hi[j];      // (a NaN proposal is outside)
+  return in;
+}
 
 static void walk_begin(vk_walk* w, int k, const double* x, const double* dz_t, int* rc) {
   const int P = w->P;
   for (int i = w->lo[k]; i < w->hi[k]; ++i) {
     double* pr = &w->prop[(size_t)i * P];
-    bool in = true;
-    for (int j = 0; j < P; ++j) {
-      pr[j] = x[(size_t)i * P + j] + dz_t[(size_t)i * P + j];
-      in = in && pr[j] >= w->box_lo[j] && pr[j] <= w->box_hi[j];      // (a NaN proposal is outside)
-    }
+    for (int j = 0; j < P; ++j) pr[j] = x[(size_t)i * P + j] + dz_t[(size_t)i * P + j];
+    const bool in = walk_in_box(w, pr);
     w->inside[i] = in ? 1 : 0;
     // a proposal outside the prior: its row keeps the walker's position (a valid point; the result is discarded)
-    const double* xs = in ? pr : &x[(size_t)i * P];
-    double* row = &w->rows[(size_t)i * VK_NPAR];
-    for (int j = 0; j < P; ++j)
-      if (w->col[j] >= 0) row[w->col[j]] = xs[j];
-    if (w->eps >= 0) {                  // the expressions of CCFModel._param_rows (ccf_model.py:589-592 of the reference)
-      const double e = xs[w->eps];
-      double apar = pow(e, -2.0 / 3.0);
-      if (w->alpha != 1.0) apar = w->alpha * apar;
-      row[VK_P_APERP] = e * apar;
-      row[VK_P_APAR] = apar;
-      row[VK_P_EPSILON] = e;
-    }
+    walk_fill_row(w, in ? pr : &x[(size_t)i * P], &w->rows[(size_t)i * VK_NPAR]);
   }
   const int r = vk_eval_batch_begin(w->ctx[k], &w->opts, &w->rows[(size_t)w->lo[k] * VK_NPAR], w->hi[k] - w->lo[k]);
   if (r != VK_OK && *rc == VK_OK) {
     *rc = r;
     w->err = w->ctx[k]->err;
+  }
+}
+
+// Two steps in one launch.  Step t + 1's proposal is x_(t+1) + dz_(t+1) with x_(t+1) either the proposal of step t (accepted)
+// or the old position (rejected): both candidates are known when step t is proposed, so all three points of a walker are
+// evaluated together and the two decisions are taken when the results arrive - the ensemble advances two steps per round
+// trip host -> GPU -> host, the limit of a small ensemble, for three evaluations instead of two.  The decisions are those of
+// the step-by-step loop: the same proposals (the same additions), the same acceptance levels.
+static void walk_begin2(vk_walk* w, int k, const double* x, const double* dz_t, const double* dz_t1, int* rc) {
+  const int P = w->P;
+  for (int i = w->lo[k]; i < w->hi[k]; ++i) {
+    const double* xi = &x[(size_t)i * P];
+    double* p0 = &w->prop3[(size_t)i * 3 * P];
+    double* pa = p0 + P;
+    double* pr = pa + P;
+    for (int j = 0; j < P; ++j) {
+      p0[j] = xi[j] + dz_t[(size_t)i * P + j];
+      pa[j] = p0[j] + dz_t1[(size_t)i * P + j];
+      pr[j] = xi[j] + dz_t1[(size_t)i * P + j];
+    }
+    const bool in0 = walk_in_box(w, p0), ina = in0 && walk_in_box(w, pa), inr = walk_in_box(w, pr);
+    w->in3[(size_t)i * 3] = in0;
+    w->in3[(size_t)i * 3 + 1] = ina;
+    w->in3[(size_t)i * 3 + 2] = inr;
+    double* row = &w->rows3[(size_t)i * 3 * VK_NPAR];
+    walk_fill_row(w, in0 ? p0 : xi, row);                                   // (outside the prior: a valid point, result discarded)
+    walk_fill_row(w, ina ? pa : (in0 ? p0 : xi), row + VK_NPAR);
+    walk_fill_row(w, inr ? pr : xi, row + 2 * VK_NPAR);
+  }
+  const int r = vk_eval_batch_begin(w->ctx[k], &w->opts, &w->rows3[(size_t)w->lo[k] * 3 * VK_NPAR], 3 * (w->hi[k] - w->lo[k]));
+  if (r != VK_OK && *rc == VK_OK) {
+    *rc = r;
+    w->err = w->ctx[k]->err;
+  }
+}
+
+static void walk_finish_accept2(vk_walk* w, int k, double* x, double* lnl, const double* logu_t, const double* logu_t1, double* chain_t,
+                                double* hist_t, int64_t* n_accept, int64_t* n_evals, int* rc) {
+  const int P = w->P;
+  const size_t step_x = (size_t)w->W * P, step_u = (size_t)w->W;
+  if (w->ctx[k]->begun_n == 0) return;                                 // its begin failed
+  const int r = vk_eval_batch_finish(w->ctx[k], &w->lnl3[(size_t)w->lo[k] * 3], &w->chi3[(size_t)w->lo[k] * 3]);
+  if (r != VK_OK) {
+    if (*rc == VK_OK) {
+      *rc = r;
+      w->err = w->ctx[k]->err;
+    }
+    return;
+  }
+  const double minus_inf = -std::numeric_limits<double>::infinity();
+  for (int i = w->lo[k]; i < w->hi[k]; ++i) {
+    double* xi = &x[(size_t)i * P];
+    const double* p0 = &w->prop3[(size_t)i * 3 * P];
+    const char* in = &w->in3[(size_t)i * 3];
+    const double* l3 = &w->lnl3[(size_t)i * 3];
+    // step t
+    const double lp0 = in[0] ? l3[0] : minus_inf;
+    if (in[0]) *n_evals += 1;
+    const bool acc0 = logu_t[i] < lp0 - lnl[i];                         // (false for NaN)
+    if (acc0) {
+      memcpy(xi, p0, (size_t)P * sizeof(double));
+      lnl[i] = lp0;
+      *n_accept += 1;
+    }
+    if (chain_t) memcpy(chain_t + (size_t)i * P, xi, (size_t)P * sizeof(double));
+    if (hist_t) hist_t[i] = lnl[i];
+    // step t + 1: the candidate that belongs to the position step t left
+    const int c = acc0 ? 1 : 2;
+    const double lp1 = in[c] ? l3[c] : minus_inf;
+    if (in[c]) *n_evals += 1;
+    if (logu_t1[i] < lp1 - lnl[i]) {
+      memcpy(xi, p0 + (size_t)c * P, (size_t)P * sizeof(double));
+      lnl[i] = lp1;
+      *n_accept += 1;
+    }
+    if (chain_t) memcpy(chain_t + step_x + (size_t)i * P, xi, (size_t)P * sizeof(double));
+    if (hist_t) hist_t[step_u + i] = lnl[i];
   }
 }
 
@@ -2043,8 +2131,8 @@ static bool process_alive(long long pid) {
 }
 
 vk_walk* vk_walk_create(vk_ctx* const* ctxs, int32_t n_ctx, const vk_eval_opts* opts, int32_t n_walkers, int32_t n_params,
-                        const int32_t* columns, const double* lo, const double* hi, const double* base_rows, double alpha, char* err,
-                        size_t errlen) {
+                        const int32_t* columns, const double* lo, const double* hi, const double* base_rows, double alpha,
+                        int32_t speculate, char* err, size_t errlen) {
   auto bail = [&](const char* msg) -> vk_walk* {
     if (err && errlen) {
       strncpy(err, msg, errlen - 1);
@@ -2108,6 +2196,19 @@ vk_walk* vk_walk_create(vk_ctx* const* ctxs, int32_t n_ctx, const vk_eval_opts* 
   w->lnl_prop.resize(n_walkers);
   w->chi_prop.resize(n_walkers);
   w->inside.resize(n_walkers);
+  // two steps per launch: three rows per walker, as long as a launch stays within the in-place buffers
+  w->speculate = speculate != 0;
+  for (int k = 0; k < w->n_half; ++k)
+    if (3 * (w->hi[k] - w->lo[k]) > kZeroCopyCap) w->speculate = false;
+  if (w->speculate) {
+    w->rows3.resize((size_t)n_walkers * 3 * VK_NPAR);
+    for (int i = 0; i < n_walkers; ++i)
+      for (int c = 0; c < 3; ++c) memcpy(&w->rows3[((size_t)i * 3 + c) * VK_NPAR], base_rows + (size_t)i * VK_NPAR, VK_NPAR * sizeof(double));
+    w->prop3.resize((size_t)n_walkers * 3 * n_params);
+    w->lnl3.resize((size_t)n_walkers * 3);
+    w->chi3.resize((size_t)n_walkers * 3);
+    w->in3.resize((size_t)n_walkers * 3);
+  }
   return w;
 }
 
@@ -2126,8 +2227,25 @@ int vk_walk_run(vk_walk* w, int64_t n_steps, double* x, double* lnl, const doubl
   int64_t acc = 0, ev = 0;
   int rc = VK_OK;
   const size_t step_x = (size_t)w->W * w->P, step_u = (size_t)w->W;
-  if (n_steps > 0) walk_begin(w, 0, x, dz, &rc);
-  for (int64_t t = 0; t < n_steps && rc == VK_OK; ++t) {
+  int64_t t0 = 0;                        // steps taken by the two-steps-per-launch loop; the rest (one step at most) below
+  if (w->speculate && n_steps >= 2) {
+    const int64_t pairs = n_steps / 2;
+    walk_begin2(w, 0, x, dz, dz + step_x, &rc);
+    for (int64_t q = 0; q < pairs && rc == VK_OK; ++q) {
+      const int64_t t = 2 * q;
+      const double* dz_t = dz + (size_t)t * step_x;
+      const double* lu_t = logu + (size_t)t * step_u;
+      double* ch = chain ? chain + (size_t)t * step_x : nullptr;
+      double* hi = lnl_hist ? lnl_hist + (size_t)t * step_u : nullptr;
+      if (w->n_half == 2) walk_begin2(w, 1, x, dz_t, dz_t + step_x, &rc);
+      walk_finish_accept2(w, 0, x, lnl, lu_t, lu_t + step_u, ch, hi, &acc, &ev, &rc);
+      if (q + 1 < pairs && rc == VK_OK) walk_begin2(w, 0, x, dz_t + 2 * step_x, dz_t + 3 * step_x, &rc);   // the next two steps go out now
+      if (w->n_half == 2) walk_finish_accept2(w, 1, x, lnl, lu_t, lu_t + step_u, ch, hi, &acc, &ev, &rc);
+    }
+    t0 = 2 * pairs;
+  }
+  if (t0 < n_steps && rc == VK_OK) walk_begin(w, 0, x, dz + (size_t)t0 * step_x, &rc);
+  for (int64_t t = t0; t < n_steps && rc == VK_OK; ++t) {
     const double* dz_t = dz + (size_t)t * step_x;
     const double* lu_t = logu + (size_t)t * step_u;
     if (w->n_half == 2) walk_begin(w, 1, x, dz_t, &rc);

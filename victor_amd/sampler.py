@@ -81,8 +81,15 @@ class EnsembleMetropolis:
 
     BLOCK = 64          # steps whose proposal increments and acceptance levels are drawn together
 
-    def __init__(self, evaluate, specs, n_walkers, seed=0, fixed=None, fit=None, native=True):
+    SPECULATE_MAX_WALKERS = 96       # two steps per launch (vk_walk_create: speculate) up to this ensemble size (measured: 1.94 x the
+                                     # Python loop at 8 walkers, 1.7 x at 64, level with one step per launch at 128, behind it beyond)
+
+    def __init__(self, evaluate, specs, n_walkers, seed=0, fixed=None, fit=None, native=True, speculate=None, native_contexts=None):
         self.native = bool(native)       # with `fit`: run() hands whole blocks of steps to the library (vk_walk_run)
+        # the library loop takes two steps per launch (three evaluations per walker for two steps: the same chain, half the
+        # round trips) while the GPU has room for it; None = by ensemble size
+        self.speculate = (int(n_walkers) <= self.SPECULATE_MAX_WALKERS) if speculate is None else bool(speculate)
+        self.native_contexts = native_contexts       # contexts the library loop spreads the ensemble over (1 or 2; None = choose)
         self._walk = None
         self.evaluate = evaluate
         self.specs = list(specs)
@@ -173,12 +180,13 @@ class EnsembleMetropolis:
             cols = np.full(len(names), N.VK_WALK_EPSILON, dtype=np.int32)
             for j, c in pairs:
                 cols[j] = c
-            ctxs = (C.c_void_p * len(engines))(*[e._ctx for e in engines])
+            n_ctx = min(len(engines), int(self.native_contexts or len(engines)))
+            ctxs = (C.c_void_p * n_ctx)(*[e._ctx for e in engines[:n_ctx]])
             err = C.create_string_buffer(512)
             lib = first._lib
-            self._walk = lib.vk_walk_create(ctxs, len(engines), C.byref(plan[4]), W, len(names),
+            self._walk = lib.vk_walk_create(ctxs, n_ctx, C.byref(plan[4]), W, len(names),
                                             cols.ctypes.data_as(C.POINTER(C.c_int32)), N.as_dp(N.f64(self.lo)), N.as_dp(N.f64(self.hi)),
-                                            N.as_dp(rows), float(alpha), err, len(err))
+                                            N.as_dp(rows), float(alpha), 1 if self.speculate else 0, err, len(err))
             if not self._walk:
                 raise InputError("vk_walk_create failed: " + err.value.decode())
             self._walk_lib = lib
@@ -489,17 +497,30 @@ class DistributedEnsemble:
         self.all_lnl.extend(np.ascontiguousarray(got[:, t, :]).reshape(world * W) for t in range(k))
 
     def run(self, n_steps):
-        """Advance ``n_steps`` in pieces of ``gather_block`` steps (the local sampler's chain does not depend on the pieces
-        ``run`` is called in), one collective behind each piece."""
+        """Advance ``n_steps`` - the local sampler in pieces of its own block of 64 steps, whatever ``gather_block`` is, so that
+        the chain (and every bit of its log-likelihoods) does not depend on how the history is exchanged - with one collective
+        behind every ``gather_block`` steps."""
         chains, lnls = [], []
-        done = 0
+        pending = []                         # rows of log-likelihoods not yet exchanged
+        held = done = 0
+        piece = EnsembleMetropolis.BLOCK
         while done < n_steps:
-            k = min(self.gather_block, n_steps - done)
+            k = min(piece, n_steps - done)
             c, l = self.local.run(k)
-            self._flush(l)
             chains.append(c)
             lnls.append(l)
+            pending.append(l)
+            held += k
             done += k
+            if held >= self.gather_block:
+                rows = np.concatenate(pending)
+                full = (held // self.gather_block) * self.gather_block
+                for a in range(0, full, self.gather_block):
+                    self._flush(rows[a:a + self.gather_block])
+                pending = [rows[full:]] if full < held else []
+                held -= full
+        if held:
+            self._flush(np.concatenate(pending))
         W, P = self.local.n_walkers, len(self.local.specs)
         chain = np.concatenate(chains) if chains else np.empty((0, W, P))
         lnl = np.concatenate(lnls) if lnls else np.empty((0, W))
