@@ -751,8 +751,9 @@ def dsplit_sharded(dist, launched, n_local, n_dev, total, steps, warmup, global_
 def walkers_distributed(dist, launched, n_local, n_dev, total, walkers=8, steps=640):
     """BASELINE config 4 on N GPUs: 8 Metropolis walkers per GPU on config/boss_cobaya_config.yaml.  One process per GPU (the
     driver's layout; the reference's own scale-out is N chains under mpirun, README.md:30): every rank advances its own walkers
-    on its own GPU and the ranks exchange the log-likelihoods of a 64-step block in ONE RCCL all-gather
-    (victor_amd/sampler.py: DistributedEnsemble) - timed with that gather and, beside it, without any.  One process driving all
+    on its own GPU and the ranks exchange the log-likelihoods of a 64-step block in ONE RCCL all-gather, enqueued on a context of
+    its own behind the block and collected one block later (victor_amd/sampler.py: DistributedEnsemble) - timed with that
+    gather and, beside it, without any.  One process driving all
     GPUs: a single ensemble of 8 N walkers whose proposals are sharded over the devices, gathered on the GPUs every step."""
     import numpy as np
     import workloads as cases
@@ -802,7 +803,7 @@ def walkers_distributed(dist, launched, n_local, n_dev, total, walkers=8, steps=
     gather, ok = None, 1.0
     with stdout_to_stderr():
         try:
-            gather = RcclGather(engine, dist, walkers * block)
+            gather = RcclGather.own_context(fit, dist, walkers * block)      # a context (stream) of its own
         except _native.CommInitTimeout as exc:
             print(f"rank {dist.rank}: {exc}", file=sys.stderr)
             sys.stderr.flush()
@@ -851,6 +852,8 @@ def walkers_distributed(dist, launched, n_local, n_dev, total, walkers=8, steps=
                 "collectives": ens.n_collectives - c0, "collectives_per_step": (ens.n_collectives - c0) / steps,
                 "evals_per_s": float(evals) / dt, "us_per_step": 1e6 * dt / steps,
                 "us_per_step_without_gather": 1e6 * dt_plain / steps, "gather_cost_ratio": dt / dt_plain,
+                "gather_us_per_collective": 1e6 * (dt - dt_plain) / max(ens.n_collectives - c0, 1),
+                "gather_overlapped": bool(ens.overlap),
                 "acceptance": ens.local.acceptance, "gather_matches_local": good})
     if gather is not None:
         gather.close()

@@ -79,7 +79,7 @@ def main():
         if dist.world > 1:
             ok = 1.0
             try:
-                gather = RcclGather(engine, dist, args.walkers * args.gather_block)
+                gather = RcclGather.own_context(fit, dist, args.walkers * args.gather_block)      # a context (stream) of its own
             except _native.CommInitTimeout as exc:                     # a thread is stuck inside RCCL on this context: fatal
                 print(f"rank {dist.rank}: {exc}", file=sys.stderr)
                 sys.stderr.flush()

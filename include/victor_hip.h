@@ -422,6 +422,15 @@ int vk_device_bus_id(const vk_ctx* ctx, char* buf, size_t len);
  * (ncclCommInitAll - no unique id, no rendezvous), context i being rank i.  Fails with VK_E_RCCL when two contexts share a
  * device (RCCL refuses that; callers then gather through the host). */
 int vk_comm_init_all(vk_ctx* const* ctxs, int32_t n);
+/* An all-gather of HOST data that is collected later (one process per GPU; after vk_comm_init): `send` (count doubles) is copied
+ * to pinned memory; upload, ncclAllGather and download are enqueued on the context's stream and nothing waits.
+ * vk_comm_allgather_host_finish waits for the download and writes recv[nranks][count], rank-major.  One gather per context at a
+ * time.  For monitoring traffic that must not sit in a caller's step: victor_amd/sampler.py exchanges the walkers'
+ * log-likelihoods of a block of steps this way, collecting one block late, on a context of the gather's own (an all-gather
+ * enqueued on a stream the walkers launch on would hold their launches back until the slowest rank has arrived). */
+int vk_comm_allgather_host_begin(vk_ctx* ctx, const double* send, int64_t count);
+int vk_comm_allgather_host_finish(vk_ctx* ctx, double* recv);
+
 /* The all-gather of such a group in one call: ncclGroupStart, one ncclAllGather per context on that context's stream
  * (d_send[i]: count doubles on device i, d_recv[i]: n*count doubles on device i), ncclGroupEnd.  Enqueued. */
 int vk_comm_allgather_group_async(vk_ctx* const* ctxs, int32_t n, const double* const* d_send, double* const* d_recv,

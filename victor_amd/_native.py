@@ -132,6 +132,8 @@ SYMBOLS = {
     "vk_comm_unique_id": (C.c_int, [C.c_char_p]),
     "vk_comm_init": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int]),
     "vk_comm_allgather_async": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
+    "vk_comm_allgather_host_begin": (C.c_int, [_vp, _dp, C.c_int64]),
+    "vk_comm_allgather_host_finish": (C.c_int, [_vp, _dp]),
     "vk_comm_destroy": (C.c_int, [_vp]),
     "vk_device_bus_id": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     "vk_comm_init_all": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32]),

@@ -226,6 +226,12 @@ struct vk_ctx {
   // RCCL (loaded lazily)
   void* rccl_lib = nullptr;
   void* comm = nullptr;
+  int comm_nranks = 0;
+  // vk_comm_allgather_host_begin / _finish: pinned host staging [1 + nranks][cap], device buffers likewise, the event behind the download
+  double* h_comm = nullptr;
+  double* d_comm = nullptr;
+  int64_t comm_cap = 0, comm_begun = 0;
+  hipEvent_t ev_comm = nullptr;
   // small host-buffer batches are launch-bound: (H2D, theory kernel, likelihood kernel, D2H) is captured once per
   // (n, options) into a hipGraph over pinned staging buffers and replayed with a single launch
   double* h_pin = nullptr;                      // pinned: params[kGraphMaxN][VK_NPAR] | lnl, chi2 [2 kGraphMaxN]
@@ -1493,6 +1499,9 @@ void vk_destroy(vk_ctx* ctx) {
   if (ctx->d_tables) (void)hipFree(ctx->d_tables);
   if (ctx->d_aux) (void)hipFree(ctx->d_aux);
   if (ctx->h_poll_failed) (void)hipHostFree(ctx->h_poll_failed);
+  if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);
+  if (ctx->d_comm) (void)hipFree(ctx->d_comm);
+  if (ctx->ev_comm) (void)hipEventDestroy(ctx->ev_comm);
   for (auto& kv : ctx->images) (void)hipFree(kv.second);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   for (auto& evt : ctx->ev)
@@ -2574,6 +2583,50 @@ int vk_comm_init(vk_ctx* ctx, const char* id, int rank, int nranks) {
     return fail(ctx, VK_E_RCCL, "ncclCommInitRank failed: %s", es ? es(rc) : "?");
   }
   ctx->rccl_lib = lib;
+  ctx->comm_nranks = nranks;
+  return VK_OK;
+}
+
+// An all-gather of host data that the caller collects LATER: the rows go into pinned memory, upload, ncclAllGather and download
+// are enqueued on the context's stream, nothing waits.  vk_comm_allgather_host_finish waits for the download's event - by
+// then, one block of walker steps later, long past - and hands the gathered rows over.
+int vk_comm_allgather_host_begin(vk_ctx* ctx, const double* send, int64_t count) {
+  if (!ctx || !ctx->comm) return fail(ctx, VK_E_RCCL, "communicator not initialised");
+  if (!send || count < 1) return fail(ctx, VK_E_ARG, "vk_comm_allgather_host_begin: NULL buffer or count < 1");
+  if (ctx->comm_begun != 0) return fail(ctx, VK_E_ARG, "vk_comm_allgather_host_begin: the previous gather has not been collected");
+  VK_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t slots = 1 + (int64_t)ctx->comm_nranks;
+  if (count > ctx->comm_cap) {
+    VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);
+    if (ctx->d_comm) (void)hipFree(ctx->d_comm);
+    ctx->h_comm = ctx->d_comm = nullptr;
+    ctx->comm_cap = 0;
+    VK_HIP(ctx, hipHostMalloc((void**)&ctx->h_comm, (size_t)slots * count * sizeof(double), hipHostMallocDefault));
+    VK_HIP(ctx, hipMalloc((void**)&ctx->d_comm, (size_t)slots * count * sizeof(double)));
+    ctx->comm_cap = count;
+  }
+  if (!ctx->ev_comm) VK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_comm, hipEventDisableTiming));
+  memcpy(ctx->h_comm, send, (size_t)count * sizeof(double));
+  VK_HIP(ctx, hipMemcpyAsync(ctx->d_comm, ctx->h_comm, (size_t)count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  const int rc = vk_comm_allgather_async(ctx, ctx->d_comm, ctx->d_comm + ctx->comm_cap, count);
+  if (rc) return rc;
+  VK_HIP(ctx, hipMemcpyAsync(ctx->h_comm + ctx->comm_cap, ctx->d_comm + ctx->comm_cap, (size_t)ctx->comm_nranks * count * sizeof(double),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  VK_HIP(ctx, hipEventRecord(ctx->ev_comm, ctx->stream));
+  ctx->comm_begun = count;
+  return VK_OK;
+}
+
+int vk_comm_allgather_host_finish(vk_ctx* ctx, double* recv) {
+  if (!ctx) return VK_E_ARG;
+  const int64_t count = ctx->comm_begun;
+  if (count == 0) return fail(ctx, VK_E_ARG, "vk_comm_allgather_host_finish: nothing was begun on this context");
+  if (!recv) return fail(ctx, VK_E_ARG, "vk_comm_allgather_host_finish: NULL buffer");
+  ctx->comm_begun = 0;
+  VK_HIP(ctx, hipSetDevice(ctx->device));
+  VK_HIP(ctx, hipEventSynchronize(ctx->ev_comm));
+  memcpy(recv, ctx->h_comm + ctx->comm_cap, (size_t)ctx->comm_nranks * count * sizeof(double));
   return VK_OK;
 }
 
@@ -2621,6 +2674,7 @@ int vk_comm_init_all(vk_ctx* const* ctxs, int32_t n) {
   for (int i = 0; i < n; ++i) {
     ctxs[i]->comm = comms[i];
     ctxs[i]->rccl_lib = lib;
+    ctxs[i]->comm_nranks = n;
   }
   return VK_OK;
 }

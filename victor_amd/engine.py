@@ -523,6 +523,15 @@ class Engine:
     def comm_allgather_async(self, d_send, d_recv, count):
         self._check(self._lib.vk_comm_allgather_async(self._ctx, d_send, d_recv, int(count)))
 
+    def comm_allgather_host_begin(self, local):
+        local = N.f64(local)
+        self._check(self._lib.vk_comm_allgather_host_begin(self._ctx, N.as_dp(local), local.size))
+
+    def comm_allgather_host_finish(self, count, nranks):
+        out = np.empty(int(count) * int(nranks))
+        self._check(self._lib.vk_comm_allgather_host_finish(self._ctx, N.as_dp(out)))
+        return out
+
     def comm_destroy(self):
         self._check(self._lib.vk_comm_destroy(self._ctx))
 

@@ -472,7 +472,7 @@ class DistributedEnsemble:
     """
 
     def __init__(self, evaluate, specs, walkers_per_rank, dist, seed=0, fixed=None, gather=None,
-                 sampler=None, fit=None, gather_block=None):
+                 sampler=None, fit=None, gather_block=None, overlap=True):
         self.dist = dist
         self.local = (sampler or EnsembleMetropolis)(evaluate, specs, walkers_per_rank, seed=seed + 7919 * dist.rank,
                                                      fixed=fixed, fit=fit)
@@ -482,19 +482,45 @@ class DistributedEnsemble:
             raise InputError("gather_block must be at least 1")
         self.all_lnl = []
         self.n_collectives = 0
+        # A gather that comes in two halves (victor_amd.sharding.RcclGather: begin / finish over vk_comm_allgather_host_begin /
+        # _finish, on a GPU context of its own) is enqueued when a block is complete and collected ONE BLOCK LATER: upload,
+        # ncclAllGather and download run on the gather's stream while the walkers take the next block, nothing on the host
+        # waits for the other ranks.  (A helper thread doing the blocking gather instead was measured and is slower than the
+        # blocking gather itself: 143-164 against 101-105 us per collective, the two threads contending for the interpreter
+        # and the HIP runtime.)  Plain callables (the ranks' socket group) are called as they are.
+        self.overlap = bool(overlap) and hasattr(self.gather, "begin") and hasattr(self.gather, "finish")
+        self._in_flight = None               # (k, W) of the block whose exchange is enqueued
 
-    def _flush(self, block):
-        """One collective for the steps' log-likelihoods in ``block`` ``[k, W]``, k <= gather_block; appends their
-        ``[k, world * W]`` rows to ``all_lnl``."""
-        k, W = block.shape
+    def _collect(self):
+        """Bring home the block enqueued last, if any."""
+        if self._in_flight is not None:
+            k, W = self._in_flight
+            self._in_flight = None
+            self._append(np.asarray(self.gather.finish()), k, W)
+
+    def _append(self, got, k, W):
         K, world = self.gather_block, self.dist.world
-        buf = block
-        if k < K:                            # a short last block travels at the full count (RCCL: equal counts, fixed buffers)
-            buf = np.full((K, W), np.nan)
-            buf[:k] = block
-        got = np.asarray(self.gather(np.ascontiguousarray(buf).reshape(K * W))).reshape(world, K, W)
-        self.n_collectives += 1
+        got = got.reshape(world, K, W)
         self.all_lnl.extend(np.ascontiguousarray(got[:, t, :]).reshape(world * W) for t in range(k))
+
+    def _padded(self, block):
+        k, W = block.shape
+        if k == self.gather_block:
+            return np.ascontiguousarray(block)
+        buf = np.full((self.gather_block, W), np.nan)        # a short last block travels at the full count (RCCL: equal counts, fixed buffers)
+        buf[:k] = block
+        return buf
+
+    def _exchange(self, block):
+        """One collective for the steps' log-likelihoods in ``block`` ``[k, W]``, k <= gather_block."""
+        k, W = block.shape
+        self.n_collectives += 1
+        if self.overlap:
+            self._collect()
+            self.gather.begin(self._padded(block).reshape(self.gather_block * W))
+            self._in_flight = (k, W)
+        else:
+            self._append(np.asarray(self.gather(self._padded(block).reshape(self.gather_block * W))), k, W)
 
     def run(self, n_steps):
         """Advance ``n_steps`` - the local sampler in pieces of its own block of 64 steps, whatever ``gather_block`` is, so that
@@ -509,18 +535,22 @@ class DistributedEnsemble:
             c, l = self.local.run(k)
             chains.append(c)
             lnls.append(l)
+            done += k
+            if not held and k == self.gather_block:      # the common case: a piece is a block
+                self._exchange(l)
+                continue
             pending.append(l)
             held += k
-            done += k
             if held >= self.gather_block:
                 rows = np.concatenate(pending)
                 full = (held // self.gather_block) * self.gather_block
                 for a in range(0, full, self.gather_block):
-                    self._flush(rows[a:a + self.gather_block])
+                    self._exchange(rows[a:a + self.gather_block])
                 pending = [rows[full:]] if full < held else []
                 held -= full
         if held:
-            self._flush(np.concatenate(pending))
+            self._exchange(np.concatenate(pending))
+        self._collect()                      # every block of this run is in all_lnl when run() returns
         W, P = self.local.n_walkers, len(self.local.specs)
         chain = np.concatenate(chains) if chains else np.empty((0, W, P))
         lnl = np.concatenate(lnls) if lnls else np.empty((0, W))

@@ -187,6 +187,20 @@ class RcclGather:
     ``count`` doubles per rank and call - for :class:`victor_amd.sampler.DistributedEnsemble` a whole block of steps
     (``gather_block * walkers``): one upload, one ``ncclAllGather``, one download per block."""
 
+    @classmethod
+    def own_context(cls, fit, dist, count, device=None):
+        """A gather with a GPU context (stream) of its OWN, created from ``fit``'s tables: an all-gather enqueued on a stream
+        the walkers launch on would hold their launches back until the slowest rank has arrived
+        (:class:`victor_amd.sampler.DistributedEnsemble` enqueues a block's exchange and collects it one block later)."""
+        from .engine import Engine
+        first = fit._get_engine()
+        key = fit._engine_key(fit._merged({}))
+        eng = Engine(fit, fit, device=first.device if device is None else device, matter_model=key, simpson_even=first.simpson_even,
+                     lib=getattr(fit, "_native_lib", None))
+        self = cls(eng, dist, count)
+        self._own_engine = eng
+        return self
+
     def __init__(self, engine, dist, count):
         self.engine, self.dist, self.count = engine, dist, int(count)
         if not one_device_per_rank(dist, engine):
@@ -207,10 +221,23 @@ class RcclGather:
         self.calls += 1
         return self.engine.download(self.d_recv, self.count * self.dist.world)
 
+    # the same gather in two halves (vk_comm_allgather_host_begin / _finish): enqueue now, collect a block of steps later
+    def begin(self, local):
+        local = np.ascontiguousarray(local, dtype=np.float64)
+        assert local.shape == (self.count,)
+        self.engine.comm_allgather_host_begin(local)
+        self.calls += 1
+
+    def finish(self):
+        return self.engine.comm_allgather_host_finish(self.count, self.dist.world)
+
     def close(self):
         self.engine.free(self.d_send)
         self.engine.free(self.d_recv)
         self.engine.comm_destroy()
+        if getattr(self, "_own_engine", None) is not None:
+            self._own_engine.close()
+            self._own_engine = None
 
 
 class DeviceGather:
