@@ -634,6 +634,39 @@ def test_c_abi_rejects_bad_calls_without_crashing():
     assert lib.vk_theory_batch(ctx, C.byref(opts), dp(rows), 4, dp(s), 6, dp(mu), 100, dp(w), 7, dp(th)) == -1
     assert lib.vk_theory_batch(ctx, C.byref(opts), dp(rows), 4, dp(s), 6, dp(mu), 100, dp(w), 2, dp(th)) == 0
     assert np.all(np.isfinite(th))
+    # the walker loop: bad descriptions are refused at creation, bad calls come back as VK_E_ARG
+    ctxs = (C.c_void_p * 1)(ctx)
+    cols = np.array([N.P_FSIGMA8, N.P_SIGMAV], dtype=np.int32)
+    lo, hi = np.array([0.05, 100.0]), np.array([1.5, 500.0])
+    base = np.ascontiguousarray(rows[:4])
+    err = C.create_string_buffer(256)
+    ip = C.POINTER(C.c_int32)
+
+    def create(n_ctx=1, n_walkers=4, n_params=2, columns=cols, lo_=lo, hi_=hi):
+        return lib.vk_walk_create(ctxs, n_ctx, C.byref(opts), n_walkers, n_params, columns.ctypes.data_as(ip), dp(lo_), dp(hi_), dp(base),
+                                  1.0, 1, err, len(err))
+
+    assert not create(n_ctx=3) and err.value
+    assert not create(n_walkers=0) and b"walkers" in err.value
+    assert not create(columns=np.array([N.P_FSIGMA8, N.P_APAR], dtype=np.int32)) and b"column" in err.value       # derived column
+    assert not create(columns=np.array([N.VK_WALK_EPSILON, N.VK_WALK_EPSILON], dtype=np.int32)) and b"twice" in err.value
+    assert not create(lo_=np.array([0.05, 600.0])) and b"hi > lo" in err.value
+    walk = create()
+    assert walk
+    x = np.array([[0.4, 350.0], [0.5, 380.0], [0.6, 300.0], [0.45, 420.0]])
+    l0 = fit.log_likelihood_batch(dict(fsigma8=x[:, 0], sigma_v=x[:, 1], aperp=rows[:4, N.P_APERP], apar=rows[:4, N.P_APAR]))[0]
+    dz = np.zeros((3, 4, 2))
+    logu = np.zeros((3, 4))
+    n_acc, n_ev = C.c_int64(0), C.c_int64(0)
+    assert lib.vk_walk_run(None, 3, dp(x), dp(l0), dp(dz), dp(logu), None, None, C.byref(n_acc), C.byref(n_ev)) == -1
+    assert lib.vk_walk_run(walk, 3, None, dp(l0), dp(dz), dp(logu), None, None, C.byref(n_acc), C.byref(n_ev)) == -1
+    assert lib.vk_walk_run(walk, 3, dp(x), dp(l0), None, dp(logu), None, None, C.byref(n_acc), C.byref(n_ev)) == -1
+    assert lib.vk_walk_run(walk, 0, dp(x), dp(l0), None, None, None, None, C.byref(n_acc), C.byref(n_ev)) == 0          # no steps: legal
+    # zero increments, acceptance level log(1) = 0: every proposal is the position itself, lnl_prop - lnl = 0 is not > 0: nothing moves
+    x0 = x.copy()
+    assert lib.vk_walk_run(walk, 3, dp(x), dp(l0), dp(dz), dp(logu), None, None, C.byref(n_acc), C.byref(n_ev)) == 0
+    assert np.array_equal(x, x0) and n_acc.value == 0 and n_ev.value == 12
+    lib.vk_walk_destroy(walk)
     # the context is still healthy
     lnl, chi2 = fit.log_likelihood_batch(rows)
     assert np.all(np.isfinite(lnl))
