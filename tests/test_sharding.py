@@ -134,6 +134,27 @@ for K in (7, 64):
 # a second run() continues the history (two more collectives at K = 64: 100 steps)
 more = ens.run(100)[2]
 assert more.shape == (250, 16) and ens.n_collectives == 3 + 2 and np.array_equal(more[:150], runs[64][1])
+# a gather that comes in two halves (RcclGather.begin / finish) is enqueued behind a block and collected one block later:
+# the same history, the same number of collectives, at most one exchange in flight
+class TwoHalves:
+    def __init__(self):
+        self.sent, self.in_flight, self.max_in_flight = None, 0, 0
+    def begin(self, local):
+        assert self.sent is None
+        self.sent = np.array(local)
+        self.in_flight += 1
+        self.max_in_flight = max(self.max_in_flight, self.in_flight)
+    def finish(self):
+        local, self.sent = self.sent, None
+        self.in_flight -= 1
+        return dist.allgather_host(local, len(local))
+for K in (7, 64):
+    g = TwoHalves()
+    late = DistributedEnsemble(evaluate, specs, walkers_per_rank=8, dist=dist, seed=5, gather=g, gather_block=K)
+    assert late.overlap
+    chain, lnl, all_lnl = late.run(150)
+    assert np.array_equal(chain, runs[K][0]) and np.array_equal(all_lnl, runs[K][1]) and late.n_collectives == -(-150 // K)
+    assert g.sent is None and g.in_flight == 0 and g.max_in_flight == 1
 print("rank", dist.rank, "ok", float(runs[1][1].sum()))
 '''
 
