@@ -338,7 +338,7 @@ def live_traffic(batch, simpson_even, log_dir=None):
                os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", str(batch), "--no-cpu-baseline",
                "--no-boss", "--no-live-traffic", "--simpson-even", simpson_even]
         try:
-            res = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=300)
+            res = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=120)
             vals = {}
             for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
