@@ -317,6 +317,24 @@ def profiled_traffic(which, batch):
             "effective_clock_ghz": rec.get("effective_clock_ghz")}
 
 
+def run_bounded(cmd, cwd, env, timeout):
+    """subprocess.run with captured output whose time-out ends the child's whole process GROUP (the profiler and the program
+    it started), so that nothing of a hung pass keeps the GPU."""
+    import signal
+    import subprocess
+    proc = subprocess.Popen(cmd, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        proc.communicate()
+        raise
+    return subprocess.CompletedProcess(cmd, proc.returncode, out, err)
+
+
 def live_traffic(batch, simpson_even, log_dir=None):
     """HBM bytes per launch of the dominant (theory) kernel, measured NOW: two child runs of this very program on the same
     batch under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` - separate passes, the program itself directly after `--`,
@@ -338,7 +356,7 @@ def live_traffic(batch, simpson_even, log_dir=None):
                os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", str(batch), "--no-cpu-baseline",
                "--no-boss", "--no-live-traffic", "--simpson-even", simpson_even]
         try:
-            res = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=120)
+            res = run_bounded(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=120)
             vals = {}
             for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
