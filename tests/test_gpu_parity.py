@@ -207,6 +207,18 @@ def test_theory_xi_on_the_cells_kernel(synth_fit, boss_fit, oracle):
                 _native.set_knob("VICTOR_HIP_FORCE_GENERIC", None)
             assert xi.shape == ref.shape == (2, len(mu), len(s))
             assert np.max(np.abs(xi - ref)) < 1e-9 * np.max(np.abs(ref)), (tag, len(s), len(mu))
+        # theory_xi projected on the host with the fit's own weights IS the theory vector (utils.multipoles_from_fn restated as
+        # W_l[100], victor_amd/tables.py): the stored cells against the kernel's own projection, 256 points, every multipole
+        from victor_amd import tables as T
+        poles = np.atleast_1d(fit.poles_s)
+        mu_p = T.mu_nodes_for(poles)
+        W = T.projection_weights(mu_p, poles)                                   # (n_ell, n_mu)
+        sub = {k: v[:256] for k, v in hp.items()}
+        xi = fit.theory_xi_batch(fit.s, mu_p, sub)                              # (256, n_mu, n_s)
+        th = fit.theory_vector_batch(sub).reshape(256, len(poles), len(fit.s))
+        proj = np.einsum("li,nij->nlj", W, xi)
+        scale = np.max(np.abs(th), axis=2, keepdims=True)
+        assert np.max(np.abs(proj - th) / scale) < 1e-11, tag
         # a NaN parameter poisons every cell of its point and nothing else
         bad = {k: v[:3].copy() for k, v in hp.items()}
         bad["sigma_v"][1] = np.nan
