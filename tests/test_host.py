@@ -784,3 +784,22 @@ def test_polling_handoff_launch_rule(lib):
         total += g
         ctxs.append(g)
     assert ctxs == [8, 8, 8, 8, 0] and total == 32
+
+
+def test_algorithmic_flop_counts_of_the_bench():
+    """The flop counts behind every roofline fraction of the bench line (bench.py: flops_per_eval, model_flops), pinned to the
+    figures DESIGN.md section 5 derives from the reference's expressions with SURVEY 8(d)'s conventions."""
+    sys.path.insert(0, _ROOT)
+    import bench
+    assert bench.flops_per_eval(40, 100, 50, 3, True) == 15_424_000            # the metric grid: 200000 x 77 + 2 x 3 x 4000
+    assert bench.flops_per_eval(30, 100, 50, 2, False) == 7_062_000            # BOSS: 150000 x 47 + 2 x 2 x 3000
+    assert bench.model_flops("streaming", 30, 100, 50, 2) == 7_062_000
+    assert bench.model_flops("dispersion", 30, 100, 50, 2) == 150_000 * 156 + 3000 * 20 + 12_000 == 23_472_000
+    assert bench.model_flops("dispersion", 30, 100, 50, 2, niter=3) == 150_000 * 120 + 3000 * 20 + 12_000
+    assert bench.model_flops("kaiser", 30, 100, 50, 2) == 3000 * 157 + 12_000 == 483_000
+    assert bench.model_flops("kaiser", 30, 100, 50, 2, linearised=True) == 3000 * 154 + 12_000
+    assert bench.model_flops("kaiser", 30, 100, 50, 2, coord_shift=False) == 3000 * 49 + 12_000
+    assert bench.model_flops("euclid_special", 30, 100, 50, 2) == 3000 * 154 + 12_000
+    assert bench.model_flops("kaiser", 30, 100, 50, 2, n_data=60) == 483_000 + 2 * 3600 + 180      # + the chi-square of a fused launch
+    assert bench.model_flops("dispersion", 40, 100, 50, 3, aniso=True) == 200_000 * 186 + 4000 * 20 + 24_000
+    assert bench.at_sustained_clock(0.57, 2.0) == pytest.approx(0.684) and bench.at_sustained_clock(0.57, None) is None
