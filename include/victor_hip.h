@@ -235,20 +235,26 @@ void vk_knobs_refresh(void);
  *   - a context reserves on demand, up to 8 waiters, out of a budget of 32 per PROCESS (enforced here; a context's launches
  *     are stream-ordered, so its reservation bounds what it has resident); without reservation the launch hands over through
  *     completion counters - the same sums in the same order, bit-identical results, ~1.2 us slower;
- *   - across processes the library cannot count: the OPERATOR keeps the sum of the budgets in use on one GPU below 64 - one
- *     process with the full budget (the GPU owner, victor_amd/broker.py: 4 contexts x 8 requests) plus up to 31 processes
- *     that evaluate one point per call in one context, or up to 63 such processes (vk_poll_budget returns 1: the number of
- *     full-budget processes per device).
+ *   - across processes the reservations of one GPU must stay below 64 in all - one process with the full budget (the GPU
+ *     owner, victor_amd/broker.py: 4 contexts x 8 requests) plus up to 31 processes that evaluate one point per call in one
+ *     context, or up to 63 such processes (vk_poll_budget returns 1: the number of full-budget processes per device).  The
+ *     processes of one user on one host enforce it among themselves through a ledger in /dev/shm, one file per GPU
+ *     (victor_hip_poll_<uid>_<PCI bus id>: a slot {pid, reserved} per process; slots of dead processes are ignored); a process
+ *     beyond the bound gets no reservation and hands over through the counters.  Processes that do not share that file
+ *     (other users, other /dev/shm namespaces) are the operator's to keep within the bound.
  * Failure mode if the rule is broken (or a launch is lost): a waiting workgroup gives up after 5 s of wall clock, the call -
  * or, for enqueued work, the next call / vk_sync on that context - returns VK_E_HIP ("waited ... for partial sums that never
  * arrived") and the context stays unusable: destroy it and create a new one.  No result of such a launch is delivered.
  * vk_poll_rule: 1 when a launch of `n_points` points, `parts` workgroups per plane and `workgroups` workgroups in all, of
  * which `workgroups_per_cu` fit on a CU of a device with `n_cu` CUs, polls under a context reservation of `reserved` waiters.
- * vk_poll_grant: how many MORE waiters a context holding `ctx_reserved` is granted when it wants `want` and the process has
- * `process_reserved` reserved in all (0 or want - ctx_reserved: all or nothing). */
+ * vk_poll_grant: how many MORE waiters a context holding `ctx_reserved` is granted when it wants `want`, the process has
+ * `process_reserved` reserved in all and the other living processes of the ledger `others_reserved` (0 or want - ctx_reserved:
+ * all or nothing).  vk_poll_device_reserved: what the ledger of `ctx`'s GPU holds for the other processes and for this one
+ * (VK_E_ARG, *others = -1, when no ledger could be mapped). */
 int32_t vk_poll_rule(int64_t n_points, int32_t parts, int64_t workgroups, int32_t workgroups_per_cu, int32_t n_cu, int32_t reserved);
-int32_t vk_poll_grant(int32_t process_reserved, int32_t ctx_reserved, int32_t want);
+int32_t vk_poll_grant(int32_t others_reserved, int32_t process_reserved, int32_t ctx_reserved, int32_t want);
 int32_t vk_poll_budget(int32_t* per_process, int32_t* xcd_slots);
+int32_t vk_poll_device_reserved(const vk_ctx* ctx, int32_t* others, int32_t* mine);
 
 /* Copies every table to `device`.  On failure returns NULL and writes a message to err. */
 vk_ctx* vk_create(const vk_tables* tables, int device, char* err, size_t errlen);

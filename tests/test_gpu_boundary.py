@@ -122,3 +122,79 @@ def test_theory_workspace_is_scratch_when_the_likelihood_is_fused():
     finally:
         for p in (d_rows, d_lnl, d_chi, d_ws):
             eng.free(p)
+
+
+_LEDGER_CHILD = r'''
+import json, sys, time
+root, n_ctx, hold = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
+sys.path.insert(0, root)
+import ctypes as C
+import numpy as np
+import victor_amd
+from tests import cases
+from victor_amd.engine import Engine
+fit = victor_amd.CCFFit(*cases.boss_options("config"))
+first = fit._get_engine()
+key = fit._engine_key(fit._merged({}))
+engines = [first] + [Engine(fit, fit, matter_model=key, simpson_even=first.simpson_even) for _ in range(n_ctx - 1)]
+opts = first.make_opts(fit.model, fit.fit_options)
+rows = fit._fit_rows(cases.halton_params(5, with_beta=True), fit.model)      # five BOSS points: planes split in two, one waiter each
+polled, out = [], []
+for e in engines:
+    out.append(np.concatenate(e.eval_batch(opts, rows)[:2]).tolist())
+    polled.append(e.last_polled())
+others, mine = C.c_int32(), C.c_int32()
+rc = first._lib.vk_poll_device_reserved(first._ctx, C.byref(others), C.byref(mine))
+print(json.dumps({"polled": polled, "others": others.value, "mine": mine.value, "rc": rc, "same": all(o == out[0] for o in out)}), flush=True)
+sys.stdin.readline() if hold else None
+'''
+
+
+def test_polling_reservations_are_kept_device_wide_across_processes():
+    """The ledger of reserved waiters (victor_hip.hip: PollLedger; one file per GPU in /dev/shm): a process reserves 5 per
+    context for five-point BOSS launches up to its own budget of 32 (six contexts, the seventh hands over through the
+    counters); a second process sees those 30 and gets its own 30; a third finds 60 taken and is granted nothing (63 is the
+    bound) - all of them return the same bits; when the first two have gone their slots no longer count."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def start(n_ctx, hold):
+        return subprocess.Popen([sys.executable, "-c", _LEDGER_CHILD, root, str(n_ctx), "1" if hold else "0"], stdin=subprocess.PIPE,
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+    def first_line(p):
+        line = p.stdout.readline()
+        assert line, p.stderr.read()[-2000:]
+        return json.loads(line)
+
+    held = []
+    try:
+        a = start(7, True)
+        ra = first_line(a)
+        held.append(a)
+        base = ra["others"]                                   # whatever other processes of this user hold on the GPU already (normally 0)
+        assert ra["rc"] == 0 and ra["polled"] == [True] * 6 + [False] and ra["mine"] == 30 and ra["same"], ra
+        b = start(6, True)
+        rb = first_line(b)
+        held.append(b)
+        assert rb["polled"] == [True] * 6 and rb["mine"] == 30 and rb["others"] == base + 30 and rb["same"], rb
+        c = start(2, False)
+        rc_ = first_line(c)
+        c.wait(timeout=60)
+        # 63 - 60 = 3 waiters left on the device: a five-point launch gets none of them
+        assert rc_["polled"] == [False, False] and rc_["mine"] == 0 and rc_["others"] == base + 60 and rc_["same"], rc_
+        assert rc_["same"] and ra["same"]
+    finally:
+        for p in held:
+            try:
+                p.stdin.write("\n")
+                p.stdin.flush()
+            except OSError:
+                pass
+            p.wait(timeout=60)
+    d = start(2, False)
+    rd = first_line(d)
+    d.wait(timeout=60)
+    assert rd["polled"] == [True, True] and rd["others"] == base and rd["mine"] == 10, rd      # the dead processes' slots do not count

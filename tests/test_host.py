@@ -771,7 +771,8 @@ def test_polling_handoff_launch_rule(lib):
     assert rule(1, 2, 80, 1, 256, 8) == 0                            # tables so large that one workgroup fills a CU: 32 slots per XCD
     assert rule(1, 2, 80, 3, 64, 8) == 0                             # a device whose XCDs offer fewer than 64 slots
     assert rule(0, 2, 0, 3, 256, 8) == 0
-    grant = lib.vk_poll_grant
+    def grant(process, ctx, want, others=0):
+        return lib.vk_poll_grant(others, process, ctx, want)
     assert grant(0, 0, 1) == 1 and grant(0, 0, 8) == 8 and grant(0, 1, 8) == 7
     assert grant(0, 8, 4) == 0                                       # already covered
     assert grant(24, 0, 8) == 8 and grant(25, 0, 8) == 0             # all or nothing at the budget's edge
@@ -784,6 +785,11 @@ def test_polling_handoff_launch_rule(lib):
         total += g
         ctxs.append(g)
     assert ctxs == [8, 8, 8, 8, 0] and total == 32
+    # across processes (the ledger in /dev/shm): whatever the others hold counts against the device's 63
+    assert grant(0, 0, 8, others=32) == 8 and grant(24, 0, 8, others=32) == 0      # an owner (32) + this process: 31 left
+    assert grant(30, 0, 1, others=32) == 1 and grant(31, 0, 1, others=32) == 0
+    assert grant(0, 0, 1, others=62) == 1 and grant(0, 0, 1, others=63) == 0       # the 64th waiter on the device: never
+    assert grant(0, 0, 8, others=60) == 0 and grant(0, 0, 3, others=60) == 3
 
 
 def test_algorithmic_flop_counts_of_the_bench():

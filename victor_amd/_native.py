@@ -98,7 +98,8 @@ SYMBOLS = {
     "vk_device_count": (C.c_int, []),
     "vk_knobs_refresh": (None, []),
     "vk_poll_rule": (C.c_int32, [C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
-    "vk_poll_grant": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
+    "vk_poll_grant": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "vk_poll_device_reserved": (C.c_int32, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "vk_poll_budget": (C.c_int32, [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "vk_create": (_vp, [C.POINTER(vk_tables), C.c_int, C.c_char_p, C.c_size_t]),
     "vk_destroy": (None, [_vp]),

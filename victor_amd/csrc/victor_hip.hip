@@ -24,8 +24,12 @@
 
 #include <dlfcn.h>
 #include <errno.h>
+#include <fcntl.h>
 #include <signal.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <sys/types.h>
+#include <unistd.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -37,6 +41,7 @@
 #include <algorithm>
 #include <atomic>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -206,6 +211,7 @@ struct vk_ctx {
   int* h_poll_failed = nullptr;        // pinned, device-mapped word a polling workgroup sets when it gives up; d_poll_failed: the
   int* d_poll_failed = nullptr;        // same word through the device's eyes
   int poll_reserved = 0;               // waiters this context may have resident at once (its share of kPollBudget; vk_poll_grant)
+  std::string bus;                     // PCI bus id of the device (the device-wide ledger of reserved waiters is kept per GPU)
   double wsum[3] = {0, 0, 0};
   int depth_mult = 1;                // joint fits: launches of this many contexts share the GPU (vk_joint_eval_device_async)
   hipEvent_t ev_joint = nullptr;
@@ -267,8 +273,9 @@ constexpr long long kPollPoints = 8;
 // are stream-ordered: never more than one in flight) out of kPollBudget = 32 per process - an owner process's default four
 // contexts x eight requests -; a launch whose context holds no reservation for its points hands over through the completion
 // counters instead (the same sums in the same order: not a bit changes).  Across processes the sum of the reservations must
-// stay below 64: ONE process with the full budget (the GPU owner of section 6) plus up to 31 single-point contexts of other
-// processes, or up to 63 processes that each evaluate one point per call in one context.
+// stay below 64 - ONE process with the full budget (the GPU owner of section 6) plus up to 31 single-point contexts of other
+// processes, or up to 63 processes that each evaluate one point per call in one context -, kept in a ledger in /dev/shm that
+// the processes of one user on one host share (PollLedger below); a process beyond the bound simply gets no reservation.
 constexpr int kPollXcdSlots = 64;
 constexpr int kPollBudget = 32;
 
@@ -276,6 +283,89 @@ namespace {
 
 thread_local std::string g_create_err;
 std::atomic<int> g_poll_reserved{0};    // waiters reserved by the contexts of this process (<= kPollBudget)
+
+// ---- the device-wide ledger of reserved waiters --------------------------------------------------------------------------
+// The per-process budget bounds ONE process; the bound that excludes a deadlock is device-wide (fewer than kPollXcdSlots
+// waiters resident on a GPU).  Processes of one user on one host therefore keep their reservations in a small file in /dev/shm,
+// one per GPU (named after its PCI bus id): a slot per process {pid, reserved}, written by its owner only; a reservation is
+// granted when the slots of the LIVING processes, the new one included, stay below the bound (optimistic: add, re-read the
+// sum, take it back if two processes raced past the bound).  Slots of dead processes (kill(pid, 0): ESRCH) are ignored and
+// reused.  No file, no mapping (a read-only /dev/shm, another namespace): the process budget alone applies, as stated in
+// include/victor_hip.h.
+constexpr int kLedgerSlots = 126;
+struct PollLedger {
+  uint32_t magic, version;
+  struct Slot { std::atomic<int32_t> pid, reserved; } slot[kLedgerSlots];
+};
+static_assert(sizeof(PollLedger) == 8 + 8 * kLedgerSlots, "ledger layout");
+constexpr uint32_t kLedgerMagic = 0x564b504cu;   // "VKPL"
+
+struct LedgerHandle {
+  PollLedger* map = nullptr;
+  int mine = -1;
+};
+std::map<std::string, LedgerHandle> g_ledgers;      // per bus id (the contexts of one process are created from one thread at a time)
+
+bool pid_gone(int32_t pid) { return pid > 0 && kill((pid_t)pid, 0) != 0 && errno == ESRCH; }
+
+std::mutex g_ledger_mu;
+
+LedgerHandle* ledger_for(const std::string& bus) {
+  std::lock_guard<std::mutex> hold(g_ledger_mu);      // (the serving threads of an owner process launch concurrently)
+  auto it = g_ledgers.find(bus);
+  if (it != g_ledgers.end()) return it->second.map ? &it->second : nullptr;
+  LedgerHandle h;
+  std::string name = "/dev/shm/victor_hip_poll_" + std::to_string((unsigned)getuid()) + "_";
+  for (char c : bus) name += (isalnum((unsigned char)c) ? c : '_');
+  const int fd = open(name.c_str(), O_RDWR | O_CREAT | O_CLOEXEC, 0600);
+  if (fd >= 0) {
+    struct stat st;
+    if (fstat(fd, &st) == 0 && (st.st_size >= (off_t)sizeof(PollLedger) || ftruncate(fd, sizeof(PollLedger)) == 0)) {
+      void* m = mmap(nullptr, sizeof(PollLedger), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+      if (m != MAP_FAILED) {
+        h.map = static_cast<PollLedger*>(m);
+        if (h.map->magic == 0) {              // a fresh (zero-filled) file: first come stamps it
+          h.map->version = 1;
+          h.map->magic = kLedgerMagic;
+        }
+        if (h.map->magic != kLedgerMagic || h.map->version != 1) {
+          munmap(m, sizeof(PollLedger));
+          h.map = nullptr;
+        }
+      }
+    }
+    close(fd);
+  }
+  if (h.map) {
+    const int32_t me = (int32_t)getpid();
+    for (int pass = 0; pass < 2 && h.mine < 0; ++pass)
+      for (int i = 0; i < kLedgerSlots && h.mine < 0; ++i) {
+        int32_t owner = h.map->slot[i].pid.load(std::memory_order_acquire);
+        const bool free_slot = pass == 0 ? owner == 0 : pid_gone(owner);
+        if (owner == me || (free_slot && h.map->slot[i].pid.compare_exchange_strong(owner, me, std::memory_order_acq_rel))) {
+          h.map->slot[i].reserved.store(0, std::memory_order_release);
+          h.mine = i;
+        }
+      }
+    if (h.mine < 0) {                          // more than 126 living processes of this user on this GPU: no polling for this one
+      munmap(h.map, sizeof(PollLedger));
+      h.map = nullptr;
+    }
+  }
+  auto& kept = g_ledgers[bus] = h;
+  return kept.map ? &kept : nullptr;
+}
+
+// waiters the OTHER living processes hold on this GPU
+int ledger_others(const LedgerHandle* h) {
+  int total = 0;
+  for (int i = 0; i < kLedgerSlots; ++i) {
+    if (i == h->mine) continue;
+    const int32_t owner = h->map->slot[i].pid.load(std::memory_order_acquire);
+    if (owner > 0 && !pid_gone(owner)) total += std::max(0, (int)h->map->slot[i].reserved.load(std::memory_order_acquire));
+  }
+  return total;
+}
 #ifdef VK_PHASES
 long long* g_stamps = nullptr;
 #endif
@@ -896,10 +986,20 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
         a.n <= kPollPoints) {
       // the context's reservation grows on demand, as far as the process's budget allows (released in vk_destroy)
       if (ctx->poll_reserved < a.n) {
+        LedgerHandle* led = ledger_for(ctx->bus);
         int seen = g_poll_reserved.load(std::memory_order_relaxed), grant;
         do {
-          grant = vk_poll_grant(seen, ctx->poll_reserved, (int32_t)a.n);
+          grant = vk_poll_grant(led ? ledger_others(led) : 0, seen, ctx->poll_reserved, (int32_t)a.n);
         } while (grant > 0 && !g_poll_reserved.compare_exchange_weak(seen, seen + grant, std::memory_order_relaxed));
+        if (grant > 0 && led) {
+          // published; if another process raced past the bound meanwhile, take it back (both may: conservative)
+          led->map->slot[led->mine].reserved.fetch_add(grant, std::memory_order_acq_rel);
+          if (ledger_others(led) + g_poll_reserved.load(std::memory_order_relaxed) >= kPollXcdSlots) {
+            led->map->slot[led->mine].reserved.fetch_sub(grant, std::memory_order_acq_rel);
+            g_poll_reserved.fetch_sub(grant, std::memory_order_relaxed);
+            grant = 0;
+          }
+        }
         ctx->poll_reserved += grant > 0 ? grant : 0;
       }
       if (vk_poll_rule(a.n, a.parts, items, (int32_t)per_cu, ctx->n_cu, ctx->poll_reserved)) {
@@ -1080,12 +1180,21 @@ int32_t vk_poll_rule(int64_t n_points, int32_t parts, int64_t workgroups, int32_
   return 1;
 }
 
-int32_t vk_poll_grant(int32_t process_reserved, int32_t ctx_reserved, int32_t want) {
+int32_t vk_poll_grant(int32_t others_reserved, int32_t process_reserved, int32_t ctx_reserved, int32_t want) {
   if (want > (int32_t)kPollPoints) want = (int32_t)kPollPoints;
-  if (want <= ctx_reserved || process_reserved < 0) return 0;
-  const int32_t room = kPollBudget - process_reserved;
+  if (want <= ctx_reserved || process_reserved < 0 || others_reserved < 0) return 0;
   const int32_t extra = want - ctx_reserved;
+  const int32_t room = std::min(kPollBudget - process_reserved,                           // this process's budget
+                                kPollXcdSlots - 1 - others_reserved - process_reserved);  // fewer than an XCD's slots on the device
   return extra <= room ? extra : 0;      // all or nothing: a launch polls for every one of its points or for none
+}
+
+int32_t vk_poll_device_reserved(const vk_ctx* ctx, int32_t* others, int32_t* mine) {
+  if (!ctx) return VK_E_ARG;
+  LedgerHandle* led = ledger_for(ctx->bus);
+  if (others) *others = led ? ledger_others(led) : -1;
+  if (mine) *mine = g_poll_reserved.load(std::memory_order_relaxed);
+  return led ? VK_OK : VK_E_ARG;
 }
 
 int32_t vk_poll_budget(int32_t* per_process, int32_t* xcd_slots) {
@@ -1191,6 +1300,14 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
   hipDeviceProp_t prop;
   if ((rc = hipGetDeviceProperties(&prop, device)) != hipSuccess) return hip_bail(rc, "hipGetDeviceProperties");
   ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  {
+    char busid[64] = {0};
+    if (hipDeviceGetPCIBusId(busid, (int)sizeof busid, device) != hipSuccess) {
+      (void)hipGetLastError();
+      snprintf(busid, sizeof busid, "device%d", device);
+    }
+    ctx->bus = busid;
+  }
   if ((rc = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
     return hip_bail(rc, "hipStreamCreate");
   for (auto& evt : ctx->ev)
@@ -1491,7 +1608,10 @@ void vk_destroy(vk_ctx* ctx) {
   if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
   if (ctx->comm) vk_comm_destroy(ctx);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->poll_reserved) g_poll_reserved.fetch_sub(ctx->poll_reserved, std::memory_order_relaxed);   // (nothing of it is in flight any more)
+  if (ctx->poll_reserved) {            // (nothing of it is in flight any more)
+    g_poll_reserved.fetch_sub(ctx->poll_reserved, std::memory_order_relaxed);
+    if (LedgerHandle* led = ledger_for(ctx->bus)) led->map->slot[led->mine].reserved.fetch_sub(ctx->poll_reserved, std::memory_order_acq_rel);
+  }
   ctx->poll_reserved = 0;
   drop_graphs(ctx);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
