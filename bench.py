@@ -313,87 +313,10 @@ def profiled_traffic(which, batch):
             "ratio_to_algorithmic": rec["theory_kernel_hbm_bytes_per_launch"] / rec["algorithmic_bytes_per_launch"],
             "kernel": rec["kernel"], "commit": tj.get("commit"), "source": tj.get("source"),
             # the kernel sources (csrc/*.h, csrc/*.hip, include/victor_hip.h) hash to what the counters were taken at
-            "sources_unchanged": (stored == sources_digest()) if stored else None,
-            "effective_clock_ghz": rec.get("effective_clock_ghz")}
+            "sources_unchanged": (stored == sources_digest()) if stored else None}
 
 
-def run_bounded(cmd, cwd, env, timeout):
-    """subprocess.run with captured output whose time-out ends the child's whole process GROUP (the profiler and the program
-    it started), so that nothing of a hung pass keeps the GPU."""
-    import signal
-    import subprocess
-    proc = subprocess.Popen(cmd, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
-    try:
-        out, err = proc.communicate(timeout=timeout)
-    except subprocess.TimeoutExpired:
-        try:
-            os.killpg(proc.pid, signal.SIGKILL)
-        except OSError:
-            pass
-        proc.communicate()
-        raise
-    return subprocess.CompletedProcess(cmd, proc.returncode, out, err)
-
-
-def live_traffic(batch, simpson_even, log_dir=None):
-    """HBM bytes per launch of the dominant (theory) kernel, measured NOW: two child runs of this very program on the same
-    batch under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` - separate passes, the program itself directly after `--`,
-    counters only (no trace domains) - corrected as MI355X_MICROARCH.md prescribes (KiB -> bytes, FETCH_SIZE x 2 on gfx950).
-    Child processes: must run before this process touches the GPU.  Returns a dict, or None when the profiler is not there or
-    a pass fails (the line then carries `traffic: null` and the last profiled figure beside it)."""
-    import csv
-    import glob
-    import shutil
-    import subprocess
-    import tempfile
-    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.isfile(exe):
-        return None
-    got = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        out_dir = tempfile.mkdtemp(prefix="victor_pmc_", dir="/tmp")
-        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out_dir, "-o", "pmc", "--", sys.executable,
-               os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", str(batch), "--no-cpu-baseline",
-               "--no-boss", "--no-live-traffic", "--simpson-even", simpson_even]
-        try:
-            res = run_bounded(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=120)
-            vals = {}
-            for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
-                with open(f) as fh:
-                    for r in csv.DictReader(fh):
-                        if r.get("Counter_Name") == counter and "vk_theory" in r.get("Kernel_Name", ""):
-                            vals.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
-            if res.returncode != 0 or not vals:
-                if log_dir:
-                    with open(os.path.join(log_dir, f"live_traffic_{counter}.err"), "w") as fh:
-                        fh.write(res.stdout[-4000:] + "\n" + res.stderr[-4000:])
-                return None
-            kernel = max(vals, key=lambda k: sum(vals[k]))
-            got[counter] = (kernel, sum(vals[kernel]) / len(vals[kernel]), len(vals[kernel]))
-        except (OSError, subprocess.TimeoutExpired, ValueError, KeyError):
-            return None
-        finally:
-            shutil.rmtree(out_dir, ignore_errors=True)
-    fetch, write = 2.0 * got["FETCH_SIZE"][1] * 1024.0, got["WRITE_SIZE"][1] * 1024.0
-    return {"bytes_per_launch": fetch + write, "read_bytes": fetch, "written_bytes": write,
-            "kernel": got["FETCH_SIZE"][0].replace("void ", "").split("(")[0], "launches_averaged": got["FETCH_SIZE"][2],
-            "method": "two child runs of this program under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, "
-                      "counters only); KiB -> bytes, FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md)"}
-
-
-def profiled_clock(which):
-    """Sustained shader clock of the workload's theory kernel in the last profile (GRBM_GUI_ACTIVE / 8 / duration,
-    profiles/traffic_latest.json), or None."""
-    tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if not os.path.isfile(tfile):
-        return None
-    with open(tfile) as fh:
-        tj = json.load(fh)
-    rec = tj.get(which) or (tj.get("model_options") or {}).get(which)
-    return (rec or {}).get("effective_clock_ghz")
-
-
-def boss_measurement(args, batch=16384, steps=20):
+def boss_measurement(args, batch=16384, steps=20, clocks=None):
     """Secondary figure: the BOSS DR12 CMASS configuration the north star's 1e5 evals/s target is quoted on
     (config/boss_config.yaml: 30 s bins x 100 mu x 50 v, l = 0,2, reconstruction-beta dependent tables, data and
     covariance, Sellentin-Heavens likelihood).  Inputs resident in HBM; same timing discipline as the main line."""
@@ -422,11 +345,10 @@ def boss_measurement(args, batch=16384, steps=20):
         eng.free(p)
     F = flops_per_eval(30, 100, 50, 2, False)
     k1 /= max(launches, 1)
+    frac = F * batch / (k1 * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if k1 > 0 else None
     return {"evals_per_s": batch * steps / dt, "batch": batch, "steps": steps, "kernel": eng.last_kernel() + "<1,2>",
             "kernels_ms": {"theory": k1, "likelihood": k2 / max(launches, 1)},
-            "fp64_valu_frac": F * batch / (k1 * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if k1 > 0 else None,
-            "frac_at_sustained_clock": at_sustained_clock(F * batch / (k1 * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if k1 > 0 else None,
-                                                          profiled_clock("boss_cmass")),
+            "fp64_valu_frac": frac, **clock_fields(frac, clocks, "boss_cmass"),
             "flops_per_eval": F, "all_finite": bool(np.all(np.isfinite(lnl))), "fused": fused,
             "traffic_profiled": profiled_traffic("boss_cmass", batch)}
 
@@ -434,6 +356,17 @@ def boss_measurement(args, batch=16384, steps=20):
 def at_sustained_clock(frac, clock_ghz):
     """The same fraction against the peak at the clock the kernel actually sustained (peak x clock / 2.4 GHz)."""
     return frac * PEAK_CLOCK_GHZ / clock_ghz if (frac and clock_ghz) else None
+
+
+def clock_fields(frac, clocks, label):
+    """`sustained_clock_ghz`, `frac_at_sustained_clock` and `clock_source` of one workload from THIS run's clock pass
+    (bench_pmc.live_clocks: {label: {...}} or None).  Without a pass, or without this label in it, the fields are null - a
+    clock measured on another lease is never quoted."""
+    rec = (clocks or {}).get(label)
+    if not rec:
+        return {"sustained_clock_ghz": None, "frac_at_sustained_clock": None, "clock_source": None}
+    return {"sustained_clock_ghz": rec["sustained_clock_ghz"], "frac_at_sustained_clock": at_sustained_clock(frac, rec["sustained_clock_ghz"]),
+            "clock_source": "this run", "clock_dispatch_ms": rec["dispatch_ms"]}
 
 
 def batch_sweep():
@@ -556,7 +489,23 @@ def walker_rates(steps=320):
     return res
 
 
-def option_rates(batch=16384, steps=4):
+MODEL_OPTIONS = (("dispersion", {"rsd_model": "dispersion"}), ("kaiser", {"rsd_model": "kaiser"}),
+                 ("euclid_special", {"rsd_model": "euclid_special"}), ("empirical_corr", {"empirical_corr": True}),
+                 ("linear_bias", {"matter_model": "linear_bias"}),
+                 ("linear_bias+empirical_corr+dispersion", {"matter_model": "linear_bias", "empirical_corr": True, "rsd_model": "dispersion"}))
+FROM_DATA_LABEL = "from_data (measured model, M+D covariance)"
+
+
+def from_data_options():
+    import workloads as cases
+    m, d = cases.boss_options("config")
+    m["input_model_data_file"] = "boss/measured_model.npy"
+    m["realspace_ccf"]["from_data"] = True
+    d["covariance_matrix"]["data_file"] = "boss/cov_md_iso.npy"
+    return m, d
+
+
+def option_rates(batch=16384, steps=4, clocks=None):
     """SURVEY.md 8(f) rows next to the headline: the other RSD models and model options of the reference on the BOSS CMASS
     configuration (and the measured real-space ccf with the model + data covariance), resident, batch 16384 - evals/s and the
     theory kernel that served them."""
@@ -593,22 +542,14 @@ def option_rates(batch=16384, steps=4):
                         coord_shift=bool(model.get("kaiser_coord_shift", True)))
         frac = F * batch / (k1 * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if k1 > 0 else None
         res[label] = {"evals_per_s": batch / dt, "ms_per_batch": dt * 1e3, "kernel": eng.last_kernel(), "fused": fused,
-                      "theory_kernel_ms": k1, "flops_per_eval": F, "fp64_valu_frac": frac,
-                      "frac_at_sustained_clock": at_sustained_clock(frac, profiled_clock(label))}
+                      "theory_kernel_ms": k1, "flops_per_eval": F, "fp64_valu_frac": frac, **clock_fields(frac, clocks, label)}
         for b in bufs:
             eng.free(b)
 
     boss = victor_amd.CCFFit(*cases.boss_options("config"))
-    for label, kw in (("dispersion", {"rsd_model": "dispersion"}), ("kaiser", {"rsd_model": "kaiser"}),
-                      ("euclid_special", {"rsd_model": "euclid_special"}), ("empirical_corr", {"empirical_corr": True}),
-                      ("linear_bias", {"matter_model": "linear_bias"}),
-                      ("linear_bias+empirical_corr+dispersion", {"matter_model": "linear_bias", "empirical_corr": True, "rsd_model": "dispersion"})):
+    for label, kw in MODEL_OPTIONS:
         run(boss, label, **kw)
-    m, d = cases.boss_options("config")
-    m["input_model_data_file"] = "boss/measured_model.npy"
-    m["realspace_ccf"]["from_data"] = True
-    d["covariance_matrix"]["data_file"] = "boss/cov_md_iso.npy"
-    run(victor_amd.CCFFit(m, d), "from_data (measured model, M+D covariance)")
+    run(victor_amd.CCFFit(*from_data_options()), FROM_DATA_LABEL)
     return {"batch": batch, "config": "BOSS DR12 CMASS", "rates": res}
 
 
@@ -882,8 +823,57 @@ def walkers_distributed(dist, launched, n_local, n_dev, total, walkers=8, steps=
     return out
 
 
+# Exit status: 0 = every measurement of the line is good; 1 = the headline's own checks failed (non-finite outputs, gathered vector
+# differs from local recomputation) or a leg's `gather_matches_local` is false; 2 = a leg of the N > 1 run raised; 3 = a leg did not
+# finish within LEG_TIMEOUT (a hung collective).  In cases 2 and 3 rank 0 has printed its line before the process ends: the headline
+# stands, the leg carries {"error": ...}.
+EXIT_LEG_FAILED = 2
+EXIT_LEG_HUNG = 3
 LEG_TIMEOUT = 300.0              # seconds the N > 1 legs (configs 4 and 5) may take together before rank 0 prints its line without them
 REAL_STDOUT = os.dup(1)          # the stdout this program was started with
+
+
+def clock_pass(args):
+    """Child mode (`--clock-pass`, started by bench_pmc.live_clocks under `rocprofv3 --pmc GRBM_GUI_ACTIVE`): launch every
+    workload the line quotes a roofline fraction for - the headline batch, BOSS CMASS, the model options - a fixed number of
+    times, resident, and print what was launched in order ({label, warm, timed, event_ms}); the parent matches the profiler's
+    dispatch records against it.  One theory kernel per call (batches <= 65536 are one launch)."""
+    import victor_amd
+    import workloads as cases
+    from victor_amd.build import build_native
+    build_native()
+    done = []
+
+    def run(label, fit, batch, with_beta, warm=2, timed=6, **kw):
+        model = fit._merged(kw)
+        eng = fit._get_engine(fit._engine_key(model))
+        o = eng.make_opts(model, fit.fit_options)
+        rows = fit._fit_rows(cases.halton_params(batch, with_beta=with_beta), model)
+        bufs = [eng.alloc(rows.size), eng.alloc(batch), eng.alloc(batch), eng.alloc(batch * eng.n_data)]
+        eng.upload(bufs[0], rows)
+        for _ in range(warm):
+            eng.eval_device_async(o, bufs[0], batch, bufs[1], bufs[2], bufs[3])
+        eng.sync()
+        eng.timing(True)
+        eng.read_timing(reset=True)
+        for _ in range(timed):
+            eng.eval_device_async(o, bufs[0], batch, bufs[1], bufs[2], bufs[3])
+        eng.sync()
+        k1, _, launches = eng.read_timing(reset=True)
+        eng.timing(False)
+        for b in bufs:
+            eng.free(b)
+        done.append({"label": label, "warm": warm, "timed": timed, "event_ms": k1 / max(launches, 1), "kernel": eng.last_kernel()})
+
+    model, data = cases.synth_options(CONFIG)
+    model["numerics"] = {"simpson_even": args.simpson_even}
+    run("config3", victor_amd.CCFFit(model, data), min(args.batch, 65536), False)
+    boss = victor_amd.CCFFit(*cases.boss_options("config"))
+    run("boss_cmass", boss, 16384, True)
+    for label, kw in MODEL_OPTIONS:
+        run(label, boss, 16384, True, timed=4, **kw)
+    run(FROM_DATA_LABEL, victor_amd.CCFFit(*from_data_options()), 16384, True, timed=4)
+    os.write(REAL_STDOUT, (json.dumps({"clock_pass": done}) + "\n").encode())
 
 
 def main():
@@ -897,11 +887,16 @@ def main():
     ap.add_argument("--no-chains", action="store_true", help="skip the chains-sharing-one-GPU measurement (child processes)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="skip the two rocprofv3 --pmc child runs that measure the theory kernel's HBM traffic (roofline.traffic)")
+    ap.add_argument("--clock-pass", action="store_true",
+                    help="child mode of the GRBM_GUI_ACTIVE counter pass: launch every measured workload a fixed number of times and "
+                         "print the sequence (bench_pmc.live_clocks)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="oracle evaluations (default: about 10 per core)")
     ap.add_argument("--simpson-even", default="simpson",
                     help="even-N Simpson convention of the velocity integral: 'simpson' (SciPy >= 1.11, default) or "
                          "'avg' (SciPy < 1.11); same cost, recorded in config.simpson_even")
     args = ap.parse_args()
+    if args.clock_pass:
+        return clock_pass(args)
 
     # Two ways to several GPUs, no torch and no MPI binding in either (victor_amd/rendezvous.py, vk_comm_*):
     #   launched   one process per GPU under a launcher (the driver: torch.distributed.run; mpirun / srun work the same) -
@@ -946,10 +941,15 @@ def main():
         base, vals, theory_o = cpu_baseline(sample, args.simpson_even)
         base["single_thread"] = cpu_single_thread(sample[:: max(1, len(sample) // 64)][:64], args.simpson_even)
     # HBM traffic of the dominant kernel, measured live: two child runs under rocprofv3 --pmc, again before the GPU is touched
-    traffic_live = None
+    # ... and the shader clock every measured kernel sustains, from a third child run (GRBM_GUI_ACTIVE): the clock behind
+    # `frac_at_sustained_clock` is measured in THIS run on THIS box, or the field is null
+    traffic_live = clocks = None
     if rank == 0 and total == 1 and not args.no_live_traffic and not args.no_boss:
+        import bench_pmc
         gdir = os.path.join(ROOT, "gpurun_out")
-        traffic_live = live_traffic(B, args.simpson_even, gdir if os.path.isdir(gdir) else None)
+        gdir = gdir if os.path.isdir(gdir) else None
+        traffic_live = bench_pmc.live_traffic(B, args.simpson_even, gdir)
+        clocks = bench_pmc.live_clocks(B, args.simpson_even, gdir)
     # the reference's own calling convention under load (P chains, one point per call): child processes again, so before the GPU
     chains = None
     if rank == 0 and total == 1 and not args.no_boss and not args.no_chains:
@@ -1087,10 +1087,10 @@ def main():
             "roofline": {"bound": "fp64-valu", "kernel": kernel_name + "<3,3>",
                          "achieved": achieved_tf, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / PEAK_FP64_VALU_TFLOPS if achieved_tf else None,
-                         # against the peak at the clock this kernel sustained in the last profile (peak x clock / 2.4 GHz)
-                         "frac_at_sustained_clock": at_sustained_clock(achieved_tf / PEAK_FP64_VALU_TFLOPS if achieved_tf else None,
-                                                                       profiled_clock("config3")),
-                         "sustained_clock_ghz": profiled_clock("config3"),
+                         # against the peak at the clock this kernel sustained (peak x clock / 2.4 GHz): the clock is measured by a
+                         # child pass of THIS run (bench_pmc.live_clocks) - null when that pass could not be made
+                         **clock_fields(achieved_tf / PEAK_FP64_VALU_TFLOPS if achieved_tf else None, clocks, "config3"),
+                         "clock_method": __import__("bench_pmc").CLOCK_METHOD if clocks else None,
                          # HBM bytes per launch of this kernel from PMC counters: measured in this run (live_traffic) when the
                          # profiler is there, else null with the last profiled figure beside it
                          "traffic": traffic_live["bytes_per_launch"] if traffic_live else None,
@@ -1114,14 +1114,14 @@ def main():
         if strong is not None:
             out["strong_scaling"] = strong
         if total == 1 and not args.no_boss:
-            out["boss_cmass"] = boss_measurement(args)
+            out["boss_cmass"] = boss_measurement(args, clocks=clocks)
             out["batch_sweep"] = batch_sweep()
             out["dsplit5"] = dsplit_measurement()
             out["host_api"] = api_latency()
             if chains is not None:
                 out["chains_sharing_one_gpu"] = chains
             out["walker_ensembles"] = walker_rates()
-            out["model_options"] = option_rates()
+            out["model_options"] = option_rates(clocks=clocks)
         if base is not None:
             chi_o = np.array([v[1] for v in vals])
             lnl_o = np.array([v[0] for v in vals])
@@ -1173,7 +1173,7 @@ def main():
         def give_up():
             msg = f"did not finish within {LEG_TIMEOUT:.0f} s (a hung collective?); the measurements above are unaffected"
             emit({k: legs.get(k, {"error": msg}) for k in ("dsplit5", "walker_ensembles")})
-            os._exit(0 if headline_ok else 1)
+            os._exit(EXIT_LEG_HUNG)          # the line is out; a hung run is not a success (nothing is restarted from here)
 
         timer = threading.Timer(LEG_TIMEOUT, give_up)
         timer.daemon = True
@@ -1195,7 +1195,7 @@ def main():
     if failed_leg:                           # ranks may be out of step with each other: no further collective, no destructors
         sys.stdout.flush()
         sys.stderr.flush()
-        os._exit(0 if headline_ok else 1)
+        os._exit(EXIT_LEG_FAILED)            # the line (with the leg's {"error": ...}) is out; a failed leg is not a success
     dist.barrier()
     dist.close()
     legs_ok = all(leg.get("gather_matches_local") is not False for leg in legs.values())
