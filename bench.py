@@ -348,7 +348,7 @@ def boss_measurement(args, batch=16384, steps=20, clocks=None):
     frac = F * batch / (k1 * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if k1 > 0 else None
     return {"evals_per_s": batch * steps / dt, "batch": batch, "steps": steps, "kernel": eng.last_kernel() + "<1,2>",
             "kernels_ms": {"theory": k1, "likelihood": k2 / max(launches, 1)},
-            "fp64_valu_frac": frac, **clock_fields(frac, clocks, "boss_cmass"),
+            "fp64_valu_frac": frac, **clock_fields(F * batch, clocks, "boss_cmass"),
             "flops_per_eval": F, "all_finite": bool(np.all(np.isfinite(lnl))), "fused": fused,
             "traffic_profiled": profiled_traffic("boss_cmass", batch)}
 
@@ -358,14 +358,19 @@ def at_sustained_clock(frac, clock_ghz):
     return frac * PEAK_CLOCK_GHZ / clock_ghz if (frac and clock_ghz) else None
 
 
-def clock_fields(frac, clocks, label):
+def clock_fields(flops_per_launch, clocks, label):
     """`sustained_clock_ghz`, `frac_at_sustained_clock` and `clock_source` of one workload from THIS run's clock pass
-    (bench_pmc.live_clocks: {label: {...}} or None).  Without a pass, or without this label in it, the fields are null - a
-    clock measured on another lease is never quoted."""
+    (bench_pmc.live_clocks: {label: {...}} or None).  The fraction is taken in the cycle domain, on the pass's own dispatches:
+    algorithmic flops of a launch / the shader cycles that launch took (GRBM_GUI_ACTIVE / 8) / the peak's flops per cycle
+    (78.6 TFLOP/s / 2.4 GHz) - the same as `frac` x 2.4 GHz / clock when both come from the same dispatches, which is the point:
+    a kernel time from one run is never paired with a clock from another.  Without a pass, or without this label in it, the
+    fields are null."""
     rec = (clocks or {}).get(label)
-    if not rec:
+    if not rec or not flops_per_launch:
         return {"sustained_clock_ghz": None, "frac_at_sustained_clock": None, "clock_source": None}
-    return {"sustained_clock_ghz": rec["sustained_clock_ghz"], "frac_at_sustained_clock": at_sustained_clock(frac, rec["sustained_clock_ghz"]),
+    per_cycle = PEAK_FP64_VALU_TFLOPS * 1e12 / (PEAK_CLOCK_GHZ * 1e9)
+    return {"sustained_clock_ghz": rec["sustained_clock_ghz"],
+            "frac_at_sustained_clock": flops_per_launch / rec["cycles_per_dispatch"] / per_cycle,
             "clock_source": "this run", "clock_dispatch_ms": rec["dispatch_ms"]}
 
 
@@ -542,7 +547,7 @@ def option_rates(batch=16384, steps=4, clocks=None):
                         coord_shift=bool(model.get("kaiser_coord_shift", True)))
         frac = F * batch / (k1 * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if k1 > 0 else None
         res[label] = {"evals_per_s": batch / dt, "ms_per_batch": dt * 1e3, "kernel": eng.last_kernel(), "fused": fused,
-                      "theory_kernel_ms": k1, "flops_per_eval": F, "fp64_valu_frac": frac, **clock_fields(frac, clocks, label)}
+                      "theory_kernel_ms": k1, "flops_per_eval": F, "fp64_valu_frac": frac, **clock_fields(F * batch, clocks, label)}
         for b in bufs:
             eng.free(b)
 
@@ -844,16 +849,18 @@ def clock_pass(args):
     build_native()
     done = []
 
-    def run(label, fit, batch, with_beta, warm=2, timed=6, **kw):
+    def run(label, fit, batch, with_beta, warm_s=0.15, timed=6, **kw):
         model = fit._merged(kw)
         eng = fit._get_engine(fit._engine_key(model))
         o = eng.make_opts(model, fit.fit_options)
         rows = fit._fit_rows(cases.halton_params(batch, with_beta=with_beta), model)
         bufs = [eng.alloc(rows.size), eng.alloc(batch), eng.alloc(batch), eng.alloc(batch * eng.n_data)]
         eng.upload(bufs[0], rows)
-        for _ in range(warm):
+        warm, t_end = 0, time.perf_counter() + warm_s       # as long a warm-up as the timed legs get; its launches are counted
+        while warm < 2 or time.perf_counter() < t_end:
             eng.eval_device_async(o, bufs[0], batch, bufs[1], bufs[2], bufs[3])
-        eng.sync()
+            eng.sync()
+            warm += 1
         eng.timing(True)
         eng.read_timing(reset=True)
         for _ in range(timed):
@@ -1089,7 +1096,7 @@ def main():
                          "frac": achieved_tf / PEAK_FP64_VALU_TFLOPS if achieved_tf else None,
                          # against the peak at the clock this kernel sustained (peak x clock / 2.4 GHz): the clock is measured by a
                          # child pass of THIS run (bench_pmc.live_clocks) - null when that pass could not be made
-                         **clock_fields(achieved_tf / PEAK_FP64_VALU_TFLOPS if achieved_tf else None, clocks, "config3"),
+                         **clock_fields(F * B, clocks, "config3"),
                          "clock_method": __import__("bench_pmc").CLOCK_METHOD if clocks else None,
                          # HBM bytes per launch of this kernel from PMC counters: measured in this run (live_traffic) when the
                          # profiler is there, else null with the last profiled figure beside it

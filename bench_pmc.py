@@ -152,9 +152,9 @@ def clocks_from_rows(rows, sequence):
         cycles = sum(r["value"] for r in mine)
         if dur_ns <= 0 or cycles <= 0:
             return None
-        out[s["label"]] = {"sustained_clock_ghz": cycles / XCDS / dur_ns, "kernel": short_kernel_name(mine[0]["kernel"]),
-                           "dispatches": len(mine), "dispatch_ms": dur_ns / len(mine) * 1e-6,
-                           "child_event_ms": s.get("event_ms")}
+        out[s["label"]] = {"sustained_clock_ghz": cycles / XCDS / dur_ns, "cycles_per_dispatch": cycles / XCDS / len(mine),
+                           "kernel": short_kernel_name(mine[0]["kernel"]), "dispatches": len(mine),
+                           "dispatch_ms": dur_ns / len(mine) * 1e-6, "child_event_ms": s.get("event_ms")}
     return out
 
 
@@ -185,6 +185,9 @@ def live_clocks(batch, simpson_even, log_dir=None):
     return clocks_from_rows(rows, sequence)
 
 
-CLOCK_METHOD = ("a child run of this program under rocprofv3 --pmc GRBM_GUI_ACTIVE (counters only): GRBM_GUI_ACTIVE / 8 / dispatch "
-                "duration, counter and timestamps of the same dispatches (MI355X_MICROARCH.md: within 3 % of the in-kernel clock for "
-                "dispatches of 10 ms or more, reads high below about 0.3 ms)")
+CLOCK_METHOD = ("a child run of this program under rocprofv3 --pmc GRBM_GUI_ACTIVE (counters only), the same kernel on the same batch: "
+                "sustained_clock_ghz = GRBM_GUI_ACTIVE / 8 / dispatch duration, counter and timestamps of the same dispatches "
+                "(MI355X_MICROARCH.md: within 3 % of the in-kernel clock for dispatches of 10 ms or more, reads high below about "
+                "0.3 ms); frac_at_sustained_clock = algorithmic flops per launch / (GRBM_GUI_ACTIVE / 8 shader cycles of a dispatch) / "
+                "(peak flops per cycle = peak / 2.4 GHz) - cycles and work of the SAME dispatches, so it does not depend on which "
+                "clock this box, or the timed loop beside it, happened to hold")

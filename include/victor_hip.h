@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 17
+#define VK_ABI_VERSION 18
 
 /* error codes */
 #define VK_OK 0
@@ -239,9 +239,17 @@ void vk_knobs_refresh(void);
  *     owner, victor_amd/broker.py: 4 contexts x 8 requests) plus up to 31 processes that evaluate one point per call in one
  *     context, or up to 63 such processes (vk_poll_budget returns 1: the number of full-budget processes per device).  The
  *     processes of one user on one host enforce it among themselves through a ledger in /dev/shm, one file per GPU
- *     (victor_hip_poll_<uid>_<PCI bus id>: a slot {pid, reserved} per process; slots of dead processes are ignored); a process
- *     beyond the bound gets no reservation and hands over through the counters.  Processes that do not share that file
- *     (other users, other /dev/shm namespaces) are the operator's to keep within the bound.
+ *     (victor_hip_poll2_<uid>_<PCI bus id>, 5 KB: a slot per owner, written by that owner only).  An owner is {pid, start time
+ *     of that pid, inode of its pid namespace, library instance} - a recycled pid does not inherit a dead process's
+ *     reservation, two copies of the library in one process keep a slot each; slots of owners that are gone (dead, a zombie,
+ *     the pid now another process) are ignored and reused; a slot written in ANOTHER pid namespace (containers sharing
+ *     /dev/shm) cannot be judged from here and counts as living, for good: the bound errs towards the counters.  The file is
+ *     opened without following symbolic links and must be a regular file of this user, closed to group and others, of the
+ *     expected size and version: otherwise the process does not poll at all.  Without /dev/shm (nothing to create the file
+ *     in) the process budget alone applies.  A process beyond the bound gets no reservation and hands over through the
+ *     counters; a launch asks for a reservation only if it would poll with it, and after a refusal only once the ledger has
+ *     changed.  Processes that do not share that file (other users, other /dev/shm mounts) are the operator's to keep within
+ *     the bound.
  * Failure mode if the rule is broken (or a launch is lost): a waiting workgroup gives up after 5 s of wall clock, the call -
  * or, for enqueued work, the next call / vk_sync on that context - returns VK_E_HIP ("waited ... for partial sums that never
  * arrived") and the context stays unusable: destroy it and create a new one.  No result of such a launch is delivered.
@@ -255,6 +263,29 @@ int32_t vk_poll_rule(int64_t n_points, int32_t parts, int64_t workgroups, int32_
 int32_t vk_poll_grant(int32_t others_reserved, int32_t process_reserved, int32_t ctx_reserved, int32_t want);
 int32_t vk_poll_budget(int32_t* per_process, int32_t* xcd_slots);
 int32_t vk_poll_device_reserved(const vk_ctx* ctx, int32_t* others, int32_t* mine);
+
+/* ---- the ledger's operations on a file of the caller's choosing, for an owner of the caller's making ------------------------
+ * DEVELOPMENT entry points (tests/test_ledger.py drives them without a GPU): like every development switch of the library they
+ * answer only with VICTOR_HIP_DEV=1 in the environment (otherwise: NULL / -1 / 0, nothing is touched).
+ * vk_ledger_open_at: opens (creates) the ledger file at `path` and claims a slot for the owner {pid, start, ns, lib}; pid <= 0:
+ *   the calling process itself (lib != 0 then stands for another copy of the library in it).  *status: 0 opened, 1 unavailable
+ *   (cannot be created), 2 untrusted (a symbolic link, another owner or mode, wrong size / magic / version, a lock nobody
+ *   releases), 3 full.  vk_ledger_close(led, keep_slot): keep_slot != 0 leaves the slot behind as a killed process would.
+ * vk_ledger_others: waiters reserved by the other owners that are living or cannot be judged.  vk_ledger_grant / _release:
+ *   the library's own grant / release protocol with *process_reserved standing for the owner's process-wide count.
+ * vk_ledger_self(what, pid): 0 pid, 1 start time, 2 pid-namespace inode, 3 library instance of the caller; 4 start time of
+ *   process `pid` (0: gone), 5: 1 if process `pid` is there (not gone, not a zombie).
+ * vk_ledger_layout: bytes of the file's header and of a slot {int64 pid, uint64 start, uint64 ns, uint64 lib, int32 reserved,
+ *   int32 pad}, number of slots, format version (header: uint32 magic "VKPL", uint32 version, uint32 generation, uint32 pad). */
+void vk_ledger_layout(int32_t* header_bytes, int32_t* slot_bytes, int32_t* slots, int32_t* version);
+uint64_t vk_ledger_self(int32_t what, int64_t pid);
+void* vk_ledger_open_at(const char* path, int64_t pid, uint64_t start, uint64_t ns, uint64_t lib, int32_t* status);
+int32_t vk_ledger_slot(const void* led);
+int32_t vk_ledger_others(const void* led);
+uint32_t vk_ledger_generation(const void* led);
+int32_t vk_ledger_grant(void* led, int32_t* process_reserved, int32_t ctx_reserved, int32_t want);
+void vk_ledger_release(void* led, int32_t* process_reserved, int32_t n);
+void vk_ledger_close(void* led, int32_t keep_slot);
 
 /* Copies every table to `device`.  On failure returns NULL and writes a message to err. */
 vk_ctx* vk_create(const vk_tables* tables, int device, char* err, size_t errlen);
@@ -447,6 +478,10 @@ int vk_comm_allgather_group_async(vk_ctx* const* ctxs, int32_t n, const double* 
  * library, /opt/rocm's otherwise); VICTOR_HIP_RCCL_LIB names another one in development runs only (VICTOR_HIP_DEV=1).  Returns VK_E_RCCL (buffer still filled) if no RCCL
  * could be loaded. */
 int vk_comm_info(char* buf, size_t len);
+/* What the LIVE communicator of `ctx` says about itself: ncclCommCount, ncclCommUserRank, ncclCommCuDevice (each -1 when the
+ * loaded library does not export the call or it fails).  VK_E_RCCL without a communicator.  A multi-GPU record carries these per
+ * rank (bench.py: config.rccl.ranks) next to the PCI bus ids the ranks compared before building it. */
+int vk_comm_rank_info(const vk_ctx* ctx, int32_t* count, int32_t* user_rank, int32_t* device);
 
 #ifdef __cplusplus
 }

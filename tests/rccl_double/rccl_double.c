@@ -1,6 +1,6 @@
 /*
  * rccl_double.c - TEST INFRASTRUCTURE, never part of the product: a stand-in for the RCCL entry points libvictor_hip.so
- * looks up with dlsym (victor_amd/csrc/victor_hip.hip: open_rccl), selected through VICTOR_HIP_RCCL_LIB.
+ * looks up with dlsym (victor_amd/csrc/vk_rccl.cpp: open_rccl), selected through VICTOR_HIP_RCCL_LIB.
  *
  * Why: a one-GPU box cannot build an RCCL communicator of two ranks (RCCL wants one device per rank), so the N > 1 branch of
  * vk_comm_init / vk_comm_allgather_async - the 128-byte id crossing processes by value, the rank-major receive layout, the
@@ -191,5 +191,23 @@ int ncclCommInitAll(comm_t** comms, int ndev, const int* devlist) {
   (void)comms; (void)ndev; (void)devlist;
   return ncclInvalidUsage;
 }
+/* what a communicator says about itself (vk_comm_rank_info: a multi-GPU record carries these per rank) */
+int ncclCommCount(const comm_t* c, int* count) {
+  if (!c || !count) return ncclInvalidArgument;
+  *count = c->nranks;
+  return ncclSuccess;
+}
+
+int ncclCommUserRank(const comm_t* c, int* rank) {
+  if (!c || !rank) return ncclInvalidArgument;
+  *rank = c->rank;
+  return ncclSuccess;
+}
+
+int ncclCommCuDevice(const comm_t* c, int* device) {
+  if (!c || !device) return ncclInvalidArgument;
+  return hipGetDevice(device) == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;      /* (ranks of the double share a device) */
+}
+
 int ncclGroupStart(void) { return ncclSuccess; }
 int ncclGroupEnd(void) { return ncclSuccess; }

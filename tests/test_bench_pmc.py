@@ -65,11 +65,17 @@ def test_sustained_clock_from_a_canned_counter_file(tmp_path):
     assert clocks["config3"]["dispatches"] == 6 and clocks["config3"]["child_event_ms"] == 22.7
     # what the line does with it: the fraction against the peak at that clock
     import bench
-    f = bench.clock_fields(0.568, clocks, "config3")
+    flops = 15_424_000 * 65536
+    f = bench.clock_fields(flops, clocks, "config3")
     assert f["clock_source"] == "this run" and f["sustained_clock_ghz"] == pytest.approx(1.98)
-    assert f["frac_at_sustained_clock"] == pytest.approx(0.568 * 2.4 / 1.98)
+    assert clocks["config3"]["cycles_per_dispatch"] == pytest.approx(1.98 * 22_640_000)
+    # cycle domain: flops of a launch / its shader cycles / the peak's flops per cycle ...
+    assert f["frac_at_sustained_clock"] == pytest.approx(flops / (1.98 * 22_640_000) / (78.6e12 / 2.4e9))
+    # ... which is `frac` x 2.4 GHz / clock when the time is that of the same dispatches (22.64 ms: 0.568)
+    frac = flops / 22.64e-3 / 78.6e12
+    assert frac == pytest.approx(0.568, abs=1e-3) and f["frac_at_sustained_clock"] == pytest.approx(bench.at_sustained_clock(frac, 1.98))
     # no pass, or a workload the pass did not cover: null, never another run's figure
-    for none in (bench.clock_fields(0.568, None, "config3"), bench.clock_fields(0.568, clocks, "dispersion")):
+    for none in (bench.clock_fields(flops, None, "config3"), bench.clock_fields(flops, clocks, "dispersion")):
         assert none == {"sustained_clock_ghz": None, "frac_at_sustained_clock": None, "clock_source": None}
 
 

@@ -151,7 +151,7 @@ sys.stdin.readline() if hold else None
 
 
 def test_polling_reservations_are_kept_device_wide_across_processes():
-    """The ledger of reserved waiters (victor_hip.hip: PollLedger; one file per GPU in /dev/shm): a process reserves 5 per
+    """The ledger of reserved waiters (victor_amd/csrc/vk_ledger.cpp; one file per GPU in /dev/shm): a process reserves 5 per
     context for five-point BOSS launches up to its own budget of 32 (six contexts, the seventh hands over through the
     counters); a second process sees those 30 and gets its own 30; a third finds 60 taken and is granted nothing (63 is the
     bound) - all of them return the same bits; when the first two have gone their slots no longer count."""

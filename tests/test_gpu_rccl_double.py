@@ -27,13 +27,14 @@ def build_double(out_dir):
 
 
 def test_double_provides_every_entry_point_the_library_looks_up(tmp_path):
-    """(CPU) the stand-in exports exactly the nccl* names victor_hip.hip passes to dlsym - a new call in the product without a
-    counterpart here would make these tests fall back to the host gather silently."""
+    """(CPU) the stand-in exports exactly the nccl* names the library's RCCL layer (vk_rccl.cpp) passes to dlsym - a new call in
+    the product without a counterpart here would make these tests fall back to the host gather silently."""
     lib = build_double(tmp_path)
     exported = set(re.findall(r" T (nccl\w+)", subprocess.run(["nm", "-D", lib], capture_output=True, text=True).stdout))
-    with open(os.path.join(ROOT, "victor_amd", "csrc", "victor_hip.hip")) as fh:
-        wanted = set(re.findall(r'dlsym\([^,]+,\s*"(nccl\w+)"\)', fh.read()))
-    assert wanted and wanted <= exported, (wanted - exported)
+    with open(os.path.join(ROOT, "victor_amd", "csrc", "vk_rccl.cpp")) as fh:
+        src = fh.read()
+    wanted = set(re.findall(r'dlsym\([^,]+,\s*"(nccl\w+)"\)', src)) | set(re.findall(r'\{"(ncclComm\w+)",', src))
+    assert len(wanted) >= 12 and wanted <= exported, (wanted - exported)
 
 
 def _env(double, tmp_path):

@@ -481,7 +481,7 @@ def test_dispersion_filter_options(tmp_path):
 
 def _gfx950_code_objects(tmp_dir):
     """Extract the gfx950 code objects from libvictor_hip.so - one clang offload bundle per translation unit in .hip_fatbin
-    (victor_hip.hip, vk_cells_streaming.hip) - into files."""
+    (victor_amd/build.py: UNITS - victor_hip.hip and one unit per family of theory-kernel instantiations) - into files."""
     import re
     import struct
     import subprocess
@@ -542,8 +542,9 @@ def test_no_kernel_of_the_library_spills(lib, tmp_path):
     cells kernel lost its grid-stride loop) - and the large-batch theory kernels keep the registers of five workgroups per CU."""
     import re
     import subprocess
+    from victor_amd.build import UNITS
     paths = _gfx950_code_objects(tmp_path)
-    assert len(paths) == 2
+    assert len(paths) == len(UNITS) == 7                    # one code object per translation unit with device code
     notes = "".join(subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
                     for co in paths)
     kernels = re.findall(r"\.name:\s+(\S+)[\s\S]*?\.private_segment_fixed_size:\s+(\d+)[\s\S]*?\.vgpr_count:\s+(\d+)", notes)

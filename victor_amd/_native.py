@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-VK_ABI_VERSION = 17
+VK_ABI_VERSION = 18
 VK_NPAR = 12
 (P_FSIGMA8, P_SIGMAV, P_APERP, P_APAR, P_EPSILON, P_BETA, P_ASTAR, P_M, P_Q, P_BIAS, P_AV, P_SPARE) = range(12)
 MATTER = {"template": 0, "linear_bias": 1, "velocity_template": 2}
@@ -140,6 +140,17 @@ SYMBOLS = {
     "vk_comm_init_all": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32]),
     "vk_comm_allgather_group_async": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int64]),
     "vk_comm_info": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "vk_comm_rank_info": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    # development entry points of the polling ledger (answer only with VICTOR_HIP_DEV=1; tests/test_ledger.py)
+    "vk_ledger_layout": (None, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "vk_ledger_self": (C.c_uint64, [C.c_int32, C.c_int64]),
+    "vk_ledger_open_at": (_vp, [C.c_char_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_int32)]),
+    "vk_ledger_slot": (C.c_int32, [_vp]),
+    "vk_ledger_others": (C.c_int32, [_vp]),
+    "vk_ledger_generation": (C.c_uint32, [_vp]),
+    "vk_ledger_grant": (C.c_int32, [_vp, C.POINTER(C.c_int32), C.c_int32, C.c_int32]),
+    "vk_ledger_release": (None, [_vp, C.POINTER(C.c_int32), C.c_int32]),
+    "vk_ledger_close": (None, [_vp, C.c_int32]),
 }
 
 _lib = None

@@ -1,4 +1,8 @@
-// victor_hip.hip - host side of libvictor_hip.so: context, table upload, kernel selection, C ABI (include/victor_hip.h).
+// victor_hip.hip - the launch side of libvictor_hip.so: context, table upload, kernel selection, the evaluating entry points of
+// the C ABI (include/victor_hip.h).  The host-only parts of the library are translation units of their own, compiled by the host
+// compiler (vk_host.h is what they share with this file): vk_ledger.cpp (the polling hand-off's launch rule and the device-wide
+// ledger of reserved waiters), vk_walk.cpp (vk_walk_*: the walkers' step loop), vk_serve.cpp (vk_serve_mailboxes), vk_rccl.cpp
+// (vk_comm_*: RCCL through dlopen).
 //
 // Device code lives in the headers next to this file:
 //   vk_common.h          argument structs, LDS table evaluation, per-point scalars (AP factors, growth amplitudes)
@@ -19,17 +23,7 @@
 
 #include <hip/hip_runtime.h>
 #include <chrono>
-#include <time.h>
 #include <cstddef>
-
-#include <dlfcn.h>
-#include <errno.h>
-#include <fcntl.h>
-#include <signal.h>
-#include <sys/mman.h>
-#include <sys/stat.h>
-#include <sys/types.h>
-#include <unistd.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -41,11 +35,12 @@
 #include <algorithm>
 #include <atomic>
 #include <map>
-#include <mutex>
 #include <string>
 #include <vector>
 
 #include "victor_hip.h"
+#include "vk_host.h"
+#include "vk_ledger.h"
 #include "vk_kernel_cells.h"
 #include "vk_kernel_fast.h"
 #include "vk_kernel_generic.h"
@@ -54,19 +49,17 @@
 #endif
 #include "vk_kernel_like.h"
 
-// The cells kernel's instantiations for the streaming model live in vk_cells_streaming.hip (another machine scheduler for that
-// translation unit, see build.py); VK_SINGLE_TU builds everything here.
-#ifndef VK_SINGLE_TU
+// The theory kernels' instantiations are generated in translation units of their own (vk_instances.h names what lives where);
+// here they are declared only.
+#include "vk_instances.h"
 namespace vk {
-#define VK_CELLS_STREAMING(NLR, NL) \
-  extern template __global__ void vk_theory_cells_kernel<NLR, NL, 0, kModeStreaming, 0>(TheoryArgs); \
-  extern template __global__ void vk_theory_cells_kernel<NLR, NL, 1, kModeStreaming, 0>(TheoryArgs);
-VK_CELLS_STREAMING(1, 1) VK_CELLS_STREAMING(1, 2) VK_CELLS_STREAMING(1, 3)
-VK_CELLS_STREAMING(2, 1) VK_CELLS_STREAMING(2, 2) VK_CELLS_STREAMING(2, 3)
-VK_CELLS_STREAMING(3, 1) VK_CELLS_STREAMING(3, 2) VK_CELLS_STREAMING(3, 3)
-#undef VK_CELLS_STREAMING
+VK_UNIT_CELLS_STREAMING(extern template)
+VK_UNIT_CELLS_DISPERSION(extern template)
+VK_UNIT_CELLS_KAISER(extern template)
+VK_UNIT_FAST_STREAMING(extern template)
+VK_UNIT_FAST_DISPERSION(extern template)
+VK_UNIT_GENERIC(extern template)
 }  // namespace vk
-#endif
 
 using namespace vk;
 
@@ -132,240 +125,22 @@ __global__ void vk_init_stage_kernel(const double* mu, const double* w_ell, int 
 // ==================================================================================================
 // host side
 // ==================================================================================================
-// Development-only tuning / A-B knobs from the environment (VICTOR_HIP_*).  They are honoured ONLY when VICTOR_HIP_DEV=1 is set
-// as well (tests/ and tools/ set it, victor_amd._native.set_knob does): a variable inherited from somebody's shell must never
-// change the kernel mapping or switch the fused path off in a production run.  Read once per context - not once per launch -
-// and again after vk_knobs_refresh().
-struct Knobs {
-  int split_s = 0, split_t = 0;        // VICTOR_HIP_SPLIT "spi,team"
-  bool force_generic = false;          // VICTOR_HIP_FORCE_GENERIC
-  long long point_cap = 0;             // VICTOR_HIP_POINT_CAP   (workgroups per CU, generic theory kernel; 0 = default)
-  long long lanes_cap = 0;             // VICTOR_HIP_LANES_CAP   (0 = uncapped)
-  int mapping = 0;                     // VICTOR_HIP_MAPPING: 0 auto, 1 point, 2 cells, 3 lanes, -1 unknown name
-  bool like_untiled = false;           // VICTOR_HIP_LIKE_UNTILED
-  bool no_graph = false;               // VICTOR_HIP_NO_GRAPH
-  bool lanes_by_chunk = false;         // VICTOR_HIP_LANES_BY_CHUNK: a workgroup takes all s bins of a 64-point chunk (A/B)
-  bool no_fuse = false;                // VICTOR_HIP_NO_FUSE: keep chi2 in its own launch (A/B of the fused path)
-  bool no_inline_row = false;          // VICTOR_HIP_NO_INLINE_ROW: single-point host calls read their row from the pinned buffer (A/B)
-  long long fuse_max = -1;             // VICTOR_HIP_FUSE_MAX: largest batch whose chi2 is taken inside the theory kernel (-1 = default)
-  int split_q = 0;                     // third field of VICTOR_HIP_SPLIT "spi,team,parts": workgroups per (mu, v) plane
-  int cells_parts = 0;                 // VICTOR_HIP_CELLS_PARTS: workgroups per point in the cells kernel (0 = choose)
-  int like_wide = -1;                  // VICTOR_HIP_LIKE_WIDE: 1 / 0 force the workgroup-per-point chi2 kernel on / off
-  long long cells_min = -1;            // VICTOR_HIP_CELLS_MIN: smallest batch that takes the cells kernel (-1 = default)
-  bool no_zero_copy = false;           // VICTOR_HIP_NO_ZERO_COPY: small host-buffer batches through the copy / graph path
-  long long zero_copy_max = -1;        // VICTOR_HIP_ZERO_COPY_MAX: largest host-buffer batch on the in-place path (-1 = default)
-  long long spin_max = -1;             // VICTOR_HIP_SPIN_MAX: largest in-place batch whose results are polled for (-1 = default, 0 = never)
-  bool no_poll = false;                // VICTOR_HIP_NO_POLL: split single-point launches hand over through the completion counters (A/B)
-};
-
-struct vk_ctx {
-  int device = -1;
-  Knobs knobs;
-  unsigned knob_gen = 0;
-  hipStream_t stream = nullptr;
-  std::string err;
-  int n_cu = 256;
-  // host copy of sizes
-  int n_s = 0, n_mu = 0, n_x = 0, n_ell = 0, n_ell_r = 0, n_beta_r = 0, n_beta_d = 0, n_beta_c = 0, N = 0;
-  double iaH = 0, template_sigma8 = 0;
-  double* d_tables = nullptr;  // one allocation holding every table
-  // device pointers into d_tables
-  const double *d_x1 = nullptr, *d_w1 = nullptr;  // single velocity node for the Kaiser-type models
-  const double* d_vr_emp = nullptr;               // beta-dependent V2, Ge1, Ge2 (degree 6 in beta), see vk_tables.vr_emp
-  const double* d_xws = nullptr;                  // [n_x + 1][2]: {kExpScale x_k, w_k} (point-major fast kernel)
-  const double* d_sva = nullptr;                  // anisotropic sigma_v block for the fast kernels (TheoryArgs::sva)
-  int sva_doubles = 0;
-  const double* d_xgw = nullptr;                  // velocity nodes grouped by quadrature weight (TheoryArgs::xgw)
-  int n_xg = 0;                                   // ... how many of them (nodes of weight zero are left out)
-  double xw_max = 0.0;                            // max |kExpScale x_k|
-  const double *d_s = nullptr, *d_mu = nullptr, *d_w = nullptr, *d_x = nullptr, *d_wx = nullptr, *d_beta_r = nullptr,
-               *d_beta_d = nullptr, *d_data = nullptr, *d_beta_c = nullptr, *d_prec = nullptr, *d_tri = nullptr, *d_logdet = nullptr,
-               *d_eig = nullptr;
-  PPView xi{}, vr{}, sv{};
-  bool fast_ok = false;      // tables qualify for vk_theory_fast_kernel
-  int matter_lb = 0, vr_beta_dep = 0, matter_vt = 0, sv_n_mu = 0;
-  double vt_amp = 0, sv_mu_inv_h = 0;
-  const double *d_sv_mu = nullptr, *d_sv2d = nullptr;
-  int uni_n = 0;             // unified refined grid (fast kernels need it)
-  double uni_u0 = 0, uni_inv_h = 0;
-  const double *d_uni_sv_v = nullptr, *d_uni_xi = nullptr, *d_uni_xic = nullptr, *d_uni_vb = nullptr, *d_uni_v2 = nullptr, *d_uni_da = nullptr, *d_uni_ge = nullptr, *d_uni_dab = nullptr, *d_uni_empb = nullptr;
-  int uni_lut_n = 0;         // > 0: union-grid form of the unified tables
-  double uni_lut_inv_g = 0;
-  const unsigned short* d_uni_lut = nullptr;
-  const double* d_uni_knots = nullptr;
-  // batch-independent staging tables and the bookkeeping of the fused / split launches (one device allocation)
-  double* d_aux = nullptr;
-  const double* d_exp_tab = nullptr;   // [ExpCfg<0>::kDoubles]
-  const double* d_exp_tab_rep = nullptr;   // [ExpCfg<1>::kDoubles]
-  const double* d_stage_mu = nullptr;  // [n_mu][kMuRec]
-  int grids_in_lds = 0;                    // LikeArgs::grids_in_lds
-  const double* inline_params = nullptr;   // set around a single-point host-buffer call: the row goes into the kernel arguments
-  bool theory_wanted = false;              // set around a host-buffer call that returns the theory vectors (TheoryArgs::want_theory)
-  bool split_as_single = false;            // set around the launches of vk_serve_mailboxes: every point is evaluated with the work
-                                           // split of a single-point call, whatever else shares its launch (kServeMaxBatch)
-  unsigned* d_counters = nullptr;      // [kCounterCap], zero between launches
-  double* d_partial = nullptr;         // [partial_doubles]
-  size_t partial_doubles = 0;
-  double* d_poll = nullptr;            // [poll_doubles] polling area of the launches that hand over without counters (kPollEmpty
-  size_t poll_doubles = 0;             // between launches; vk_common.h), or NULL
-  int* h_poll_failed = nullptr;        // pinned, device-mapped word a polling workgroup sets when it gives up; d_poll_failed: the
-  int* d_poll_failed = nullptr;        // same word through the device's eyes
-  int poll_reserved = 0;               // waiters this context may have resident at once (its share of kPollBudget; vk_poll_grant)
-  std::string bus;                     // PCI bus id of the device (the device-wide ledger of reserved waiters is kept per GPU)
-  double wsum[3] = {0, 0, 0};
-  int depth_mult = 1;                // joint fits: launches of this many contexts share the GPU (vk_joint_eval_device_async)
-  hipEvent_t ev_joint = nullptr;
-  std::map<int, double*> images;     // LDS images per (kernel kind, real-space multipoles, dispersion tables), built on first use
-  std::map<const void*, int> lds_opt_in;   // dynamic LDS above 64 KiB a kernel has been opted in for (launch_on_stream)
-  const char* last_kernel = "none";  // theory kernel variant of the most recent launch
-  bool last_fused = false;           // ... and whether it took the chi-square as well
-  bool last_polled = false;          // ... and whether its split planes were handed over by polling (vk_poll_rule)
-  // scratch for the host-buffer entry points
-  double* d_scratch = nullptr;
-  size_t scratch_bytes = 0;
-  // timing
-  bool timing = false;
-  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-  double theory_ms = 0, like_ms = 0;
-  long long launches = 0;
-  bool pending = false;
-  // RCCL (loaded lazily)
-  void* rccl_lib = nullptr;
-  void* comm = nullptr;
-  int comm_nranks = 0;
-  // vk_comm_allgather_host_begin / _finish: pinned host staging [1 + nranks][cap], device buffers likewise, the event behind the download
-  double* h_comm = nullptr;
-  double* d_comm = nullptr;
-  int64_t comm_cap = 0, comm_begun = 0;
-  hipEvent_t ev_comm = nullptr;
-  // small host-buffer batches are launch-bound: (H2D, theory kernel, likelihood kernel, D2H) is captured once per
-  // (n, options) into a hipGraph over pinned staging buffers and replayed with a single launch
-  double* h_pin = nullptr;                      // pinned: params[kGraphMaxN][VK_NPAR] | lnl, chi2 [2 kGraphMaxN]
-  std::map<std::string, hipGraphExec_t> graphs;  // key: n + option bytes + requested outputs
-  std::map<std::string, int> graph_seen;         // a key is captured on its second use (the first one runs eagerly)
-  std::map<std::string, const char*> graph_kernel;
-  bool graphs_off = false;
-  double* h_zc = nullptr;                       // pinned, device-mapped: params[kZeroCopyCap][VK_NPAR] | lnl, chi2 [2 kZeroCopyCap]
-  double* d_zc = nullptr;                       // the same memory through the device's eyes
-  bool zero_copy_off = false;
-  bool spin_off = false;               // results did not become visible to polling on this system (eval_batch_zero_copy)
-  int64_t begun_n = 0;                 // vk_eval_batch_begin: rows of the batch awaiting vk_eval_batch_finish (< 0: evaluated already)
-  std::vector<double> begun_sync;      // ... their results in that case
-  bool zc_spin = false;                // the in-place launch in flight polls for its results (zc_begin / zc_finish)
-  std::chrono::steady_clock::time_point zc_t0;
-  int spin_timeouts = 0;
-};
-
-constexpr int64_t kGraphMaxN = 4096;
-constexpr int64_t kZeroCopyCap = 4096;     // capacity of the in-place buffers (points)
-constexpr long long kCounterCap = 16384;   // points per launch that may share work between workgroups (completion counters)
-constexpr long long kPartialPoints = 2048;  // batches up to this many points may split a point's work over workgroups (partial sums)
-constexpr int kServeMaxBatch = 32;          // requests one launch of the mailbox server carries (vk_ctx::split_as_single)
-// Points per launch whose split work is handed over by polling (TheoryArgs::poll): one waiting workgroup per point.  Few, so
-// that the waiting workgroups of every launch in flight on the GPU - other contexts, other processes - can never fill an
-// XCD (64 workgroup slots at least) and keep the workgroups they wait for off it.
-constexpr long long kPollPoints = 8;
-// The bound behind "never fill an XCD" (include/victor_hip.h: vk_poll_rule).  A polling launch is taken only
-// when at least two of its workgroups fit on a CU (LDS and launch bounds), so an XCD of 32 CUs has kPollXcdSlots = 64 workgroup
-// slots at least; a deadlock needs one XCD's slots ALL held by waiting workgroups (one per point of a polling launch in flight)
-// whose producers cannot be placed, so fewer than 64 waiters resident on the whole device exclude it.  What the library
-// enforces is its own process's share: every context reserves the waiters its polling launches may have resident (its launches
-// are stream-ordered: never more than one in flight) out of kPollBudget = 32 per process - an owner process's default four
-// contexts x eight requests -; a launch whose context holds no reservation for its points hands over through the completion
-// counters instead (the same sums in the same order: not a bit changes).  Across processes the sum of the reservations must
-// stay below 64 - ONE process with the full budget (the GPU owner of section 6) plus up to 31 single-point contexts of other
-// processes, or up to 63 processes that each evaluate one point per call in one context -, kept in a ledger in /dev/shm that
-// the processes of one user on one host share (PollLedger below); a process beyond the bound simply gets no reservation.
-constexpr int kPollXcdSlots = 64;
-constexpr int kPollBudget = 32;
+using vkh::check_opts;
+using vkh::cpu_relax;
+using vkh::fail;
+using vkh::host_scratch;
+using vkh::HostScratch;
+using vkh::sync_knobs;
+using vkh::zc_begin;
+using vkh::zc_finish;
+using vkl::kPollPoints;
 
 namespace {
 
 thread_local std::string g_create_err;
-std::atomic<int> g_poll_reserved{0};    // waiters reserved by the contexts of this process (<= kPollBudget)
+std::atomic<int> g_poll_reserved{0};    // waiters reserved by the contexts of this copy of the library (<= kPollBudget)
+constexpr int kPollRetryLaunches = 256; // a context whose reservation was refused asks again after this many launches at the latest
 
-// ---- the device-wide ledger of reserved waiters --------------------------------------------------------------------------
-// The per-process budget bounds ONE process; the bound that excludes a deadlock is device-wide (fewer than kPollXcdSlots
-// waiters resident on a GPU).  Processes of one user on one host therefore keep their reservations in a small file in /dev/shm,
-// one per GPU (named after its PCI bus id): a slot per process {pid, reserved}, written by its owner only; a reservation is
-// granted when the slots of the LIVING processes, the new one included, stay below the bound (optimistic: add, re-read the
-// sum, take it back if two processes raced past the bound).  Slots of dead processes (kill(pid, 0): ESRCH) are ignored and
-// reused.  No file, no mapping (a read-only /dev/shm, another namespace): the process budget alone applies, as stated in
-// include/victor_hip.h.
-constexpr int kLedgerSlots = 126;
-struct PollLedger {
-  uint32_t magic, version;
-  struct Slot { std::atomic<int32_t> pid, reserved; } slot[kLedgerSlots];
-};
-static_assert(sizeof(PollLedger) == 8 + 8 * kLedgerSlots, "ledger layout");
-constexpr uint32_t kLedgerMagic = 0x564b504cu;   // "VKPL"
-
-struct LedgerHandle {
-  PollLedger* map = nullptr;
-  int mine = -1;
-};
-std::map<std::string, LedgerHandle> g_ledgers;      // per bus id (the contexts of one process are created from one thread at a time)
-
-bool pid_gone(int32_t pid) { return pid > 0 && kill((pid_t)pid, 0) != 0 && errno == ESRCH; }
-
-std::mutex g_ledger_mu;
-
-LedgerHandle* ledger_for(const std::string& bus) {
-  std::lock_guard<std::mutex> hold(g_ledger_mu);      // (the serving threads of an owner process launch concurrently)
-  auto it = g_ledgers.find(bus);
-  if (it != g_ledgers.end()) return it->second.map ? &it->second : nullptr;
-  LedgerHandle h;
-  std::string name = "/dev/shm/victor_hip_poll_" + std::to_string((unsigned)getuid()) + "_";
-  for (char c : bus) name += (isalnum((unsigned char)c) ? c : '_');
-  const int fd = open(name.c_str(), O_RDWR | O_CREAT | O_CLOEXEC, 0600);
-  if (fd >= 0) {
-    struct stat st;
-    if (fstat(fd, &st) == 0 && (st.st_size >= (off_t)sizeof(PollLedger) || ftruncate(fd, sizeof(PollLedger)) == 0)) {
-      void* m = mmap(nullptr, sizeof(PollLedger), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-      if (m != MAP_FAILED) {
-        h.map = static_cast<PollLedger*>(m);
-        if (h.map->magic == 0) {              // a fresh (zero-filled) file: first come stamps it
-          h.map->version = 1;
-          h.map->magic = kLedgerMagic;
-        }
-        if (h.map->magic != kLedgerMagic || h.map->version != 1) {
-          munmap(m, sizeof(PollLedger));
-          h.map = nullptr;
-        }
-      }
-    }
-    close(fd);
-  }
-  if (h.map) {
-    const int32_t me = (int32_t)getpid();
-    for (int pass = 0; pass < 2 && h.mine < 0; ++pass)
-      for (int i = 0; i < kLedgerSlots && h.mine < 0; ++i) {
-        int32_t owner = h.map->slot[i].pid.load(std::memory_order_acquire);
-        const bool free_slot = pass == 0 ? owner == 0 : pid_gone(owner);
-        if (owner == me || (free_slot && h.map->slot[i].pid.compare_exchange_strong(owner, me, std::memory_order_acq_rel))) {
-          h.map->slot[i].reserved.store(0, std::memory_order_release);
-          h.mine = i;
-        }
-      }
-    if (h.mine < 0) {                          // more than 126 living processes of this user on this GPU: no polling for this one
-      munmap(h.map, sizeof(PollLedger));
-      h.map = nullptr;
-    }
-  }
-  auto& kept = g_ledgers[bus] = h;
-  return kept.map ? &kept : nullptr;
-}
-
-// waiters the OTHER living processes hold on this GPU
-int ledger_others(const LedgerHandle* h) {
-  int total = 0;
-  for (int i = 0; i < kLedgerSlots; ++i) {
-    if (i == h->mine) continue;
-    const int32_t owner = h->map->slot[i].pid.load(std::memory_order_acquire);
-    if (owner > 0 && !pid_gone(owner)) total += std::max(0, (int)h->map->slot[i].reserved.load(std::memory_order_acquire));
-  }
-  return total;
-}
 #ifdef VK_PHASES
 long long* g_stamps = nullptr;
 #endif
@@ -409,26 +184,6 @@ void load_knobs(vk_ctx* ctx) {
   ctx->knobs = k;
 }
 
-inline void sync_knobs(vk_ctx* ctx) {
-  if (ctx->knob_gen != g_knob_gen.load(std::memory_order_relaxed)) load_knobs(ctx);
-}
-
-int fail(vk_ctx* ctx, int code, const char* fmt, ...) {
-  char buf[512];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof buf, fmt, ap);
-  va_end(ap);
-  if (ctx) ctx->err = buf;
-  return code;
-}
-
-#define VK_HIP(ctx, call)                                                                         \
-  do {                                                                                            \
-    hipError_t e_ = (call);                                                                       \
-    if (e_ != hipSuccess) return fail((ctx), VK_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
-  } while (0)
-
 struct Uploader {
   std::vector<double> host;
   size_t add(const double* p, size_t n) {
@@ -455,16 +210,6 @@ int ensure_scratch(vk_ctx* ctx, size_t bytes) {
   ctx->scratch_bytes = 0;
   VK_HIP(ctx, hipMalloc((void**)&ctx->d_scratch, bytes));
   ctx->scratch_bytes = bytes;
-  return VK_OK;
-}
-
-int check_opts(vk_ctx* ctx, const vk_eval_opts* o) {
-  if (!o) return fail(ctx, VK_E_ARG, "opts is NULL");
-  if (o->rsd_model < VK_RSD_STREAMING || o->rsd_model > VK_RSD_EUCLID)
-    return fail(ctx, VK_E_ARG, "unknown rsd_model %d", o->rsd_model);
-  if (o->niter < 0 || o->niter > 64) return fail(ctx, VK_E_ARG, "niter must be in 0..64");
-  if (o->like_form < VK_LIKE_GAUSSIAN || o->like_form > VK_LIKE_PERCIVAL)
-    return fail(ctx, VK_E_ARG, "unknown likelihood form %d", o->like_form);
   return VK_OK;
 }
 
@@ -511,22 +256,14 @@ void choose_split(const vk_ctx* ctx, long long n, int n_s, int* spi, int* team, 
   *parts = (int)(q < 1 ? 1 : (q > 2 ? 2 : q));
 }
 
-// VK_LITE: development build that compiles only the instantiations the two bench workloads (BOSS: isotropic xi^r, l = 0,2;
-// config 3: three real-space multipoles, l = 0,2,4; lattice grid, streaming) reach - a tenth of the compile time.  Never shipped.
-#ifdef VK_LITE
-#define VK_LITE_KEEP(NLR, NL, GRID, MODE) (((NLR) == 1 && (NL) == 2) || ((NLR) == 3 && (NL) == 3)) && (GRID) == 0 && (MODE) == 0
-#else
-#define VK_LITE_KEEP(NLR, NL, GRID, MODE) true
-#endif
-
 template <int RSD, int NLR>
 int launch_generic_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: if constexpr (VK_LITE_KEEP(NLR, 1, 0, RSD)) return launch_on_stream(ctx, vk_theory_kernel<RSD, NLR, 1>, grid, lds, a); break;
-    case 2: if constexpr (VK_LITE_KEEP(NLR, 2, 0, RSD)) return launch_on_stream(ctx, vk_theory_kernel<RSD, NLR, 2>, grid, lds, a); break;
-    case 3: if constexpr (VK_LITE_KEEP(NLR, 3, 0, RSD)) return launch_on_stream(ctx, vk_theory_kernel<RSD, NLR, 3>, grid, lds, a); break;
+    case 1: return launch_on_stream(ctx, vk_theory_kernel<RSD, NLR, 1>, grid, lds, a); break;
+    case 2: return launch_on_stream(ctx, vk_theory_kernel<RSD, NLR, 2>, grid, lds, a); break;
+    case 3: return launch_on_stream(ctx, vk_theory_kernel<RSD, NLR, 3>, grid, lds, a); break;
   }
-  return fail(ctx, VK_E_ARG, "n_ell must be 1..3 (or a VK_LITE development build)");
+  return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
 }
 
 template <int RSD>
@@ -542,44 +279,44 @@ int launch_generic(vk_ctx* ctx, const TheoryArgs& a, int nlr, int grid, size_t l
 template <int NLR, int GRID, int MODE>
 int launch_fast_ngf(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: if constexpr (VK_LITE_KEEP(NLR, 1, GRID, MODE)) return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 1, GRID, MODE>, grid, lds, a); break;
-    case 2: if constexpr (VK_LITE_KEEP(NLR, 2, GRID, MODE)) return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 2, GRID, MODE>, grid, lds, a); break;
-    case 3: if constexpr (VK_LITE_KEEP(NLR, 3, GRID, MODE)) return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 3, GRID, MODE>, grid, lds, a); break;
+    case 1: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 1, GRID, MODE>, grid, lds, a); break;
+    case 2: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 2, GRID, MODE>, grid, lds, a); break;
+    case 3: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 3, GRID, MODE>, grid, lds, a); break;
   }
-  return fail(ctx, VK_E_ARG, "n_ell must be 1..3 (or a VK_LITE development build)");
+  return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
 }
 
 // anisotropic sigma_v(r, mu) template on the fast kernels (SVA instantiations): streaming model, lattice form
 template <int NLR>
 int launch_fast_sva(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: if constexpr (VK_LITE_KEEP(NLR, 1, 1, 0)) return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 1, 0, kModeStreaming, 1>, grid, lds, a); break;
-    case 2: if constexpr (VK_LITE_KEEP(NLR, 2, 1, 0)) return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 2, 0, kModeStreaming, 1>, grid, lds, a); break;
-    case 3: if constexpr (VK_LITE_KEEP(NLR, 3, 1, 0)) return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 3, 0, kModeStreaming, 1>, grid, lds, a); break;
+    case 1: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 1, 0, kModeStreaming, 1>, grid, lds, a); break;
+    case 2: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 2, 0, kModeStreaming, 1>, grid, lds, a); break;
+    case 3: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 3, 0, kModeStreaming, 1>, grid, lds, a); break;
   }
-  return fail(ctx, VK_E_ARG, "n_ell must be 1..3 (or a VK_LITE development build)");
+  return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
 }
 
 // ... and the dispersion model with it (cells kernel only)
 template <int NLR>
 int launch_cells_sva_disp(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: if constexpr (VK_LITE_KEEP(NLR, 1, 1, 2)) return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 1, 0, kModeDispersion, 1>, grid, lds, a); break;
-    case 2: if constexpr (VK_LITE_KEEP(NLR, 2, 1, 2)) return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 2, 0, kModeDispersion, 1>, grid, lds, a); break;
-    case 3: if constexpr (VK_LITE_KEEP(NLR, 3, 1, 2)) return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 3, 0, kModeDispersion, 1>, grid, lds, a); break;
+    case 1: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 1, 0, kModeDispersion, 1>, grid, lds, a); break;
+    case 2: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 2, 0, kModeDispersion, 1>, grid, lds, a); break;
+    case 3: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 3, 0, kModeDispersion, 1>, grid, lds, a); break;
   }
-  return fail(ctx, VK_E_ARG, "n_ell must be 1..3 (or a VK_LITE development build)");
+  return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
 }
 
 template <int NLR>
 int launch_cells_sva(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   if (a.rsd == VK_RSD_DISPERSION) return launch_cells_sva_disp<NLR>(ctx, a, grid, lds);
   switch (a.n_ell) {
-    case 1: if constexpr (VK_LITE_KEEP(NLR, 1, 1, 0)) return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 1, 0, kModeStreaming, 1>, grid, lds, a); break;
-    case 2: if constexpr (VK_LITE_KEEP(NLR, 2, 1, 0)) return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 2, 0, kModeStreaming, 1>, grid, lds, a); break;
-    case 3: if constexpr (VK_LITE_KEEP(NLR, 3, 1, 0)) return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 3, 0, kModeStreaming, 1>, grid, lds, a); break;
+    case 1: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 1, 0, kModeStreaming, 1>, grid, lds, a); break;
+    case 2: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 2, 0, kModeStreaming, 1>, grid, lds, a); break;
+    case 3: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 3, 0, kModeStreaming, 1>, grid, lds, a); break;
   }
-  return fail(ctx, VK_E_ARG, "n_ell must be 1..3 (or a VK_LITE development build)");
+  return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
 }
 
 template <int NLR, int GRID>
@@ -601,11 +338,11 @@ int launch_fast_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
 template <int NLR, int GRID>
 int launch_lanes_ng(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: if constexpr (VK_LITE_KEEP(NLR, 1, GRID, 0)) return launch_on_stream(ctx, vk_theory_lanes_kernel<NLR, 1, GRID>, grid, lds, a); break;
-    case 2: if constexpr (VK_LITE_KEEP(NLR, 2, GRID, 0)) return launch_on_stream(ctx, vk_theory_lanes_kernel<NLR, 2, GRID>, grid, lds, a); break;
-    case 3: if constexpr (VK_LITE_KEEP(NLR, 3, GRID, 0)) return launch_on_stream(ctx, vk_theory_lanes_kernel<NLR, 3, GRID>, grid, lds, a); break;
+    case 1: return launch_on_stream(ctx, vk_theory_lanes_kernel<NLR, 1, GRID>, grid, lds, a); break;
+    case 2: return launch_on_stream(ctx, vk_theory_lanes_kernel<NLR, 2, GRID>, grid, lds, a); break;
+    case 3: return launch_on_stream(ctx, vk_theory_lanes_kernel<NLR, 3, GRID>, grid, lds, a); break;
   }
-  return fail(ctx, VK_E_ARG, "n_ell must be 1..3 (or a VK_LITE development build)");
+  return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
 }
 
 template <int NLR>
@@ -617,11 +354,11 @@ int launch_lanes_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
 template <int NLR, int GRID, int MODE>
 int launch_cells_ngf(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: if constexpr (VK_LITE_KEEP(NLR, 1, GRID, MODE)) return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 1, GRID, MODE>, grid, lds, a); break;
-    case 2: if constexpr (VK_LITE_KEEP(NLR, 2, GRID, MODE)) return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 2, GRID, MODE>, grid, lds, a); break;
-    case 3: if constexpr (VK_LITE_KEEP(NLR, 3, GRID, MODE)) return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 3, GRID, MODE>, grid, lds, a); break;
+    case 1: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 1, GRID, MODE>, grid, lds, a); break;
+    case 2: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 2, GRID, MODE>, grid, lds, a); break;
+    case 3: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 3, GRID, MODE>, grid, lds, a); break;
   }
-  return fail(ctx, VK_E_ARG, "n_ell must be 1..3 (or a VK_LITE development build)");
+  return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
 }
 
 template <int NLR, int GRID>
@@ -643,9 +380,9 @@ int launch_cells_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
 template <int RSD>
 int launch_xi_smu(vk_ctx* ctx, const TheoryArgs& a, int nlr, int grid, size_t lds) {
   switch (nlr) {
-    case 1: if constexpr (VK_LITE_KEEP(1, 2, 1, 0)) return launch_on_stream(ctx, vk_xi_smu_kernel<RSD, 1>, grid, lds, a); break;
-    case 2: if constexpr (VK_LITE_KEEP(1, 2, 1, 0)) return launch_on_stream(ctx, vk_xi_smu_kernel<RSD, 2>, grid, lds, a); break;
-    case 3: if constexpr (VK_LITE_KEEP(1, 2, 1, 0)) return launch_on_stream(ctx, vk_xi_smu_kernel<RSD, 3>, grid, lds, a); break;
+    case 1: return launch_on_stream(ctx, vk_xi_smu_kernel<RSD, 1>, grid, lds, a); break;
+    case 2: return launch_on_stream(ctx, vk_xi_smu_kernel<RSD, 2>, grid, lds, a); break;
+    case 3: return launch_on_stream(ctx, vk_xi_smu_kernel<RSD, 3>, grid, lds, a); break;
   }
   return fail(ctx, VK_E_ARG, "bad number of real-space multipoles %d", nlr);
 }
@@ -984,23 +721,25 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
     const long long per_cu = std::min<long long>((a.rsd == VK_RSD_STREAMING && !sva && !a.from_data) ? 3 : 2, (160 * 1024) / (long long)(lds ? lds : 1));
     if (a.parts > 1 && ctx->d_poll && !ctx->knobs.no_poll && (size_t)a.n * a.n_s * kMaxParts * kMaxEll <= ctx->poll_doubles &&
         a.n <= kPollPoints) {
-      // the context's reservation grows on demand, as far as the process's budget allows (released in vk_destroy)
-      if (ctx->poll_reserved < a.n) {
-        LedgerHandle* led = ledger_for(ctx->bus);
-        int seen = g_poll_reserved.load(std::memory_order_relaxed), grant;
-        do {
-          grant = vk_poll_grant(led ? ledger_others(led) : 0, seen, ctx->poll_reserved, (int32_t)a.n);
-        } while (grant > 0 && !g_poll_reserved.compare_exchange_weak(seen, seen + grant, std::memory_order_relaxed));
-        if (grant > 0 && led) {
-          // published; if another process raced past the bound meanwhile, take it back (both may: conservative)
-          led->map->slot[led->mine].reserved.fetch_add(grant, std::memory_order_acq_rel);
-          if (ledger_others(led) + g_poll_reserved.load(std::memory_order_relaxed) >= kPollXcdSlots) {
-            led->map->slot[led->mine].reserved.fetch_sub(grant, std::memory_order_acq_rel);
-            g_poll_reserved.fetch_sub(grant, std::memory_order_relaxed);
-            grant = 0;
-          }
+      // The context's reservation grows on demand, as far as the process's budget and the device-wide ledger allow (released in
+      // vk_destroy) - asked for only by a launch that WOULD poll with it (the rule first: a context whose launches can never
+      // poll takes nothing from the 63 waiters of the device), and after a refusal only once the ledger has moved (somebody
+      // returned a reservation, a slot changed hands) or every kPollRetryLaunches launches: a refused context must not walk the
+      // ledger on every launch of a 20 us path.
+      if (ctx->poll_reserved < a.n && vk_poll_rule(a.n, a.parts, items, (int32_t)per_cu, ctx->n_cu, (int32_t)a.n)) {
+        int led_status = vkl::kUnavailable;
+        vkl::Ledger* led = vkl::for_device(ctx->bus, &led_status);
+        // no ledger to be had (no /dev/shm): the process budget alone; a ledger that is there but not ours to trust, or full: no polling
+        const bool may_ask = led_status == vkl::kOpened || led_status == vkl::kUnavailable;
+        const uint32_t gen = vkl::generation(led);
+        const bool refused_before = ctx->poll_refused_want > 0 && ctx->poll_refused_want <= a.n;
+        if (may_ask && (!refused_before || gen != ctx->poll_refused_gen || ++ctx->poll_refused_launches >= kPollRetryLaunches)) {
+          const int grant = vkl::grant(led, &g_poll_reserved, ctx->poll_reserved, (int)a.n);
+          ctx->poll_reserved += grant;
+          ctx->poll_refused_want = grant > 0 ? 0 : (int)a.n;
+          ctx->poll_refused_gen = gen;
+          ctx->poll_refused_launches = 0;
         }
-        ctx->poll_reserved += grant > 0 ? grant : 0;
       }
       if (vk_poll_rule(a.n, a.parts, items, (int32_t)per_cu, ctx->n_cu, ctx->poll_reserved)) {
         a.poll = 1;
@@ -1095,66 +834,33 @@ void harvest_timing(vk_ctx* ctx) {
   ctx->pending = false;
 }
 
-// ---- RCCL via dlopen -------------------------------------------------------------------------------
-typedef struct { char internal[VK_COMM_ID_BYTES]; } rccl_id_t;
-typedef int (*fn_get_id)(rccl_id_t*);
-typedef int (*fn_init_rank)(void**, int, rccl_id_t, int);
-typedef int (*fn_allgather)(const void*, void*, size_t, int, void*, hipStream_t);
-typedef int (*fn_destroy)(void*);
-typedef int (*fn_init_all)(void**, int, const int*);
-typedef int (*fn_group)(void);
-typedef const char* (*fn_errstr)(int);
-
-// Path of the shared object that defines `addr` (empty if unknown)
-std::string object_of(const void* addr) {
-  Dl_info info;
-  if (addr && dladdr(addr, &info) && info.dli_fname) return info.dli_fname;
-  return std::string();
-}
-
-std::string dir_of(const std::string& path) {
-  const size_t cut = path.find_last_of('/');
-  return cut == std::string::npos ? std::string() : path.substr(0, cut);
-}
-
-// The HIP runtime this library is actually running on.  libamdhip64 has one soname (libamdhip64.so.7) in every ROCm 7
-// install, so whichever copy the process mapped first serves everybody: /opt/rocm's when this library is loaded into a
-// fresh interpreter, PyTorch's bundled copy when torch was imported before (torch.distributed launchers).
-std::string hip_runtime_path() { return object_of(reinterpret_cast<const void*>(&hipGetDeviceCount)); }
-
-// RCCL must come from the same ROCm install as that runtime (its kernels and its HIP calls are built against it), so
-// look next to the mapped libamdhip64 first and only then fall back to the loader's search order.
-void* open_rccl(std::string* how = nullptr) {
-  static void* lib = nullptr;
-  static std::string chosen;
-  if (!lib) {
-    std::vector<std::string> names;
-    // development override (tests/rccl_double): like every other VICTOR_HIP_* switch it is honoured only with VICTOR_HIP_DEV=1 -
-    // a variable inherited from somebody's shell must never swap the collective library of a production run
-    const char* dev = getenv("VICTOR_HIP_DEV");
-    if (dev && strcmp(dev, "1") == 0)
-      if (const char* env = getenv("VICTOR_HIP_RCCL_LIB")) names.push_back(env);
-    const std::string dir = dir_of(hip_runtime_path());
-    if (!dir.empty()) {
-      names.push_back(dir + "/librccl.so.1");
-      names.push_back(dir + "/librccl.so");
-    }
-    names.push_back("librccl.so.1");
-    names.push_back("librccl.so");
-    names.push_back("/opt/rocm/lib/librccl.so.1");
-    for (const std::string& nm : names) {
-      lib = dlopen(nm.c_str(), RTLD_NOW | RTLD_GLOBAL);
-      if (lib) {
-        chosen = nm;
-        break;
-      }
-    }
-  }
-  if (how) *how = chosen;
-  return lib;
-}
-
 }  // namespace
+
+// ---- the internal entry points the host-compiled units share with this file (vk_host.h) -----------------------------------
+void vkh::sync_knobs(vk_ctx* ctx) {
+  if (ctx->knob_gen != g_knob_gen.load(std::memory_order_relaxed)) load_knobs(ctx);
+}
+
+int vkh::fail(vk_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+int vkh::check_opts(vk_ctx* ctx, const vk_eval_opts* o) {
+  if (!o) return fail(ctx, VK_E_ARG, "opts is NULL");
+  if (o->rsd_model < VK_RSD_STREAMING || o->rsd_model > VK_RSD_EUCLID)
+    return fail(ctx, VK_E_ARG, "unknown rsd_model %d", o->rsd_model);
+  if (o->niter < 0 || o->niter > 64) return fail(ctx, VK_E_ARG, "niter must be in 0..64");
+  if (o->like_form < VK_LIKE_GAUSSIAN || o->like_form > VK_LIKE_PERCIVAL)
+    return fail(ctx, VK_E_ARG, "unknown likelihood form %d", o->like_form);
+  return VK_OK;
+}
+
 
 extern "C" {
 
@@ -1170,37 +876,12 @@ int vk_debug_read_stamps(long long* out) {
 
 void vk_knobs_refresh(void) { g_knob_gen.fetch_add(1, std::memory_order_relaxed); }
 
-// ---- the launch rule of the polling hand-off: pure functions of their arguments (include/victor_hip.h) --------------------
-int32_t vk_poll_rule(int64_t n_points, int32_t parts, int64_t workgroups, int32_t workgroups_per_cu, int32_t n_cu, int32_t reserved) {
-  if (parts < 2 || n_points < 1 || n_points > kPollPoints) return 0;      // nothing to hand over / more waiters than a launch may hold
-  if (workgroups_per_cu < 2 || n_cu < 8) return 0;                         // an XCD must offer kPollXcdSlots = 32 CUs x 2 slots at least
-  if ((long long)(n_cu / 8) * workgroups_per_cu < kPollXcdSlots) return 0;
-  if (workgroups > (long long)workgroups_per_cu * n_cu) return 0;          // the launch must fit on the chip at once
-  if (n_points > reserved) return 0;                                       // its waiters must be covered by the context's reservation
-  return 1;
-}
-
-int32_t vk_poll_grant(int32_t others_reserved, int32_t process_reserved, int32_t ctx_reserved, int32_t want) {
-  if (want > (int32_t)kPollPoints) want = (int32_t)kPollPoints;
-  if (want <= ctx_reserved || process_reserved < 0 || others_reserved < 0) return 0;
-  const int32_t extra = want - ctx_reserved;
-  const int32_t room = std::min(kPollBudget - process_reserved,                           // this process's budget
-                                kPollXcdSlots - 1 - others_reserved - process_reserved);  // fewer than an XCD's slots on the device
-  return extra <= room ? extra : 0;      // all or nothing: a launch polls for every one of its points or for none
-}
-
 int32_t vk_poll_device_reserved(const vk_ctx* ctx, int32_t* others, int32_t* mine) {
   if (!ctx) return VK_E_ARG;
-  LedgerHandle* led = ledger_for(ctx->bus);
-  if (others) *others = led ? ledger_others(led) : -1;
+  vkl::Ledger* led = vkl::for_device(ctx->bus, nullptr);
+  if (others) *others = led ? vkl::others(led) : -1;
   if (mine) *mine = g_poll_reserved.load(std::memory_order_relaxed);
   return led ? VK_OK : VK_E_ARG;
-}
-
-int32_t vk_poll_budget(int32_t* per_process, int32_t* xcd_slots) {
-  if (per_process) *per_process = kPollBudget;
-  if (xcd_slots) *xcd_slots = kPollXcdSlots;
-  return (kPollXcdSlots - 1) / kPollBudget;       // processes per device that may each use their full budget
 }
 
 int vk_device_count(void) {
@@ -1259,6 +940,14 @@ vk_ctx* vk_create(const vk_tables* t, int device, char* err, size_t errlen) {
     return nullptr;
   };
   if (!t) return bail("tables is NULL");
+  {
+    // the host-compiled units (vk_walk.cpp, vk_serve.cpp, vk_rccl.cpp) read the context's fields: one layout in every unit
+    size_t off[3] = {0, 0, 0};
+    const size_t sz[3] = {vkh::ctx_layout_walk(&off[0]), vkh::ctx_layout_serve(&off[1]), vkh::ctx_layout_rccl(&off[2])};
+    for (int u = 0; u < 3; ++u)
+      if (sz[u] != sizeof(vk_ctx) || off[u] != offsetof(vk_ctx, spin_timeouts))
+        return bail("internal: the translation units of this library disagree about the context's layout (a broken build)");
+  }
   if (t->n_s < 1 || t->n_mu < 2 || t->n_x < 3 || t->n_ell < 1 || t->n_ell > kMaxEll || t->n_ell_r < 1 ||
       t->n_ell_r > kMaxEll)
     return bail("bad grid sizes (need n_s>=1, n_mu>=2, n_x>=3, 1<=n_ell<=3, 1<=n_ell_r<=3)");
@@ -1608,10 +1297,8 @@ void vk_destroy(vk_ctx* ctx) {
   if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
   if (ctx->comm) vk_comm_destroy(ctx);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->poll_reserved) {            // (nothing of it is in flight any more)
-    g_poll_reserved.fetch_sub(ctx->poll_reserved, std::memory_order_relaxed);
-    if (LedgerHandle* led = ledger_for(ctx->bus)) led->map->slot[led->mine].reserved.fetch_sub(ctx->poll_reserved, std::memory_order_acq_rel);
-  }
+  if (ctx->poll_reserved)              // (nothing of it is in flight any more)
+    vkl::release(vkl::for_device(ctx->bus, nullptr), &g_poll_reserved, ctx->poll_reserved);
   ctx->poll_reserved = 0;
   drop_graphs(ctx);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
@@ -1863,17 +1550,6 @@ static int eval_batch_graph(vk_ctx* ctx, const vk_eval_opts* opts, const double*
   return 1;
 }
 
-// spin-wait hint of the polling loop below
-static inline void cpu_relax() {
-#if defined(__x86_64__) || defined(__i386__)
-  __builtin_ia32_pause();
-#elif defined(__aarch64__)
-  asm volatile("yield" ::: "memory");
-#else
-  asm volatile("" ::: "memory");
-#endif
-}
-
 constexpr int64_t kSpinMaxDefault = 256;         // in-place batches up to this size poll for their results (eval_batch_zero_copy)
 constexpr uint64_t kSpinSentinel = 0x7ff8dead5ca1ab1eULL;   // a quiet NaN with a payload no arithmetic produces
 constexpr int64_t kZeroCopyMaxDefault = 4096;   // host-buffer batches up to this size: parameters read in place, results written in place
@@ -1903,7 +1579,7 @@ static bool ensure_zero_copy(vk_ctx* ctx) {
   return true;
 }
 
-static int zc_begin(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, int64_t n, bool want_out, double* d_th) {
+extern "C++" int vkh::zc_begin(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, int64_t n, bool want_out, double* d_th) {
   const int64_t zc_max = ctx->knobs.zero_copy_max >= 0 ? std::min<int64_t>(ctx->knobs.zero_copy_max, kZeroCopyCap) : kZeroCopyMaxDefault;
   if (n > zc_max || ctx->timing || !want_out || !ensure_zero_copy(ctx)) return 0;
   double* h_out = ctx->h_zc + (size_t)kZeroCopyCap * VK_NPAR;
@@ -1931,7 +1607,7 @@ static int zc_begin(vk_ctx* ctx, const vk_eval_opts* opts, const double* params,
 }
 
 // 1 = the results are in lnl / chi2, 0 = not yet (only with block == false), < 0 = error
-static int zc_finish(vk_ctx* ctx, int64_t n, double* lnl, double* chi2, bool block) {
+extern "C++" int vkh::zc_finish(vk_ctx* ctx, int64_t n, double* lnl, double* chi2, bool block) {
   double* h_out = ctx->h_zc + (size_t)kZeroCopyCap * VK_NPAR;
   volatile uint64_t* slots = reinterpret_cast<volatile uint64_t*>(h_out);
   bool arrived = false;
@@ -1990,9 +1666,8 @@ static int eval_batch_zero_copy(vk_ctx* ctx, const vk_eval_opts* opts, const dou
   return zc_finish(ctx, n, lnl, chi2, true);
 }
 
-// scratch of the host-buffer entry points: parameters | theory workspace | lnl | chi2
-struct HostScratch { double *d_par, *d_th, *d_lnl, *d_chi; };
-static int host_scratch(vk_ctx* ctx, int64_t n, HostScratch* sc) {
+// scratch of the host-buffer entry points: parameters | theory workspace | lnl | chi2 (vk_host.h: HostScratch)
+extern "C++" int vkh::host_scratch(vk_ctx* ctx, int64_t n, HostScratch* sc) {
   // small batches share one scratch layout sized for kGraphMaxN so that captured graphs stay valid across sizes
   const int64_t n_lay = n <= kGraphMaxN ? kGraphMaxN : n;
   const int rc = ensure_scratch(ctx, (size_t)n_lay * (VK_NPAR + ctx->N + 2) * sizeof(double));
@@ -2082,507 +1757,6 @@ int vk_eval_batch_finish(vk_ctx* ctx, double* lnl, double* chi2) {
   return rc < 0 ? rc : VK_OK;
 }
 
-// ---- lock-step Metropolis walkers advanced natively (include/victor_hip.h: vk_walk_*) ------------------------------------
-// The step of victor_amd/sampler.py: EnsembleMetropolis.run restated in C++: the same two half-ensembles on two contexts, the
-// same pipelining (half A of step t + 1 is on the GPU while the host accepts / rejects half B of step t), the same rows, the
-// same launches - so the same chain -, without the ~20 NumPy calls per step that made the host the limit of an 8-walker step.
-struct vk_walk {
-  vk_ctx* ctx[2] = {nullptr, nullptr};
-  int n_half = 0;                       // 1 or 2
-  int lo[2] = {0, 0}, hi[2] = {0, 0};   // walkers of each half
-  vk_eval_opts opts{};
-  int W = 0, P = 0;
-  std::vector<int> col;                 // row column per sampled parameter, or VK_WALK_EPSILON
-  int eps = -1;                         // index of the parameter that is epsilon, or -1
-  double alpha = 1.0;
-  std::vector<double> box_lo, box_hi, rows, prop, lnl_prop, chi_prop;
-  std::vector<char> inside;
-  // two steps per launch (vk_walk_create: speculate): per walker the proposal of step t and BOTH proposals of step t + 1 - from
-  // the accepted and from the rejected position - travel in one launch; three rows, proposals, results per walker
-  bool speculate = false;
-  std::vector<double> rows3, prop3, lnl3, chi3;
-  std::vector<char> in3;
-  std::string err;
-};
-
-// the sampled columns of one row from the walker's coordinates `xs` (CCFModel._param_rows, ccf_model.py:589-592 of the reference)
-static inline void walk_fill_row(const vk_walk* w, const double* xs, double* row) {
-  for (int j = 0; j < w->P; ++j)
-    if (w->col[j] >= 0) row[w->col[j]] = xs[j];
-  if (w->eps >= 0) {
-    const double e = xs[w->eps];
-    double apar = pow(e, -2.0 / 3.0);
-    if (w->alpha != 1.0) apar = w->alpha * apar;
-    row[VK_P_APERP] = e * apar;
-    row[VK_P_APAR] = apar;
-    row[VK_P_EPSILON] = e;
-  }
-}
-
-static inline bool walk_in_box(const vk_walk* w, const double* p) {
-  bool in = true;
-  for (int j = 0; j < w->P; ++j) in = in && p[j] >= w->box_lo[j] && p[j] <= w->box_hi[j];      // (a NaN proposal is outside)
-  return in;
-}
-
-static void walk_begin(vk_walk* w, int k, const double* x, const double* dz_t, int* rc) {
-  const int P = w->P;
-  for (int i = w->lo[k]; i < w->hi[k]; ++i) {
-    double* pr = &w->prop[(size_t)i * P];
-    for (int j = 0; j < P; ++j) pr[j] = x[(size_t)i * P + j] + dz_t[(size_t)i * P + j];
-    const bool in = walk_in_box(w, pr);
-    w->inside[i] = in ? 1 : 0;
-    // a proposal outside the prior: its row keeps the walker's position (a valid point; the result is discarded)
-    walk_fill_row(w, in ? pr : &x[(size_t)i * P], &w->rows[(size_t)i * VK_NPAR]);
-  }
-  const int r = vk_eval_batch_begin(w->ctx[k], &w->opts, &w->rows[(size_t)w->lo[k] * VK_NPAR], w->hi[k] - w->lo[k]);
-  if (r != VK_OK && *rc == VK_OK) {
-    *rc = r;
-    w->err = w->ctx[k]->err;
-  }
-}
-
-// Two steps in one launch.  Step t + 1's proposal is x_(t+1) + dz_(t+1) with x_(t+1) either the proposal of step t (accepted)
-// or the old position (rejected): both candidates are known when step t is proposed, so all three points of a walker are
-// evaluated together and the two decisions are taken when the results arrive - the ensemble advances two steps per round
-// trip host -> GPU -> host, the limit of a small ensemble, for three evaluations instead of two.  The decisions are those of
-// the step-by-step loop: the same proposals (the same additions), the same acceptance levels.
-static void walk_begin2(vk_walk* w, int k, const double* x, const double* dz_t, const double* dz_t1, int* rc) {
-  const int P = w->P;
-  for (int i = w->lo[k]; i < w->hi[k]; ++i) {
-    const double* xi = &x[(size_t)i * P];
-    double* p0 = &w->prop3[(size_t)i * 3 * P];
-    double* pa = p0 + P;
-    double* pr = pa + P;
-    for (int j = 0; j < P; ++j) {
-      p0[j] = xi[j] + dz_t[(size_t)i * P + j];
-      pa[j] = p0[j] + dz_t1[(size_t)i * P + j];
-      pr[j] = xi[j] + dz_t1[(size_t)i * P + j];
-    }
-    const bool in0 = walk_in_box(w, p0), ina = in0 && walk_in_box(w, pa), inr = walk_in_box(w, pr);
-    w->in3[(size_t)i * 3] = in0;
-    w->in3[(size_t)i * 3 + 1] = ina;
-    w->in3[(size_t)i * 3 + 2] = inr;
-    double* row = &w->rows3[(size_t)i * 3 * VK_NPAR];
-    walk_fill_row(w, in0 ? p0 : xi, row);                                   // (outside the prior: a valid point, result discarded)
-    walk_fill_row(w, ina ? pa : (in0 ? p0 : xi), row + VK_NPAR);
-    walk_fill_row(w, inr ? pr : xi, row + 2 * VK_NPAR);
-  }
-  const int r = vk_eval_batch_begin(w->ctx[k], &w->opts, &w->rows3[(size_t)w->lo[k] * 3 * VK_NPAR], 3 * (w->hi[k] - w->lo[k]));
-  if (r != VK_OK && *rc == VK_OK) {
-    *rc = r;
-    w->err = w->ctx[k]->err;
-  }
-}
-
-static void walk_finish_accept2(vk_walk* w, int k, double* x, double* lnl, const double* logu_t, const double* logu_t1, double* chain_t,
-                                double* hist_t, int64_t* n_accept, int64_t* n_evals, int* rc) {
-  const int P = w->P;
-  const size_t step_x = (size_t)w->W * P, step_u = (size_t)w->W;
-  if (w->ctx[k]->begun_n == 0) return;                                 // its begin failed
-  const int r = vk_eval_batch_finish(w->ctx[k], &w->lnl3[(size_t)w->lo[k] * 3], &w->chi3[(size_t)w->lo[k] * 3]);
-  if (r != VK_OK) {
-    if (*rc == VK_OK) {
-      *rc = r;
-      w->err = w->ctx[k]->err;
-    }
-    return;
-  }
-  const double minus_inf = -std::numeric_limits<double>::infinity();
-  for (int i = w->lo[k]; i < w->hi[k]; ++i) {
-    double* xi = &x[(size_t)i * P];
-    const double* p0 = &w->prop3[(size_t)i * 3 * P];
-    const char* in = &w->in3[(size_t)i * 3];
-    const double* l3 = &w->lnl3[(size_t)i * 3];
-    // step t
-    const double lp0 = in[0] ? l3[0] : minus_inf;
-    if (in[0]) *n_evals += 1;
-    const bool acc0 = logu_t[i] < lp0 - lnl[i];                         // (false for NaN)
-    if (acc0) {
-      memcpy(xi, p0, (size_t)P * sizeof(double));
-      lnl[i] = lp0;
-      *n_accept += 1;
-    }
-    if (chain_t) memcpy(chain_t + (size_t)i * P, xi, (size_t)P * sizeof(double));
-    if (hist_t) hist_t[i] = lnl[i];
-    // step t + 1: the candidate that belongs to the position step t left
-    const int c = acc0 ? 1 : 2;
-    const double lp1 = in[c] ? l3[c] : minus_inf;
-    if (in[c]) *n_evals += 1;
-    if (logu_t1[i] < lp1 - lnl[i]) {
-      memcpy(xi, p0 + (size_t)c * P, (size_t)P * sizeof(double));
-      lnl[i] = lp1;
-      *n_accept += 1;
-    }
-    if (chain_t) memcpy(chain_t + step_x + (size_t)i * P, xi, (size_t)P * sizeof(double));
-    if (hist_t) hist_t[step_u + i] = lnl[i];
-  }
-}
-
-static void walk_finish_accept(vk_walk* w, int k, double* x, double* lnl, const double* logu_t, int64_t* n_accept, int64_t* n_evals, int* rc) {
-  const int P = w->P;
-  if (w->ctx[k]->begun_n == 0) return;                                 // its begin failed
-  const int r = vk_eval_batch_finish(w->ctx[k], &w->lnl_prop[w->lo[k]], &w->chi_prop[w->lo[k]]);
-  if (r != VK_OK) {
-    if (*rc == VK_OK) {
-      *rc = r;
-      w->err = w->ctx[k]->err;
-    }
-    return;
-  }
-  for (int i = w->lo[k]; i < w->hi[k]; ++i) {
-    double lp = w->lnl_prop[i];
-    if (w->inside[i]) *n_evals += 1; else lp = -std::numeric_limits<double>::infinity();
-    if (logu_t[i] < lp - lnl[i]) {                                     // (false for NaN)
-      memcpy(&x[(size_t)i * P], &w->prop[(size_t)i * P], (size_t)P * sizeof(double));
-      lnl[i] = lp;
-      *n_accept += 1;
-    }
-  }
-}
-
-// ---- mailboxes: many one-point callers, one launch (include/victor_hip.h) ---------------------------------------------
-// Is process `pid` still there?  kill(pid, 0) answers for zombies as well (a dead child nobody has waited for yet), so the
-// state letter of /proc/<pid>/stat decides for those (victor_amd/broker.py: _pid_alive is the same test).
-static bool process_alive(long long pid) {
-  if (pid <= 0) return false;
-  if (kill((pid_t)pid, 0) != 0) return errno == EPERM;
-  char path[64], buf[512];
-  snprintf(path, sizeof path, "/proc/%lld/stat", pid);
-  FILE* f = fopen(path, "r");
-  if (!f) return true;                       // no /proc here: kill() has spoken
-  const size_t got = fread(buf, 1, sizeof buf - 1, f);
-  fclose(f);
-  buf[got] = 0;
-  const char* close_paren = strrchr(buf, ')');            // the command name may contain anything, also ')'
-  if (!close_paren || close_paren[1] != ' ' || !close_paren[2]) return true;
-  return close_paren[2] != 'Z';
-}
-
-vk_walk* vk_walk_create(vk_ctx* const* ctxs, int32_t n_ctx, const vk_eval_opts* opts, int32_t n_walkers, int32_t n_params,
-                        const int32_t* columns, const double* lo, const double* hi, const double* base_rows, double alpha,
-                        int32_t speculate, char* err, size_t errlen) {
-  auto bail = [&](const char* msg) -> vk_walk* {
-    if (err && errlen) {
-      strncpy(err, msg, errlen - 1);
-      err[errlen - 1] = 0;
-    }
-    return nullptr;
-  };
-  if (!ctxs || n_ctx < 1 || n_ctx > 2 || !ctxs[0] || (n_ctx == 2 && !ctxs[1]) || !opts || !columns || !lo || !hi || !base_rows)
-    return bail("vk_walk_create: NULL argument");
-  if (n_walkers < 1 || n_params < 1 || n_params > VK_NPAR) return bail("vk_walk_create: need 1 <= walkers, 1 <= parameters <= VK_NPAR");
-  if (n_ctx == 2 && (ctxs[0] == ctxs[1] || ctxs[0]->N != ctxs[1]->N)) return bail("vk_walk_create: the two contexts must be different and hold the same tables");
-  for (int c = 0; c < n_ctx; ++c)
-    if (!ctxs[c]->d_data) return bail("vk_walk_create: context was created without a data vector");
-  if (check_opts(ctxs[0], opts) != VK_OK) return bail(ctxs[0]->err.c_str());
-  vk_walk* w = new (std::nothrow) vk_walk();
-  if (!w) return bail("out of memory");
-  w->W = n_walkers;
-  w->P = n_params;
-  w->opts = *opts;
-  w->alpha = alpha;
-  const int h = (n_ctx == 2 && n_walkers >= 2) ? n_walkers / 2 : n_walkers;
-  w->ctx[0] = ctxs[0];
-  w->lo[0] = 0;
-  w->hi[0] = h;
-  w->n_half = 1;
-  if (h < n_walkers) {
-    w->ctx[1] = ctxs[1];
-    w->lo[1] = h;
-    w->hi[1] = n_walkers;
-    w->n_half = 2;
-  }
-  for (int k = 0; k < w->n_half; ++k)
-    if (w->hi[k] - w->lo[k] > kZeroCopyCap) {
-      delete w;
-      return bail("vk_walk_create: at most 4096 walkers per half-ensemble");
-    }
-  int n_eps = 0;
-  for (int j = 0; j < n_params; ++j) {
-    const int c = columns[j];
-    if (c == VK_WALK_EPSILON) {
-      w->eps = j;
-      ++n_eps;
-    } else if (c < 0 || c >= VK_NPAR || (c >= VK_P_APERP && c <= VK_P_EPSILON)) {
-      delete w;
-      return bail("vk_walk_create: a sampled parameter must name a row column other than aperp / apar / epsilon, or VK_WALK_EPSILON");
-    }
-    if (!(hi[j] > lo[j])) {
-      delete w;
-      return bail("vk_walk_create: the prior box needs hi > lo");
-    }
-    w->col.push_back(c);
-  }
-  if (n_eps > 1) {
-    delete w;
-    return bail("vk_walk_create: epsilon sampled twice");
-  }
-  w->box_lo.assign(lo, lo + n_params);
-  w->box_hi.assign(hi, hi + n_params);
-  w->rows.assign(base_rows, base_rows + (size_t)n_walkers * VK_NPAR);
-  w->prop.resize((size_t)n_walkers * n_params);
-  w->lnl_prop.resize(n_walkers);
-  w->chi_prop.resize(n_walkers);
-  w->inside.resize(n_walkers);
-  // two steps per launch: three rows per walker, as long as a launch stays within the in-place buffers
-  w->speculate = speculate != 0;
-  for (int k = 0; k < w->n_half; ++k)
-    if (3 * (w->hi[k] - w->lo[k]) > kZeroCopyCap) w->speculate = false;
-  if (w->speculate) {
-    w->rows3.resize((size_t)n_walkers * 3 * VK_NPAR);
-    for (int i = 0; i < n_walkers; ++i)
-      for (int c = 0; c < 3; ++c) memcpy(&w->rows3[((size_t)i * 3 + c) * VK_NPAR], base_rows + (size_t)i * VK_NPAR, VK_NPAR * sizeof(double));
-    w->prop3.resize((size_t)n_walkers * 3 * n_params);
-    w->lnl3.resize((size_t)n_walkers * 3);
-    w->chi3.resize((size_t)n_walkers * 3);
-    w->in3.resize((size_t)n_walkers * 3);
-  }
-  return w;
-}
-
-void vk_walk_destroy(vk_walk* w) { delete w; }
-
-const char* vk_walk_last_error(const vk_walk* w) { return w ? w->err.c_str() : ""; }
-
-int vk_walk_run(vk_walk* w, int64_t n_steps, double* x, double* lnl, const double* dz, const double* logu, double* chain,
-                double* lnl_hist, int64_t* n_accept, int64_t* n_evals) {
-  if (!w || n_steps < 0 || !x || !lnl || (n_steps > 0 && (!dz || !logu))) return VK_E_ARG;
-  for (int k = 0; k < w->n_half; ++k)
-    if (w->ctx[k]->begun_n != 0) {
-      w->err = "vk_walk_run: a batch begun on one of the contexts has not been collected";
-      return VK_E_ARG;
-    }
-  int64_t acc = 0, ev = 0;
-  int rc = VK_OK;
-  const size_t step_x = (size_t)w->W * w->P, step_u = (size_t)w->W;
-  int64_t t0 = 0;                        // steps taken by the two-steps-per-launch loop; the rest (one step at most) below
-  if (w->speculate && n_steps >= 2) {
-    const int64_t pairs = n_steps / 2;
-    walk_begin2(w, 0, x, dz, dz + step_x, &rc);
-    for (int64_t q = 0; q < pairs && rc == VK_OK; ++q) {
-      const int64_t t = 2 * q;
-      const double* dz_t = dz + (size_t)t * step_x;
-      const double* lu_t = logu + (size_t)t * step_u;
-      double* ch = chain ? chain + (size_t)t * step_x : nullptr;
-      double* hi = lnl_hist ? lnl_hist + (size_t)t * step_u : nullptr;
-      if (w->n_half == 2) walk_begin2(w, 1, x, dz_t, dz_t + step_x, &rc);
-      walk_finish_accept2(w, 0, x, lnl, lu_t, lu_t + step_u, ch, hi, &acc, &ev, &rc);
-      if (q + 1 < pairs && rc == VK_OK) walk_begin2(w, 0, x, dz_t + 2 * step_x, dz_t + 3 * step_x, &rc);   // the next two steps go out now
-      if (w->n_half == 2) walk_finish_accept2(w, 1, x, lnl, lu_t, lu_t + step_u, ch, hi, &acc, &ev, &rc);
-    }
-    t0 = 2 * pairs;
-  }
-  if (t0 < n_steps && rc == VK_OK) walk_begin(w, 0, x, dz + (size_t)t0 * step_x, &rc);
-  for (int64_t t = t0; t < n_steps && rc == VK_OK; ++t) {
-    const double* dz_t = dz + (size_t)t * step_x;
-    const double* lu_t = logu + (size_t)t * step_u;
-    if (w->n_half == 2) walk_begin(w, 1, x, dz_t, &rc);
-    walk_finish_accept(w, 0, x, lnl, lu_t, &acc, &ev, &rc);
-    if (t + 1 < n_steps && rc == VK_OK) walk_begin(w, 0, x, dz_t + step_x, &rc);      // half A of the next step goes out now
-    if (w->n_half == 2) walk_finish_accept(w, 1, x, lnl, lu_t, &acc, &ev, &rc);
-    if (chain) memcpy(chain + (size_t)t * step_x, x, step_x * sizeof(double));
-    if (lnl_hist) memcpy(lnl_hist + (size_t)t * step_u, lnl, step_u * sizeof(double));
-  }
-  if (rc != VK_OK)                       // nothing may stay begun on the contexts: collect (and drop) what is in flight
-    for (int k = 0; k < w->n_half; ++k)
-      if (w->ctx[k]->begun_n != 0) (void)vk_eval_batch_finish(w->ctx[k], nullptr, nullptr);
-  if (n_accept) *n_accept += acc;
-  if (n_evals) *n_evals += ev;
-  return rc;
-}
-
-// ---- the mailbox layout is mirrored field by field in victor_amd/broker.py ----
-static_assert(sizeof(vk_mailbox) == 256, "vk_mailbox is mirrored field by field in victor_amd/broker.py");
-static_assert(offsetof(vk_mailbox, row) == 64 && offsetof(vk_mailbox, resp_seq) == 192, "vk_mailbox layout");
-
-int vk_serve_mailboxes(vk_ctx* const* ctxs, int32_t n_ctx, const vk_eval_opts* opts, vk_mailbox* boxes, int32_t n_boxes,
-                       const volatile uint32_t* stop, double gather_window_us, int32_t max_batch, double max_seconds,
-                       vk_serve_stats* stats) {
-  if (!ctxs || n_ctx < 1 || n_ctx > 8 || !ctxs[0]) return VK_E_ARG;
-  vk_ctx* lead = ctxs[0];
-  int rc = check_opts(lead, opts);
-  if (rc) return rc;
-  if (!boxes || n_boxes < 1 || n_boxes > 1024 || !stop || !(max_seconds > 0)) return fail(lead, VK_E_ARG, "vk_serve_mailboxes: bad arguments");
-  for (int c = 0; c < n_ctx; ++c) {
-    if (!ctxs[c] || !ctxs[c]->d_data) return fail(lead, VK_E_ARG, "vk_serve_mailboxes: context %d is NULL or was created without a data vector", c);
-    if (ctxs[c]->N != lead->N) return fail(lead, VK_E_ARG, "vk_serve_mailboxes: the contexts must hold the same tables");
-  }
-  using clock = std::chrono::steady_clock;
-  const auto t_start = clock::now();
-  const auto window = std::chrono::nanoseconds((long long)(std::max(gather_window_us, 0.0) * 1e3));
-  const int cap = (max_batch >= 1 && max_batch <= kServeMaxBatch) ? max_batch : kServeMaxBatch;
-  // Mailboxes of clients that died without detaching are handed on HERE, at the start of a slice, when no launch of this loop
-  // carries anybody's request: a box freed while a flight still held its dead owner's request could be claimed by a new client
-  // whose first sequence number equals the one in flight - and would then be answered with the dead client's result.  The
-  // sequence words are zeroed before FREE is published (release); clients only ever claim FREE boxes (under their file lock)
-  // and this only touches ATTACHED boxes of dead processes, so the two never write the same box.
-  for (int b = 0; b < n_boxes; ++b) {
-    vk_mailbox& box = boxes[b];
-    if (box.state == VK_BOX_ATTACHED && !process_alive((long long)box.client_pid)) {
-      box.req_seq = 0;
-      box.resp_seq = 0;
-      __atomic_store_n(&box.state, (uint32_t)VK_BOX_FREE, __ATOMIC_RELEASE);
-    }
-  }
-  // One launch per context may be in flight: a round's requests go to a free context at once and its results are handed back
-  // when they have arrived, while the requests that come in meanwhile take the next context - the launches overlap on the GPU
-  // like those of separate processes (each context has its own stream), and chains that post together still share one.
-  struct Flight {
-    bool active = false;
-    int n = 0;
-    clock::time_point t0;
-    std::vector<int> idx;
-    std::vector<uint64_t> seq;
-    std::vector<double> rows, lnl, chi2;
-  };
-  std::vector<Flight> fl(n_ctx);
-  for (auto& f : fl) {
-    f.idx.resize(n_boxes);
-    f.seq.resize(n_boxes);
-    f.rows.resize((size_t)n_boxes * VK_NPAR);
-    f.lnl.resize(n_boxes);
-    f.chi2.resize(n_boxes);
-  }
-  std::vector<uint64_t> taken(n_boxes, 0);   // req_seq of the request of this mailbox that is in flight (0: none)
-  std::vector<int> pend(n_boxes);
-  std::vector<uint64_t> pend_seq(n_boxes);
-  auto deliver = [&](Flight& f, int code) {
-    for (int k = 0; k < f.n; ++k) {
-      vk_mailbox& box = boxes[f.idx[k]];
-      box.lnl = code == VK_OK ? f.lnl[k] : -std::numeric_limits<double>::infinity();
-      box.chi2 = code == VK_OK ? f.chi2[k] : std::numeric_limits<double>::infinity();
-      box.status = code;
-      __atomic_store_n(&box.resp_seq, f.seq[k], __ATOMIC_RELEASE);
-      taken[f.idx[k]] = 0;
-    }
-    if (stats) {
-      stats->batches += 1;
-      stats->evals += (uint64_t)f.n;
-      if ((uint64_t)f.n > stats->max_batch) stats->max_batch = (uint64_t)f.n;
-      stats->busy_seconds += std::chrono::duration<double>(clock::now() - f.t0).count();
-    }
-    f.active = false;
-  };
-  auto t_last_work = t_start;
-  auto t_first_pending = t_start;
-  bool waiting = false;
-  int last_batch = 0;
-  for (;;) {
-    // results that have arrived
-    int in_flight = 0, served = 0;       // launches in flight, requests they carry
-    for (int c = 0; c < n_ctx; ++c) {
-      Flight& f = fl[c];
-      if (!f.active) continue;
-      const int done = zc_finish(ctxs[c], f.n, f.lnl.data(), f.chi2.data(), false);
-      if (done != 0) {
-        deliver(f, done < 0 ? done : VK_OK);
-        t_last_work = clock::now();
-      } else {
-        ++in_flight;
-        served += f.n;
-      }
-    }
-    // one scan: who is attached, who has a new request
-    int n = 0, attached = 0;
-    for (int b = 0; b < n_boxes; ++b) {
-      vk_mailbox& box = boxes[b];
-      if (box.state != VK_BOX_ATTACHED) continue;
-      ++attached;
-      const uint64_t r = __atomic_load_n(&box.req_seq, __ATOMIC_ACQUIRE);
-      if (r != box.resp_seq && r != taken[b]) {
-        pend[n] = b;
-        pend_seq[n] = r;
-        ++n;
-      }
-    }
-    const auto now = clock::now();
-    // the slice is over (or the owner is leaving): nothing new is started, what is in flight is brought home, then back to
-    // the caller - also under a load that never leaves a quiet moment
-    const bool expired = *stop || std::chrono::duration<double>(now - t_start).count() >= max_seconds;
-    if (expired) {
-      if (in_flight == 0) return VK_OK;
-      cpu_relax();
-      continue;
-    }
-    if (n == 0) {
-      waiting = false;
-      if (in_flight) {
-        cpu_relax();
-        continue;
-      }
-      const auto idle = now - t_last_work;
-      if (idle > std::chrono::milliseconds(50)) {
-        struct timespec ts = {0, 1000000};
-        nanosleep(&ts, nullptr);
-      } else if (idle > std::chrono::microseconds(200)) {
-        struct timespec ts = {0, 50000};
-        nanosleep(&ts, nullptr);
-      } else {
-        cpu_relax();
-      }
-      continue;
-    }
-    int free_ctx = -1;
-    for (int c = 0; c < n_ctx && free_ctx < 0; ++c)
-      if (!fl[c].active) free_ctx = c;
-    if (free_ctx < 0) {                 // every context is busy: the requests wait (and gather) until one comes back
-      cpu_relax();
-      continue;
-    }
-    // chains in lock-step post within a few microseconds of each other: give the ones that were part of the previous round
-    // (and one more) the window to arrive, so that they share a launch instead of splitting into ever smaller batches -
-    // but only among the chains that are not being served already
-    // (with no more clients than contexts every request simply takes a context of its own, at once: measured, 4 chains on 4
-    // contexts 160 k evaluations/s without the window against 144 k with it - tools/gpu_broker_sweep.py, profiles/r04)
-    const int expect = std::min(std::min(attached - served, last_batch + 1), cap);
-    if (n < expect && window.count() > 0 && attached > n_ctx) {
-      if (!waiting) {
-        waiting = true;
-        t_first_pending = now;
-      }
-      if (now - t_first_pending < window) {
-        cpu_relax();
-        continue;
-      }
-      if (stats) stats->windows_timed_out += 1;
-    }
-    waiting = false;
-    Flight& f = fl[free_ctx];
-    vk_ctx* ctx = ctxs[free_ctx];
-    if (n > cap) n = cap;                              // the others stay pending: the next free context takes them
-    f.n = n;
-    for (int k = 0; k < n; ++k) {
-      f.idx[k] = pend[k];
-      f.seq[k] = pend_seq[k];
-      taken[pend[k]] = pend_seq[k];
-      memcpy(&f.rows[(size_t)k * VK_NPAR], boxes[pend[k]].row, VK_NPAR * sizeof(double));
-    }
-    f.t0 = clock::now();
-    f.active = true;
-    last_batch = n;
-    HostScratch sc;
-    rc = hipSetDevice(ctx->device) == hipSuccess ? host_scratch(ctx, n, &sc) : VK_E_HIP;
-    if (rc == VK_OK) {
-      sync_knobs(ctx);
-      ctx->split_as_single = true;
-      rc = zc_begin(ctx, opts, f.rows.data(), n, true, sc.d_th);
-      if (rc == 0) {                    // no in-place buffers on this system (or a development knob): the blocking call
-        rc = vk_eval_batch(ctx, opts, f.rows.data(), n, f.lnl.data(), f.chi2.data(), nullptr);
-        ctx->split_as_single = false;
-        deliver(f, rc);
-        t_last_work = clock::now();
-        rc = 1;
-      }
-    }
-    ctx->split_as_single = false;
-    if (rc < 0) {
-      deliver(f, rc);                   // the requesting mailboxes learn about it; the loop goes on
-      t_last_work = clock::now();
-    }
-  }
-}
-
 static int general_grid(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, int64_t n, const double* s,
                         int32_t n_s, const double* mu, int32_t n_mu, const double* w_ell, int32_t n_ell, double* out,
                         bool project) {
@@ -2592,7 +1766,7 @@ static int general_grid(vk_ctx* ctx, const vk_eval_opts* opts, const double* par
   if (rc) return rc;
   if (n < 0 || n_s < 1 || n_mu < 2 || !params || !s || !mu || !out) return fail(ctx, VK_E_ARG, "bad arguments");
   if (ctx->begun_n != 0) return fail(ctx, VK_E_ARG, "a batch begun with vk_eval_batch_begin is awaiting vk_eval_batch_finish on this context");
-  if (project && (n_ell < 1 || n_ell > kMaxEll || !w_ell)) return fail(ctx, VK_E_ARG, "n_ell must be 1..3 (or a VK_LITE development build)");
+  if (project && (n_ell < 1 || n_ell > kMaxEll || !w_ell)) return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
   if (n == 0) return VK_OK;
   VK_HIP(ctx, hipSetDevice(ctx->device));
   const int ne = project ? n_ell : 1;
@@ -2673,181 +1847,6 @@ int vk_theory_batch(vk_ctx* ctx, const vk_eval_opts* opts, const double* params,
 int vk_xi_smu_batch(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, int64_t n, const double* s,
                     int32_t n_s, const double* mu, int32_t n_mu, double* out) {
   return general_grid(ctx, opts, params, n, s, n_s, mu, n_mu, nullptr, 0, out, false);
-}
-
-// ---- RCCL -----------------------------------------------------------------------------------------
-int vk_comm_unique_id(char* id_out) {
-  void* lib = open_rccl();
-  if (!lib || !id_out) return VK_E_RCCL;
-  auto get = (fn_get_id)dlsym(lib, "ncclGetUniqueId");
-  if (!get) return VK_E_RCCL;
-  rccl_id_t id;
-  if (get(&id) != 0) return VK_E_RCCL;
-  memcpy(id_out, id.internal, VK_COMM_ID_BYTES);
-  return VK_OK;
-}
-
-int vk_comm_init(vk_ctx* ctx, const char* id, int rank, int nranks) {
-  if (!ctx || !id) return VK_E_ARG;
-  void* lib = open_rccl();
-  if (!lib) return fail(ctx, VK_E_RCCL, "cannot load librccl (looked next to %s first): %s", hip_runtime_path().c_str(), dlerror());
-  auto init = (fn_init_rank)dlsym(lib, "ncclCommInitRank");
-  if (!init) return fail(ctx, VK_E_RCCL, "ncclCommInitRank not found");
-  VK_HIP(ctx, hipSetDevice(ctx->device));
-  rccl_id_t uid;
-  memcpy(uid.internal, id, VK_COMM_ID_BYTES);
-  int rc = init(&ctx->comm, nranks, uid, rank);
-  if (rc != 0) {
-    auto es = (fn_errstr)dlsym(lib, "ncclGetErrorString");
-    ctx->comm = nullptr;
-    return fail(ctx, VK_E_RCCL, "ncclCommInitRank failed: %s", es ? es(rc) : "?");
-  }
-  ctx->rccl_lib = lib;
-  ctx->comm_nranks = nranks;
-  return VK_OK;
-}
-
-// An all-gather of host data that the caller collects LATER: the rows go into pinned memory, upload, ncclAllGather and download
-// are enqueued on the context's stream, nothing waits.  vk_comm_allgather_host_finish waits for the download's event - by
-// then, one block of walker steps later, long past - and hands the gathered rows over.
-int vk_comm_allgather_host_begin(vk_ctx* ctx, const double* send, int64_t count) {
-  if (!ctx || !ctx->comm) return fail(ctx, VK_E_RCCL, "communicator not initialised");
-  if (!send || count < 1) return fail(ctx, VK_E_ARG, "vk_comm_allgather_host_begin: NULL buffer or count < 1");
-  if (ctx->comm_begun != 0) return fail(ctx, VK_E_ARG, "vk_comm_allgather_host_begin: the previous gather has not been collected");
-  VK_HIP(ctx, hipSetDevice(ctx->device));
-  const int64_t slots = 1 + (int64_t)ctx->comm_nranks;
-  if (count > ctx->comm_cap) {
-    VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);
-    if (ctx->d_comm) (void)hipFree(ctx->d_comm);
-    ctx->h_comm = ctx->d_comm = nullptr;
-    ctx->comm_cap = 0;
-    VK_HIP(ctx, hipHostMalloc((void**)&ctx->h_comm, (size_t)slots * count * sizeof(double), hipHostMallocDefault));
-    VK_HIP(ctx, hipMalloc((void**)&ctx->d_comm, (size_t)slots * count * sizeof(double)));
-    ctx->comm_cap = count;
-  }
-  if (!ctx->ev_comm) VK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_comm, hipEventDisableTiming));
-  memcpy(ctx->h_comm, send, (size_t)count * sizeof(double));
-  VK_HIP(ctx, hipMemcpyAsync(ctx->d_comm, ctx->h_comm, (size_t)count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  const int rc = vk_comm_allgather_async(ctx, ctx->d_comm, ctx->d_comm + ctx->comm_cap, count);
-  if (rc) return rc;
-  VK_HIP(ctx, hipMemcpyAsync(ctx->h_comm + ctx->comm_cap, ctx->d_comm + ctx->comm_cap, (size_t)ctx->comm_nranks * count * sizeof(double),
-                             hipMemcpyDeviceToHost, ctx->stream));
-  VK_HIP(ctx, hipEventRecord(ctx->ev_comm, ctx->stream));
-  ctx->comm_begun = count;
-  return VK_OK;
-}
-
-int vk_comm_allgather_host_finish(vk_ctx* ctx, double* recv) {
-  if (!ctx) return VK_E_ARG;
-  const int64_t count = ctx->comm_begun;
-  if (count == 0) return fail(ctx, VK_E_ARG, "vk_comm_allgather_host_finish: nothing was begun on this context");
-  if (!recv) return fail(ctx, VK_E_ARG, "vk_comm_allgather_host_finish: NULL buffer");
-  ctx->comm_begun = 0;
-  VK_HIP(ctx, hipSetDevice(ctx->device));
-  VK_HIP(ctx, hipEventSynchronize(ctx->ev_comm));
-  memcpy(recv, ctx->h_comm + ctx->comm_cap, (size_t)ctx->comm_nranks * count * sizeof(double));
-  return VK_OK;
-}
-
-int vk_comm_allgather_async(vk_ctx* ctx, const double* d_send, double* d_recv, int64_t count) {
-  if (!ctx || !ctx->comm) return fail(ctx, VK_E_RCCL, "communicator not initialised");
-  if (!d_send || !d_recv || count < 0) return fail(ctx, VK_E_ARG, "vk_comm_allgather_async: NULL buffer or negative count");
-  auto ag = (fn_allgather)dlsym(ctx->rccl_lib, "ncclAllGather");
-  if (!ag) return fail(ctx, VK_E_RCCL, "ncclAllGather not found");
-  const int kNcclDouble = 8;  // ncclFloat64 in rccl.h
-  int rc = ag(d_send, d_recv, (size_t)count, kNcclDouble, ctx->comm, ctx->stream);
-  if (rc != 0) return fail(ctx, VK_E_RCCL, "ncclAllGather failed (%d)", rc);
-  return VK_OK;
-}
-
-int vk_device_bus_id(const vk_ctx* ctx, char* buf, size_t len) {
-  if (!ctx || !buf || len < 16) return VK_E_ARG;
-  if (hipDeviceGetPCIBusId(buf, (int)len, ctx->device) != hipSuccess) {
-    (void)hipGetLastError();
-    snprintf(buf, len, "device%d", ctx->device);
-  }
-  return VK_OK;
-}
-
-int vk_comm_init_all(vk_ctx* const* ctxs, int32_t n) {
-  if (!ctxs || n < 1 || !ctxs[0]) return VK_E_ARG;
-  vk_ctx* lead = ctxs[0];
-  std::vector<int> devs(n);
-  for (int i = 0; i < n; ++i) {
-    if (!ctxs[i]) return fail(lead, VK_E_ARG, "context %d is NULL", i);
-    if (ctxs[i]->comm) return fail(lead, VK_E_ARG, "context %d already has a communicator", i);
-    devs[i] = ctxs[i]->device;
-    for (int j = 0; j < i; ++j)
-      if (devs[j] == devs[i]) return fail(lead, VK_E_RCCL, "contexts %d and %d share device %d: RCCL needs one device per rank", j, i, devs[i]);
-  }
-  void* lib = open_rccl();
-  if (!lib) return fail(lead, VK_E_RCCL, "cannot load librccl (looked next to %s first): %s", hip_runtime_path().c_str(), dlerror());
-  auto init = (fn_init_all)dlsym(lib, "ncclCommInitAll");
-  if (!init) return fail(lead, VK_E_RCCL, "ncclCommInitAll not found");
-  std::vector<void*> comms(n, nullptr);
-  const int rc = init(comms.data(), n, devs.data());
-  if (rc != 0) {
-    auto es = (fn_errstr)dlsym(lib, "ncclGetErrorString");
-    return fail(lead, VK_E_RCCL, "ncclCommInitAll failed: %s", es ? es(rc) : "?");
-  }
-  for (int i = 0; i < n; ++i) {
-    ctxs[i]->comm = comms[i];
-    ctxs[i]->rccl_lib = lib;
-    ctxs[i]->comm_nranks = n;
-  }
-  return VK_OK;
-}
-
-int vk_comm_allgather_group_async(vk_ctx* const* ctxs, int32_t n, const double* const* d_send, double* const* d_recv,
-                                  int64_t count) {
-  if (!ctxs || n < 1 || !ctxs[0] || !d_send || !d_recv || count < 0) return VK_E_ARG;
-  vk_ctx* lead = ctxs[0];
-  for (int i = 0; i < n; ++i) {
-    if (!ctxs[i] || !ctxs[i]->comm) return fail(lead, VK_E_RCCL, "context %d has no communicator", i);
-    if (!d_send[i] || !d_recv[i]) return fail(lead, VK_E_ARG, "vk_comm_allgather_group_async: NULL buffer for context %d", i);
-  }
-  auto ag = (fn_allgather)dlsym(lead->rccl_lib, "ncclAllGather");
-  auto gs = (fn_group)dlsym(lead->rccl_lib, "ncclGroupStart");
-  auto ge = (fn_group)dlsym(lead->rccl_lib, "ncclGroupEnd");
-  if (!ag || !gs || !ge) return fail(lead, VK_E_RCCL, "ncclAllGather / ncclGroupStart / ncclGroupEnd not found");
-  const int kNcclDouble = 8;  // ncclFloat64 in rccl.h
-  int rc = gs();
-  for (int i = 0; i < n && rc == 0; ++i) rc = ag(d_send[i], d_recv[i], (size_t)count, kNcclDouble, ctxs[i]->comm, ctxs[i]->stream);
-  const int rc_end = ge();
-  if (rc != 0 || rc_end != 0) return fail(lead, VK_E_RCCL, "grouped ncclAllGather failed (%d, %d)", rc, rc_end);
-  return VK_OK;
-}
-
-// Which HIP runtime and which RCCL this process ended up with (a multi-GPU record must be diagnosable from its JSON line)
-int vk_comm_info(char* buf, size_t len) {
-  if (!buf || len == 0) return VK_E_ARG;
-  int hip_rt = 0, hip_drv = 0, rccl_ver = 0;
-  (void)hipRuntimeGetVersion(&hip_rt);
-  (void)hipDriverGetVersion(&hip_drv);
-  std::string asked, rccl_path;
-  void* lib = open_rccl(&asked);
-  if (lib) {
-    typedef int (*fn_ver)(int*);
-    if (auto ver = (fn_ver)dlsym(lib, "ncclGetVersion")) (void)ver(&rccl_ver);
-    rccl_path = object_of(dlsym(lib, "ncclAllGather"));
-  }
-  const std::string hip_path = hip_runtime_path();
-  const bool same_dir = lib && !rccl_path.empty() && dir_of(rccl_path) == dir_of(hip_path);
-  snprintf(buf, len,
-           "{\"hip_runtime\": \"%s\", \"hip_runtime_version\": %d, \"hip_driver_version\": %d, \"built_with_hip\": \"%d.%d.%d\", "
-           "\"rccl\": \"%s\", \"rccl_opened_as\": \"%s\", \"rccl_version\": %d, \"rccl_next_to_hip_runtime\": %s}",
-           hip_path.c_str(), hip_rt, hip_drv, HIP_VERSION_MAJOR, HIP_VERSION_MINOR, HIP_VERSION_PATCH,
-           lib ? rccl_path.c_str() : "", asked.c_str(), rccl_ver, same_dir ? "true" : "false");
-  return lib ? VK_OK : VK_E_RCCL;
-}
-
-int vk_comm_destroy(vk_ctx* ctx) {
-  if (!ctx || !ctx->comm) return VK_OK;
-  auto destroy = (fn_destroy)dlsym(ctx->rccl_lib, "ncclCommDestroy");
-  if (destroy) destroy(ctx->comm);
-  ctx->comm = nullptr;
-  return VK_OK;
 }
 
 }  // extern "C"

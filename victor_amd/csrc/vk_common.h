@@ -4,6 +4,7 @@
 
 #include "victor_hip.h"
 #include "vk_devmath.h"
+#include "vk_views.h"
 
 namespace vk {
 
@@ -27,13 +28,7 @@ constexpr int kMaxParts = 8;             // workgroups that may share one (point
 // --------------------------------------------------------------------------------------------------
 // device-side views
 // --------------------------------------------------------------------------------------------------
-struct PPView {           // a vk_pp living in global memory (device pointers)
-  int n_int;
-  int lead;
-  double inv_h;
-  const double* knots;
-  const double* coef;
-};
+// (PPView - a vk_pp living in global memory, device pointers - is in vk_views.h: the host-compiled units hold it in vk_ctx)
 
 constexpr int kLikeRed = 4 * kWaves;     // doubles of reduction scratch behind the theory vector of a fused tail (4 sums x kWaves)
 struct LikeArgs {
