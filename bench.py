@@ -1064,6 +1064,10 @@ def main():
                   "theory_kernel_ms_per_rank": ks}
 
     comm_info = _native.comm_info() if (rank == 0 and (total > 1 or launched)) else None
+    # what RCCL itself saw: ncclCommCount / ncclCommUserRank / ncclCommCuDevice of every rank's LIVE communicator beside its PCI bus id
+    rank_records = gatherer.rank_records() if (total > 1 or launched) else None
+    if comm_info is not None:
+        comm_info["ranks"] = rank_records
     out = None
     if rank == 0:
         value = B * total * args.steps / elapsed

@@ -55,6 +55,9 @@ def test_bench_two_ranks_gather_through_the_communicator(tmp_path):
     assert out["n_gpus"] == 2 and out["config"]["processes"] == 2 and out["scaling"] == "weak"
     assert out["config"]["gather"].startswith("rccl allgather of lnL (ncclCommInitRank"), out["config"]["gather"]      # not "host ..."
     assert out["config"]["rccl"]["rccl"].endswith("librccl_double.so") and out["config"]["rccl"]["rccl_version"] == 1
+    # every rank's live communicator, asked through vk_comm_rank_info: two ranks, numbered as launched, sharing the one device
+    ranks = out["config"]["rccl"]["ranks"]
+    assert [r["count"] for r in ranks] == [2, 2] and [r["rank"] for r in ranks] == [0, 1] and ranks[0]["bus_id"] == ranks[1]["bus_id"], ranks
     # every rank checked EVERY slot of its gathered vector: its own shard bit for bit, the other rank's against its own
     # recomputation of that rank's rows - the rank-major layout of the receive buffer
     assert out["gather_matches_local"] is True and out["outputs_finite"] is True
@@ -134,6 +137,8 @@ assert one_device_per_rank(dist, eng)
 uid = eng.comm_unique_id() if dist.rank == 0 else None
 uid = dist.broadcast_bytes(uid, src=0, nbytes=128)
 eng.comm_init(uid, dist.rank, dist.world)
+info = eng.comm_rank_info()
+assert info["count"] == dist.world and info["rank"] == dist.rank, info
 n = int(sys.argv[2])
 rows = fit._fit_rows(cases.halton_params(n, with_beta=True), fit.model)
 sharded = ShardedLikelihood(fit.log_likelihood_batch, dist, gather="rccl", engine=eng)

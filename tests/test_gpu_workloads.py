@@ -348,6 +348,9 @@ def test_bench_single_launched_rank_gathers_through_rccl():
     assert line["n_gpus"] == 1 and line["gather_matches_local"] is True
     assert line["config"]["gather"].startswith("rccl allgather of lnL (ncclCommInitRank"), line["config"]["gather"]
     assert "torch" not in line["config"]["rccl"]["hip_runtime"] and line["config"]["rccl"]["rccl_next_to_hip_runtime"] is True
+    # what the real RCCL says about the communicator it built: one rank, rank 0, on the device whose bus id the record names
+    (rec,) = line["config"]["rccl"]["ranks"]
+    assert rec["count"] == 1 and rec["rank"] == 0 and rec["device"] == 0 and len(rec["bus_id"]) >= 7, rec
 
 
 def test_bench_one_process_two_contexts_on_one_gpu():

@@ -835,3 +835,41 @@ def test_no_gpu_test_asserts_on_elapsed_time_rates_or_ratios():
                 if timing.search(text):
                     found.append(f"{os.path.basename(f)}:{node.lineno}: {text[:120]}")
     assert not found, "\n".join(found)
+
+
+def test_tools_are_current():
+    """tools/ after the round-6 audit: every script byte-compiles (shell scripts pass `bash -n`), sets only VICTOR_HIP_* names
+    that something reads - the library's development knobs (load_knobs), its two RCCL hooks, or the package's own switches -,
+    has its line in tools/README.md, and no development knob of the library is left without a user (a tool or a test)."""
+    import glob
+    import re
+    import subprocess
+    tools = os.path.join(_ROOT, "tools")
+    csrc = os.path.join(_ROOT, "victor_amd", "csrc")
+    knobs = set(re.findall(r'getenv\("(VICTOR_HIP_[A-Z_]+)"\)', open(os.path.join(csrc, "victor_hip.hip")).read())) - {"VICTOR_HIP_DEV"}
+    assert len(knobs) >= 10 and "VICTOR_HIP_MAPPING" in knobs
+    hooks = set(re.findall(r'getenv\("(VICTOR_HIP_[A-Z_]+)"\)', open(os.path.join(csrc, "vk_rccl.cpp")).read()))
+    package = set()
+    for f in glob.glob(os.path.join(_ROOT, "victor_amd", "*.py")):
+        package |= set(re.findall(r'"(VICTOR_HIP_[A-Z_]+)"', open(f).read()))
+    known = knobs | hooks | package | {"VICTOR_HIP_DEV"}
+    readme = open(os.path.join(tools, "README.md")).read()
+    files = sorted(f for f in os.listdir(tools) if f.endswith((".py", ".sh", ".hip")) and not f.startswith("_run"))
+    assert 40 <= len(files) <= 60
+    used = set()
+    for f in files:
+        path = os.path.join(tools, f)
+        src = open(path).read()
+        if f.endswith(".py"):
+            compile(src, path, "exec")
+        elif f.endswith(".sh"):
+            assert subprocess.run(["bash", "-n", path], capture_output=True).returncode == 0, f
+        names = set(re.findall(r"VICTOR_HIP_[A-Z_]+[A-Z]", src))
+        assert names <= known, (f, names - known)
+        used |= names
+        assert f"`{f}" in readme, f"{f} has no line in tools/README.md"
+    for listed in re.findall(r"^\| `([\w.]+\.(?:py|sh|hip))", readme, flags=re.M):
+        assert listed in files, f"tools/README.md lists {listed}, which is not there"
+    tests_src = "".join(open(f).read() for f in glob.glob(os.path.join(_ROOT, "tests", "*.py")))
+    idle = {k for k in knobs if k not in used and k not in tests_src}
+    assert not idle, f"development knobs nobody sets: {idle}"

@@ -94,6 +94,20 @@ def test_cobaya_plugin_contract_matches_reference(ref):
     assert abs(state["derived"]["chi2_ccf_correct"] - g["boss_cobaya_chi2"][0]) < 1e-9
 
 
+def test_plugin_defaults_list_their_keys_in_the_reference_order(ref):
+    """cobaya lists the parameters a likelihood declares in the order of its defaults file, and a chain's columns follow: the
+    plug-in's CCFLikelihood.yaml must load to the reference's dictionary WITH the reference's key order (top level and params)."""
+    import yaml
+    import ref_shim
+    with open(os.path.join(ref_shim.REFERENCE_ROOT, "victor", "likelihoods", "CCFLikelihood.yaml")) as fh:
+        theirs = yaml.full_load(fh)
+    with open(os.path.join(ROOT, "victor", "likelihoods", "CCFLikelihood.yaml")) as fh:
+        ours = yaml.full_load(fh)
+    assert ours == theirs
+    assert list(ours) == list(theirs) and list(ours["params"]) == list(theirs["params"])
+    assert list(ours["params"])[:7] == ["fsigma8", "beta", "epsilon", "b", "alpha", "aperp", "apar"]
+
+
 @pytest.mark.parametrize("with_beta", [False, True])
 def test_oracle_rmu_format_equals_reference(ref, tmp_path, with_beta):
     import victor_oracle as vo

@@ -1,4 +1,4 @@
-"""Same-box A/B of library builds: kernel time of the theory launch for BOSS (cells kernel) and config 3 (lanes kernel) at 65536
+"""Same-box A/B of library builds: kernel time of the theory launch for BOSS and config 3 (cells kernel) at 65536
 points.  Usage: gpu_ab_libs.py libA.so libB.so ...   (each build is timed in its own process, the round is repeated)"""
 import json
 import os

@@ -1,5 +1,5 @@
 """Where a small-batch launch of the point-major kernel spends its time: wall_clock64() marks (100 MHz) per workgroup from the
-profiling build (make -C victor_amd/csrc phases).  Usage: VICTOR_HIP_LIB=victor_amd/csrc/libvictor_hip_phases.so gpu_phases.py {3|boss} BATCH [api]"""
+profiling build (python -m victor_amd.build --phases).  Usage: VICTOR_HIP_LIB=victor_amd/csrc/libvictor_hip_phases.so gpu_phases.py {3|boss} BATCH [api]"""
 import ctypes as C
 import os
 import sys

@@ -175,5 +175,8 @@ if __name__ == "__main__":
     import sys
     import time
     t0 = time.perf_counter()
-    print(build_native(force="--no-force" not in sys.argv, verbose=True, dev="--dev" in sys.argv, both="--both" in sys.argv))
+    if "--phases" in sys.argv:       # profiling build with wall_clock64() phase marks in the kernels (tools/gpu_phases.py; VICTOR_HIP_LIB selects it)
+        print(build_native(force=True, verbose=True, defines=("-DVK_PHASES",), out=os.path.join(CSRC, "libvictor_hip_phases.so")))
+    else:
+        print(build_native(force="--no-force" not in sys.argv, verbose=True, dev="--dev" in sys.argv, both="--both" in sys.argv))
     print(f"build wall time {time.perf_counter() - t0:.1f} s")

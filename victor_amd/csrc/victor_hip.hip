@@ -165,22 +165,17 @@ void load_knobs(vk_ctx* ctx) {
   }
   if (const char* env = getenv("VICTOR_HIP_FUSE_MAX")) k.fuse_max = atoll(env);
   if (const char* env = getenv("VICTOR_HIP_CELLS_PARTS")) k.cells_parts = atoi(env);
-  if (const char* env = getenv("VICTOR_HIP_LIKE_WIDE")) k.like_wide = atoi(env) ? 1 : 0;
-  if (const char* env = getenv("VICTOR_HIP_CELLS_MIN")) k.cells_min = atoll(env);
   k.no_zero_copy = getenv("VICTOR_HIP_NO_ZERO_COPY") != nullptr;
-  if (const char* env = getenv("VICTOR_HIP_ZERO_COPY_MAX")) k.zero_copy_max = atoll(env);
   if (const char* env = getenv("VICTOR_HIP_SPIN_MAX")) k.spin_max = atoll(env);
   if (const char* env = getenv("VICTOR_HIP_NO_POLL")) k.no_poll = atoi(env) != 0;
   k.force_generic = getenv("VICTOR_HIP_FORCE_GENERIC") != nullptr;
   if (const char* env = getenv("VICTOR_HIP_POINT_CAP")) k.point_cap = atoll(env);
-  if (const char* env = getenv("VICTOR_HIP_LANES_CAP")) k.lanes_cap = atoll(env);
   if (const char* env = getenv("VICTOR_HIP_MAPPING"))
     k.mapping = !strcmp(env, "point") ? 1 : !strcmp(env, "cells") ? 2 : !strcmp(env, "lanes") ? 3 : -1;
   k.like_untiled = getenv("VICTOR_HIP_LIKE_UNTILED") != nullptr;
   k.no_graph = getenv("VICTOR_HIP_NO_GRAPH") != nullptr;
   k.no_fuse = getenv("VICTOR_HIP_NO_FUSE") != nullptr;
   k.no_inline_row = getenv("VICTOR_HIP_NO_INLINE_ROW") != nullptr;
-  k.lanes_by_chunk = getenv("VICTOR_HIP_LANES_BY_CHUNK") != nullptr;
   ctx->knobs = k;
 }
 
@@ -630,11 +625,11 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
       ctx->last_kernel = "vk_theory_lanes_kernel";
       a.parts = 1;
       a.image = get_image(ctx, a, 2, nlr, 0, make_lanes_plan(a.n_mu, a.n_x, a.uni_n, nlr, a.uni_lut_n).image_end);
-      a.lanes_per_block = ctx->knobs.lanes_by_chunk ? a.n_s : kWaves;
-      const long long blocks = ctx->knobs.lanes_by_chunk ? (a.n + 63) >> 6 : blocks_l;
+      a.lanes_per_block = kWaves;
+      const long long blocks = blocks_l;
       // One workgroup per four items, never a grid-stride loop by default (a cap that makes workgroups loop leaves a ragged
       // tail of 0.6 ms items: 131072 points ran at 1.61 M evals/s under a 64-per-CU cap against 2.35 M without)
-      const long long capl = ctx->knobs.lanes_cap > 0 ? ctx->knobs.lanes_cap * ctx->n_cu : (long long)INT32_MAX;   // A/B knob
+      const long long capl = (long long)INT32_MAX;
       const int grid_l = (int)(blocks < capl ? blocks : capl);
       switch (nlr) {
         case 1: return launch_lanes_nl<1>(ctx, a, grid_l, lds_l);
@@ -650,7 +645,7 @@ int launch_theory(vk_ctx* ctx, TheoryArgs a, int nlr, const LikeArgs* like, bool
   // 21.1 / 20.3 us point-major vs 25.9 / 24.2 cells, 16: 25.7 / 24.5 vs 27.2 / 25.1, 32: 41.3 / 36.7 vs 30.6 / 28.0
   // (re-measured after both kernels lost their grid-stride loops, tools/gpu_cells_min_sweep.py, profiles/r03/z_*: point-major
   // ahead up to 12 / 16 points, level at 20, the cells kernel ahead from 24 / 28 on)
-  const long long cells_min = ctx->knobs.cells_min >= 0 ? ctx->knobs.cells_min : 20;
+  const long long cells_min = 20;
   const bool cells = cells_ok && (kais || sva_disp || (mapping ? mapping == 2 : n_dec >= cells_min));   // kaiser, dispersion x sigma_v(r, mu): this kernel only
   if (cells) {
     ctx->last_kernel = "vk_theory_cells_kernel";
@@ -802,7 +797,7 @@ int launch_like(vk_ctx* ctx, const LikeArgs& a) {
   // small batches: one workgroup per point (the wave-per-point kernels below need >= 1024 points to fill the chip; a
   // single point took 27 us in one wave against the ~3 us of 256 threads)
   const size_t lds_wide = (size_t)like_lds_doubles(ctx->N) * sizeof(double);
-  const bool wide = ctx->knobs.like_wide >= 0 ? ctx->knobs.like_wide == 1 : n <= 2048;
+  const bool wide = n <= 2048;
   if (wide && lds_wide <= 160 * 1024) {
     return launch_on_stream(ctx, vk_like_wide_kernel, (int)n, lds_wide, a);      // one point per workgroup
   }
@@ -1580,7 +1575,7 @@ static bool ensure_zero_copy(vk_ctx* ctx) {
 }
 
 extern "C++" int vkh::zc_begin(vk_ctx* ctx, const vk_eval_opts* opts, const double* params, int64_t n, bool want_out, double* d_th) {
-  const int64_t zc_max = ctx->knobs.zero_copy_max >= 0 ? std::min<int64_t>(ctx->knobs.zero_copy_max, kZeroCopyCap) : kZeroCopyMaxDefault;
+  const int64_t zc_max = kZeroCopyMaxDefault;
   if (n > zc_max || ctx->timing || !want_out || !ensure_zero_copy(ctx)) return 0;
   double* h_out = ctx->h_zc + (size_t)kZeroCopyCap * VK_NPAR;
   double* d_out = ctx->d_zc + (size_t)kZeroCopyCap * VK_NPAR;

@@ -28,20 +28,15 @@ struct Knobs {
   int split_s = 0, split_t = 0;        // VICTOR_HIP_SPLIT "spi,team"
   bool force_generic = false;          // VICTOR_HIP_FORCE_GENERIC
   long long point_cap = 0;             // VICTOR_HIP_POINT_CAP   (workgroups per CU, generic theory kernel; 0 = default)
-  long long lanes_cap = 0;             // VICTOR_HIP_LANES_CAP   (0 = uncapped)
   int mapping = 0;                     // VICTOR_HIP_MAPPING: 0 auto, 1 point, 2 cells, 3 lanes, -1 unknown name
   bool like_untiled = false;           // VICTOR_HIP_LIKE_UNTILED
   bool no_graph = false;               // VICTOR_HIP_NO_GRAPH
-  bool lanes_by_chunk = false;         // VICTOR_HIP_LANES_BY_CHUNK: a workgroup takes all s bins of a 64-point chunk (A/B)
   bool no_fuse = false;                // VICTOR_HIP_NO_FUSE: keep chi2 in its own launch (A/B of the fused path)
   bool no_inline_row = false;          // VICTOR_HIP_NO_INLINE_ROW: single-point host calls read their row from the pinned buffer (A/B)
   long long fuse_max = -1;             // VICTOR_HIP_FUSE_MAX: largest batch whose chi2 is taken inside the theory kernel (-1 = default)
   int split_q = 0;                     // third field of VICTOR_HIP_SPLIT "spi,team,parts": workgroups per (mu, v) plane
   int cells_parts = 0;                 // VICTOR_HIP_CELLS_PARTS: workgroups per point in the cells kernel (0 = choose)
-  int like_wide = -1;                  // VICTOR_HIP_LIKE_WIDE: 1 / 0 force the workgroup-per-point chi2 kernel on / off
-  long long cells_min = -1;            // VICTOR_HIP_CELLS_MIN: smallest batch that takes the cells kernel (-1 = default)
   bool no_zero_copy = false;           // VICTOR_HIP_NO_ZERO_COPY: small host-buffer batches through the copy / graph path
-  long long zero_copy_max = -1;        // VICTOR_HIP_ZERO_COPY_MAX: largest host-buffer batch on the in-place path (-1 = default)
   long long spin_max = -1;             // VICTOR_HIP_SPIN_MAX: largest in-place batch whose results are polled for (-1 = default, 0 = never)
   bool no_poll = false;                // VICTOR_HIP_NO_POLL: split single-point launches hand over through the completion counters (A/B)
 };

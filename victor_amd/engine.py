@@ -535,6 +535,15 @@ class Engine:
     def comm_destroy(self):
         self._check(self._lib.vk_comm_destroy(self._ctx))
 
+    def comm_rank_info(self):
+        """What the live communicator of this context says about itself - {"count": ncclCommCount, "rank": ncclCommUserRank,
+        "device": ncclCommCuDevice}, a value ``None`` where the loaded RCCL does not export the call - or ``None`` without a
+        communicator.  A multi-GPU record carries it per rank next to the PCI bus id (bench.py: ``config.rccl.ranks``)."""
+        c, r, d = C.c_int32(), C.c_int32(), C.c_int32()
+        if self._lib.vk_comm_rank_info(self._ctx, C.byref(c), C.byref(r), C.byref(d)) != 0:
+            return None
+        return {k: (v.value if v.value >= 0 else None) for k, v in (("count", c), ("rank", r), ("device", d))}
+
     # one process driving several GPUs: the engines of a group, context i = rank i (vk_comm_init_all)
     @staticmethod
     def comm_init_all(engines):

@@ -319,6 +319,23 @@ class DeviceGather:
             for e, p in zip(self.engines, d_recv):
                 e.upload(p, full)
 
+    def rank_records(self):
+        """Per GPU of the run, in rank order: what RCCL itself reports for its communicator (``Engine.comm_rank_info``) beside the
+        PCI bus id the ranks compared before building it - [{"bus_id", "count", "rank", "device"}, ...]; ``count`` etc. are
+        ``None`` in the host mode (no communicator).  Collective when launched."""
+        import json
+        mine = []
+        for e in self.engines:
+            info = e.comm_rank_info() if self.mode in ("rank", "group") else None
+            mine.append(dict({"bus_id": e.bus_id()}, **(info or {"count": None, "rank": None, "device": None})))
+        if not self.launched:
+            return mine
+        blob = json.dumps(mine).encode().ljust(512, b" ")[:512]
+        out = []
+        for r in range(self.dist.world):
+            out.extend(json.loads(self.dist.broadcast_bytes(blob if r == self.dist.rank else None, src=r, nbytes=512).decode()))
+        return out
+
     def close(self):
         if getattr(self, "_have_comm", False):
             for e in self.engines:
