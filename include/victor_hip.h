@@ -321,8 +321,9 @@ int vk_eval_batch_finish(vk_ctx* ctx, double* lnl, double* chi2);
  * from the priors / proposal widths of the same `params:` block (config/boss_cobaya_config.yaml:50-97 of the reference).
  * vk_walk_run is that sampler's step loop in the library: the ensemble as two halves on two contexts (vk_eval_batch_begin /
  * _finish: half A of step t + 1 is on the GPU while half B of step t is accepted / rejected), rows formed as
- * CCFModel._param_rows forms them, the caller's pre-drawn random numbers - the same launches and the same decisions as the
- * Python loop, hence the same chain (tests/test_gpu_workloads.py), without the host's ~20 NumPy calls per step.
+ * CCFModel._param_rows forms them (one routine for the Alcock-Paczynski factors: vk_epsilon_to_ap), the caller's pre-drawn
+ * random numbers - without `speculate` the same launches as the Python loop, hence the same chain bit for bit
+ * (tests/test_gpu_workloads.py), without the host's ~20 NumPy calls per step.
  *   columns[j]   row column (VK_P_*) the j-th sampled parameter is written to, or VK_WALK_EPSILON: the parameter is epsilon and
  *                the columns APERP, APAR, EPSILON follow from it (apar = alpha eps^(-2/3), aperp = eps apar, ccf_model.py:589-592)
  *   lo, hi       uniform prior box; a proposal outside it is evaluated at the walker's position, discarded, and reads -inf
@@ -331,9 +332,16 @@ int vk_eval_batch_finish(vk_ctx* ctx, double* lnl, double* chi2);
  *                the old position (rejected) - both are known when step t is proposed, so a walker's three points travel in one
  *                launch and both decisions are taken when the results arrive: two steps per round trip host -> GPU -> host
  *                (what bounds a small ensemble: the GPU is far from full) for three evaluations instead of two.  The same
- *                proposals, the same acceptance levels: the chain of the step-by-step loop; n_evals counts the evaluations the
- *                step-by-step loop would have made.  Worth it while three times the ensemble still fits the idle part of
- *                the GPU (victor_amd/sampler.py chooses; ignored when a launch would exceed 4096 rows)
+ *                proposals, the same acceptance levels as the step-by-step loop; n_evals counts the evaluations that loop
+ *                would have made.  PARITY WITH THE STEP-BY-STEP LOOP IS TO ROUNDING, NOT BIT FOR BIT: a launch of three rows
+ *                per walker takes another work split than one of one row, so the log-likelihoods agree to ~1e-13 relative
+ *                and an acceptance `logu < lnL' - lnL` decided within that margin may fall the other way; positions and
+ *                decisions were identical over every chain compared so far (thousands of steps), the stored lnL differ in
+ *                their last bits.  A caller who needs the step-by-step chain bit for bit passes speculate = 0.  What does NOT
+ *                vary: the chain for a given `speculate` is independent of how a run is cut into vk_walk_run calls - a left-
+ *                over single step travels in a launch of the same shape (its two candidate rows idle).  Worth it while three
+ *                times the ensemble still fits the idle part of the GPU (victor_amd/sampler.py chooses; ignored when a launch
+ *                would exceed 4096 rows)
  * vk_walk_run: x [W][P] and lnl [W] are the ensemble's state (in / out); dz [n_steps][W][P] the proposal increments, logu
  * [n_steps][W] the log acceptance levels; chain [n_steps][W][P] and lnl_hist [n_steps][W] receive the state after every step
  * (either may be NULL); *n_accept and *n_evals are incremented.  One or two contexts holding the same tables (two: the halves
@@ -348,6 +356,10 @@ int vk_walk_run(vk_walk* w, int64_t n_steps, double* x, double* lnl, const doubl
                 double* lnl_hist, int64_t* n_accept, int64_t* n_evals);
 const char* vk_walk_last_error(const vk_walk* w);
 void vk_walk_destroy(vk_walk* w);
+/* apar[i] = alpha * eps[i]^(-2/3) (alpha == 1: no multiply), aperp[i] = eps[i] * apar[i] with libm's pow, as the reference
+ * evaluates them on Python floats (ccf_model.py:589-592): the one routine behind every row the package forms from an epsilon.
+ * Pure host arithmetic: no context, no GPU. */
+void vk_epsilon_to_ap(const double* eps, int64_t n, double alpha, double* aperp, double* apar);
 
 /* Theory multipoles on a caller-supplied s grid: out[n][n_ell][n_s] with the caller's own
  * projection weights w_ell[n_ell][n_mu] on mu[n_mu] (host buffers). */

@@ -873,3 +873,24 @@ def test_tools_are_current():
     tests_src = "".join(open(f).read() for f in glob.glob(os.path.join(_ROOT, "tests", "*.py")))
     idle = {k for k in knobs if k not in used and k not in tests_src}
     assert not idle, f"development knobs nobody sets: {idle}"
+
+
+def test_one_routine_forms_the_alcock_paczynski_factors(lib):
+    """apar = alpha * eps^(-2/3), aperp = eps * apar (reference: ccf_model.py:589-592, on Python floats): the library's
+    vk_epsilon_to_ap gives the bits of that Python expression, and CCFModel._param_rows on ARRAYS goes through it - so a batch
+    row, a single-point row and a row of the walkers' native step loop are the same row."""
+    import victor_amd
+    from victor_amd import _native as N2
+    rng = np.random.default_rng(7)
+    eps = np.concatenate([rng.uniform(0.5, 1.5, 4000), [1.0, 0.8, 1.2, 1.04, 1e-3, 37.0]])
+    for alpha in (1.0, 0.97, 1):
+        aperp, apar = N2.epsilon_to_ap(eps, alpha)
+        want_apar = np.array([alpha * float(e) ** (-2 / 3) for e in eps])
+        assert np.array_equal(apar, want_apar) and np.array_equal(aperp, eps * want_apar)
+    model, _ = cases.boss_options("config")
+    m = victor_amd.CCFModel(model)
+    batch = {"fsigma8": np.full(eps.size, 0.47), "beta": np.full(eps.size, 0.37), "epsilon": eps, "alpha": 0.97}
+    rows = m._param_rows(batch, need_beta=True)
+    for i in (0, 17, eps.size - 1):
+        one = m._param_rows({"fsigma8": 0.47, "beta": 0.37, "epsilon": float(eps[i]), "alpha": 0.97}, need_beta=True)
+        assert np.array_equal(rows[i], one[0])

@@ -116,6 +116,7 @@ SYMBOLS = {
     "vk_walk_run": (C.c_int, [_vp, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "vk_walk_last_error": (C.c_char_p, [_vp]),
     "vk_walk_destroy": (None, [_vp]),
+    "vk_epsilon_to_ap": (None, [_dp, C.c_int64, C.c_double, _dp, _dp]),
     "vk_theory_batch": (C.c_int, [_vp, _optp, _dp, C.c_int64, _dp, C.c_int32, _dp, C.c_int32, _dp, C.c_int32, _dp]),
     "vk_xi_smu_batch": (C.c_int, [_vp, _optp, _dp, C.c_int64, _dp, C.c_int32, _dp, C.c_int32, _dp]),
     "vk_device_alloc": (_vp, [_vp, C.c_size_t]),
@@ -210,6 +211,16 @@ def comm_info():
     info = json.loads(buf.value.decode() or "{}")
     info["rccl_loaded"] = rc == 0
     return info
+
+
+def epsilon_to_ap(eps, alpha=1.0, aperp=None, apar=None):
+    """(aperp, apar) from an array of epsilons through the library's one routine (vk_epsilon_to_ap: libm's pow, as the
+    reference's Python floats take it) - also what the walkers' native step loop uses, so every route forms the same rows."""
+    eps = f64(eps)
+    aperp = np.empty_like(eps) if aperp is None else aperp
+    apar = np.empty_like(eps) if apar is None else apar
+    load().vk_epsilon_to_ap(as_dp(eps), eps.size, float(alpha), as_dp(aperp), as_dp(apar))
+    return aperp, apar
 
 
 def as_dp(a):

@@ -405,8 +405,17 @@ class CCFModel:
             raise KeyError("beta")                                   # as ccf_model.py:587
         if "epsilon" in params:
             eps = col("epsilon")
-            apar = col("alpha", 1) * eps ** (-2 / 3)
-            aperp = eps * apar
+            if isinstance(eps, float):
+                apar = col("alpha", 1) * eps ** (-2 / 3)
+                aperp = eps * apar
+            else:                                  # arrays: the library's routine (libm's pow, as the scalar path and the reference)
+                alpha = col("alpha", 1)
+                if isinstance(alpha, float):
+                    aperp, apar = N.epsilon_to_ap(eps, alpha)
+                else:
+                    aperp, apar = N.epsilon_to_ap(eps, 1.0)
+                    apar = alpha * apar
+                    aperp = eps * apar
         else:
             aperp = col("aperp", 1)
             apar = col("apar", 1)

@@ -41,16 +41,24 @@ struct vk_walk {
   std::string err;
 };
 
-// the sampled columns of one row from the walker's coordinates `xs` (CCFModel._param_rows, ccf_model.py:589-592 of the reference)
+// The Alcock-Paczynski factors from epsilon (ccf_model.py:589-592 of the reference: apar = alpha * epsilon**(-2/3), aperp =
+// epsilon * apar, on Python floats: libm's pow) - ONE routine for every row the package forms from an epsilon: the walkers'
+// rows below and, through vk_epsilon_to_ap, CCFModel._param_rows and the Python step loop (NumPy's vectorised power may
+// differ from libm's in the last bit on hosts where it runs through SVML).
+static inline void eps_to_ap(double e, double alpha, double* aperp, double* apar) {
+  double a = pow(e, -2.0 / 3.0);
+  if (alpha != 1.0) a = alpha * a;
+  *apar = a;
+  *aperp = e * a;
+}
+
+// the sampled columns of one row from the walker's coordinates `xs` (CCFModel._param_rows)
 static inline void walk_fill_row(const vk_walk* w, const double* xs, double* row) {
   for (int j = 0; j < w->P; ++j)
     if (w->col[j] >= 0) row[w->col[j]] = xs[j];
   if (w->eps >= 0) {
     const double e = xs[w->eps];
-    double apar = pow(e, -2.0 / 3.0);
-    if (w->alpha != 1.0) apar = w->alpha * apar;
-    row[VK_P_APERP] = e * apar;
-    row[VK_P_APAR] = apar;
+    eps_to_ap(e, w->alpha, &row[VK_P_APERP], &row[VK_P_APAR]);
     row[VK_P_EPSILON] = e;
   }
 }
@@ -83,6 +91,9 @@ static void walk_begin(vk_walk* w, int k, const double* x, const double* dz_t, i
 // evaluated together and the two decisions are taken when the results arrive - the ensemble advances two steps per round
 // trip host -> GPU -> host, the limit of a small ensemble, for three evaluations instead of two.  The decisions are those of
 // the step-by-step loop: the same proposals (the same additions), the same acceptance levels.
+// dz_t1 == NULL: the LAST step of a run of odd length, sent in the shape of a two-step launch (the two candidate rows hold the
+// walker's position, their results are discarded): a launch's work split follows its number of rows, so every log-likelihood of
+// a run comes from launches of one shape and its last bits do not depend on how the caller cuts the run into pieces.
 static void walk_begin2(vk_walk* w, int k, const double* x, const double* dz_t, const double* dz_t1, int* rc) {
   const int P = w->P;
   for (int i = w->lo[k]; i < w->hi[k]; ++i) {
@@ -92,8 +103,8 @@ static void walk_begin2(vk_walk* w, int k, const double* x, const double* dz_t, 
     double* pr = pa + P;
     for (int j = 0; j < P; ++j) {
       p0[j] = xi[j] + dz_t[(size_t)i * P + j];
-      pa[j] = p0[j] + dz_t1[(size_t)i * P + j];
-      pr[j] = xi[j] + dz_t1[(size_t)i * P + j];
+      pa[j] = dz_t1 ? p0[j] + dz_t1[(size_t)i * P + j] : std::numeric_limits<double>::quiet_NaN();      // (NaN: outside the box)
+      pr[j] = dz_t1 ? xi[j] + dz_t1[(size_t)i * P + j] : std::numeric_limits<double>::quiet_NaN();
     }
     const bool in0 = walk_in_box(w, p0), ina = in0 && walk_in_box(w, pa), inr = walk_in_box(w, pr);
     w->in3[(size_t)i * 3] = in0;
@@ -111,6 +122,7 @@ static void walk_begin2(vk_walk* w, int k, const double* x, const double* dz_t, 
   }
 }
 
+// logu_t1 == NULL: the launch carried one step only (walk_begin2 with dz_t1 == NULL)
 static void walk_finish_accept2(vk_walk* w, int k, double* x, double* lnl, const double* logu_t, const double* logu_t1, double* chain_t,
                                 double* hist_t, int64_t* n_accept, int64_t* n_evals, int* rc) {
   const int P = w->P;
@@ -141,6 +153,7 @@ static void walk_finish_accept2(vk_walk* w, int k, double* x, double* lnl, const
     }
     if (chain_t) memcpy(chain_t + (size_t)i * P, xi, (size_t)P * sizeof(double));
     if (hist_t) hist_t[i] = lnl[i];
+    if (!logu_t1) continue;
     // step t + 1: the candidate that belongs to the position step t left
     const int c = acc0 ? 1 : 2;
     const double lp1 = in[c] ? l3[c] : minus_inf;
@@ -264,6 +277,11 @@ vk_walk* vk_walk_create(vk_ctx* const* ctxs, int32_t n_ctx, const vk_eval_opts* 
 
 void vk_walk_destroy(vk_walk* w) { delete w; }
 
+void vk_epsilon_to_ap(const double* eps, int64_t n, double alpha, double* aperp, double* apar) {
+  if (!eps || !aperp || !apar) return;
+  for (int64_t i = 0; i < n; ++i) eps_to_ap(eps[i], alpha, &aperp[i], &apar[i]);
+}
+
 const char* vk_walk_last_error(const vk_walk* w) { return w ? w->err.c_str() : ""; }
 
 int vk_walk_run(vk_walk* w, int64_t n_steps, double* x, double* lnl, const double* dz, const double* logu, double* chain,
@@ -293,6 +311,18 @@ int vk_walk_run(vk_walk* w, int64_t n_steps, double* x, double* lnl, const doubl
       if (w->n_half == 2) walk_finish_accept2(w, 1, x, lnl, lu_t, lu_t + step_u, ch, hi, &acc, &ev, &rc);
     }
     t0 = 2 * pairs;
+  }
+  if (w->speculate && t0 < n_steps && rc == VK_OK) {
+    // one step left over: the same three-rows-per-walker launch with the candidate rows idle (walk_begin2)
+    const double* dz_t = dz + (size_t)t0 * step_x;
+    const double* lu_t = logu + (size_t)t0 * step_u;
+    double* ch = chain ? chain + (size_t)t0 * step_x : nullptr;
+    double* hi = lnl_hist ? lnl_hist + (size_t)t0 * step_u : nullptr;
+    walk_begin2(w, 0, x, dz_t, nullptr, &rc);
+    if (w->n_half == 2) walk_begin2(w, 1, x, dz_t, nullptr, &rc);
+    walk_finish_accept2(w, 0, x, lnl, lu_t, nullptr, ch, hi, &acc, &ev, &rc);
+    if (w->n_half == 2) walk_finish_accept2(w, 1, x, lnl, lu_t, nullptr, ch, hi, &acc, &ev, &rc);
+    t0 = n_steps;
   }
   if (t0 < n_steps && rc == VK_OK) walk_begin(w, 0, x, dz + (size_t)t0 * step_x, &rc);
   for (int64_t t = t0; t < n_steps && rc == VK_OK; ++t) {

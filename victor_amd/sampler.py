@@ -74,9 +74,19 @@ class EnsembleMetropolis:
     the same NumPy expressions, so a chain is the same chain whichever route evaluates it (tests/test_gpu_workloads.py).
 
     ``native`` (default, with ``fit``): :meth:`run` hands each block of pre-drawn random numbers to ``vk_walk_run``
-    (include/victor_hip.h) - the same two half-ensembles, the same pipelining, the same rows and launches as the Python loop
-    below, which remains the definition (``native=False``) and the route of :meth:`step`; what goes are the ~20 NumPy calls per
-    step that made the host the limit of a small ensemble (8 walkers: 26-28 -> 17-18 us per step).
+    (include/victor_hip.h) - the same two half-ensembles, the same pipelining, the same rows (one routine forms the
+    Alcock-Paczynski factors on every route: ``vk_epsilon_to_ap``) as the Python loop below, which remains the definition
+    (``native=False``) and the route of :meth:`step`; what goes are the ~20 NumPy calls per step that made the host the limit of
+    a small ensemble (8 walkers: 26-28 -> 17-18 us per step).
+
+    ``speculate`` (default up to ``SPECULATE_MAX_WALKERS`` walkers): the library loop takes TWO steps per launch.  **Parity with
+    the Python loop is then to rounding, not bit for bit**: a launch of three rows per walker takes another work split than one
+    of one row, so the log-likelihoods agree to ~1e-13 relative (the tests allow 1e-9) and an acceptance
+    ``logu < lnL' - lnL`` decided within that margin could fall the other way - positions and decisions were identical in
+    every comparison made (tests/test_gpu_workloads.py: thousands of steps against the Python loop, the dictionary route and an
+    oracle-driven chain), the stored log-likelihoods differ in their last bits.  Pass ``speculate=False`` where the chain of
+    ``native=False`` is wanted bit for bit (one step per launch: the same launches).  For a given setting the chain does not
+    depend on how :meth:`run` is cut into pieces: a left-over single step travels in a launch of the same shape.
     """
 
     BLOCK = 64          # steps whose proposal increments and acceptance levels are drawn together
@@ -166,7 +176,7 @@ class EnsembleMetropolis:
             "p_lnl": [C.cast(out[0].ctypes.data + lo * 8, N._dp) for lo, _ in bounds],
             "p_chi": [C.cast(out[1].ctypes.data + lo * 8, N._dp) for lo, _ in bounds],
             "t1": np.empty_like(x), "t2": np.empty_like(x), "e": [np.empty(hi - lo) for lo, hi in bounds],
-            "a": [np.empty(hi - lo) for lo, hi in bounds]}
+            "a": [np.empty(hi - lo) for lo, hi in bounds], "t_aperp": [np.empty(hi - lo) for lo, hi in bounds]}
         # views of the halves, made once: a slice is a new array object every time it is written down
         d = self._direct
         d["t1h"] = [d["t1"][lo:hi] for lo, hi in bounds]
@@ -266,11 +276,9 @@ class EnsembleMetropolis:
         if d["eps"] is not None:                      # the expressions of CCFModel._param_rows, on the same (contiguous) arrays
             eps, apar = d["e"][k], d["a"][k]
             c_aperp, c_apar, c_eps = d["derived"][k]
-            np.copyto(eps, xs[:, d["eps"]])           # as _batch() hands it over: the same loop of np.power
-            np.power(eps, -2 / 3, out=apar)
-            if d["alpha"] is not None:
-                np.multiply(d["alpha"], apar, out=apar)
-            np.multiply(eps, apar, out=c_aperp)
+            np.copyto(eps, xs[:, d["eps"]])           # as _batch() hands it over, through the same routine (vk_epsilon_to_ap)
+            N.epsilon_to_ap(eps, 1.0 if d["alpha"] is None else d["alpha"], aperp=d["t_aperp"][k], apar=apar)
+            c_aperp[:] = d["t_aperp"][k]
             c_apar[:] = apar
             c_eps[:] = eps
         eng = d["engines"][k]
