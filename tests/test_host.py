@@ -894,3 +894,32 @@ def test_one_routine_forms_the_alcock_paczynski_factors(lib):
     for i in (0, 17, eps.size - 1):
         one = m._param_rows({"fsigma8": 0.47, "beta": 0.37, "epsilon": float(eps[i]), "alpha": 0.97}, need_beta=True)
         assert np.array_equal(rows[i], one[0])
+
+
+def test_every_kernel_is_generated_in_exactly_one_translation_unit(lib, tmp_path):
+    """vk_instances.h says which theory-kernel instantiation lives in which unit; victor_hip.hip (the launch side) declares all
+    of them `extern template`.  An instantiation the launch code reaches that is in no list would silently be generated in
+    victor_hip.hip again (and the half-minute build would grow back towards its minute and a half): in the shipped library
+    every kernel name occurs in exactly one code object, the theory kernels in none that also holds the chi-square kernels'
+    unit, and the build's unit lists cover every source file of csrc/."""
+    import glob
+    import re
+    import subprocess
+    from victor_amd.build import CSRC, HOST_UNITS, UNITS
+    assert sorted(u for u, _, _ in UNITS) == sorted(os.path.basename(f) for f in glob.glob(os.path.join(CSRC, "*.hip")))
+    assert sorted(HOST_UNITS) == sorted(os.path.basename(f) for f in glob.glob(os.path.join(CSRC, "*.cpp")))
+    where = {}
+    for i, co in enumerate(_gfx950_code_objects(tmp_path)):
+        notes = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
+        for name in set(re.findall(r"\.name:\s+(\S+)", notes)):
+            where.setdefault(name, []).append(i)
+    assert len(where) > 200
+    twice = {k: v for k, v in where.items() if len(v) != 1}
+    assert not twice, twice
+    home = {i for k, v in where.items() if "vk_like_tiled_kernel" in k for i in v}          # victor_hip.hip's code object
+    assert len(home) == 1
+    strays = [k for k, v in where.items() if v[0] in home and re.search(r"vk_theory_(cells|fast)_kernel|vk_theory_kernel|vk_xi_smu_kernel", k)]
+    assert not strays, strays
+    # the lists themselves: 18 + 45 + 45 cells, 45 + 36 point-major, 36 + 12 generic instantiations
+    counts = {fam: sum(1 for k in where if fam in k) for fam in ("vk_theory_cells_kernel", "vk_theory_fast_kernel", "vk_theory_kernelI", "vk_xi_smu_kernel")}
+    assert counts == {"vk_theory_cells_kernel": 108, "vk_theory_fast_kernel": 81, "vk_theory_kernelI": 36, "vk_xi_smu_kernel": 12}, counts
