@@ -81,11 +81,20 @@ def test_product_never_imports_oracle():
     """The shipped package must not reference anything under oracle/."""
     for base, _, files in os.walk(os.path.join(ROOT, "victor_amd")):
         for f in files:
-            if f.endswith((".py", ".hip", ".h")):
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(base, f)).read()
                 assert "victor_oracle" not in text and "ref_shim" not in text, f
     for f in ("victor/__init__.py", "victor/likelihoods/CCFLikelihood.py"):
         assert "oracle" not in open(os.path.join(ROOT, f)).read()
+    # the bench: the oracle is the checker of its `cpu_baseline` leg and nothing else - imported inside the worker that runs in
+    # child processes (bench_legs.cpu_worker), never by the measured path
+    import ast
+    for f in ("bench.py", "bench_pmc.py"):          # (bench.py NAMES the oracle in the text of the `cpu_baseline.sample` field)
+        assert not re.search(r"^\s*(import|from)\s+victor_oracle", open(os.path.join(ROOT, f)).read(), flags=re.M), f
+    tree = ast.parse(open(os.path.join(ROOT, "bench_legs.py")).read())
+    users = [n.name for n in tree.body if isinstance(n, ast.FunctionDef) and "victor_oracle" in ast.unparse(n)]
+    assert users == ["cpu_worker"], users
+    assert not any(isinstance(n, (ast.Import, ast.ImportFrom)) and "oracle" in ast.unparse(n) for n in tree.body)
 
 
 # --------------------------------------------------------------------------- host set-up parity
@@ -662,7 +671,7 @@ def test_no_torch_in_the_product_or_the_bench():
     import glob
     import re
     files = glob.glob(os.path.join(_ROOT, "victor_amd", "**", "*.py"), recursive=True) + glob.glob(os.path.join(_ROOT, "victor", "**", "*.py"), recursive=True) + \
-        glob.glob(os.path.join(_ROOT, "examples", "*.py")) + [os.path.join(_ROOT, "bench.py"), os.path.join(_ROOT, "bench_pmc.py"), os.path.join(_ROOT, "__graft_entry__.py")]
+        glob.glob(os.path.join(_ROOT, "examples", "*.py")) + [os.path.join(_ROOT, "bench.py"), os.path.join(_ROOT, "bench_legs.py"), os.path.join(_ROOT, "bench_pmc.py"), os.path.join(_ROOT, "__graft_entry__.py")]
     for f in files:
         assert not re.search(r"^\s*(import torch|from torch)", open(f).read(), flags=re.M), f
 
