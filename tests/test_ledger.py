@@ -330,3 +330,26 @@ def test_processes_racing_for_the_bound_never_pass_it(lib, path):
                 p.stdin.write("\n")
                 p.stdin.flush()
                 p.wait(timeout=20)
+
+
+def test_ledger_operations_are_clean_under_the_sanitizers(tmp_path):
+    """vk_ledger.cpp is plain POSIX C++ (no HIP): compiled on its own with -fsanitize=address,undefined and driven through the
+    same operations (tests/helpers/asan_ledger.py) in an interpreter with the sanitizer runtimes preloaded - any report fails
+    the run.  (GPU sanitizers are not available on the pool; this is the CPU build the sanitizers can see.)"""
+    import shutil
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("no g++")
+    rt = [subprocess.run([gxx, f"-print-file-name={n}"], capture_output=True, text=True).stdout.strip() for n in ("libasan.so", "libubsan.so")]
+    if not all(os.path.isabs(r) and os.path.isfile(r) for r in rt):
+        pytest.skip("sanitizer runtimes not installed")
+    so = str(tmp_path / "libvk_ledger_san.so")
+    build = subprocess.run([gxx, "-g", "-O1", "-std=c++17", "-fPIC", "-shared", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                            "-fno-sanitize-recover=undefined", "-I", os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "victor_amd", "csrc", "vk_ledger.cpp"), "-o", so], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-2000:]
+    env = dict(os.environ, LD_PRELOAD=":".join(rt), ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=23", VICTOR_HIP_DEV="1")
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "asan_ledger.py"), so], env=env, capture_output=True,
+                         text=True, timeout=120)
+    assert run.returncode == 0 and "clean" in run.stdout, (run.stdout[-1000:], run.stderr[-3000:])
+    assert "ERROR: AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr, run.stderr[-3000:]
