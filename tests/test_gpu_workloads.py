@@ -732,3 +732,32 @@ def test_contexts_give_their_memory_back():
     for _ in range(40):
         use_once()
     assert abs(free_bytes() - start) < 64 << 20, (start, free_bytes())
+
+
+@pytest.mark.gpu
+def test_live_counter_passes_of_the_bench():
+    """What bench.py does before it touches the GPU - three child runs of itself under `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE,
+    GRBM_GUI_ACTIVE; counters only, the interpreter directly behind `--`) - on a small batch: the HBM traffic of the theory
+    kernel and, from ONE child that launches every workload the line quotes a roofline fraction for, the shader cycles and
+    the duration of the same dispatches.  Structure only: which kernel, how many dispatches, that counters and timestamps came
+    back for every workload - the figures themselves are the bench's to report."""
+    import bench
+    import bench_pmc
+    if not bench_pmc.rocprof_path():
+        pytest.skip("rocprofv3 not installed")
+    batch = 4096
+    t = bench_pmc.live_traffic(batch, "simpson")
+    assert t is not None, "a FETCH_SIZE / WRITE_SIZE pass failed (gpurun_out/live_*.err)"
+    assert t["kernel"] == "vk::vk_theory_cells_kernel<3, 3, 0, 0, 0>" and t["launches_averaged"] == 4          # 1 warm-up + 3 steps
+    assert t["written_bytes"] >= batch * 120 * 8 and t["bytes_per_launch"] == t["read_bytes"] + t["written_bytes"]   # the theory workspace at least
+    c = bench_pmc.live_clocks(batch, "simpson")
+    assert c is not None, "the GRBM_GUI_ACTIVE pass failed or its dispatch records do not match what the child launched"
+    labels = ["config3", "boss_cmass"] + [name for name, _ in bench.MODEL_OPTIONS] + [bench.FROM_DATA_LABEL]
+    assert list(c) == labels
+    for name, rec in c.items():
+        assert "vk_theory_cells_kernel" in rec["kernel"] and rec["dispatches"] == (6 if name in ("config3", "boss_cmass") else 4), (name, rec)
+        assert rec["cycles_per_dispatch"] > 0, (name, rec)
+        rec["child_event_ms"], rec["dispatch_ms"], rec["sustained_clock_ghz"]                 # (present; their values are the bench's to report)
+    assert c["config3"]["kernel"] == "vk::vk_theory_cells_kernel<3, 3, 0, 0, 0>" and c["kaiser"]["kernel"] == c["euclid_special"]["kernel"]
+    f = bench.clock_fields(1.0e9, c, "config3")
+    assert f["clock_source"] == "this run" and f["frac_at_sustained_clock"] is not None
