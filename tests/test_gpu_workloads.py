@@ -748,7 +748,7 @@ def test_live_counter_passes_of_the_bench():
     batch = 4096
     t = bench_pmc.live_traffic(batch, "simpson")
     assert t is not None, "a FETCH_SIZE / WRITE_SIZE pass failed (gpurun_out/live_*.err)"
-    assert t["kernel"] == "vk::vk_theory_cells_kernel<3, 3, 0, 0, 0>" and t["launches_averaged"] == 4          # 1 warm-up + 3 steps
+    assert t["kernel"] == "vk::vk_theory_cells_kernel<3, 3, 0, 0, 0>" and t["launches_averaged"] >= 4          # pre-warm + 1 warm-up + 3 steps
     assert t["written_bytes"] >= batch * 120 * 8 and t["bytes_per_launch"] == t["read_bytes"] + t["written_bytes"]   # the theory workspace at least
     c = bench_pmc.live_clocks(batch, "simpson")
     assert c is not None, "the GRBM_GUI_ACTIVE pass failed or its dispatch records do not match what the child launched"
