@@ -254,9 +254,9 @@ void choose_split(const vk_ctx* ctx, long long n, int n_s, int* spi, int* team, 
 template <int RSD, int NLR>
 int launch_generic_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: return launch_on_stream(ctx, vk_theory_kernel<RSD, NLR, 1>, grid, lds, a); break;
-    case 2: return launch_on_stream(ctx, vk_theory_kernel<RSD, NLR, 2>, grid, lds, a); break;
-    case 3: return launch_on_stream(ctx, vk_theory_kernel<RSD, NLR, 3>, grid, lds, a); break;
+    case 1: return launch_on_stream(ctx, vk_theory_kernel<RSD, NLR, 1>, grid, lds, a);
+    case 2: return launch_on_stream(ctx, vk_theory_kernel<RSD, NLR, 2>, grid, lds, a);
+    case 3: return launch_on_stream(ctx, vk_theory_kernel<RSD, NLR, 3>, grid, lds, a);
   }
   return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
 }
@@ -274,9 +274,9 @@ int launch_generic(vk_ctx* ctx, const TheoryArgs& a, int nlr, int grid, size_t l
 template <int NLR, int GRID, int MODE>
 int launch_fast_ngf(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 1, GRID, MODE>, grid, lds, a); break;
-    case 2: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 2, GRID, MODE>, grid, lds, a); break;
-    case 3: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 3, GRID, MODE>, grid, lds, a); break;
+    case 1: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 1, GRID, MODE>, grid, lds, a);
+    case 2: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 2, GRID, MODE>, grid, lds, a);
+    case 3: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 3, GRID, MODE>, grid, lds, a);
   }
   return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
 }
@@ -285,9 +285,9 @@ int launch_fast_ngf(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
 template <int NLR>
 int launch_fast_sva(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 1, 0, kModeStreaming, 1>, grid, lds, a); break;
-    case 2: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 2, 0, kModeStreaming, 1>, grid, lds, a); break;
-    case 3: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 3, 0, kModeStreaming, 1>, grid, lds, a); break;
+    case 1: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 1, 0, kModeStreaming, 1>, grid, lds, a);
+    case 2: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 2, 0, kModeStreaming, 1>, grid, lds, a);
+    case 3: return launch_on_stream(ctx, vk_theory_fast_kernel<NLR, 3, 0, kModeStreaming, 1>, grid, lds, a);
   }
   return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
 }
@@ -296,9 +296,9 @@ int launch_fast_sva(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
 template <int NLR>
 int launch_cells_sva_disp(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 1, 0, kModeDispersion, 1>, grid, lds, a); break;
-    case 2: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 2, 0, kModeDispersion, 1>, grid, lds, a); break;
-    case 3: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 3, 0, kModeDispersion, 1>, grid, lds, a); break;
+    case 1: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 1, 0, kModeDispersion, 1>, grid, lds, a);
+    case 2: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 2, 0, kModeDispersion, 1>, grid, lds, a);
+    case 3: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 3, 0, kModeDispersion, 1>, grid, lds, a);
   }
   return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
 }
@@ -307,9 +307,9 @@ template <int NLR>
 int launch_cells_sva(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   if (a.rsd == VK_RSD_DISPERSION) return launch_cells_sva_disp<NLR>(ctx, a, grid, lds);
   switch (a.n_ell) {
-    case 1: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 1, 0, kModeStreaming, 1>, grid, lds, a); break;
-    case 2: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 2, 0, kModeStreaming, 1>, grid, lds, a); break;
-    case 3: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 3, 0, kModeStreaming, 1>, grid, lds, a); break;
+    case 1: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 1, 0, kModeStreaming, 1>, grid, lds, a);
+    case 2: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 2, 0, kModeStreaming, 1>, grid, lds, a);
+    case 3: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 3, 0, kModeStreaming, 1>, grid, lds, a);
   }
   return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
 }
@@ -333,9 +333,9 @@ int launch_fast_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
 template <int NLR, int GRID>
 int launch_lanes_ng(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: return launch_on_stream(ctx, vk_theory_lanes_kernel<NLR, 1, GRID>, grid, lds, a); break;
-    case 2: return launch_on_stream(ctx, vk_theory_lanes_kernel<NLR, 2, GRID>, grid, lds, a); break;
-    case 3: return launch_on_stream(ctx, vk_theory_lanes_kernel<NLR, 3, GRID>, grid, lds, a); break;
+    case 1: return launch_on_stream(ctx, vk_theory_lanes_kernel<NLR, 1, GRID>, grid, lds, a);
+    case 2: return launch_on_stream(ctx, vk_theory_lanes_kernel<NLR, 2, GRID>, grid, lds, a);
+    case 3: return launch_on_stream(ctx, vk_theory_lanes_kernel<NLR, 3, GRID>, grid, lds, a);
   }
   return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
 }
@@ -349,9 +349,9 @@ int launch_lanes_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
 template <int NLR, int GRID, int MODE>
 int launch_cells_ngf(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
   switch (a.n_ell) {
-    case 1: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 1, GRID, MODE>, grid, lds, a); break;
-    case 2: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 2, GRID, MODE>, grid, lds, a); break;
-    case 3: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 3, GRID, MODE>, grid, lds, a); break;
+    case 1: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 1, GRID, MODE>, grid, lds, a);
+    case 2: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 2, GRID, MODE>, grid, lds, a);
+    case 3: return launch_on_stream(ctx, vk_theory_cells_kernel<NLR, 3, GRID, MODE>, grid, lds, a);
   }
   return fail(ctx, VK_E_ARG, "n_ell must be 1..3");
 }
@@ -375,9 +375,9 @@ int launch_cells_nl(vk_ctx* ctx, const TheoryArgs& a, int grid, size_t lds) {
 template <int RSD>
 int launch_xi_smu(vk_ctx* ctx, const TheoryArgs& a, int nlr, int grid, size_t lds) {
   switch (nlr) {
-    case 1: return launch_on_stream(ctx, vk_xi_smu_kernel<RSD, 1>, grid, lds, a); break;
-    case 2: return launch_on_stream(ctx, vk_xi_smu_kernel<RSD, 2>, grid, lds, a); break;
-    case 3: return launch_on_stream(ctx, vk_xi_smu_kernel<RSD, 3>, grid, lds, a); break;
+    case 1: return launch_on_stream(ctx, vk_xi_smu_kernel<RSD, 1>, grid, lds, a);
+    case 2: return launch_on_stream(ctx, vk_xi_smu_kernel<RSD, 2>, grid, lds, a);
+    case 3: return launch_on_stream(ctx, vk_xi_smu_kernel<RSD, 3>, grid, lds, a);
   }
   return fail(ctx, VK_E_ARG, "bad number of real-space multipoles %d", nlr);
 }
