@@ -879,9 +879,23 @@ def test_tools_are_current():
         assert f"`{f}" in readme, f"{f} has no line in tools/README.md"
     for listed in re.findall(r"^\| `([\w.]+\.(?:py|sh|hip))", readme, flags=re.M):
         assert listed in files, f"tools/README.md lists {listed}, which is not there"
+    for name in set(re.findall(r"VICTOR_HIP_[A-Z_]+[A-Z]", "".join(open(f).read() for f in glob.glob(os.path.join(_ROOT, "tests", "test_gpu_*.py"))))):
+        assert name in known, f"a GPU test names {name}, which nothing reads"
+    # the tests set knobs through helpers that add the prefix (tests/test_gpu_parity.py: knobs(NO_FUSE="1"), {"LIKE_WIDE": "0"})
     tests_src = "".join(open(f).read() for f in glob.glob(os.path.join(_ROOT, "tests", "*.py")))
-    idle = {k for k in knobs if k not in used and k not in tests_src}
+    def in_tests(knob):
+        short = knob[len("VICTOR_HIP_"):]
+        return knob in tests_src or re.search(r"\b%s=|\"%s\"\s*:" % (short, short), tests_src) is not None
+    idle = {k for k in knobs if k not in used and not in_tests(k)}
     assert not idle, f"development knobs nobody sets: {idle}"
+    # ... and every knob a test sets that way is one the library reads
+    for short in set(re.findall(r"knobs\(([^)]*)\)", tests_src)) | set():
+        for name in re.findall(r"\b([A-Z][A-Z_]+)=", short):
+            assert "VICTOR_HIP_" + name in knobs, f"a test sets VICTOR_HIP_{name}, which the library does not read"
+    for line in tests_src.splitlines():
+        if re.search(r"for kn in \(", line):                         # ... or as dictionaries handed to knobs(**kn)
+            for name in re.findall(r"\"([A-Z][A-Z_]+)\":", line):
+                assert "VICTOR_HIP_" + name in knobs, f"a test sets VICTOR_HIP_{name}, which the library does not read"
 
 
 def test_one_routine_forms_the_alcock_paczynski_factors(lib):

@@ -165,6 +165,7 @@ void load_knobs(vk_ctx* ctx) {
   }
   if (const char* env = getenv("VICTOR_HIP_FUSE_MAX")) k.fuse_max = atoll(env);
   if (const char* env = getenv("VICTOR_HIP_CELLS_PARTS")) k.cells_parts = atoi(env);
+  if (const char* env = getenv("VICTOR_HIP_LIKE_WIDE")) k.like_wide = atoi(env) ? 1 : 0;
   k.no_zero_copy = getenv("VICTOR_HIP_NO_ZERO_COPY") != nullptr;
   if (const char* env = getenv("VICTOR_HIP_SPIN_MAX")) k.spin_max = atoll(env);
   if (const char* env = getenv("VICTOR_HIP_NO_POLL")) k.no_poll = atoi(env) != 0;
@@ -797,7 +798,7 @@ int launch_like(vk_ctx* ctx, const LikeArgs& a) {
   // small batches: one workgroup per point (the wave-per-point kernels below need >= 1024 points to fill the chip; a
   // single point took 27 us in one wave against the ~3 us of 256 threads)
   const size_t lds_wide = (size_t)like_lds_doubles(ctx->N) * sizeof(double);
-  const bool wide = n <= 2048;
+  const bool wide = ctx->knobs.like_wide >= 0 ? ctx->knobs.like_wide == 1 : n <= 2048;
   if (wide && lds_wide <= 160 * 1024) {
     return launch_on_stream(ctx, vk_like_wide_kernel, (int)n, lds_wide, a);      // one point per workgroup
   }

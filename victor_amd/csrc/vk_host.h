@@ -36,6 +36,8 @@ struct Knobs {
   long long fuse_max = -1;             // VICTOR_HIP_FUSE_MAX: largest batch whose chi2 is taken inside the theory kernel (-1 = default)
   int split_q = 0;                     // third field of VICTOR_HIP_SPLIT "spi,team,parts": workgroups per (mu, v) plane
   int cells_parts = 0;                 // VICTOR_HIP_CELLS_PARTS: workgroups per point in the cells kernel (0 = choose)
+  int like_wide = -1;                  // VICTOR_HIP_LIKE_WIDE: 1 / 0 force the workgroup-per-point chi2 kernel on / off (the parity tests
+                                       // reach the wave-per-point and tiled K2 at small batches through it)
   bool no_zero_copy = false;           // VICTOR_HIP_NO_ZERO_COPY: small host-buffer batches through the copy / graph path
   long long spin_max = -1;             // VICTOR_HIP_SPIN_MAX: largest in-place batch whose results are polled for (-1 = default, 0 = never)
   bool no_poll = false;                // VICTOR_HIP_NO_POLL: split single-point launches hand over through the completion counters (A/B)
